@@ -1,0 +1,348 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the REFERENCE (builder container only).
+
+Run:  python tests/golden/make_golden.py            (needs /root/reference; never runs on the GPU box)
+
+What it does:
+  * creates three import stubs in a temp dir (``clip``, ``aitviewer.renderables.lines``, ``yacs.config``) --
+    none of them touches arithmetic -- and four seeded synthetic normaliser files under a temp cwd;
+  * puts ``/root/reference/src`` on sys.path and constructs the reference's own modules directly
+    (in2INDenoiser, InterDenoiser, Influence, Mixer, ClassifierFreeSampleModel{,X2}, MixerDiffusion,
+    MotionDiffusion, alignment / rotation helpers), bypassing the MixerMDM facade (needs CLIP + checkpoints);
+  * re-draws every parameter N(0, std) so zero_module'd layers are non-trivial;
+  * stores inputs, weights (reference state_dict key names, minus the 5000-row pe buffers) and the
+    reference's outputs as small .npz fixtures.  Fixtures are data only; no reference source is copied.
+"""
+import os
+import sys
+import tempfile
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/src"
+
+STUBS = {
+    "clip/__init__.py": "def load(*a, **k): raise RuntimeError('clip stub')\n"
+                        "def tokenize(*a, **k): raise RuntimeError('clip stub')\n",
+    "aitviewer/__init__.py": "",
+    "aitviewer/renderables/__init__.py": "",
+    "aitviewer/renderables/lines.py": "class Lines: pass\n",
+    "yacs/__init__.py": "",
+    "yacs/config.py": "class CfgNode(dict):\n    pass\n",
+}
+
+
+def setup():
+    tmp = tempfile.mkdtemp(prefix="mmdm_golden_")
+    for rel, src in STUBS.items():
+        p = os.path.join(tmp, "stubs", rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        open(p, "w").write(src)
+    cwd = os.path.join(tmp, "cwd")
+    os.makedirs(os.path.join(cwd, "data", "HumanML3D"))
+    rng = np.random.default_rng(3)
+    stats = {}
+    for key, rel in [("mean_ih", "data/global_mean.npy"), ("mean_hml", "data/HumanML3D/mean_ih_new.npy")]:
+        stats[key] = rng.normal(0, 0.1, 262).astype(np.float32)
+        np.save(os.path.join(cwd, rel), stats[key])
+    for key, rel in [("std_ih", "data/global_std.npy"), ("std_hml", "data/HumanML3D/std_ih_new.npy")]:
+        stats[key] = rng.uniform(0.5, 1.5, 262).astype(np.float32)
+        np.save(os.path.join(cwd, rel), stats[key])
+    os.chdir(cwd)
+    sys.dont_write_bytecode = True
+    sys.path[:0] = [os.path.join(tmp, "stubs"), REF]
+    return stats
+
+
+STATS = setup()
+
+import torch  # noqa: E402
+from models.in2in import in2INDenoiser  # noqa: E402
+from models.intergen import InterDenoiser  # noqa: E402
+from models.mixermdm import Mixer  # noqa: E402
+from models.utils.influence import Influence, InfluenceBlockCross  # noqa: E402
+from models.utils.layers import AdaLN, VanillaSelfAttention, VanillaCrossAttention, FFN  # noqa: E402
+from models.utils.blocks import TransformerBlock, TransformerBlockDoubleCond  # noqa: E402
+from models.utils.utils import PositionalEncoding  # noqa: E402
+from models.utils.cfg_sampler import ClassifierFreeSampleModel, ClassifierFreeSampleModelX2  # noqa: E402
+from models.utils import gaussian_diffusion as gd  # noqa: E402
+from utils import alignment as al  # noqa: E402
+from utils import rotation_conversions as rc  # noqa: E402
+from utils import quaternion as qt  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def reinit(mod, seed, std=0.1):
+    """Per-parameter seeding (crc32 of the parameter name + seed): modules that share a parameter name and
+    shape get identical values, so fixtures can store one weight set for several variants."""
+    import zlib
+    for name, p in mod.named_parameters():
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) + seed)
+        p.copy_(torch.randn(p.shape, generator=g) * std)
+    mod.eval()
+    return mod
+
+
+def sd(mod, prefix=""):
+    """state_dict as numpy, without the [5000, D] pe buffers (recomputed; pinned separately by pe.npz)."""
+    return {"w:" + prefix + k: v.numpy() for k, v in mod.state_dict().items() if not k.endswith("sequence_pos_encoder.pe")}
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def save(name, **arrs):
+    out = {k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()}
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB  ({len(out)} arrays)")
+
+
+# ---- G1 schedule ---------------------------------------------------------------------------------
+def g_schedule():
+    out = {"betas_cosine_1000": gd.get_named_beta_schedule("cosine", 1000),
+           "betas_linear_1000": gd.get_named_beta_schedule("linear", 1000)}
+    for strat in ["ddim50", "ddim1000", "ddim20"]:
+        d = gd.MixerDiffusion(use_timesteps=gd.space_timesteps(1000, strat), betas=out["betas_cosine_1000"],
+                              model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                              loss_type=gd.LossType.MSE, rescale_timesteps=False)
+        out[strat + ":timestep_map"] = np.array(d.timestep_map)
+        for a in ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"]:
+            out[strat + ":" + a] = getattr(d, a)
+    out["space:[1000]"] = np.array(sorted(gd.space_timesteps(1000, [1000])))
+    out["space:10,15,20@300"] = np.array(sorted(gd.space_timesteps(300, "10,15,20")))
+    out["space:ddim25@1000"] = np.array(sorted(gd.space_timesteps(1000, "ddim25")))
+    save("schedule", **out)
+
+
+# ---- G2 pe ---------------------------------------------------------------------------------------
+def g_pe():
+    rows = [0, 1, 299, 999]
+    out = {"rows": np.array(rows)}
+    for D in [64, 512, 1024]:
+        out[f"pe{D}"] = PositionalEncoding(D, dropout=0).pe[rows]
+    save("pe", **out)
+
+
+# ---- G3 layers -----------------------------------------------------------------------------------
+def g_layers():
+    D, F_, H, T, B = 32, 64, 4, 12, 2
+    x, y, e1, e2 = rnd(1, B, T, D), rnd(2, B, T, D), rnd(3, B, D), rnd(4, B, D)
+    out = {"x": x, "y": y, "emb": e1, "emb2": e2, "H": H}
+    m = reinit(AdaLN(D), 10); out.update(sd(m, "adaln.")); out["adaln:out"] = m(x, e1)
+    m = reinit(VanillaSelfAttention(D, H, 0.1), 11); out.update(sd(m, "sa.")); out["sa:out"] = m(x, e1, None)
+    m = reinit(VanillaCrossAttention(D, D, H, 0.1, D), 12); out.update(sd(m, "ca.")); out["ca:out"] = m(x, y, e1, None)
+    m = reinit(FFN(D, F_, 0.1, D), 13); out.update(sd(m, "ffn.")); out["ffn:out"] = m(x, e1)
+    m = reinit(TransformerBlockDoubleCond("individual", latent_dim=D, num_heads=H, ff_size=F_, dropout=0.1), 14)
+    out.update(sd(m, "bdc_ind.")); out["bdc_ind:out"] = m(x, None, e1, None, None)
+    m = reinit(TransformerBlockDoubleCond("interaction", latent_dim=D, num_heads=H, ff_size=F_, dropout=0.1), 15)
+    out.update(sd(m, "bdc_int.")); out["bdc_int:out"] = m(x, y, e1, e2, None)
+    m = reinit(TransformerBlock(latent_dim=D, num_heads=H, ff_size=F_, dropout=0.1), 16)
+    out.update(sd(m, "blk.")); out["blk:out"] = m(x, y, e1, None)
+    m = reinit(InfluenceBlockCross(latent_dim=D, num_heads=H, ff_size=F_), 17)
+    out.update(sd(m, "ibc.")); out["ibc:out"] = m(x, y, e1, e2, None)
+    save("layers", **out)
+
+
+# ---- G4 denoisers --------------------------------------------------------------------------------
+DEN = dict(latent_dim=16, ff_size=32, num_layers=2, num_heads=2, dropout=0.1)
+
+
+def g_denoisers():
+    B, T = 2, 12
+    out = {"H": DEN["num_heads"], "t": np.array([980, 0])}
+    t = torch.tensor([980, 0])
+    x1, x2 = rnd(20, B, T, 262), rnd(21, B, T, 524)
+    c1, c3 = rnd(22, B, 768), rnd(23, B, 768 * 3)
+    out.update(x_ind=x1, x_int=x2, cond_ind=c1, cond_int=c3)
+    m = reinit(in2INDenoiser(262, mode="individual", **DEN), 30); out.update(sd(m, "ind.")); out["ind:out"] = m(x1, t, cond=c1)
+    m = reinit(in2INDenoiser(262, mode="interaction", **DEN), 31); out.update(sd(m, "int.")); out["int:out"] = m(x2, t, cond=c3)
+    m = reinit(InterDenoiser(262, **DEN), 32); out.update(sd(m, "ig.")); out["ig:out"] = m(x2, t, cond=c3)
+    save("denoisers", **out)
+
+
+# ---- G5 influence --------------------------------------------------------------------------------
+def g_influence():
+    D, B, T = 32, 2, 12
+    mi, mI, ci, cI = rnd(40, B, T, D), rnd(41, B, T, D), rnd(42, B, D), rnd(43, B, D)
+    out = dict(m_i=mi, m_I=mI, cond_i=ci, cond_I=cI, H=4)
+    for mode in [1, 2, 3, 4]:
+        m = reinit(Influence(D, 2, 4, 64, mode), 50)   # name-seeded: modes differ only in out.{weight,bias} shape
+        w = sd(m, f"m{mode}.")
+        out.update(w if mode == 4 else {k: v for k, v in w.items() if ".out." in k})
+        out[f"m{mode}:out"] = m(mi, mI, ci, cI, None)
+    save("influence", **out)
+
+
+# ---- G6 geometry ---------------------------------------------------------------------------------
+def near_valid_motion(seed, B, T):
+    """262-d motions whose rot6d block is close to real rotations, plus hand-picked edge cases."""
+    m = rnd(seed, B, T, 262)
+    aa = rnd(seed + 1, B, T, 21, 3) * 1.2
+    aa[0, 0, 0] = 0.0                                   # angle == 0
+    aa[0, 0, 1] = torch.tensor([1e-7, 0.0, 0.0])        # below the 1e-6 small-angle switch
+    aa[0, 0, 2] = torch.tensor([3.14159, 0.0, 0.0])     # angle ~ pi
+    aa[0, 0, 3] = torch.tensor([0.0, 3.1415926, 0.0])
+    aa[0, 0, 4] = torch.tensor([2.0, -2.0, 1.0])        # angle = 3 > pi/2 both signs
+    r6 = rc.matrix_to_rotation_6d(rc.axis_angle_to_matrix(aa)) + rnd(seed + 2, B, T, 21, 6) * 0.01
+    m[:, :, 132:258] = r6.reshape(B, T, 126)
+    return m
+
+
+def g_geometry():
+    B, T = 2, 12
+    a, b = rnd(60, B, T, 262), rnd(61, B, T, 262)
+    c, d = near_valid_motion(62, B, T), near_valid_motion(65, B, T)
+    d[1, :, 0:3] = d[1, :1, 0:3]                        # zero root displacement for sample 1 (moved motion)
+    c[0, :, 0] = torch.linspace(0, 1, T); c[0, :, 2] = 0.0  # collinear +x trajectory
+    d[0, :, 0] = torch.linspace(0, -1, T); d[0, :, 2] = 0.0  # anti-parallel trajectory (qbetween near w=0)
+    out = {}
+    for nm, m in [("rand_a", a), ("rand_b", b), ("valid_c", c), ("valid_d", d)]:
+        out[nm] = m
+        s = al.ih_to_smpl(m)
+        out[nm + ":ih_to_smpl"] = s
+        out[nm + ":smpl_to_ih"] = al.smpl_to_ih(s)
+        cm = al.center_motion(s)
+        out[nm + ":center"] = cm
+        out[nm + ":center_ih"] = al.smpl_to_ih(cm)
+    for nm, m1, m2 in [("rand", a, b), ("valid", c, d)]:
+        s1, s2 = al.ih_to_smpl(m1), al.ih_to_smpl(m2)
+        r1, r2 = al.align_motions(s1, s2, None)
+        out[nm + ":align_m1"] = r1
+        out[nm + ":align_m2"] = r2
+        out[nm + ":align_m2_ih"] = al.smpl_to_ih(r2)
+    # helper KATs
+    d6 = rnd(70, 64, 6)
+    out["kat:d6"] = d6
+    mat = rc.rotation_6d_to_matrix(d6)
+    out["kat:d6_matrix"] = mat
+    q = rc.matrix_to_quaternion(mat)
+    out["kat:matrix_quat"] = q
+    out["kat:quat_aa"] = rc.quaternion_to_axis_angle(q)
+    aa = rnd(71, 64, 3) * 2
+    aa[0] = 0.0
+    aa[1] = torch.tensor([5e-7, 0, 0])
+    out["kat:aa"] = aa
+    out["kat:aa_quat"] = rc.axis_angle_to_quaternion(aa)
+    out["kat:aa_matrix"] = rc.axis_angle_to_matrix(aa)
+    out["kat:aa_d6"] = rc.matrix_to_rotation_6d(rc.axis_angle_to_matrix(aa))
+    v0, v1 = rnd(72, 64, 3), rnd(73, 64, 3)
+    out["kat:v0"], out["kat:v1"] = v0, v1
+    qb = qt.qbetween(v0, v1)
+    out["kat:qbetween"] = qb
+    out["kat:qrot"] = qt.qrot(qb, v0)
+    save("geometry", **out)
+
+
+# ---- G7-G10 mixer --------------------------------------------------------------------------------
+def build_mixer(mode=4, align=True, force=None, model2="in2IN"):
+    d1 = in2INDenoiser(262, mode="individual", **DEN)
+    d2 = in2INDenoiser(262, mode="interaction", **DEN) if model2 == "in2IN" else InterDenoiser(262, **DEN)
+    mix = Mixer(d1, d2, nfeats=262, latent_dim=16, ff_size=32, text_dim=768, n_blocks=2, n_heads=2,
+                mixing_mode=mode, store_influence=True, force_influence_val=force, mode="eval", align=align)
+    return reinit(mix, 100)
+
+
+def reset_hist(mix):
+    mix.history_influence_i1, mix.history_influence_i2 = [], []
+    mix.history_out1, mix.history_out2, mix.history_out_influenced = [], [], []
+
+
+def make_diffusion(strategy):
+    return gd.MixerDiffusion(use_timesteps=gd.space_timesteps(1000, strategy), betas=gd.get_named_beta_schedule("cosine", 1000),
+                             model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                             loss_type=gd.LossType.MSE, rescale_timesteps=False)
+
+
+def g_mixer():
+    B, T = 2, 8
+    out = {k: v for k, v in STATS.items()}
+    out.update(d_heads=2, m_heads=2, cfg_scale=3.5)
+    B2 = 2 * B
+    x1, x2 = rnd(80, B2, T, 524), rnd(81, B2, T, 524)
+    cond = rnd(82, B2, 8 * 768)
+    cond[B:] = 0
+    t = torch.full((B2,), 640, dtype=torch.long)
+    out.update(x1=x1, x2=x2, cond=cond, t=t)
+    # G7: weights differ per mixing mode only through influence.out -> store the mode-4 set fully and per-mode 'influence.out'
+    for mode in [1, 2, 3, 4]:
+        for align in [True, False]:
+            for force in ([None, 0.0, 1.0] if mode == 4 else [None]):
+                mix = build_mixer(mode, align, force)
+                if mode == 4 and align and force is None:
+                    out.update(sd(mix, "mix."))          # the one full weight set (name-seeded)
+                elif mode == 1 and align:
+                    out.update({k.replace("w:mix.", "w:mix_out1."): v for k, v in sd(mix, "mix.").items() if "influence.out." in k})
+                reset_hist(mix)
+                tag = f"fwd:m{mode}:a{int(align)}:f{force}"
+                out[tag] = mix(x1, t, cond=cond, mask=None, x2=x2)
+                if mode == 4 and force is None:
+                    out[tag + ":influence_i1"] = mix.history_influence_i1[0]
+                    out[tag + ":influence_i2"] = mix.history_influence_i2[0]
+                    out[tag + ":out1"] = mix.history_out1[0]
+                    out[tag + ":out2"] = mix.history_out2[0]
+    # G8 CFG wrapper + G9 ddim_sample at t>0 and t==0, G10 tiny loop (mode 4, align)
+    mix = build_mixer(4, True, None)
+    cfg = ClassifierFreeSampleModelX2(mix, 3.5)
+    xb, xb2, cb = rnd(83, B, T, 524), rnd(84, B, T, 524), rnd(85, B, 8 * 768)
+    out.update(cfg_x=xb, cfg_x2=xb2, cfg_cond=cb)
+    reset_hist(mix)
+    out["cfg:out"] = cfg(xb, xb2, torch.full((B,), 640, dtype=torch.long), cond=cb, mask=None)
+    diff = make_diffusion("ddim50")
+    for i in [32, 0]:
+        reset_hist(mix)
+        r = diff.ddim_sample(cfg, xb, xb2, torch.tensor([i] * B), clip_denoised=False, model_kwargs={"mask": None, "cond": cb})
+        for k in ["sample", "sample2", "pred_xstart", "pred_xstart2"]:
+            out[f"ddim:i{i}:{k}"] = r[k]
+    for strat in ["ddim50", "ddim20"]:
+        reset_hist(mix)
+        diff = make_diffusion(strat)
+        xT = rnd(86, B, T, 524)
+        out[f"loop:{strat}:x_T"] = xT
+        res = diff.ddim_sample_loop(cfg, (B, T, 524), noise=xT.clone(), clip_denoised=False, progress=False,
+                                    model_kwargs={"mask": None, "cond": cb})
+        out[f"loop:{strat}:output"] = res
+        n = len(mix.history_out1)
+        out[f"loop:{strat}:nsteps"] = n
+        for name, lst in [("influence_i1", mix.history_influence_i1), ("influence_i2", mix.history_influence_i2),
+                          ("out1", mix.history_out1), ("out2", mix.history_out2), ("out_influenced", mix.history_out_influenced)]:
+            out[f"loop:{strat}:{name}:sum"] = np.array([float(v.double().sum()) for v in lst])
+            out[f"loop:{strat}:{name}:abssum"] = np.array([float(v.double().abs().sum()) for v in lst])
+            if strat == "ddim50":
+                for k in [0, n - 1]:
+                    out[f"loop:{strat}:{name}:{k}"] = lst[k]
+    # InterGen as model2, one forward
+    mix = build_mixer(4, True, None, model2="InterGen")
+    # name-seeded: denoiser2.* keys of InterDenoiser are a subset of the in2IN ones with identical values,
+    # EXCEPT nothing extra is needed: TransformerBlock has the same sa/ca/ffn parameter names.
+    reset_hist(mix)
+    out["fwd:intergen"] = mix(x1, t, cond=cond, mask=None, x2=x2)
+    save("mixer", **out)
+
+
+# ---- G11 single chain ----------------------------------------------------------------------------
+def g_single():
+    B, T = 2, 12
+    m = reinit(in2INDenoiser(262, mode="individual", **DEN), 30)
+    cfg = ClassifierFreeSampleModel(m, 3.5)
+    out = dict(sd(m, "ind."))
+    out.update(H=DEN["num_heads"], cfg_scale=3.5)
+    xT, c = rnd(90, B, T, 262), rnd(91, B, 768)
+    out.update(x_T=xT, cond=c)
+    out["cfg:out"] = cfg(xT, torch.full((B,), 500, dtype=torch.long), cond=c, mask=None)
+    for strat in ["ddim50", "ddim20"]:
+        diff = gd.MotionDiffusion(use_timesteps=gd.space_timesteps(1000, strat), motion_rep="global", mode="individual",
+                                  betas=gd.get_named_beta_schedule("cosine", 1000),
+                                  model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                                  loss_type=gd.LossType.MSE, rescale_timesteps=False)
+        out[f"loop:{strat}:output"] = diff.ddim_sample_loop(cfg, (B, T, 262), noise=xT.clone(), clip_denoised=False, progress=False,
+                                                            model_kwargs={"mask": None, "cond": c})
+    save("single", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["schedule", "pe", "layers", "denoisers", "influence", "geometry", "mixer", "single"]
+    for w in which:
+        globals()["g_" + w]()
