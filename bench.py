@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- generated motions/sec of the 2-person MixerMDM denoising loop (1000-step DDIM eta=0, T=300) on N MI355X.
+
+A "step" is one DDIM step of the whole hot path (two denoisers + geometry + Influence mixer + blend + two-chain
+update) over one batch of B motions per GPU (BASELINE.json configs[2]: B=16, T=300, fp32).  value = N*B motions per
+1000 steps of the measured per-step time.  One JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X fp32 matrix peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
+
+
+def algorithmic_flops_per_motion_step(T, D=1024, F=2048, L=8, Dm=512, Fm=1024, Lm=4):
+    """478.4 GFLOP at T=300."""
+    d1 = 2 * T * (L * (4 * D * D + 2 * D * F + 2 * (T + 1) * D) + 2 * 262 * D)
+    d2 = 4 * T * (L * (8 * D * D + 2 * D * F + 4 * (T + 1) * D) + 2 * 262 * D)
+    inf = 2 * T * (Lm * (8 * Dm * Dm + 2 * Dm * Fm + 4 * (T + 1) * Dm) + 23 * Dm)
+    ada = 2 * L * 2 * 2 * D * D * 4 + 2 * L * 4 * 2 * 2 * D * D * 2 + 2 * Lm * 4 * 2 * Dm * Dm * 4
+    return 4 * d1 + 2 * d2 + 4 * inf + 8 * (2 * T * 262 * Dm) + ada
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="motions per GPU (weak scaling)")
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--profile-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd.synthetic import synthetic_state_dict, mixer_shapes, synthetic_stats, synthetic_inputs, FULL_DIMS
+
+    B, T, S = args.batch, args.frames, 1000
+    # weights: rank 0 draws them on the host, one RCCL broadcast of the packed vector over xGMI (no other collective on the path)
+    shapes = mixer_shapes(**FULL_DIMS)
+    total = sum(int(torch.Size(s).numel()) for s in shapes.values())
+    flat = torch.empty(total, device=device, dtype=torch.float32)
+    sd_cpu = None
+    if rank == 0:
+        sd_cpu = synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, **FULL_DIMS)
+        flat.copy_(torch.cat([sd_cpu[k].reshape(-1) for k in shapes]))
+    if world > 1:
+        dist.broadcast(flat, 0)
+    sd, off = {}, 0
+    for k, shp in shapes.items():
+        n = int(torch.Size(shp).numel())
+        sd[k] = flat[off:off + n].view(shp)
+        off += n
+    stats = synthetic_stats()
+    smp = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, **FULL_DIMS)
+    smp.load_state_dict(sd)
+    smp.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+    smp.prepare()
+    smp.set_schedule("ddim1000")
+    del flat, sd
+    cond, xT = synthetic_inputs(B, T, seed_cond=1 + 1000 * rank, seed_x=2 + 1000 * rank)   # each rank = its own shard of the batch
+    cond, xT = cond.to(device), xT.to(device)
+    use_graph = not args.no_graph
+    if args.warmup + args.steps > S:
+        raise SystemExit("warmup + steps must be <= 1000")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    smp.begin(cond, xT)                      # inputs resident in HBM before the timed region
+    smp.run(args.warmup, use_graph)          # untimed warm-up (includes the graph capture)
+    barrier()
+    t0 = time.perf_counter()
+    smp.run(args.steps, use_graph)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    finite = bool(torch.isfinite(smp.state()["x"]).all().item())
+
+    # dominant kernel: the fp32 MFMA GEMM -- live HIP-event timing of every launch, eager, on the handle's stream
+    roof = None
+    if rank == 0 and args.profile_steps > 0 and args.warmup + args.steps + args.profile_steps <= S:
+        smp.profile(True)
+        smp.run(args.profile_steps, use_graph=False)
+        g_ms, g_n, g_fl = smp.profile_read(0)
+        a_ms, a_n, a_fl = smp.profile_read(1)
+        smp.profile(False)
+        ach = g_fl / (g_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
+                "gflop_per_launch": round(g_fl / g_n / 1e9, 3), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
+                "attention": {"achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a_ms / args.profile_steps, 3),
+                              "launches_per_step": a_n // args.profile_steps}}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sd_cpu, stats, T, args.cpu_steps)
+
+    if rank == 0:
+        flops = algorithmic_flops_per_motion_step(T)
+        value = world * B / (ms_per_step * 1e-3 * S)
+        line = {
+            "metric": "generated motions/sec (1000-step DDPM, T=300, 2-person)", "value": round(value, 5), "unit": "motions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 2-person MixerMDM (in2IN individual + in2IN interaction + Mixer mode 4, align, CFG 3.5), "
+                                   "T=%d, ddim1000 (eta=0), batch %d per GPU, fp32, random-init weights" % (T, B),
+                       "batch_per_gpu": B, "frames": T, "sampler_steps": S, "hipgraph": use_graph, "parallelism": "batch-sharded x%d, no in-loop collective" % world},
+            "achieved_tflops_algorithmic": round(flops * B * world / (ms_per_step * 1e-3) / 1e12, 2),
+            "frac_of_f32_mfma_peak": round(flops * B / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "outputs_finite": finite,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    smp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd_cpu, stats, T, nsteps):
+    """The oracle (a PyTorch-CPU port of the reference path, parity-pinned by tests/golden) timed on this host's cores:
+    `nsteps` consecutive DDIM steps at B=1 after one untimed step, extrapolated to the 1000-step loop."""
+    import torch
+    from oracle import mixer as MX, schedule as OS
+    from oracle.layers import pe_table
+    from mixermdm_amd.synthetic import synthetic_inputs
+    W = dict(sd_cpu)
+    W["sequence_pos_encoder.pe"] = pe_table(512)
+    W["denoiser1.sequence_pos_encoder.pe"] = pe_table(1024)
+    W["denoiser2.sequence_pos_encoder.pe"] = pe_table(1024)
+    ostats = (stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+    sch = OS.make_schedule("cosine", 1000, "ddim1000")
+    spec = MX.MixerSpec(d_heads=8, m_heads=8)
+    cond, xT = synthetic_inputs(1, T)
+    x, x2 = xT.clone(), xT.clone()
+    with torch.no_grad():
+        x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 999, x, x2, cond)
+        t0 = time.perf_counter()
+        for k in range(nsteps):
+            x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 998 - k, x, x2, cond)
+        dt = (time.perf_counter() - t0) / nsteps
+    return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d consecutive DDIM steps (i=998..) of the same workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), "
+                      "%.3f s/step, extrapolated x1000 steps" % (nsteps, T, torch.__version__, dt),
+            "s_per_step_b1": round(dt, 4)}
+
+
+if __name__ == "__main__":
+    main()

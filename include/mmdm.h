@@ -1,0 +1,194 @@
+/* mmdm.h -- C ABI of libmmdm_hip.so: the MI355X (gfx950) implementation of MixerMDM's denoising hot path.
+ *
+ * The reference (pabloruizponce/MixerMDM) has no FFI layer: its boundary for this path is a Python
+ * nn.Module protocol.  This header is what a binding of that protocol calls; each entry
+ * point names the reference code it replaces (paths relative to /root/reference).  INTEGRATION.md shows the
+ * ctypes stub that wires these into the reference's `src/models/mixermdm.py`.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless it is documented as host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing synchronises the host
+ *     except mmdm_sample_sync / mmdm_destroy;
+ *   - the callee never frees or keeps caller memory (weights are copied into the handle's packed layout);
+ *   - return value: 0 = MMDM_OK, otherwise an mmdm_status; mmdm_last_error() gives the message
+ *     (thread-local for the stateless kernels, per handle otherwise);
+ *   - one handle per device, not thread-safe, no allocation after mmdm_prepare() (graph-capturable).
+ */
+#ifndef MMDM_H
+#define MMDM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MMDM_OK = 0,
+    MMDM_ERR_ARG = 1,      /* bad shape / alignment / enum */
+    MMDM_ERR_STATE = 2,    /* missing weight, prepare() not called, ... */
+    MMDM_ERR_HIP = 3,      /* a HIP runtime call or kernel launch failed */
+    MMDM_ERR_UNSUPPORTED = 4
+} mmdm_status;
+
+const char* mmdm_last_error(void);
+/* "gfx950;<build id>" -- lets the host check that the right library was loaded. */
+const char* mmdm_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. Stateless kernels (used by the handle below and exposed for per-kernel parity tests).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Epilogues of mmdm_linear_f32. */
+enum {
+    MMDM_EPI_BIAS = 0,       /* C = A W^T + b                                   nn.Linear */
+    MMDM_EPI_BIAS_GELU = 1,  /* C = gelu_erf(A W^T + b)                         FFN.linear1+activation  src/models/utils/layers.py:104 */
+    MMDM_EPI_BIAS_RESID = 2, /* C = A W^T + b + R   (R may alias C)             "+ x" residuals         src/models/utils/blocks.py:50-63 */
+    MMDM_EPI_BIAS_PE = 3,    /* C = A W^T + b + pe[m % period]                  motion_embed + PositionalEncoding  src/models/in2in.py:426-431 */
+    MMDM_EPI_BIAS_SILU = 4   /* C = silu(A W^T + b)                             TimestepEmbedder time_embed.0+SiLU src/models/utils/utils.py:47-51 */
+};
+
+/* y = x W^T + b with a fused epilogue; exact fp32 (v_mfma_f32_32x32x2_f32).
+ * A [M,K] row stride lda; W [N,K] row stride ldw (nn.Linear layout); bias [N] or NULL; C [M,N] row stride ldc;
+ * extra: R [M,N] row stride ld_extra (RESID) or pe table [period, N] row stride ld_extra (PE).
+ * Replaces torch.nn.functional.linear at every call site on the path (SURVEY.md 2.3 K1,K2,K4,K6,K7,K8). */
+int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
+                    int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
+
+/* AdaLN apply: out[s,t,:] = LN_{eps=1e-6,no affine}(h[s,t,:]) * (1 + ss[row(s), 0:D]) + ss[row(s), D:2D],
+ * row(s) = s % ss_rows.  ss is the output of Linear(SiLU(emb)) (scale first, shift second), row stride ss_ld.
+ * Replaces AdaLN.forward  src/models/utils/layers.py:15-25. */
+int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss_rows, float* out, int nseq, int T, int D, void* stream);
+
+/* Multi-head attention core with add_zero_attn (one extra key, logit 0, value 0), no masks, scale 1/sqrt(dh).
+ * Q/K/V/O are [nseq, T*, H*dh] views with row strides ld*; the K/V sequence for query sequence s is
+ * (s + kv_seq_shift) % nseq (used by the interaction denoiser: person a attends to person b's keys).
+ * Replaces the SDPA inside nn.MultiheadAttention  src/models/utils/layers.py:33-44, 74-87. */
+int mmdm_attention_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                       int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
+
+/* out[r,:] = silu(time_row[:] + txt[r,:]) for r < rows; time_row = time_tab + (*step_idx) * D.
+ * Replaces `embed_timestep(t) + text_embed(c)` followed by AdaLN's SiLU  in2in.py:415-422, layers.py:9-10. */
+int mmdm_cond_silu_f32(const float* time_tab, const int* step_idx, const float* txt, float* out, int rows, int D, void* stream);
+
+/* Mixer pre-processing of the two denoisers' outputs (CFG-doubled batch n = 2B):
+ *   o1, o2 [n,T,524] (normalised) -> out1, out2 [n,T,524]: denormalise (HML3D stats for o1, InterHuman stats for o2),
+ *   and if align != 0: ih_to_smpl, align_motions(target = o2 person, moved = o1 person), smpl_to_ih.
+ * stats = [mean_hml | std_hml | mean_ih | std_ih], 4*262 floats.
+ * Replaces src/models/mixermdm.py:691-719 + src/utils/alignment.py:11-158. */
+int mmdm_mixer_pre_f32(const float* o1, const float* o2, const float* stats, float* out1, float* out2,
+                       int n, int T, int align, void* stream);
+
+/* Influence head: w[r, 0:nw] = sigmoid(h[r,:] Wout^T + b), nw = 1 or 23; h rows are [rows, D].
+ * Replaces Influence.out + sigmoid  src/models/utils/influence.py:124-125. */
+int mmdm_influence_head_f32(const float* h, const float* Wout, const float* bout, float* w, int rows, int D, int nw, void* stream);
+
+/* Mean over time: out[s,:] = mean_t h[s,t,:]  (Influence modes 1 and 3, influence.py:120-121). */
+int mmdm_mean_time_f32(const float* h, float* out, int nseq, int T, int D, void* stream);
+
+/* Expand influence to 262 channels, blend, CFG-combine:
+ *   mix = out2 + infl * (out1 - out2)   (per person);   model_out[b] = s*mix[b] + (1-s)*mix[B+b].
+ * w: [2 persons, 2B, Tw, nw] where Tw = T (modes 2,4) or 1 (modes 1,3) and nw = 1 (modes 1,2) or 23 (modes 3,4);
+ * force: if use_force != 0 every influence value is replaced by `force`.
+ * hist_i1/hist_i2 [2B,T,262], hist_mix [2B,T,524]: optional side outputs (NULL to skip).
+ * Replaces src/models/mixermdm.py:739-801 + ClassifierFreeSampleModelX2 combine  src/models/utils/cfg_sampler.py:49-55. */
+int mmdm_blend_cfg_f32(const float* out1, const float* out2, const float* w, int mode, int use_force, float force,
+                       float cfg_scale, float* model_out, float* hist_i1, float* hist_i2, float* hist_mix,
+                       int B, int T, void* stream);
+
+/* process_xstart + two-chain DDIM (eta = 0) update, in place on x and x2 [B,T,524]:
+ *   i = *step_idx;  if i > 0: x0_1 = norm_hml(smpl_to_ih(center_motion(ih_to_smpl(m)))) per person (center only if align),
+ *                             x0_2 = norm_ih(m);   else x0_1 = x0_2 = m        (m = model_out)
+ *   eps = (coef[0][i]*x - x0) / coef[1][i];  x = x0*coef[2][i] + coef[3][i]*eps      (both chains)
+ * coef: [4, S] fp32 = sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, sqrt(alphas_cumprod_prev), sqrt(1-alphas_cumprod_prev).
+ * pred_xstart2 (optional) receives x0_2.  `floor_ws` is a [B*2] float scratch.
+ * Replaces MixerDiffusion.p_mean_variance.process_xstart + ddim_sample  src/models/utils/gaussian_diffusion.py:2031-2062, 1936-1965
+ * and center_motion  src/utils/alignment.py:161-222. */
+int mmdm_xstart_ddim_f32(const float* model_out, const float* stats, const float* coef, int S, const int* step_idx,
+                         float* x, float* x2, float* pred_xstart, float* pred_xstart2, float* floor_ws,
+                         int B, int T, int align, void* stream);
+
+/* Single-chain DDIM update (configs 1-2): x = x0*coef[2][i] + coef[3][i]*(coef[0][i]*x - x0)/coef[1][i], x0 = s*m[b] + (1-s)*m[B+b].
+ * m is the denoiser output on the CFG-doubled batch [2B, T, C]; pred_xstart (optional) receives x0.
+ * Replaces ClassifierFreeSampleModel combine + GaussianDiffusion.ddim_sample  cfg_sampler.py:24-28, gaussian_diffusion.py:799-849. */
+int mmdm_cfg_ddim_f32(const float* m, const float* coef, int S, const int* step_idx, float cfg_scale,
+                      float* x, float* pred_xstart, int B, int T, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. The sampler handle: weights + workspace + captured step graph.
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct mmdm_handle_s* mmdm_handle;
+
+typedef struct {
+    /* denoisers (src/models/in2in.py:358-399; configs/models/{individual,in2IN}.yaml) */
+    int d_latent, d_ff, d_layers, d_heads;
+    /* mixer / Influence (src/models/mixermdm.py:606-657; configs/models/MixerMDM.yaml GENERATOR) */
+    int m_latent, m_ff, m_layers, m_heads;
+    int nfeats;        /* 262 */
+    int text_dim;      /* 768 */
+    int mixing_mode;   /* 1..4  (MIXING_MODE) */
+    int align;         /* Mixer(align=...) */
+    int xstart_align;  /* MixerDiffusion(align=...): the reference always leaves this True */
+    int model2_kind;   /* 0 = in2IN interaction (three embs), 1 = InterGen InterDenoiser (one shared emb) */
+    int use_force;     /* FORCE_INFLUENCE_VAL is not None */
+    float force_val;
+    float cfg_scale;   /* CFG_WEIGHT */
+    int max_batch;     /* B (before CFG doubling) the workspace is sized for */
+    int max_frames;    /* T */
+    int single_only;   /* 1: only denoiser1 is used (single-person configs 1-2); mixer/denoiser2 weights not required */
+} mmdm_config;
+
+int mmdm_create(const mmdm_config* cfg, mmdm_handle* out);
+void mmdm_destroy(mmdm_handle h);
+const char* mmdm_handle_error(mmdm_handle h);
+
+/* Copy one parameter (reference state_dict key of `Mixer`, e.g. "denoiser1.blocks.0.sa_block.attention.in_proj_weight",
+ * "influence.out.weight", "motion_embed.weight", "embed_timestep.time_embed.0.bias"; src/models/mixermdm.py:134-148) from
+ * device memory `src` ([rows, cols] row-major; cols = 1 for vectors) into the handle's packed layout.
+ * "*.sequence_pos_encoder.pe" buffers are accepted and ignored (tables are regenerated: utils.py:24-35). */
+int mmdm_set_weight(mmdm_handle h, const char* name, const float* src, int64_t rows, int64_t cols, void* stream);
+
+/* stats: HOST pointer, 4*262 floats [mean_hml | std_hml | mean_ih | std_ih]  (src/utils/utils.py:44-82). */
+int mmdm_set_norm_stats(mmdm_handle h, const float* stats_host);
+
+/* Schedule (HOST pointers): S respaced steps; timestep_map[S] (original t the model sees, gaussian_diffusion.py:2200-2205);
+ * coef [4*S] fp32 as in mmdm_xstart_ddim_f32.  Builds the per-step timestep-embedding tables. */
+int mmdm_set_schedule(mmdm_handle h, const int* timestep_map, const float* coef, int S, void* stream);
+
+/* Check that every weight is present; allocate nothing afterwards. */
+int mmdm_prepare(mmdm_handle h);
+
+/* Begin a sampling call: cond [B, 8*text_dim] (layout src/models/mixermdm.py:342-354) or [B, text_dim] (single_only),
+ * x_T [B,T,524] (or [B,T,262]); both chains start from x_T (gaussian_diffusion.py:1863).  Precomputes the text embeddings. */
+int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, int B, int T, void* stream);
+
+/* Optional history side outputs (src/models/mixermdm.py:794-796, 805-808), CFG-doubled batch 2B.  Each pointer may be NULL.
+ * Slot k of a buffer receives the step whose position in the loop is k*every (k = 0 .. ceil(S/every)-1). */
+int mmdm_set_history(mmdm_handle h, float* influence_i1, float* influence_i2, float* out1, float* out2, float* out_influenced, int every);
+
+/* Run `nsteps` consecutive DDIM steps starting at the handle's current position (S-1 after mmdm_begin, counting down).
+ * use_graph != 0: one step is captured into a hipGraph on first use (per (B,T)) and replayed.
+ * = MixerDiffusion.ddim_sample_loop_progressive body  gaussian_diffusion.py:1871-1899. */
+int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream);
+
+/* Device pointers owned by the handle, valid until destroy: current chains and the last pred_xstart(2). */
+int mmdm_get_state(mmdm_handle h, float** x, float** x2, float** pred_xstart, float** pred_xstart2, float** model_out);
+
+/* Teacher-forced pieces for parity tests (operate on caller buffers, CFG-doubled batch n = 2B rows in x/cond):
+ *   which: 0 = denoiser1 (individual; x [n,T,262], cond [n,text_dim]) -> out [n,T,262]
+ *          1 = denoiser2 (interaction; x [n,T,524], cond [n,3*text_dim]) -> out [n,T,524]
+ *          2 = Mixer.forward (x = x1 [n,T,524], x2 [n,T,524], cond [n,8*text_dim]) -> out [n,T,524] (out_influenced)
+ * t = original (remapped) timestep shared by all rows.  Replaces in2INDenoiser.forward / Mixer.forward. */
+int mmdm_module_forward(mmdm_handle h, int which, const float* x, const float* x2, const float* cond, int t,
+                        float* out, int n, int T, void* stream);
+
+/* Live kernel timing for bench.py: wraps hipEvents on `stream` around every launch of the kernel class `which`
+ * (0 = linear/GEMM, 1 = attention) during mmdm_run(use_graph=0) and accumulates. */
+int mmdm_profile_enable(mmdm_handle h, int on);
+int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMDM_H */

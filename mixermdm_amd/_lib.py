@@ -1,0 +1,83 @@
+"""ctypes binding of libmmdm_hip.so (C ABI: include/mmdm.h).  Fails loudly; never falls back to CPU code."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class MMDMError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmmdm_hip.so")
+
+
+class Config(C.Structure):
+    """mmdm_config (include/mmdm.h)."""
+    _fields_ = [(n, C.c_int) for n in ("d_latent", "d_ff", "d_layers", "d_heads", "m_latent", "m_ff", "m_layers", "m_heads",
+                                        "nfeats", "text_dim", "mixing_mode", "align", "xstart_align", "model2_kind", "use_force")] + \
+               [("force_val", C.c_float), ("cfg_scale", C.c_float)] + \
+               [(n, C.c_int) for n in ("max_batch", "max_frames", "single_only")]
+
+
+# every symbol include/mmdm.h declares: name -> (restype, argtypes)
+_I, _VP = C.c_int, C.c_void_p
+SYMBOLS = {
+    "mmdm_last_error": (C.c_char_p, []),
+    "mmdm_version": (C.c_char_p, []),
+    "mmdm_linear_f32": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
+    "mmdm_adaln_f32": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _I, _VP]),
+    "mmdm_attention_f32": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "mmdm_cond_silu_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "mmdm_mixer_pre_f32": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "mmdm_influence_head_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "mmdm_mean_time_f32": (_I, [_VP, _VP, _I, _I, _I, _VP]),
+    "mmdm_blend_cfg_f32": (_I, [_VP, _VP, _VP, _I, _I, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _I, _I, _VP]),
+    "mmdm_xstart_ddim_f32": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "mmdm_cfg_ddim_f32": (_I, [_VP, _VP, _I, _VP, C.c_float, _VP, _VP, _I, _I, _I, _VP]),
+    "mmdm_create": (_I, [C.POINTER(Config), C.POINTER(_VP)]),
+    "mmdm_destroy": (None, [_VP]),
+    "mmdm_handle_error": (C.c_char_p, [_VP]),
+    "mmdm_set_weight": (_I, [_VP, C.c_char_p, _VP, C.c_int64, C.c_int64, _VP]),
+    "mmdm_set_norm_stats": (_I, [_VP, _VP]),
+    "mmdm_set_schedule": (_I, [_VP, _VP, _VP, _I, _VP]),
+    "mmdm_prepare": (_I, [_VP]),
+    "mmdm_begin": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
+    "mmdm_set_history": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I]),
+    "mmdm_run": (_I, [_VP, _I, _I, _VP]),
+    "mmdm_get_state": (_I, [_VP] + [C.POINTER(_VP)] * 5),
+    "mmdm_module_forward": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _VP]),
+    "mmdm_profile_enable": (_I, [_VP, _I]),
+    "mmdm_profile_read": (_I, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+
+
+def load_library():
+    """dlopen the in-tree library and bind every declared symbol (no GPU needed for this)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise MMDMError(f"{path} not found: build it with `python -m mixermdm_amd.build` (hipcc, gfx950). "
+                        "There is no CPU fallback for the denoising path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc, handle=None):
+    if rc == 0:
+        return
+    lib = load_library()
+    msg = (lib.mmdm_handle_error(handle) if handle else None) or lib.mmdm_last_error() or b""
+    msg = msg.decode(errors="replace")
+    if "Mixing mode not recognized" in msg or "Mode not recognized" in msg:
+        raise ValueError(msg)        # the reference raises ValueError here (mixermdm.py:786, influence.py:90)
+    raise MMDMError(f"[mmdm status {rc}] {msg}")

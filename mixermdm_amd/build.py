@@ -1,0 +1,41 @@
+"""Build libmmdm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmmdm_hip.so")
+SOURCES = ["mmdm.hip", "gemm_f32.hip", "attn_f32.hip", "rowops.hip", "geometry.hip"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".o")]
+    deps.append(os.path.join(HERE, "..", "include", "mmdm.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,442 @@
+// Geometry, blend and DDIM-update kernels of the Mixer step (gfx950).  HBM-bound elementwise work over
+// [n, T, 2 persons, 262] motion tensors; one thread per (sample, person, frame, joint) so that the 21 rotation
+// round trips (6D -> matrix -> quaternion -> axis-angle -> quaternion -> matrix -> 6D) spread over lanes.
+//
+// Reference restated here (value-for-value, branch-free versions of the reference's masked-index code):
+//   src/utils/alignment.py:11-67 (ih_to_smpl / smpl_to_ih), :69-158 (align_trajectories / align_motions), :161-222 (center_motion)
+//   src/utils/rotation_conversions.py:38-120, 449-571;  src/utils/quaternion.py:54-73 (qrot), 386-396 (qbetween)
+//   src/utils/utils.py:44-82 (normalisers);  src/models/mixermdm.py:691-801;  src/models/utils/cfg_sampler.py:49-55
+//   src/models/utils/gaussian_diffusion.py:2031-2062 (process_xstart), 1936-1965 (two-chain DDIM, eta = 0), 558-562
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "kernels.h"
+
+namespace {
+
+constexpr int NF = MMDM_NF;          // 262
+constexpr int NF2 = 2 * MMDM_NF;     // 524
+constexpr int NJ = MMDM_NJ;          // 22
+constexpr int ROT0 = 132;            // first rot6d channel
+constexpr int FEET0 = 258;
+constexpr int R_HIP = 2, L_HIP = 1;  // FACE_JOINT_INDX[:2]  src/utils/paramUtil.py:89
+
+struct V3 { float x, y, z; };
+struct Q4 { float w, x, y, z; };
+
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// quaternion.py:54-73
+__device__ __forceinline__ V3 qrot(Q4 q, V3 v) {
+    const V3 qv{q.x, q.y, q.z};
+    const V3 uv = cross3(qv, v);
+    const V3 uuv = cross3(qv, uv);
+    return V3{v.x + 2.f * (q.w * uv.x + uuv.x), v.y + 2.f * (q.w * uv.y + uuv.y), v.z + 2.f * (q.w * uv.z + uuv.z)};
+}
+
+// quaternion.py:386-396 + qnormalize :28-30
+__device__ __forceinline__ Q4 qbetween(V3 a, V3 b) {
+    const V3 v = cross3(a, b);
+    const float w = sqrtf((a.x * a.x + a.y * a.y + a.z * a.z) * (b.x * b.x + b.y * b.y + b.z * b.z)) + (a.x * b.x + a.y * b.y + a.z * b.z) + 1e-8f;
+    const float n = sqrtf(w * w + v.x * v.x + v.y * v.y + v.z * v.z);
+    return Q4{w / n, v.x / n, v.y / n, v.z / n};
+}
+
+__device__ __forceinline__ float sqrt_pos(float x) { return x > 0.f ? sqrtf(x) : 0.f; }                 // rotation_conversions.py:85-95
+__device__ __forceinline__ float copysign_ref(float a, float b) { return ((a < 0.f) != (b < 0.f)) ? -a : a; }  // :68-82
+__device__ __forceinline__ float half_sinc(float half, float ang) {                                      // :466-475 / :497-507
+    return (fabsf(ang) < 1e-6f) ? (0.5f - (ang * ang) / 48.f) : (sinf(half) / ang);
+}
+
+// rot6d (interleaved) -> rot6d after the ih_to_smpl -> smpl_to_ih round trip (the two "* -1" cancel exactly).
+__device__ __forceinline__ void rot6d_roundtrip(const float d[6], float out[6]) {
+    // rotation_6d_to_matrix :511-534 (a1 = d[0,2,4], a2 = d[1,3,5]; F.normalize eps 1e-12)
+    float a1x = d[0], a1y = d[2], a1z = d[4], a2x = d[1], a2y = d[3], a2z = d[5];
+    float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float dt = b1x * a2x + b1y * a2y + b1z * a2z;
+    float b2x = a2x - dt * b1x, b2y = a2y - dt * b1y, b2z = a2z - dt * b1z;
+    const float n2 = fmaxf(sqrtf(b2x * b2x + b2y * b2y + b2z * b2z), 1e-12f);
+    b2x /= n2; b2y /= n2; b2z /= n2;
+    const float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
+    // rows: m0 = b1, m1 = b2, m2 = b3.   matrix_to_quaternion :98-120
+    const float m00 = b1x, m01 = b1y, m02 = b1z, m10 = b2x, m11 = b2y, m12 = b2z, m20 = b3x, m21 = b3y, m22 = b3z;
+    const float qw = 0.5f * sqrt_pos(1.f + m00 + m11 + m22);
+    const float qx = copysign_ref(0.5f * sqrt_pos(1.f + m00 - m11 - m22), m21 - m12);
+    const float qy = copysign_ref(0.5f * sqrt_pos(1.f - m00 + m11 - m22), m02 - m20);
+    const float qz = copysign_ref(0.5f * sqrt_pos(1.f - m00 - m11 + m22), m10 - m01);
+    // quaternion_to_axis_angle :480-508
+    const float nrm = sqrtf(qx * qx + qy * qy + qz * qz);
+    const float half = atan2f(nrm, qw);
+    const float ang = 2.f * half;
+    const float s1 = half_sinc(half, ang);
+    const float ax = qx / s1, ay = qy / s1, az = qz / s1;     // (ih_to_smpl's *-1 and smpl_to_ih's *-1 cancel)
+    // axis_angle_to_quaternion :449-477
+    const float ang2 = sqrtf(ax * ax + ay * ay + az * az);
+    const float half2 = 0.5f * ang2;
+    const float s2 = half_sinc(half2, ang2);
+    const float r = cosf(half2), i = ax * s2, j = ay * s2, k = az * s2;
+    // quaternion_to_matrix :38-65 (first two rows), matrix_to_rotation_6d :540-571 (interleave)
+    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    out[0] = 1.f - two_s * (j * j + k * k);   // m00
+    out[2] = two_s * (i * j - k * r);         // m01
+    out[4] = two_s * (i * k + j * r);         // m02
+    out[1] = two_s * (i * j + k * r);         // m10
+    out[3] = 1.f - two_s * (i * i + k * k);   // m11
+    out[5] = two_s * (j * k - i * r);         // m12
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Mixer pre-processing: denormalise both denoiser outputs, align the individual prediction to the interaction one.
+// grid: n * 2 persons * T blocks of 32 threads?  -> flat: one thread per (b, p, t, j), j in [0, 22).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mixer_pre_kernel(const float* __restrict__ o1, const float* __restrict__ o2, const float* __restrict__ stats,
+                                                         float* __restrict__ out1, float* __restrict__ out2, int n, int T, int align) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = n * 2 * T * NJ;
+    if (idx >= total) return;
+    const int j = idx % NJ;
+    const int t = (idx / NJ) % T;
+    const int p = (idx / (NJ * T)) % 2;
+    const int b = idx / (NJ * T * 2);
+    const float* mh = stats, *sh = stats + NF, *mi = stats + 2 * NF, *si = stats + 3 * NF;
+    const size_t seq = (size_t)b * T * NF2 + (size_t)p * NF;      // start of (b, frame 0, person p)
+    const size_t off = seq + (size_t)t * NF2;
+    const float* a = o1 + off;   // individual denoiser, HML3D normalisation
+    const float* c = o2 + off;   // interaction denoiser, InterHuman normalisation
+    float* y1 = out1 + off;
+    float* y2 = out2 + off;
+
+    // interaction stream: pos / vel pass through (denormalised); rot6d re-orthonormalised when align
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        y2[3 * j + k] = c[3 * j + k] * si[3 * j + k] + mi[3 * j + k];
+        y2[66 + 3 * j + k] = c[66 + 3 * j + k] * si[66 + 3 * j + k] + mi[66 + 3 * j + k];
+    }
+    if (j < 21) {
+        float d[6], r[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = c[ROT0 + 6 * j + k] * si[ROT0 + 6 * j + k] + mi[ROT0 + 6 * j + k];
+        if (align) rot6d_roundtrip(d, r);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) y2[ROT0 + 6 * j + k] = align ? r[k] : d[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = a[ROT0 + 6 * j + k] * sh[ROT0 + 6 * j + k] + mh[ROT0 + 6 * j + k];
+        if (align) rot6d_roundtrip(d, r);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) y1[ROT0 + 6 * j + k] = align ? r[k] : d[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            y2[FEET0 + k] = c[FEET0 + k] * si[FEET0 + k] + mi[FEET0 + k];
+            // after align_motions (201-d) smpl_to_ih appends the zero hand padding as "feet"
+            y1[FEET0 + k] = align ? 0.f : (a[FEET0 + k] * sh[FEET0 + k] + mh[FEET0 + k]);
+        }
+    }
+
+    V3 pos{a[3 * j] * sh[3 * j] + mh[3 * j], a[3 * j + 1] * sh[3 * j + 1] + mh[3 * j + 1], a[3 * j + 2] * sh[3 * j + 2] + mh[3 * j + 2]};
+    V3 vel{a[66 + 3 * j] * sh[66 + 3 * j] + mh[66 + 3 * j], a[66 + 3 * j + 1] * sh[66 + 3 * j + 1] + mh[66 + 3 * j + 1],
+           a[66 + 3 * j + 2] * sh[66 + 3 * j + 2] + mh[66 + 3 * j + 2]};
+    if (align) {
+        // align_motions(motion1 = interaction person (target), motion2 = individual person (moved))  alignment.py:112-158
+        const float* a0 = o1 + seq;                               // frame 0
+        const float* aL = o1 + seq + (size_t)(T - 1) * NF2;       // last frame (mask=None: alignment.py:86-88)
+        const float* c0 = o2 + seq;
+        const float* cL = o2 + seq + (size_t)(T - 1) * NF2;
+        const V3 p1_0{c0[0] * si[0] + mi[0], c0[1] * si[1] + mi[1], c0[2] * si[2] + mi[2]};
+        const V3 p1_L{cL[0] * si[0] + mi[0], cL[1] * si[1] + mi[1], cL[2] * si[2] + mi[2]};
+        const V3 p2_0{a0[0] * sh[0] + mh[0], a0[1] * sh[1] + mh[1], a0[2] * sh[2] + mh[2]};
+        const V3 p2_L{aL[0] * sh[0] + mh[0], aL[1] * sh[1] + mh[1], aL[2] * sh[2] + mh[2]};
+        const V3 dl{p1_0.x - p2_0.x, p1_0.y - p2_0.y, p1_0.z - p2_0.z};
+        const V3 t2_0{p2_0.x + dl.x, p2_0.y + dl.y, p2_0.z + dl.z};     // translated root, frame 0
+        const V3 t2_L{p2_L.x + dl.x, p2_L.y + dl.y, p2_L.z + dl.z};
+        V3 v1{p1_L.x - p1_0.x, 0.f, p1_L.z - p1_0.z};
+        V3 v2{t2_L.x - t2_0.x, 0.f, t2_L.z - t2_0.z};
+        const float n1 = sqrtf(v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + 1e-8f);
+        const float n2 = sqrtf(v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + 1e-8f);
+        v1 = V3{v1.x / n1, v1.y / n1, v1.z / n1};
+        v2 = V3{v2.x / n2, v2.y / n2, v2.z / n2};
+        const Q4 q = qbetween(v2, v1);
+        const V3 r0 = qrot(q, t2_0);                                     // rotated root, frame 0
+        const V3 d2{p1_0.x - r0.x, p1_0.y - r0.y, p1_0.z - r0.z};
+        const V3 pr = qrot(q, V3{pos.x + dl.x, pos.y + dl.y, pos.z + dl.z});
+        pos = V3{pr.x + d2.x, pr.y + d2.y, pr.z + d2.z};
+        vel = qrot(q, vel);
+    }
+    y1[3 * j] = pos.x; y1[3 * j + 1] = pos.y; y1[3 * j + 2] = pos.z;
+    y1[66 + 3 * j] = vel.x; y1[66 + 3 * j + 1] = vel.y; y1[66 + 3 * j + 2] = vel.z;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Influence expansion + blend + CFG combine.  One thread per (b, t, channel c in [0,524)).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int influence_index(int c) {   // 262 channels -> 23 groups  mixermdm.py:767-784
+    return c < 66 ? c / 3 : (c < 132 ? (c - 66) / 3 : (c < FEET0 ? (c - ROT0) / 6 : 22));
+}
+
+// History slot selection under graph replay: slot = *loop_pos / every when *loop_pos % every == 0, else none.
+__device__ __forceinline__ long hist_slot(const int* loop_pos, int every) {
+    if (!loop_pos) return 0;
+    const int lp = *loop_pos;
+    return (lp % every == 0) ? (long)(lp / every) : -1;
+}
+
+__global__ __launch_bounds__(256) void blend_cfg_kernel(const float* __restrict__ out1, const float* __restrict__ out2, const float* __restrict__ w,
+                                                         int Tw, int nw, int use_force, float force, float s,
+                                                         float* __restrict__ model_out, float* __restrict__ hist_i1, float* __restrict__ hist_i2,
+                                                         float* __restrict__ hist_mix, const int* __restrict__ loop_pos, int every, int B, int T) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * T * NF2;
+    if (idx >= total) return;
+    const long slot = hist_slot(loop_pos, every);
+    if (slot < 0) { hist_i1 = nullptr; hist_i2 = nullptr; hist_mix = nullptr; }
+    else {
+        if (hist_i1) hist_i1 += (size_t)slot * 2 * B * T * NF;
+        if (hist_i2) hist_i2 += (size_t)slot * 2 * B * T * NF;
+        if (hist_mix) hist_mix += (size_t)slot * 2 * B * T * NF2;
+    }
+    const int ch = (int)(idx % NF2);
+    const int t = (int)((idx / NF2) % T);
+    const int b = (int)(idx / ((size_t)NF2 * T));
+    const int p = ch >= NF ? 1 : 0;
+    const int c = ch - p * NF;
+    const int wi = nw == 1 ? 0 : influence_index(c);
+    const int tw = Tw == 1 ? 0 : t;
+    float mix[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                       // u = 0: cond row b, u = 1: uncond row B + b
+        const int row = b + u * B;
+        const size_t e = ((size_t)row * T + t) * NF2 + ch;
+        float wv = w[(((size_t)p * 2 * B + row) * Tw + tw) * nw + wi];
+        if (use_force) wv = 1.0f * force;
+        const float v1 = out1[e], v2 = out2[e];
+        mix[u] = v2 + wv * (v1 - v2);
+        if (hist_mix) hist_mix[e] = mix[u];
+        float* hi = p ? hist_i2 : hist_i1;
+        if (hi) hi[((size_t)row * T + t) * NF + c] = wv;
+    }
+    model_out[idx] = s * mix[0] + (1.0f - s) * mix[1];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// process_xstart + two-chain DDIM update.
+// ---------------------------------------------------------------------------------------------------------
+// floor[b, p] = min over (t, joint) of position Y   (center_motion "Put on Floor", alignment.py:182-184)
+__global__ __launch_bounds__(256) void floor_kernel(const float* __restrict__ m, float* __restrict__ floor_ws, int T) {
+    const int bp = blockIdx.x;                   // b * 2 + p
+    const float* base = m + (size_t)(bp >> 1) * T * NF2 + (size_t)(bp & 1) * NF;
+    float v = INFINITY;
+    for (int i = threadIdx.x; i < T * NJ; i += blockDim.x) {
+        const int t = i / NJ, j = i % NJ;
+        v = fminf(v, base[(size_t)t * NF2 + 3 * j + 1]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) floor_ws[bp] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+}
+
+__device__ __forceinline__ float ddim(float x, float x0, float c0, float c1, float c2, float c3) {
+    const float eps = (c0 * x - x0) / c1;        // _predict_eps_from_xstart  gaussian_diffusion.py:558-562
+    return x0 * c2 + c3 * eps;                   // eta = 0 mean             :1949-1956
+}
+
+__global__ __launch_bounds__(256) void xstart_ddim_kernel(const float* __restrict__ m, const float* __restrict__ stats, const float* __restrict__ coef,
+                                                           int S, const int* __restrict__ step_idx, float* __restrict__ x, float* __restrict__ x2,
+                                                           float* __restrict__ px1, float* __restrict__ px2, const float* __restrict__ floor_ws,
+                                                           int B, int T, int align) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = B * 2 * T * NJ;
+    if (idx >= total) return;
+    const int j = idx % NJ;
+    const int t = (idx / NJ) % T;
+    const int p = (idx / (NJ * T)) % 2;
+    const int b = idx / (NJ * T * 2);
+    const int i = *step_idx;
+    const float c0 = coef[i], c1 = coef[S + i], c2 = coef[2 * S + i], c3 = coef[3 * S + i];
+    const bool norm = i > 0;                                     // `if t[0] > 0`  gaussian_diffusion.py:2052
+    const float* mh = stats, *sh = stats + NF, *mi = stats + 2 * NF, *si = stats + 3 * NF;
+    const size_t seq = (size_t)b * T * NF2 + (size_t)p * NF;
+    const size_t off = seq + (size_t)t * NF2;
+    const float* mo = m + off;
+
+    // channels owned by this thread: pos j (3), vel j (3), rot j (6, j < 21) or feet (4, j == 21)
+    float raw[12], v1[12];
+    int ch[12];
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ch[cnt] = 3 * j + k; ++cnt; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ch[cnt] = 66 + 3 * j + k; ++cnt; }
+    if (j < 21) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ch[cnt] = ROT0 + 6 * j + k; ++cnt; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ch[cnt] = FEET0 + k; ++cnt; }
+        ch[10] = 0; ch[11] = 0;
+    }
+    const int nch = (j < 21) ? 12 : 10;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { raw[k] = (k < nch) ? mo[ch[k]] : 0.f; v1[k] = raw[k]; }
+
+    if (norm && align) {
+        // center_motion  alignment.py:161-222 on the ih_to_smpl'ed motion (positions / velocities unchanged by ih_to_smpl)
+        const float fl = floor_ws[b * 2 + p];
+        const float* f0 = m + seq;                                // frame 0
+        const V3 root{f0[0], f0[1] - fl, f0[2]};
+        const V3 rh{f0[3 * R_HIP], f0[3 * R_HIP + 1] - fl, f0[3 * R_HIP + 2]};
+        const V3 lhp{f0[3 * L_HIP], f0[3 * L_HIP + 1] - fl, f0[3 * L_HIP + 2]};
+        V3 ac{rh.x - lhp.x, rh.y - lhp.y, rh.z - lhp.z};
+        const float an = sqrtf(ac.x * ac.x + ac.y * ac.y + ac.z * ac.z);
+        ac = V3{ac.x / an, ac.y / an, ac.z / an};
+        V3 fw = cross3(V3{0.f, 1.f, 0.f}, ac);
+        const float fn = sqrtf(fw.x * fw.x + fw.y * fw.y + fw.z * fw.z);
+        fw = V3{fw.x / fn, fw.y / fn, fw.z / fn};
+        const Q4 q = qbetween(fw, V3{0.f, 0.f, 1.f});
+        const V3 xz{root.x * 1.f, root.y * 0.f, root.z * 1.f};
+        const V3 pc = qrot(q, V3{raw[0] - xz.x, (raw[1] - fl) - xz.y, raw[2] - xz.z});
+        const V3 vc = qrot(q, V3{raw[3], raw[4], raw[5]});
+        v1[0] = pc.x; v1[1] = pc.y; v1[2] = pc.z;
+        v1[3] = vc.x; v1[4] = vc.y; v1[5] = vc.z;
+        if (j < 21) {
+            float d[6], r[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d[k] = raw[6 + k];
+            rot6d_roundtrip(d, r);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v1[6 + k] = r[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v1[6 + k] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        if (k >= nch) continue;
+        const int c = ch[k];
+        float x0a = v1[k], x0b = raw[k];
+        if (norm) {
+            x0a = (x0a - mh[c]) / sh[c];
+            x0b = (x0b - mi[c]) / si[c];
+        }
+        const size_t e = off + c;
+        x[e] = ddim(x[e], x0a, c0, c1, c2, c3);
+        x2[e] = ddim(x2[e], x0b, c0, c1, c2, c3);
+        if (px1) px1[e] = x0a;
+        if (px2) px2[e] = x0b;
+    }
+}
+
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* __restrict__ m, const float* __restrict__ coef, int S, const int* __restrict__ step_idx,
+                                                        float s, float* __restrict__ x, float* __restrict__ px, size_t per_batch_total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per_batch_total) return;
+    const int i = *step_idx;
+    const float x0 = s * m[idx] + (1.0f - s) * m[per_batch_total + idx];   // cfg_sampler.py:24-28
+    x[idx] = ddim(x[idx], x0, coef[i], coef[S + i], coef[2 * S + i], coef[3 * S + i]);
+    if (px) px[idx] = x0;
+}
+
+__global__ void step_dec_kernel(int* step_idx, int* loop_pos) { *step_idx -= 1; *loop_pos += 1; }
+__global__ void set_step_kernel(int* step_idx, int* loop_pos, int s, int l) { *step_idx = s; *loop_pos = l; }
+
+__global__ void hist_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t count, const int* __restrict__ loop_pos, int every) {
+    const long slot = hist_slot(loop_pos, every);
+    if (slot < 0) return;
+    float* d = dst + (size_t)slot * count;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) d[i] = src[i];
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int n, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * D) return;
+    dst[i] = src[(size_t)idx[i / D] * D + (i % D)];
+}
+
+}  // namespace
+
+extern "C" int mmdm_mixer_pre_f32(const float* o1, const float* o2, const float* stats, float* out1, float* out2,
+                                  int n, int T, int align, void* stream) {
+    if (n == 0 || T == 0) return MMDM_OK;
+    if (!o1 || !o2 || !stats || !out1 || !out2 || n < 0 || T < 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_mixer_pre_f32: bad arguments");
+    const int total = n * 2 * T * MMDM_NJ;
+    hipLaunchKernelGGL(mixer_pre_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), o1, o2, stats, out1, out2, n, T, align);
+    return mmdm_check_launch("mixer_pre");
+}
+
+extern "C" int mmdm_blend_cfg_f32(const float* out1, const float* out2, const float* w, int mode, int use_force, float force,
+                                  float cfg_scale, float* model_out, float* hist_i1, float* hist_i2, float* hist_mix,
+                                  int B, int T, void* stream) {
+    if (B == 0 || T == 0) return MMDM_OK;
+    if (!out1 || !out2 || !w || !model_out || B < 0 || T < 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_blend_cfg_f32: bad arguments");
+    if (mode < 1 || mode > 4) return mmdm_set_error(MMDM_ERR_ARG, "Mixing mode not recognized");   // mixermdm.py:786
+    const int Tw = (mode == 2 || mode == 4) ? T : 1;
+    const int nw = (mode >= 3) ? 23 : 1;
+    const size_t total = (size_t)B * T * NF2;
+    hipLaunchKernelGGL(blend_cfg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       out1, out2, w, Tw, nw, use_force, force, cfg_scale, model_out, hist_i1, hist_i2, hist_mix, (const int*)nullptr, 1, B, T);
+    return mmdm_check_launch("blend_cfg");
+}
+
+// Same as mmdm_blend_cfg_f32 with the history slot chosen on the device (graph replay): see hist_slot().
+int mmdm_blend_cfg_dyn(const float* out1, const float* out2, const float* w, int mode, int use_force, float force, float cfg_scale,
+                       float* model_out, float* hist_i1, float* hist_i2, float* hist_mix, const int* loop_pos, int every,
+                       int B, int T, hipStream_t st) {
+    if (mode < 1 || mode > 4) return mmdm_set_error(MMDM_ERR_ARG, "Mixing mode not recognized");
+    const int Tw = (mode == 2 || mode == 4) ? T : 1;
+    const int nw = (mode >= 3) ? 23 : 1;
+    const size_t total = (size_t)B * T * NF2;
+    hipLaunchKernelGGL(blend_cfg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       out1, out2, w, Tw, nw, use_force, force, cfg_scale, model_out, hist_i1, hist_i2, hist_mix, loop_pos, every, B, T);
+    return mmdm_check_launch("blend_cfg");
+}
+
+int mmdm_hist_copy(const float* src, float* dst, size_t count, const int* loop_pos, int every, hipStream_t st) {
+    hipLaunchKernelGGL(hist_copy_kernel, dim3(1024), dim3(256), 0, st, src, dst, count, loop_pos, every);
+    return mmdm_check_launch("hist_copy");
+}
+
+int mmdm_set_step(int* step_idx, int* loop_pos, int s, int l, hipStream_t st) {
+    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, step_idx, loop_pos, s, l);
+    return mmdm_check_launch("set_step");
+}
+
+int mmdm_gather_rows(const float* src, const int* idx, float* dst, int n, int D, hipStream_t st) {
+    const size_t total = (size_t)n * D;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, idx, dst, n, D);
+    return mmdm_check_launch("gather_rows");
+}
+
+extern "C" int mmdm_xstart_ddim_f32(const float* model_out, const float* stats, const float* coef, int S, const int* step_idx,
+                                    float* x, float* x2, float* pred_xstart, float* pred_xstart2, float* floor_ws,
+                                    int B, int T, int align, void* stream) {
+    if (B == 0 || T == 0) return MMDM_OK;
+    if (!model_out || !stats || !coef || !step_idx || !x || !x2 || !floor_ws || S <= 0 || B < 0 || T < 0)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_xstart_ddim_f32: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (align) {
+        hipLaunchKernelGGL(floor_kernel, dim3(B * 2), dim3(256), 0, st, model_out, floor_ws, T);
+        if (int rc = mmdm_check_launch("floor")) return rc;
+    }
+    const int total = B * 2 * T * MMDM_NJ;
+    hipLaunchKernelGGL(xstart_ddim_kernel, dim3((total + 255) / 256), dim3(256), 0, st, model_out, stats, coef, S, step_idx, x, x2,
+                       pred_xstart, pred_xstart2, floor_ws, B, T, align);
+    return mmdm_check_launch("xstart_ddim");
+}
+
+extern "C" int mmdm_cfg_ddim_f32(const float* m, const float* coef, int S, const int* step_idx, float cfg_scale,
+                                 float* x, float* pred_xstart, int B, int T, int C, void* stream) {
+    if (B == 0 || T == 0) return MMDM_OK;
+    if (!m || !coef || !step_idx || !x || S <= 0 || B < 0 || T < 0 || C <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_cfg_ddim_f32: bad arguments");
+    const size_t total = (size_t)B * T * C;
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       m, coef, S, step_idx, cfg_scale, x, pred_xstart, total);
+    return mmdm_check_launch("cfg_ddim");
+}
+
+int mmdm_step_dec(int* step_idx, int* loop_pos, hipStream_t st) {
+    hipLaunchKernelGGL(step_dec_kernel, dim3(1), dim3(1), 0, st, step_idx, loop_pos);
+    return mmdm_check_launch("step_dec");
+}

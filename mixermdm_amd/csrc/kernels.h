@@ -1,0 +1,27 @@
+// Internal helpers shared by the HIP translation units of libmmdm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mmdm.h"
+
+// printf-style: records the message for mmdm_last_error() and returns `code`.
+int mmdm_set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// hipGetLastError() after a launch; returns MMDM_OK or MMDM_ERR_HIP (message recorded).
+int mmdm_check_launch(const char* what);
+// One-time per-process kernel attribute setup (dynamic LDS sizes); safe to call repeatedly, never during capture.
+int mmdm_kernels_init(void);
+int mmdm_gemm_init(void);
+
+constexpr int MMDM_NF = 262;      // pose features per person (src/models/in2in.py:426, INPUT_DIM)
+constexpr int MMDM_NJ = 22;       // joints
+
+int mmdm_attn_init(void);
+int mmdm_step_dec(int* step_idx, int* loop_pos, hipStream_t st);
+int mmdm_set_step(int* step_idx, int* loop_pos, int s, int l, hipStream_t st);
+int mmdm_gather_rows(const float* src, const int* idx, float* dst, int n, int D, hipStream_t st);
+int mmdm_hist_copy(const float* src, float* dst, size_t count, const int* loop_pos, int every, hipStream_t st);
+int mmdm_blend_cfg_dyn(const float* out1, const float* out2, const float* w, int mode, int use_force, float force, float cfg_scale,
+                       float* model_out, float* hist_i1, float* hist_i2, float* hist_mix, const int* loop_pos, int every,
+                       int B, int T, hipStream_t st);
+int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
+                       int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);

@@ -1,0 +1,783 @@
+// Host side of libmmdm_hip.so: handle, packed weights, workspace, per-step orchestration and hipGraph replay.
+//
+// One step = MixerDiffusion.ddim_sample on the CFG-doubled batch (reference call stack: SURVEY.md 3.2;
+// src/models/utils/gaussian_diffusion.py:1871-1965, src/models/utils/cfg_sampler.py:38-56, src/models/mixermdm.py:660-810).
+// Everything the reference re-uploads per step (timestep tensors, schedule scalars, normaliser stats) lives on the
+// device; the step index is a device word that the kernels read, so ONE captured graph serves every step.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int mmdm_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int mmdm_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return MMDM_OK;
+}
+
+int mmdm_kernels_init(void) {
+    static int state = -1;  // -1 not tried, 0 ok
+    if (state == 0) return MMDM_OK;
+    int rc = mmdm_gemm_init();
+    if (!rc) rc = mmdm_attn_init();
+    if (!rc) state = 0;
+    return rc;
+}
+
+extern "C" const char* mmdm_last_error(void) { return g_err; }
+extern "C" const char* mmdm_version(void) { return "gfx950;mmdm-hip r1"; }
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));    \
+    } while (0)
+#define RC(expr)                     \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc) return _rc;         \
+    } while (0)
+
+namespace {
+
+constexpr int NF = MMDM_NF, NF2 = 2 * MMDM_NF;
+constexpr int NFP = 264;  // motion_embed weight rows padded to a multiple of 4 floats (16-byte loads)
+
+// ------------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------------
+struct Slot {            // one destination of mmdm_set_weight
+    float* dst = nullptr;
+    int64_t rows = 0, cols = 0;   // expected source shape
+    int64_t ld = 0;               // destination row stride (>= cols)
+    bool required = true, set = false;
+};
+
+struct LayerW {
+    float *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;
+    float *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b;
+    float *f1_w, *f1_b, *f2_w, *f2_b;
+};
+
+struct StackW {          // a transformer stack: denoiser blocks or Influence blocks
+    int D = 0, F = 0, L = 0, H = 0, n_ada = 0;
+    bool has_ca = false;
+    float *ada_w = nullptr, *ada_b = nullptr;   // [L*n_ada*2D, D], [L*n_ada*2D]  (slots: sa, [ca_q, ca_kv,] ffn)
+    std::vector<LayerW> layers;
+};
+
+struct ModuleW {         // denoiser or mixer front/back ends
+    StackW st;
+    float *pe = nullptr;                         // [5000, D]
+    float *me_w = nullptr, *me_b = nullptr;      // motion_embed [D, 262] stored with ld NFP
+    float *te_w = nullptr, *te_b = nullptr;      // text_embed [D, text_dim]
+    float *t0_w = nullptr, *t0_b = nullptr, *t2_w = nullptr, *t2_b = nullptr;   // embed_timestep.time_embed.{0,2}
+    float *out_w = nullptr, *out_b = nullptr;    // out.linear [262, D] / influence.out [nw, D]
+    float *time_tab = nullptr;                   // [S, D] = time_embed(pe[timestep_map])  (built by set_schedule)
+};
+
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev[2];               // pairs (start, stop) per launch, per class
+    size_t used[2] = {0, 0};
+    double flops[2] = {0, 0};
+    double ms[2] = {0, 0};
+    int64_t launches[2] = {0, 0};
+};
+
+}  // namespace
+
+struct mmdm_handle_s {
+    mmdm_config cfg;
+    char err[512] = "";
+    std::vector<void*> allocs;
+    std::unordered_map<std::string, Slot> slots;
+    ModuleW d1, d2, mx;
+    int nw = 23;
+    bool prepared = false;
+
+    // schedule
+    int S = 0;
+    int* d_tmap = nullptr;       // [Smax]
+    float* d_coef = nullptr;     // [4*Smax]
+    float* d_stats = nullptr;    // [4*262]
+    bool stats_set = false;
+    int* d_step = nullptr;       // [2]: step_idx, loop_pos
+    int host_step = -1;          // mirror of step_idx
+    int Smax = 1000;
+
+    // call state
+    int B = 0, T = 0;
+    bool begun = false;
+
+    // workspace
+    float *h = nullptr, *xn = nullptr, *qkv = nullptr, *kv = nullptr, *att = nullptr, *f1 = nullptr;   // stack scratch
+    float *mI = nullptr;                                   // Influence CA source  [R, Dm]
+    float *o1 = nullptr, *o2 = nullptr, *out1 = nullptr, *out2 = nullptr;   // [n,T,524]
+    float *w23 = nullptr, *hpool = nullptr;
+    float *model_out = nullptr, *x = nullptr, *x2 = nullptr, *px1 = nullptr, *px2 = nullptr, *floor_ws = nullptr;
+    float *cond_cat = nullptr;                             // [n, 8*text_dim]
+    float *txt_d1 = nullptr, *txt_d2 = nullptr, *txt_mx = nullptr;      // text_embed outputs
+    float *se_d1 = nullptr, *se_d2 = nullptr, *se_mx = nullptr;         // silu(time + text)
+    float *ss_d1 = nullptr, *ss_d2 = nullptr, *ss_mx = nullptr;         // AdaLN (scale|shift) for every layer/norm
+    float *tt_tmp = nullptr, *tt_tmp2 = nullptr;           // [Smax, maxD] schedule scratch
+
+    // history
+    float *hist_i1 = nullptr, *hist_i2 = nullptr, *hist_o1 = nullptr, *hist_o2 = nullptr, *hist_mix = nullptr;
+    int hist_every = 1;
+
+    // graph
+    hipGraphExec_t gexec = nullptr;
+    int gB = 0, gT = 0;
+    bool g_hist = false;
+
+    Prof prof;
+};
+
+namespace {
+
+int herr(mmdm_handle h, int code) {
+    if (code) snprintf(h->err, sizeof(h->err), "%s", g_err);
+    return code;
+}
+
+int dalloc(mmdm_handle h, float** p, size_t nfloats) {
+    void* q = nullptr;
+    if (nfloats == 0) nfloats = 1;
+    HIPCHK(hipMalloc(&q, nfloats * sizeof(float)));
+    h->allocs.push_back(q);
+    *p = static_cast<float*>(q);
+    return MMDM_OK;
+}
+
+int add_slot(mmdm_handle h, const std::string& name, float** p, int64_t rows, int64_t cols, int64_t ld = 0, bool zero = false) {
+    if (ld == 0) ld = cols;
+    RC(dalloc(h, p, (size_t)rows * ld));
+    if (zero || ld != cols) HIPCHK(hipMemset(*p, 0, (size_t)rows * ld * sizeof(float)));
+    Slot s;
+    s.dst = *p; s.rows = rows; s.cols = cols; s.ld = ld;
+    h->slots[name] = s;
+    return MMDM_OK;
+}
+
+// slot that points into an already allocated packed buffer
+void add_view(mmdm_handle h, const std::string& name, float* p, int64_t rows, int64_t cols) {
+    Slot s;
+    s.dst = p; s.rows = rows; s.cols = cols; s.ld = cols;
+    h->slots[name] = s;
+}
+
+void add_ignored(mmdm_handle h, const std::string& name) {
+    Slot s;
+    s.required = false;
+    h->slots[name] = s;
+}
+
+int build_stack(mmdm_handle h, StackW& st, const std::string& pfx, int D, int F, int L, int H, bool has_ca, bool ca_keys_ignored) {
+    st.D = D; st.F = F; st.L = L; st.H = H; st.has_ca = has_ca; st.n_ada = has_ca ? 4 : 2;
+    RC(dalloc(h, &st.ada_w, (size_t)L * st.n_ada * 2 * D * D));
+    RC(dalloc(h, &st.ada_b, (size_t)L * st.n_ada * 2 * D));
+    st.layers.resize(L);
+    for (int i = 0; i < L; ++i) {
+        LayerW& lw = st.layers[i];
+        memset(&lw, 0, sizeof(lw));
+        const std::string b = pfx + "blocks." + std::to_string(i) + ".";
+        auto ada = [&](const char* norm, int slot) {
+            add_view(h, b + norm + ".emb_layers.1.weight", st.ada_w + ((size_t)i * st.n_ada + slot) * 2 * D * D, 2 * D, D);
+            add_view(h, b + norm + ".emb_layers.1.bias", st.ada_b + ((size_t)i * st.n_ada + slot) * 2 * D, 2 * D, 1);
+        };
+        ada("sa_block.norm", 0);
+        ada("ffn.norm", has_ca ? 3 : 1);
+        RC(add_slot(h, b + "sa_block.attention.in_proj_weight", &lw.sa_in_w, 3 * D, D));
+        RC(add_slot(h, b + "sa_block.attention.in_proj_bias", &lw.sa_in_b, 3 * D, 1));
+        RC(add_slot(h, b + "sa_block.attention.out_proj.weight", &lw.sa_out_w, D, D));
+        RC(add_slot(h, b + "sa_block.attention.out_proj.bias", &lw.sa_out_b, D, 1));
+        RC(add_slot(h, b + "ffn.linear1.weight", &lw.f1_w, F, D));
+        RC(add_slot(h, b + "ffn.linear1.bias", &lw.f1_b, F, 1));
+        RC(add_slot(h, b + "ffn.linear2.weight", &lw.f2_w, D, F));
+        RC(add_slot(h, b + "ffn.linear2.bias", &lw.f2_b, D, 1));
+        if (has_ca) {
+            ada("ca_block.norm", 1);
+            ada("ca_block.xf_norm", 2);
+            RC(add_slot(h, b + "ca_block.attention.in_proj_weight", &lw.ca_in_w, 3 * D, D));
+            RC(add_slot(h, b + "ca_block.attention.in_proj_bias", &lw.ca_in_b, 3 * D, 1));
+            RC(add_slot(h, b + "ca_block.attention.out_proj.weight", &lw.ca_out_w, D, D));
+            RC(add_slot(h, b + "ca_block.attention.out_proj.bias", &lw.ca_out_b, D, 1));
+        } else if (ca_keys_ignored) {
+            // individual mode carries unused cross-attention weights in its state_dict (blocks.py:45-47, 55-56)
+            for (const char* k : {"ca_block.norm.emb_layers.1.weight", "ca_block.norm.emb_layers.1.bias", "ca_block.xf_norm.emb_layers.1.weight",
+                                  "ca_block.xf_norm.emb_layers.1.bias", "ca_block.attention.in_proj_weight", "ca_block.attention.in_proj_bias",
+                                  "ca_block.attention.out_proj.weight", "ca_block.attention.out_proj.bias"})
+                add_ignored(h, b + k);
+        }
+    }
+    return MMDM_OK;
+}
+
+int build_module(mmdm_handle h, ModuleW& m, const std::string& pfx, const std::string& stack_pfx, int D, int F, int L, int H,
+                 bool has_ca, bool ca_ignored, const std::string& out_name, int out_rows) {
+    const int td = h->cfg.text_dim;
+    RC(build_stack(h, m.st, stack_pfx, D, F, L, H, has_ca, ca_ignored));
+    RC(add_slot(h, pfx + "sequence_pos_encoder.pe", &m.pe, 5000, D));
+    add_ignored(h, pfx + "embed_timestep.sequence_pos_encoder.pe");
+    RC(add_slot(h, pfx + "motion_embed.weight", &m.me_w, D, NF, NFP));
+    RC(add_slot(h, pfx + "motion_embed.bias", &m.me_b, D, 1));
+    RC(add_slot(h, pfx + "text_embed.weight", &m.te_w, D, td));
+    RC(add_slot(h, pfx + "text_embed.bias", &m.te_b, D, 1));
+    RC(add_slot(h, pfx + "embed_timestep.time_embed.0.weight", &m.t0_w, D, D));
+    RC(add_slot(h, pfx + "embed_timestep.time_embed.0.bias", &m.t0_b, D, 1));
+    RC(add_slot(h, pfx + "embed_timestep.time_embed.2.weight", &m.t2_w, D, D));
+    RC(add_slot(h, pfx + "embed_timestep.time_embed.2.bias", &m.t2_b, D, 1));
+    RC(add_slot(h, out_name + ".weight", &m.out_w, out_rows, D));
+    RC(add_slot(h, out_name + ".bias", &m.out_b, out_rows, 1));
+    RC(dalloc(h, &m.time_tab, (size_t)h->Smax * D));
+    return MMDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// profiled launches
+// ------------------------------------------------------------------------------------------------------
+struct Ctx {
+    mmdm_handle h;
+    hipStream_t st;
+};
+
+int prof_begin(const Ctx& c, int cls, double flops) {
+    Prof& p = c.h->prof;
+    if (!p.on) return MMDM_OK;
+    if (p.used[cls] + 2 > p.ev[cls].size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            p.ev[cls].push_back(e);
+        }
+    }
+    p.flops[cls] += flops;
+    HIPCHK(hipEventRecord(p.ev[cls][p.used[cls]], c.st));
+    return MMDM_OK;
+}
+
+int prof_end(const Ctx& c, int cls) {
+    Prof& p = c.h->prof;
+    if (!p.on) return MMDM_OK;
+    HIPCHK(hipEventRecord(p.ev[cls][p.used[cls] + 1], c.st));
+    p.used[cls] += 2;
+    return MMDM_OK;
+}
+
+int linear(const Ctx& c, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+           int epi = MMDM_EPI_BIAS, const float* extra = nullptr, int ld_extra = 0, int period = 0, int Kw = 0) {
+    RC(prof_begin(c, 0, 2.0 * M * N * K));
+    RC(mmdm_linear_f32_ex(A, lda, W, ldw, Kw ? Kw : K, bias, C, ldc, M, N, K, epi, extra, ld_extra, period, c.st));
+    return prof_end(c, 0);
+}
+
+int attention(const Ctx& c, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+              int nseq, int Tq, int Tk, int H, int dh, int shift) {
+    RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh));
+    RC(mmdm_attention_f32(Q, ldq, K, ldk, V, ldv, O, ldo, nseq, Tq, Tk, H, dh, shift, c.st));
+    return prof_end(c, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// transformer stack
+// ------------------------------------------------------------------------------------------------------
+struct StackRun {
+    int nseq, T;
+    const float* ss;        // [rows, ss_ld] AdaLN projections of every layer/norm
+    int ss_ld;
+    int sa_row0, sa_rows;   // rows of `ss` used by sa_block.norm (row = row0 + s % rows)
+    int ca_row0, ca_rows;   // ... by ca_block.norm and ca_block.xf_norm
+    int ffn_row0, ffn_rows; // ... by ffn.norm
+    int ca_mode;            // 0 none; 1 keys/values = the other half of the layer INPUT (in2in.py:439-440); 2 = fixed `kv_src`
+    const float* kv_src;
+};
+
+// h [nseq*T, D] is updated in place through the L blocks (TransformerBlockDoubleCond / TransformerBlock / InfluenceBlockCross).
+int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
+    mmdm_handle H = c.h;
+    const int D = w.D, F = w.F, R = r.nseq * r.T, dh = D / w.H;
+    for (int l = 0; l < w.L; ++l) {
+        const LayerW& lw = w.layers[l];
+        auto ss_at = [&](int slot, int row0) { return r.ss + (size_t)row0 * r.ss_ld + ((size_t)l * w.n_ada + slot) * 2 * D; };
+        // --- self attention (layers.py:36-45)
+        RC(mmdm_adaln_f32(hbuf, ss_at(0, r.sa_row0), r.ss_ld, r.sa_rows, H->xn, r.nseq, r.T, D, c.st));
+        RC(linear(c, H->xn, D, lw.sa_in_w, D, lw.sa_in_b, H->qkv, 3 * D, R, 3 * D, D));
+        RC(attention(c, H->qkv, 3 * D, H->qkv + D, 3 * D, H->qkv + 2 * D, 3 * D, H->att, D, r.nseq, r.T, r.T, w.H, dh, 0));
+        if (r.ca_mode) {
+            // keys/values of the cross attention come from the layer INPUT of the other stream (or a fixed source):
+            // project them before the residual below overwrites h.
+            const float* src = r.ca_mode == 1 ? hbuf : r.kv_src;
+            RC(mmdm_adaln_f32(src, ss_at(2, r.ca_row0), r.ss_ld, r.ca_rows, H->xn, r.nseq, r.T, D, c.st));
+            RC(linear(c, H->xn, D, lw.ca_in_w + (size_t)D * D, D, lw.ca_in_b + D, H->kv, 2 * D, R, 2 * D, D));
+        }
+        RC(linear(c, H->att, D, lw.sa_out_w, D, lw.sa_out_b, hbuf, D, R, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+        // --- cross attention (layers.py:77-88)
+        if (r.ca_mode) {
+            RC(mmdm_adaln_f32(hbuf, ss_at(1, r.ca_row0), r.ss_ld, r.ca_rows, H->xn, r.nseq, r.T, D, c.st));
+            RC(linear(c, H->xn, D, lw.ca_in_w, D, lw.ca_in_b, H->qkv, D, R, D, D));
+            RC(attention(c, H->qkv, D, H->kv, 2 * D, H->kv + D, 2 * D, H->att, D, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
+            RC(linear(c, H->att, D, lw.ca_out_w, D, lw.ca_out_b, hbuf, D, R, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+        }
+        // --- FFN (layers.py:99-106)
+        RC(mmdm_adaln_f32(hbuf, ss_at(w.has_ca ? 3 : 1, r.ffn_row0), r.ss_ld, r.ffn_rows, H->xn, r.nseq, r.T, D, c.st));
+        RC(linear(c, H->xn, D, lw.f1_w, D, lw.f1_b, H->f1, F, R, F, D, MMDM_EPI_BIAS_GELU));
+        RC(linear(c, H->f1, F, lw.f2_w, F, lw.f2_b, hbuf, D, R, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
+    }
+    return MMDM_OK;
+}
+
+// emb rows -> silu -> all AdaLN projections of a module.  se = silu(time_tab[step] + txt), ss = se W_ada^T + b_ada.
+int cond_vectors(const Ctx& c, const ModuleW& m, const float* txt, float* se, float* ss, int rows) {
+    const StackW& w = m.st;
+    RC(mmdm_cond_silu_f32(m.time_tab, c.h->d_step, txt, se, rows, w.D, c.st));
+    const int N = w.L * w.n_ada * 2 * w.D;
+    return linear(c, se, w.D, w.ada_w, w.D, w.ada_b, ss, N, rows, N, w.D);
+}
+
+// motion_embed + positional encoding of one person slice (in2in.py:426-431): x [nb*T rows, ld 524 or 262] -> h rows
+int embed(const Ctx& c, const ModuleW& m, const float* xsrc, int ldx, float* hdst, int nb, int T) {
+    return linear(c, xsrc, ldx, m.me_w, NFP, m.me_b, hdst, m.st.D, nb * T, m.st.D, NF, MMDM_EPI_BIAS_PE, m.pe, m.st.D, T, NFP);
+}
+
+// denoiser1 on the CFG-doubled batch n; xa [B or n rows...]: source rows are taken from `x` with `xrows` samples, repeated to n.
+// Sequence order in h: person-major: seq = p*n + b.
+int run_denoiser(const Ctx& c, const ModuleW& m, bool interaction, const float* x, int xb, int npers, int ldx, int n, int T,
+                 const float* ss, int ss_ld, float* out, int ldo) {
+    mmdm_handle H = c.h;
+    const int D = m.st.D;
+    // embed: `x` holds xb samples (xb == n, or xb == n/2 when cond/uncond halves share the same x: cfg_sampler.py:41-42)
+    for (int p = 0; p < npers; ++p)
+        for (int rep = 0; rep < n / xb; ++rep)
+            RC(embed(c, m, x + (size_t)p * NF, ldx, H->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
+    StackRun r;
+    r.nseq = npers * n; r.T = T; r.ss = ss; r.ss_ld = ss_ld;
+    r.sa_row0 = 0; r.sa_rows = npers * n;
+    r.ffn_row0 = 0; r.ffn_rows = npers * n;
+    r.ca_row0 = 2 * n; r.ca_rows = n;
+    r.ca_mode = interaction ? 1 : 0;
+    r.kv_src = nullptr;
+    RC(run_stack(c, m.st, H->h, r));
+    for (int p = 0; p < npers; ++p)   // FinalLayer (layers.py:109-116), per person, concatenated on the channel axis (in2in.py:455-461)
+        RC(linear(c, H->h + (size_t)p * n * T * D, D, m.out_w, D, m.out_b, out + (size_t)p * NF, ldo, n * T, NF, D));
+    return MMDM_OK;
+}
+
+// text_embed of cond slices (in2in.py:415-417, mixermdm.py:677-682): txt[row0 + r] = te(cond[r, col0 : col0+td])
+int text_rows(const Ctx& c, const ModuleW& m, const float* cond, int ldc, int col0, float* txt, int row0, int n) {
+    const int td = c.h->cfg.text_dim;
+    return linear(c, cond + col0, ldc, m.te_w, td, m.te_b, txt + (size_t)row0 * m.st.D, m.st.D, n, m.st.D, td);
+}
+
+int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
+    // Everything after the two denoisers: mixermdm.py:691-801 + cfg combine.  n = 2B.
+    mmdm_handle H = c.h;
+    const int n = 2 * B, Dm = H->mx.st.D;
+    const mmdm_config& cf = H->cfg;
+    RC(mmdm_mixer_pre_f32(H->o1, H->o2, H->d_stats, H->out1, H->out2, n, T, cf.align, c.st));
+    // motion_embed + PE of the four streams (mixermdm.py:722-732); seq = p*n + b
+    for (int p = 0; p < 2; ++p) {
+        RC(embed(c, H->mx, H->out1 + (size_t)p * NF, NF2, H->h + (size_t)p * n * T * Dm, n, T));
+        RC(embed(c, H->mx, H->out2 + (size_t)p * NF, NF2, H->mI + (size_t)p * n * T * Dm, n, T));
+    }
+    StackRun r;
+    r.nseq = 2 * n; r.T = T; r.ss = H->ss_mx; r.ss_ld = H->mx.st.L * H->mx.st.n_ada * 2 * Dm;
+    r.sa_row0 = 0; r.sa_rows = 2 * n;          // cond_i1 | cond_i2
+    r.ca_row0 = 2 * n; r.ca_rows = n;          // cond_I
+    r.ffn_row0 = 2 * n; r.ffn_rows = n;        // FFN is conditioned on cond_I (influence.py:46)
+    r.ca_mode = 2; r.kv_src = H->mI;
+    RC(run_stack(c, H->mx.st, H->h, r));
+    const int mode = cf.mixing_mode;
+    if (mode == 1 || mode == 3) {
+        RC(mmdm_mean_time_f32(H->h, H->hpool, 2 * n, T, Dm, c.st));
+        RC(mmdm_influence_head_f32(H->hpool, H->mx.out_w, H->mx.out_b, H->w23, 2 * n, Dm, H->nw, c.st));
+    } else {
+        RC(mmdm_influence_head_f32(H->h, H->mx.out_w, H->mx.out_b, H->w23, 2 * n * T, Dm, H->nw, c.st));
+    }
+    const int* lp = dyn_hist ? H->d_step + 1 : nullptr;
+    RC(mmdm_blend_cfg_dyn(H->out1, H->out2, H->w23, mode, cf.use_force, cf.force_val, cf.cfg_scale, H->model_out,
+                          dyn_hist ? H->hist_i1 : nullptr, dyn_hist ? H->hist_i2 : nullptr, dyn_hist ? H->hist_mix : nullptr,
+                          lp, H->hist_every, B, T, c.st));
+    if (dyn_hist && H->hist_o1) RC(mmdm_hist_copy(H->out1, H->hist_o1, (size_t)n * T * NF2, lp, H->hist_every, c.st));
+    if (dyn_hist && H->hist_o2) RC(mmdm_hist_copy(H->out2, H->hist_o2, (size_t)n * T * NF2, lp, H->hist_every, c.st));
+    return MMDM_OK;
+}
+
+int ss_ld_of(const ModuleW& m) { return m.st.L * m.st.n_ada * 2 * m.st.D; }
+
+// One full sampler step on the handle's state (x, x2, step index on the device).
+int run_step(const Ctx& c) {
+    mmdm_handle H = c.h;
+    const int B = H->B, T = H->T, n = 2 * B;
+    if (H->cfg.single_only) {
+        RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, n));
+        RC(run_denoiser(c, H->d1, false, H->x, B, 1, NF, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF));
+        RC(mmdm_cfg_ddim_f32(H->o1, H->d_coef, H->S, H->d_step, H->cfg.cfg_scale, H->x, H->px1, B, T, NF, c.st));
+        return mmdm_step_dec(H->d_step, H->d_step + 1, c.st);
+    }
+    RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n));
+    RC(cond_vectors(c, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n));
+    RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n));
+    RC(run_denoiser(c, H->d1, false, H->x, B, 2, NF2, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF2));
+    RC(run_denoiser(c, H->d2, true, H->x2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
+    RC(mixer_core(c, B, T, true));
+    RC(mmdm_xstart_ddim_f32(H->model_out, H->d_stats, H->d_coef, H->S, H->d_step, H->x, H->x2, H->px1, H->px2, H->floor_ws,
+                            B, T, H->cfg.xstart_align, c.st));
+    return mmdm_step_dec(H->d_step, H->d_step + 1, c.st);
+}
+
+// text embeddings of the three modules from a CFG-doubled cond [n, 8*td] (rows B.. are zero: cfg_sampler.py:45-46)
+int text_all(const Ctx& c, const float* cond, int n) {
+    mmdm_handle H = c.h;
+    const int td = H->cfg.text_dim, ldc = 8 * td;
+    // denoiser1: person 1 <- ind_ind1, person 2 <- ind_ind2 (mixermdm.py:672-673)
+    RC(text_rows(c, H->d1, cond, ldc, 3 * td, H->txt_d1, 0, n));
+    RC(text_rows(c, H->d1, cond, ldc, 4 * td, H->txt_d1, n, n));
+    // denoiser2 rows: [emb_individual1 | emb_individual2 | emb(interaction)] (in2in.py:415-417); InterGen shares one emb (intergen.py:270)
+    const bool ig = H->cfg.model2_kind == 1;
+    RC(text_rows(c, H->d2, cond, ldc, ig ? 0 : 1 * td, H->txt_d2, 0, n));
+    RC(text_rows(c, H->d2, cond, ldc, ig ? 0 : 2 * td, H->txt_d2, n, n));
+    RC(text_rows(c, H->d2, cond, ldc, 0, H->txt_d2, 2 * n, n));
+    // mixer rows: [cond_i1 | cond_i2 | cond_I] (mixermdm.py:677-682)
+    RC(text_rows(c, H->mx, cond, ldc, 6 * td, H->txt_mx, 0, n));
+    RC(text_rows(c, H->mx, cond, ldc, 7 * td, H->txt_mx, n, n));
+    RC(text_rows(c, H->mx, cond, ldc, 5 * td, H->txt_mx, 2 * n, n));
+    return MMDM_OK;
+}
+
+// time_tab[i] = time_embed(pe[timestep_map[i]])  (utils.py:54-55) for all respaced steps
+int build_time_tab(const Ctx& c, ModuleW& m) {
+    mmdm_handle H = c.h;
+    const int D = m.st.D, S = H->S;
+    RC(mmdm_gather_rows(m.pe, H->d_tmap, H->tt_tmp, S, D, c.st));
+    RC(linear(c, H->tt_tmp, D, m.t0_w, D, m.t0_b, H->tt_tmp2, D, S, D, D, MMDM_EPI_BIAS_SILU));
+    return linear(c, H->tt_tmp2, D, m.t2_w, D, m.t2_b, m.time_tab, D, S, D, D);
+}
+
+size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------
+extern "C" const char* mmdm_handle_error(mmdm_handle h) { return h ? h->err : "null handle"; }
+
+extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
+    if (!cfg || !out) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: null argument");
+    if (cfg->nfeats != NF) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: nfeats must be 262");
+    if (cfg->d_latent <= 0 || cfg->d_heads <= 0 || cfg->d_latent % cfg->d_heads || cfg->d_latent % 4 || cfg->d_ff % 4)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: bad denoiser dims");
+    if (!cfg->single_only && (cfg->m_latent <= 0 || cfg->m_heads <= 0 || cfg->m_latent % cfg->m_heads || cfg->m_latent % 4 || cfg->m_ff % 4))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: bad mixer dims");
+    if (!cfg->single_only && (cfg->mixing_mode < 1 || cfg->mixing_mode > 4)) return mmdm_set_error(MMDM_ERR_ARG, "Mode not recognized");
+    if (cfg->max_batch <= 0 || cfg->max_frames <= 0 || cfg->text_dim <= 0 || cfg->text_dim % 4)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: bad max_batch / max_frames / text_dim");
+    RC(mmdm_kernels_init());
+    mmdm_handle h = new mmdm_handle_s();
+    h->cfg = *cfg;
+    const mmdm_config& c = h->cfg;
+    h->nw = (c.mixing_mode >= 3) ? 23 : 1;
+    int rc = MMDM_OK;
+    auto fail = [&](int code) { mmdm_destroy(h); return code; };
+    const int D = c.d_latent, F = c.d_ff, B = c.max_batch, T = c.max_frames, n = 2 * B, td = c.text_dim;
+    const int Dm = c.single_only ? 4 : c.m_latent, Fm = c.single_only ? 4 : c.m_ff;
+    if ((rc = build_module(h, h->d1, "denoiser1.", "denoiser1.", D, F, c.d_layers, c.d_heads, false, true, "denoiser1.out.linear", NF))) return fail(rc);
+    if (!c.single_only) {
+        if ((rc = build_module(h, h->d2, "denoiser2.", "denoiser2.", D, F, c.d_layers, c.d_heads, true, false, "denoiser2.out.linear", NF))) return fail(rc);
+        if ((rc = build_module(h, h->mx, "", "influence.", Dm, Fm, c.m_layers, c.m_heads, true, false, "influence.out", h->nw))) return fail(rc);
+    }
+    const int npers = c.single_only ? 1 : 2;
+    const size_t R = (size_t)npers * n * T;
+    const size_t Dx = max2(D, Dm), Fx = max2(F, Fm);
+    float** bufs[] = {&h->h, &h->xn, &h->att};
+    for (float** b : bufs)
+        if ((rc = dalloc(h, b, R * Dx))) return fail(rc);
+    if ((rc = dalloc(h, &h->qkv, R * 3 * Dx))) return fail(rc);
+    if ((rc = dalloc(h, &h->kv, R * 2 * Dx))) return fail(rc);
+    if ((rc = dalloc(h, &h->f1, R * Fx))) return fail(rc);
+    const size_t PT = (size_t)n * T * (c.single_only ? NF : NF2);
+    if ((rc = dalloc(h, &h->o1, PT))) return fail(rc);
+    if ((rc = dalloc(h, &h->x, PT / 2)) || (rc = dalloc(h, &h->px1, PT / 2))) return fail(rc);
+    if ((rc = dalloc(h, &h->txt_d1, (size_t)npers * n * D)) || (rc = dalloc(h, &h->se_d1, (size_t)npers * n * D)) ||
+        (rc = dalloc(h, &h->ss_d1, (size_t)npers * n * ss_ld_of(h->d1))))
+        return fail(rc);
+    if (!c.single_only) {
+        if ((rc = dalloc(h, &h->mI, R * Dm)) || (rc = dalloc(h, &h->o2, PT)) || (rc = dalloc(h, &h->out1, PT)) || (rc = dalloc(h, &h->out2, PT)) ||
+            (rc = dalloc(h, &h->w23, (size_t)2 * n * T * 23)) || (rc = dalloc(h, &h->hpool, (size_t)2 * n * Dm)) ||
+            (rc = dalloc(h, &h->model_out, PT / 2)) || (rc = dalloc(h, &h->x2, PT / 2)) || (rc = dalloc(h, &h->px2, PT / 2)) ||
+            (rc = dalloc(h, &h->floor_ws, (size_t)2 * B)) ||
+            (rc = dalloc(h, &h->txt_d2, (size_t)3 * n * D)) || (rc = dalloc(h, &h->se_d2, (size_t)3 * n * D)) ||
+            (rc = dalloc(h, &h->ss_d2, (size_t)3 * n * ss_ld_of(h->d2))) ||
+            (rc = dalloc(h, &h->txt_mx, (size_t)3 * n * Dm)) || (rc = dalloc(h, &h->se_mx, (size_t)3 * n * Dm)) ||
+            (rc = dalloc(h, &h->ss_mx, (size_t)3 * n * ss_ld_of(h->mx))))
+            return fail(rc);
+    }
+    if ((rc = dalloc(h, &h->cond_cat, (size_t)n * 8 * td))) return fail(rc);
+    if ((rc = dalloc(h, &h->tt_tmp, (size_t)h->Smax * Dx)) || (rc = dalloc(h, &h->tt_tmp2, (size_t)h->Smax * Dx))) return fail(rc);
+    if ((rc = dalloc(h, &h->d_coef, (size_t)4 * h->Smax)) || (rc = dalloc(h, &h->d_stats, 4 * NF))) return fail(rc);
+    float* tmp = nullptr;
+    if ((rc = dalloc(h, &tmp, h->Smax))) return fail(rc);
+    h->d_tmap = reinterpret_cast<int*>(tmp);
+    if ((rc = dalloc(h, &tmp, 4))) return fail(rc);
+    h->d_step = reinterpret_cast<int*>(tmp);
+    *out = h;
+    return MMDM_OK;
+}
+
+extern "C" void mmdm_destroy(mmdm_handle h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    for (int k = 0; k < 2; ++k)
+        for (hipEvent_t e : h->prof.ev[k]) (void)hipEventDestroy(e);
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+extern "C" int mmdm_set_weight(mmdm_handle h, const char* name, const float* src, int64_t rows, int64_t cols, void* stream) {
+    if (!h || !name) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_weight: null argument");
+    auto it = h->slots.find(name);
+    if (it == h->slots.end()) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "Unexpected key in state_dict: \"%s\"", name));
+    Slot& s = it->second;
+    if (!s.dst) { s.set = true; return MMDM_OK; }   // accepted and ignored
+    if (!src) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_weight(%s): null source", name));
+    if (rows != s.rows || cols != s.cols)
+        return herr(h, mmdm_set_error(MMDM_ERR_ARG, "size mismatch for %s: got [%lld, %lld], expected [%lld, %lld]", name, (long long)rows,
+                                      (long long)cols, (long long)s.rows, (long long)s.cols));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpy2DAsync(s.dst, s.ld * sizeof(float), src, cols * sizeof(float), cols * sizeof(float), rows, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return herr(h, mmdm_set_error(MMDM_ERR_HIP, "mmdm_set_weight(%s): %s", name, hipGetErrorString(e)));
+    s.set = true;
+    h->prepared = false;
+    return MMDM_OK;
+}
+
+extern "C" int mmdm_set_norm_stats(mmdm_handle h, const float* stats_host) {
+    if (!h || !stats_host) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_norm_stats: null argument");
+    hipError_t e = hipMemcpy(h->d_stats, stats_host, 4 * NF * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return herr(h, mmdm_set_error(MMDM_ERR_HIP, "mmdm_set_norm_stats: %s", hipGetErrorString(e)));
+    h->stats_set = true;
+    return MMDM_OK;
+}
+
+extern "C" int mmdm_prepare(mmdm_handle h) {
+    if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_prepare: null handle");
+    std::string missing;
+    int nmiss = 0;
+    for (auto& kv : h->slots)
+        if (kv.second.required && !kv.second.set) {
+            if (nmiss < 4) missing += (nmiss ? ", " : "") + kv.first;
+            ++nmiss;
+        }
+    if (nmiss) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "Missing key(s) in state_dict (%d): %s%s", nmiss, missing.c_str(), nmiss > 4 ? ", ..." : ""));
+    if (!h->cfg.single_only && !h->stats_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_prepare: normaliser stats not set"));
+    h->prepared = true;
+    return MMDM_OK;
+}
+
+extern "C" int mmdm_set_schedule(mmdm_handle h, const int* timestep_map, const float* coef, int S, void* stream) {
+    if (!h || !timestep_map || !coef) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_schedule: null argument");
+    if (S <= 0 || S > h->Smax) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_schedule: S=%d outside [1, %d]", S, h->Smax));
+    if (!h->prepared) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_set_schedule: call mmdm_prepare first"));
+    for (int i = 0; i < S; ++i)
+        if (timestep_map[i] < 0 || timestep_map[i] >= 5000) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_schedule: timestep %d out of the pe table", timestep_map[i]));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipMemcpyAsync(h->d_tmap, timestep_map, S * sizeof(int), hipMemcpyHostToDevice, st));
+    for (int k = 0; k < 4; ++k)
+        HIPCHK(hipMemcpyAsync(h->d_coef + (size_t)k * S, coef + (size_t)k * S, S * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));   // host buffers may be transient
+    h->S = S;
+    Ctx c{h, st};
+    const bool pon = h->prof.on;
+    h->prof.on = false;
+    int rc = build_time_tab(c, h->d1);
+    if (!rc && !h->cfg.single_only) rc = build_time_tab(c, h->d2);
+    if (!rc && !h->cfg.single_only) rc = build_time_tab(c, h->mx);
+    h->prof.on = pon;
+    h->begun = false;
+    return herr(h, rc);
+}
+
+extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, int B, int T, void* stream) {
+    if (!h || !cond || !x_T) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_begin: null argument");
+    if (!h->prepared || h->S == 0) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_begin: prepare() and set_schedule() first"));
+    if (B <= 0 || B > h->cfg.max_batch || T <= 0 || T > h->cfg.max_frames)
+        return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_begin: B=%d T=%d exceed the handle's max_batch=%d / max_frames=%d", B, T, h->cfg.max_batch, h->cfg.max_frames));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Ctx c{h, st};
+    const int n = 2 * B, td = h->cfg.text_dim;
+    const bool pon = h->prof.on;
+    h->prof.on = false;
+    int rc = MMDM_OK;
+    if (h->cfg.single_only) {
+        HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n * td * sizeof(float), st));
+        HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * td * sizeof(float), hipMemcpyDeviceToDevice, st));
+        rc = linear(c, h->cond_cat, td, h->d1.te_w, td, h->d1.te_b, h->txt_d1, h->d1.st.D, n, h->d1.st.D, td);
+        HIPCHK(hipMemcpyAsync(h->x, x_T, (size_t)B * T * NF * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n * 8 * td * sizeof(float), st));
+        HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * 8 * td * sizeof(float), hipMemcpyDeviceToDevice, st));
+        rc = text_all(c, h->cond_cat, n);
+        HIPCHK(hipMemcpyAsync(h->x, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->x2, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));   // img2 = img.clone()
+    }
+    h->prof.on = pon;
+    if (rc) return herr(h, rc);
+    RC(mmdm_set_step(h->d_step, h->d_step + 1, h->S - 1, 0, st));
+    h->host_step = h->S - 1;
+    if (h->B != B || h->T != T) {
+        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    }
+    h->B = B; h->T = T; h->begun = true;
+    h->hist_i1 = h->hist_i2 = h->hist_o1 = h->hist_o2 = h->hist_mix = nullptr;
+    h->hist_every = 1;
+    return MMDM_OK;
+}
+
+extern "C" int mmdm_set_history(mmdm_handle h, float* influence_i1, float* influence_i2, float* out1, float* out2, float* out_influenced, int every) {
+    if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_history: null handle");
+    if (!h->begun) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_set_history: call after mmdm_begin"));
+    if (every <= 0) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_history: every must be >= 1"));
+    h->hist_i1 = influence_i1; h->hist_i2 = influence_i2; h->hist_o1 = out1; h->hist_o2 = out2; h->hist_mix = out_influenced;
+    h->hist_every = every;
+    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // pointers are baked into the graph
+    return MMDM_OK;
+}
+
+extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) {
+    if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: null handle");
+    if (!h->begun) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_run: call mmdm_begin first"));
+    if (nsteps < 0 || nsteps > h->host_step + 1)
+        return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: %d steps requested, %d left in the schedule", nsteps, h->host_step + 1));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Ctx c{h, st};
+    if (use_graph && !h->prof.on) {
+        if (!st) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: graph capture needs a non-default stream"));
+        if (!h->gexec) {
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            int rc = run_step(c);
+            hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return herr(h, rc); }
+            if (e != hipSuccess) return herr(h, mmdm_set_error(MMDM_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e)));
+            e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) { h->gexec = nullptr; return herr(h, mmdm_set_error(MMDM_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e))); }
+        }
+        for (int k = 0; k < nsteps; ++k) HIPCHK(hipGraphLaunch(h->gexec, st));
+    } else {
+        for (int k = 0; k < nsteps; ++k) {
+            int rc = run_step(c);
+            if (rc) return herr(h, rc);
+        }
+    }
+    h->host_step -= nsteps;
+    return MMDM_OK;
+}
+
+extern "C" int mmdm_get_state(mmdm_handle h, float** x, float** x2, float** pred_xstart, float** pred_xstart2, float** model_out) {
+    if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_get_state: null handle");
+    if (x) *x = h->x;
+    if (x2) *x2 = h->x2;
+    if (pred_xstart) *pred_xstart = h->px1;
+    if (pred_xstart2) *pred_xstart2 = h->px2;
+    if (model_out) *model_out = h->model_out;
+    return MMDM_OK;
+}
+
+extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, const float* x2, const float* cond, int t,
+                                   float* out, int n, int T, void* stream) {
+    if (!h || !x || !cond || !out) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: null argument");
+    if (!h->prepared) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_module_forward: call mmdm_prepare first"));
+    if (n <= 0 || (n & 1) || n / 2 > h->cfg.max_batch || T <= 0 || T > h->cfg.max_frames)
+        return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: n=%d (even, <= 2*max_batch) T=%d out of range", n, T));
+    if (t < 0 || t >= 5000) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: timestep %d out of range", t));
+    if (which < 0 || which > 2 || (h->cfg.single_only && which != 0)) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: bad module %d", which));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Ctx c{h, st};
+    const int td = h->cfg.text_dim;
+    // a one-entry schedule at slot 0 of the tables: time_tab[0] = time_embed(pe[t]); restored by the next set_schedule
+    const int S_keep = h->S;
+    h->S = 1;
+    h->begun = false;
+    int rc = MMDM_OK;
+    HIPCHK(hipMemcpyAsync(h->d_tmap, &t, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    RC(mmdm_set_step(h->d_step, h->d_step + 1, 0, 0, st));
+    auto done = [&](int code) { h->S = 0; (void)S_keep; return herr(h, code); };   // schedule must be set again
+    if (which == 0) {
+        if ((rc = build_time_tab(c, h->d1))) return done(rc);
+        if ((rc = linear(c, cond, td, h->d1.te_w, td, h->d1.te_b, h->txt_d1, h->d1.st.D, n, h->d1.st.D, td))) return done(rc);
+        if ((rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, n))) return done(rc);
+        rc = run_denoiser(c, h->d1, false, x, n, 1, NF, n, T, h->ss_d1, ss_ld_of(h->d1), out, NF);
+        return done(rc);
+    }
+    if (which == 1) {
+        if ((rc = build_time_tab(c, h->d2))) return done(rc);
+        const bool ig = h->cfg.model2_kind == 1;
+        const int ldc = 3 * td;
+        if ((rc = text_rows(c, h->d2, cond, ldc, ig ? 0 : td, h->txt_d2, 0, n))) return done(rc);
+        if ((rc = text_rows(c, h->d2, cond, ldc, ig ? 0 : 2 * td, h->txt_d2, n, n))) return done(rc);
+        if ((rc = text_rows(c, h->d2, cond, ldc, 0, h->txt_d2, 2 * n, n))) return done(rc);
+        if ((rc = cond_vectors(c, h->d2, h->txt_d2, h->se_d2, h->ss_d2, 3 * n))) return done(rc);
+        rc = run_denoiser(c, h->d2, true, x, n, 2, NF2, n, T, h->ss_d2, ss_ld_of(h->d2), out, NF2);
+        return done(rc);
+    }
+    if (!x2) return done(mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: Mixer.forward needs x2"));
+    if ((rc = build_time_tab(c, h->d1)) || (rc = build_time_tab(c, h->d2)) || (rc = build_time_tab(c, h->mx))) return done(rc);
+    if ((rc = text_all(c, cond, n))) return done(rc);
+    if ((rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, 2 * n))) return done(rc);
+    if ((rc = cond_vectors(c, h->d2, h->txt_d2, h->se_d2, h->ss_d2, 3 * n))) return done(rc);
+    if ((rc = cond_vectors(c, h->mx, h->txt_mx, h->se_mx, h->ss_mx, 3 * n))) return done(rc);
+    if ((rc = run_denoiser(c, h->d1, false, x, n, 2, NF2, n, T, h->ss_d1, ss_ld_of(h->d1), h->o1, NF2))) return done(rc);
+    if ((rc = run_denoiser(c, h->d2, true, x2, n, 2, NF2, n, T, h->ss_d2, ss_ld_of(h->d2), h->o2, NF2))) return done(rc);
+    // Mixer.forward returns out_influenced for the whole CFG-doubled batch: reuse the blend kernel's history output.
+    h->hist_i1 = h->hist_i2 = h->hist_o1 = h->hist_o2 = nullptr;
+    h->hist_mix = out;
+    h->hist_every = 1;
+    rc = mixer_core(c, n / 2, T, true);
+    h->hist_mix = nullptr;
+    return done(rc);
+}
+
+extern "C" int mmdm_profile_enable(mmdm_handle h, int on) {
+    if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_profile_enable: null handle");
+    h->prof.on = on != 0;
+    if (on)
+        for (int k = 0; k < 2; ++k) { h->prof.used[k] = 0; h->prof.flops[k] = 0; h->prof.ms[k] = 0; h->prof.launches[k] = 0; }
+    return MMDM_OK;
+}
+
+extern "C" int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launches, double* flops) {
+    if (!h || which < 0 || which > 1) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_profile_read: bad argument");
+    Prof& p = h->prof;
+    HIPCHK(hipDeviceSynchronize());
+    double ms = 0;
+    for (size_t i = 0; i + 1 < p.used[which]; i += 2) {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, p.ev[which][i], p.ev[which][i + 1]));
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int64_t)(p.used[which] / 2);
+    if (flops) *flops = p.flops[which];
+    return MMDM_OK;
+}

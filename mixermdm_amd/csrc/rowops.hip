@@ -1,0 +1,139 @@
+// Row-wise HBM-bound kernels of the denoising path (gfx950): AdaLN apply, conditioning-vector SiLU,
+// time mean, Influence head.  One 64-lane wavefront per row, 16-byte loads, wave-shuffle reductions.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "kernels.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// out = LN(h) * (1 + scale) + shift ; one wave per row; row cached in registers (D <= 64*4*MAXV).
+// Reference: AdaLN.forward src/models/utils/layers.py:15-25 (LayerNorm eps 1e-6, biased variance, no affine).
+template <int MAXV>
+__global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h, const float* __restrict__ ss, int ss_ld, int ss_rows,
+                                                     float* __restrict__ out, int rows, int T, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* hp = h + (size_t)row * D;
+    const int nv = D >> 2;                                   // float4 per row (D % 4 == 0 checked on host)
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) v[i] = *reinterpret_cast<const f32x4*>(hp + 4 * c);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 d = v[i] - mean;
+            q += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-6f);
+    const float* sp = ss + (size_t)((row / T) % ss_rows) * ss_ld;
+    float* op = out + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(sp + 4 * c);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(sp + D + 4 * c);
+            *reinterpret_cast<f32x4*>(op + 4 * c) = (v[i] - mean) * rstd * (1.0f + sc) + sh;
+        }
+    }
+}
+
+__global__ void cond_silu_kernel(const float* __restrict__ time_tab, const int* __restrict__ step_idx, const float* __restrict__ txt,
+                                 float* __restrict__ out, int rows, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * D) return;
+    const int d = (int)(i % D);
+    const float e = time_tab[(size_t)(*step_idx) * D + d] + txt[i];
+    out[i] = e / (1.0f + expf(-e));
+}
+
+__global__ void mean_time_kernel(const float* __restrict__ h, float* __restrict__ out, int T, int D) {
+    const int seq = blockIdx.y;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const float* p = h + (size_t)seq * T * D + d;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += p[(size_t)t * D];
+    out[(size_t)seq * D + d] = s / (float)T;
+}
+
+// w[row, o] = sigmoid(h[row,:] . Wout[o,:] + b[o]); one wave per row, nw <= 23 outputs.
+// Reference: Influence.forward tail src/models/utils/influence.py:124-125.
+__global__ __launch_bounds__(256) void influence_head_kernel(const float* __restrict__ h, const float* __restrict__ W, const float* __restrict__ b,
+                                                              float* __restrict__ w, int rows, int D, int nw) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* hp = h + (size_t)row * D;
+    for (int o = 0; o < nw; ++o) {
+        const float* wp = W + (size_t)o * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += hp[c] * wp[c];
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float z = s + b[o];
+            w[(size_t)row * nw + o] = 1.0f / (1.0f + expf(-z));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss_rows, float* out, int nseq, int T, int D, void* stream) {
+    if (nseq == 0 || T == 0) return MMDM_OK;
+    if (!h || !ss || !out || nseq < 0 || T < 0 || D <= 0 || ss_rows <= 0 || ss_ld < 2 * D)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_adaln_f32: bad arguments nseq=%d T=%d D=%d ss_ld=%d ss_rows=%d", nseq, T, D, ss_ld, ss_rows);
+    if ((D & 3) || (ss_ld & 3) || ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(ss) | reinterpret_cast<uintptr_t>(out)) & 15))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_adaln_f32: D and ss_ld must be multiples of 4 and pointers 16-byte aligned");
+    if (D > 64 * 4 * 8) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_adaln_f32: D=%d > 2048", D);
+    const int rows = nseq * T;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((rows + 3) / 4), block(256);
+    if (D <= 256) hipLaunchKernelGGL(adaln_kernel<1>, grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);
+    else if (D <= 512) hipLaunchKernelGGL(adaln_kernel<2>, grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);
+    else if (D <= 1024) hipLaunchKernelGGL(adaln_kernel<4>, grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);
+    else hipLaunchKernelGGL(adaln_kernel<8>, grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);
+    return mmdm_check_launch("adaln");
+}
+
+extern "C" int mmdm_cond_silu_f32(const float* time_tab, const int* step_idx, const float* txt, float* out, int rows, int D, void* stream) {
+    if (rows == 0) return MMDM_OK;
+    if (!time_tab || !step_idx || !txt || !out || rows < 0 || D <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_cond_silu_f32: bad arguments");
+    const size_t n = (size_t)rows * D;
+    hipLaunchKernelGGL(cond_silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), time_tab, step_idx, txt, out, rows, D);
+    return mmdm_check_launch("cond_silu");
+}
+
+extern "C" int mmdm_mean_time_f32(const float* h, float* out, int nseq, int T, int D, void* stream) {
+    if (nseq == 0) return MMDM_OK;
+    if (!h || !out || nseq < 0 || T <= 0 || D <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_mean_time_f32: bad arguments");
+    hipLaunchKernelGGL(mean_time_kernel, dim3((D + 255) / 256, nseq), dim3(256), 0, static_cast<hipStream_t>(stream), h, out, T, D);
+    return mmdm_check_launch("mean_time");
+}
+
+extern "C" int mmdm_influence_head_f32(const float* h, const float* Wout, const float* bout, float* w, int rows, int D, int nw, void* stream) {
+    if (rows == 0) return MMDM_OK;
+    if (!h || !Wout || !bout || !w || rows < 0 || D <= 0 || nw <= 0 || nw > 23)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_influence_head_f32: bad arguments rows=%d D=%d nw=%d", rows, D, nw);
+    hipLaunchKernelGGL(influence_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), h, Wout, bout, w, rows, D, nw);
+    return mmdm_check_launch("influence_head");
+}

@@ -1,0 +1,137 @@
+"""Torch-tensor front ends of the stateless HIP kernels (include/mmdm.h section 1).
+
+Every function takes contiguous fp32 CUDA(=HIP) tensors, launches on torch's current stream and returns a new
+tensor.  No function here computes anything in Python: a non-CUDA tensor raises.
+"""
+import ctypes as C
+import torch
+
+from ._lib import load_library, check
+
+EPI = {"bias": 0, "gelu": 1, "resid": 2, "pe": 3, "silu": 4}
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("mixermdm_amd ops run on the GPU only (no CPU fallback): got a CPU tensor")
+        if t.dtype != torch.float32 and t.dtype != torch.int32:
+            raise TypeError(f"fp32 tensors expected, got {t.dtype}")
+
+
+def linear(x, weight, bias=None, epilogue="bias", extra=None, period=0, out=None):
+    """y = x @ weight.T + bias with a fused epilogue; x [..., K] (last-dim stride 1, uniform row stride)."""
+    _chk(x, weight, bias, extra)
+    K = x.shape[-1]
+    N = weight.shape[0]
+    x2 = x.reshape(-1, K) if x.is_contiguous() else x
+    assert x2.dim() == 2 and x2.stride(1) == 1 and weight.stride(1) == 1
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    ld_extra = extra.stride(0) if extra is not None else 0
+    check(load_library().mmdm_linear_f32(_p(x2), x2.stride(0), _p(weight), weight.stride(0), _p(bias), _p(out), out.stride(0),
+                                         M, N, K, EPI[epilogue], _p(extra), ld_extra, period, _stream()))
+    return out.reshape(*x.shape[:-1], N) if x.is_contiguous() else out
+
+
+def adaln(h, ss, ss_rows=None):
+    """h [nseq, T, D]; ss [rows, 2D] (scale | shift); row(s) = s % ss_rows."""
+    _chk(h, ss)
+    nseq, T, D = h.shape
+    h = h.contiguous()
+    out = torch.empty_like(h)
+    check(load_library().mmdm_adaln_f32(_p(h), _p(ss), ss.stride(0), ss_rows or ss.shape[0], _p(out), nseq, T, D, _stream()))
+    return out
+
+
+def attention(q, k, v, num_heads, kv_seq_shift=0):
+    """q [nseq, Tq, H*dh], k/v [nseq, Tk, H*dh] (may be column slices of a packed projection); add_zero_attn semantics."""
+    _chk(q, k, v)
+    nseq, Tq, HD = q.shape
+    Tk = k.shape[1]
+    for t in (q, k, v):
+        assert t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1), "rows must be uniformly strided"
+    out = torch.empty(nseq, Tq, HD, device=q.device, dtype=torch.float32)
+    check(load_library().mmdm_attention_f32(_p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(out), HD,
+                                            nseq, Tq, Tk, num_heads, HD // num_heads, kv_seq_shift, _stream()))
+    return out
+
+
+def cond_silu(time_tab, step_idx, txt):
+    _chk(time_tab, step_idx, txt)
+    out = torch.empty_like(txt)
+    check(load_library().mmdm_cond_silu_f32(_p(time_tab), _p(step_idx), _p(txt), _p(out), txt.shape[0], txt.shape[1], _stream()))
+    return out
+
+
+def mixer_pre(o1, o2, stats, align=True):
+    _chk(o1, o2, stats)
+    n, T, _ = o1.shape
+    out1, out2 = torch.empty_like(o1), torch.empty_like(o2)
+    check(load_library().mmdm_mixer_pre_f32(_p(o1.contiguous()), _p(o2.contiguous()), _p(stats), _p(out1), _p(out2), n, T, int(align), _stream()))
+    return out1, out2
+
+
+def influence_head(h, weight, bias):
+    _chk(h, weight, bias)
+    D = h.shape[-1]
+    rows = h.numel() // D
+    nw = weight.shape[0]
+    w = torch.empty(*h.shape[:-1], nw, device=h.device, dtype=torch.float32)
+    check(load_library().mmdm_influence_head_f32(_p(h.contiguous()), _p(weight.contiguous()), _p(bias), _p(w), rows, D, nw, _stream()))
+    return w
+
+
+def mean_time(h):
+    _chk(h)
+    nseq, T, D = h.shape
+    out = torch.empty(nseq, D, device=h.device, dtype=torch.float32)
+    check(load_library().mmdm_mean_time_f32(_p(h.contiguous()), _p(out), nseq, T, D, _stream()))
+    return out
+
+
+def blend_cfg(out1, out2, w, mode, cfg_scale, force=None, want_hist=False):
+    """out1/out2 [2B,T,524]; w [2, 2B, Tw, nw].  Returns model_out [B,T,524] (+ influence_i1, influence_i2, out_influenced)."""
+    _chk(out1, out2, w)
+    n, T, _ = out1.shape
+    B = n // 2
+    mo = torch.empty(B, T, 524, device=out1.device, dtype=torch.float32)
+    h1 = h2 = hm = None
+    if want_hist:
+        h1 = torch.empty(n, T, 262, device=out1.device, dtype=torch.float32)
+        h2 = torch.empty_like(h1)
+        hm = torch.empty_like(out1)
+    check(load_library().mmdm_blend_cfg_f32(_p(out1.contiguous()), _p(out2.contiguous()), _p(w.contiguous()), mode, int(force is not None),
+                                            float(force or 0.0), float(cfg_scale), _p(mo), _p(h1), _p(h2), _p(hm), B, T, _stream()))
+    return (mo, h1, h2, hm) if want_hist else mo
+
+
+def xstart_ddim(model_out, stats, coef, step_idx, x, x2, align=True):
+    """In place on x, x2.  Returns (pred_xstart, pred_xstart2)."""
+    _chk(model_out, stats, coef, step_idx, x, x2)
+    B, T, _ = model_out.shape
+    S = coef.shape[1]
+    p1, p2 = torch.empty_like(x), torch.empty_like(x)
+    ws = torch.empty(2 * B, device=x.device, dtype=torch.float32)
+    check(load_library().mmdm_xstart_ddim_f32(_p(model_out.contiguous()), _p(stats), _p(coef), S, _p(step_idx), _p(x), _p(x2), _p(p1), _p(p2),
+                                              _p(ws), B, T, int(align), _stream()))
+    return p1, p2
+
+
+def cfg_ddim(m, coef, step_idx, cfg_scale, x):
+    _chk(m, coef, step_idx, x)
+    B, T, Cc = x.shape
+    p = torch.empty_like(x)
+    check(load_library().mmdm_cfg_ddim_f32(_p(m.contiguous()), _p(coef), coef.shape[1], _p(step_idx), float(cfg_scale), _p(x), _p(p), B, T, Cc, _stream()))
+    return p

@@ -1,0 +1,201 @@
+"""Python owner of an mmdm_handle (include/mmdm.h section 2): weights, schedule, the DDIM host loop.
+
+The loop itself is one C call per chunk of steps (``mmdm_run``), optionally replaying a captured hipGraph; Python only
+decides how many steps to run and where the history buffers live.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from ._lib import Config, load_library, check
+from .schedule import make_schedule
+
+STATS_ORDER = ("mean_hml", "std_hml", "mean_ih", "std_ih")
+
+
+def pe_table(d_model, max_len=5000):
+    """PositionalEncoding buffer, generated exactly like the reference (src/models/utils/utils.py:24-35) with torch on the
+    host, then handed to the library as the ``sequence_pos_encoder.pe`` entry of the state dict."""
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-np.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+class Sampler:
+    """One handle = one device, one (max_batch, max_frames) workspace."""
+
+    def __init__(self, *, d_latent, d_ff, d_layers, d_heads, m_latent=0, m_ff=0, m_layers=0, m_heads=1, mixing_mode=4, align=True,
+                 xstart_align=True, model2_kind=0, force_influence_val=None, cfg_scale=3.5, max_batch=1, max_frames=300,
+                 single_only=False, text_dim=768, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("mixermdm_amd.Sampler needs an MI355X (HIP device); there is no CPU path")
+        self.lib = load_library()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.cfg = Config(d_latent, d_ff, d_layers, d_heads, m_latent, m_ff, m_layers, m_heads, 262, text_dim, mixing_mode, int(align),
+                          int(xstart_align), model2_kind, int(force_influence_val is not None), float(force_influence_val or 0.0),
+                          float(cfg_scale), max_batch, max_frames, int(single_only))
+        self.single_only = single_only
+        self.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_create(C.byref(self.cfg), C.byref(self.h)))
+            # graph capture is not allowed on the legacy default stream: the handle works on its own stream
+            self.stream = torch.cuda.Stream(device=self.device)
+        self.schedule = None
+        self._hist = None
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.mmdm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _s(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    # ---- weights ----------------------------------------------------------------------------------
+    def load_state_dict(self, sd):
+        """sd: Mixer state_dict (reference key names; src/models/mixermdm.py:134-148); strict: unknown keys raise here, missing
+        keys raise in prepare().  pe buffers are regenerated if absent."""
+        sd = dict(sd)
+        D, Dm = self.cfg.d_latent, self.cfg.m_latent
+        pes = [("denoiser1.sequence_pos_encoder.pe", D)]
+        if not self.single_only:
+            pes += [("denoiser2.sequence_pos_encoder.pe", D), ("sequence_pos_encoder.pe", Dm)]
+        for k, d in pes:
+            if k not in sd:
+                sd[k] = pe_table(d)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        keep = []
+        with torch.cuda.device(self.device):
+            for k, v in sd.items():
+                t = v.detach().to(device=self.device, dtype=torch.float32).contiguous()
+                keep.append(t)
+                rows, cols = (t.shape[0], 1) if t.dim() == 1 else (t.shape[0], t.shape[1])
+                check(self.lib.mmdm_set_weight(self.h, k.encode(), C.c_void_p(t.data_ptr()), rows, cols, self._s()), self.h)
+            self.stream.synchronize()
+        return self
+
+    def set_norm_stats(self, mean_hml, std_hml, mean_ih, std_ih):
+        arr = np.concatenate([np.asarray(a, dtype=np.float32).reshape(262) for a in (mean_hml, std_hml, mean_ih, std_ih)])
+        arr = np.ascontiguousarray(arr)
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_set_norm_stats(self.h, arr.ctypes.data_as(C.c_void_p)), self.h)
+        return self
+
+    def prepare(self):
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_prepare(self.h), self.h)
+        return self
+
+    # ---- schedule ---------------------------------------------------------------------------------
+    def set_schedule(self, sampling_strategy="ddim50", beta_scheduler="cosine", diffusion_steps=1000):
+        sch = make_schedule(beta_scheduler, diffusion_steps, sampling_strategy)
+        tmap = np.ascontiguousarray(np.array(sch.timestep_map, dtype=np.int32))
+        coef = np.ascontiguousarray(sch.device_coefficients())
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_set_schedule(self.h, tmap.ctypes.data_as(C.c_void_p), coef.ctypes.data_as(C.c_void_p), sch.num_timesteps, self._s()), self.h)
+        self.schedule = sch
+        return sch
+
+    # ---- sampling ---------------------------------------------------------------------------------
+    def begin(self, cond, x_T):
+        cond = cond.to(self.device, torch.float32).contiguous()
+        x_T = x_T.to(self.device, torch.float32).contiguous()
+        B, T = x_T.shape[:2]
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_begin(self.h, C.c_void_p(cond.data_ptr()), C.c_void_p(x_T.data_ptr()), B, T, self._s()), self.h)
+        self._keep = (cond, x_T)
+        self.B, self.T = B, T
+        self._hist = None
+        return self
+
+    def set_history(self, names=("influence_i1", "influence_i2", "out1", "out2", "out_influenced"), every=1):
+        """Allocate history buffers [slots, 2B, T, C] for the requested side outputs (mixermdm.py:794-796, 805-808)."""
+        S = self.schedule.num_timesteps
+        slots = (S + every - 1) // every
+        n = 2 * self.B
+        bufs = {}
+        for nm in ("influence_i1", "influence_i2", "out1", "out2", "out_influenced"):
+            if nm in names:
+                Cc = 262 if nm.startswith("influence") else 524
+                bufs[nm] = torch.empty(slots, n, self.T, Cc, device=self.device, dtype=torch.float32)
+        ptr = lambda nm: C.c_void_p(bufs[nm].data_ptr() if nm in bufs else 0)
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_set_history(self.h, ptr("influence_i1"), ptr("influence_i2"), ptr("out1"), ptr("out2"), ptr("out_influenced"), every), self.h)
+        self._hist = bufs
+        return bufs
+
+    def run(self, nsteps=None, use_graph=True):
+        if nsteps is None:
+            nsteps = self.schedule.num_timesteps
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_run(self.h, nsteps, int(use_graph), self._s()), self.h)
+        return self
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def state(self):
+        """Views (no copy) of the handle's x, x2, pred_xstart, pred_xstart2, model_out after the queued work completes."""
+        ptrs = [C.c_void_p() for _ in range(5)]
+        check(self.lib.mmdm_get_state(self.h, *[C.byref(p) for p in ptrs]), self.h)
+        self.stream.synchronize()
+        Cc = 262 if self.single_only else 524
+        shape = (self.B, self.T, Cc)
+        out = {}
+        for nm, p in zip(("x", "x2", "pred_xstart", "pred_xstart2", "model_out"), ptrs):
+            out[nm] = _from_ptr(p.value, shape, self.device) if p.value else None
+        return out
+
+    def sample(self, cond, x_T, use_graph=True, history=None, history_every=1):
+        """Full loop: MixerDiffusion.ddim_sample_loop (gaussian_diffusion.py:1769-1820) -> last pred_xstart2 (or pred_xstart, single)."""
+        self.begin(cond, x_T)
+        hist = self.set_history(history, history_every) if history else None
+        self.run(None, use_graph)
+        st = self.state()
+        res = st["pred_xstart"] if self.single_only else st["pred_xstart2"]
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return (res.clone(), hist) if history else res.clone()
+
+    # ---- teacher-forced module forwards (tests / swappable inner protocol) ----------------------------
+    def module_forward(self, which, x, cond, t, x2=None):
+        """which: 0 denoiser1, 1 denoiser2, 2 Mixer.forward; inputs are the CFG-doubled batch.  Invalidates the schedule."""
+        x = x.to(self.device, torch.float32).contiguous()
+        cond = cond.to(self.device, torch.float32).contiguous()
+        x2c = x2.to(self.device, torch.float32).contiguous() if x2 is not None else None
+        n, T = x.shape[:2]
+        out = torch.empty(n, T, 262 if which == 0 else 524, device=self.device, dtype=torch.float32)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_module_forward(self.h, which, C.c_void_p(x.data_ptr()), C.c_void_p(x2c.data_ptr() if x2c is not None else 0),
+                                               C.c_void_p(cond.data_ptr()), int(t), C.c_void_p(out.data_ptr()), n, T, self._s()), self.h)
+        self.stream.synchronize()
+        self.schedule = None
+        return out
+
+    # ---- profiling ----------------------------------------------------------------------------------
+    def profile(self, on=True):
+        check(self.lib.mmdm_profile_enable(self.h, int(on)), self.h)
+
+    def profile_read(self, which):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        check(self.lib.mmdm_profile_read(self.h, which, C.byref(ms), C.byref(n), C.byref(fl)), self.h)
+        return ms.value, n.value, fl.value
+
+
+def _from_ptr(ptr, shape, device):
+    """Wrap a device pointer owned by the handle as a torch tensor (no copy) via __cuda_array_interface__."""
+    class _Holder:
+        pass
+    hld = _Holder()
+    hld.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 3, "strides": None}
+    return torch.as_tensor(hld, device=device)

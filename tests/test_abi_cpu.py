@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mmdm.h declares; host logic matches the golden tables.
+No compute entry point is called here (no GPU in this container)."""
+import os
+import re
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mixermdm_amd._lib import load_library, SYMBOLS
+    lib = load_library()
+    hdr = open(os.path.join(ROOT, "include", "mmdm.h")).read()
+    declared = set(re.findall(r"\b(mmdm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mmdm_handle_s"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in mmdm.h but not exported"
+    assert declared == set(SYMBOLS), (declared ^ set(SYMBOLS))
+    assert lib.mmdm_version().startswith(b"gfx950;")
+
+
+def test_config_struct_matches_header_field_order():
+    from mixermdm_amd._lib import Config
+    hdr = open(os.path.join(ROOT, "include", "mmdm.h")).read()
+    body = hdr[hdr.index("typedef struct {"):hdr.index("} mmdm_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"(?:int|float)\s+([^;]+);", body):
+        names += [n.strip() for n in decl.split(",")]
+    assert names == [f[0] for f in Config._fields_]
+
+
+def test_product_schedule_matches_reference_tables(golden):
+    from mixermdm_amd import schedule as S
+    g, _, _ = golden("schedule")
+    np.testing.assert_array_equal(S.get_named_beta_schedule("cosine", 1000), g["betas_cosine_1000"])
+    np.testing.assert_array_equal(S.get_named_beta_schedule("linear", 1000), g["betas_linear_1000"])
+    for strat in ["ddim50", "ddim1000", "ddim20"]:
+        sc = S.make_schedule("cosine", 1000, strat)
+        np.testing.assert_array_equal(np.array(sc.timestep_map), g[strat + ":timestep_map"])
+        for a in ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"]:
+            np.testing.assert_array_equal(getattr(sc, a), g[strat + ":" + a])
+        co = sc.device_coefficients()
+        assert co.dtype == np.float32 and co.shape == (4, sc.num_timesteps)
+        # the kernels' coefficients are the fp32 gather + fp32 sqrt the reference performs (gaussian_diffusion.py:1264-1277, 1949-1956)
+        np.testing.assert_array_equal(co[2], np.sqrt(g[strat + ":alphas_cumprod_prev"].astype(np.float32)))
+        np.testing.assert_array_equal(co[3], np.sqrt(np.float32(1) - g[strat + ":alphas_cumprod_prev"].astype(np.float32)))
+    np.testing.assert_array_equal(sorted(S.space_timesteps(300, "10,15,20")), g["space:10,15,20@300"])
+    with pytest.raises(ValueError):
+        S.space_timesteps(1000, "ddim999")
+    with pytest.raises(NotImplementedError):
+        S.get_named_beta_schedule("sqrt", 10)
+
+
+def test_pe_table_matches_reference_rows(golden):
+    from mixermdm_amd.sampler import pe_table
+    g, _, _ = golden("pe")
+    for D in [64, 512, 1024]:
+        np.testing.assert_array_equal(pe_table(D)[g["rows"]].numpy(), g[f"pe{D}"])
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from mixermdm_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(torch.zeros(4, 8), torch.zeros(8, 8))
+
+
+def test_synthetic_state_dict_keys_cover_reference_names(golden):
+    """Synthetic key set == reference Mixer.state_dict() keys (minus pe buffers), checked against the captured fixture."""
+    from mixermdm_amd.synthetic import mixer_shapes
+    g, _, _ = golden("mixer")
+    ref = {k[len("w:mix."):]: v.shape for k, v in g.items() if k.startswith("w:mix.")}
+    mine = mixer_shapes(d_latent=16, d_ff=32, d_layers=2, m_latent=16, m_ff=32, m_layers=2, mixing_mode=4)
+    assert set(ref) == set(mine), set(ref) ^ set(mine)
+    for k in ref:
+        assert tuple(ref[k]) == tuple(mine[k]), k

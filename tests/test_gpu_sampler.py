@@ -1,0 +1,272 @@
+"""GPU: the sampler handle (weights -> module forwards -> DDIM steps -> loop) against the reference-captured golden
+vectors (tiny dims, tests/golden/mixer.npz) and against the CPU oracle at the real model dimensions.
+
+Tolerances: one Mixer.forward / one DDIM step: all but 0.05 % of elements within atol 2e-4 + rtol 2e-4 (geometry is
+ill-conditioned for a few elements), none beyond 5e-2.  Loops: distributional (mean / 99th percentile).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mixer as MX            # noqa: E402  (checker only)
+from oracle import denoiser as DN         # noqa: E402
+from oracle import schedule as OS         # noqa: E402
+from oracle.layers import pe_table        # noqa: E402
+from test_gpu_kernels import assert_close, rnd, dev   # noqa: E402
+
+STEP_TOL = dict(atol=2e-4, rtol=2e-4, frac=5e-4, hard=5e-2)
+
+
+def golden_sampler(golden, mode=4, align=True, force=None, model2_kind=0, max_batch=2, out1=False):
+    from mixermdm_amd.sampler import Sampler
+    g, w, t = golden("mixer")
+    W = w("mix.")
+    if mode in (1, 2):
+        W.update(w("mix_out1."))
+    s = Sampler(d_latent=16, d_ff=32, d_layers=2, d_heads=int(g["d_heads"]), m_latent=16, m_ff=32, m_layers=2, m_heads=int(g["m_heads"]),
+                mixing_mode=mode, align=align, force_influence_val=force, model2_kind=model2_kind, cfg_scale=float(g["cfg_scale"]),
+                max_batch=max_batch, max_frames=16)
+    s.load_state_dict(W)
+    s.set_norm_stats(g["mean_hml"], g["std_hml"], g["mean_ih"], g["std_ih"])
+    s.prepare()
+    return s, g, t
+
+
+@pytest.mark.parametrize("mode,align,force", [(4, True, None), (4, False, None), (4, True, 0.0), (4, True, 1.0), (1, True, None),
+                                              (2, True, None), (3, True, None), (3, False, None)])
+def test_mixer_forward_vs_reference_golden(golden, mode, align, force):
+    """HIP Mixer.forward == the reference's Mixer.forward output captured in tests/golden/mixer.npz."""
+    s, g, t = golden_sampler(golden, mode, align, force)
+    out = s.module_forward(2, t("x1"), t("cond"), int(g["t"][0]), x2=t("x2"))
+    assert_close(out, t(f"fwd:m{mode}:a{int(align)}:f{force}"), what="Mixer.forward", **STEP_TOL)
+    s.close()
+
+
+def test_mixer_forward_intergen_golden(golden):
+    s, g, t = golden_sampler(golden, model2_kind=1)
+    out = s.module_forward(2, t("x1"), t("cond"), int(g["t"][0]), x2=t("x2"))
+    assert_close(out, t("fwd:intergen"), what="Mixer.forward (InterGen)", **STEP_TOL)
+    s.close()
+
+
+def test_denoisers_vs_reference_golden(golden):
+    from mixermdm_amd.sampler import Sampler
+    g, w, t = golden("denoisers")
+    H = int(g["H"])
+    # module_forward shares one t across rows: run each fixture row's timestep separately
+    for kind, key, which, xk, ck in [(0, "ind.", 0, "x_ind", "cond_ind"), (0, "int.", 1, "x_int", "cond_int"), (1, "ig.", 1, "x_int", "cond_int")]:
+        W = {}
+        sd = w(key)
+        if which == 0:
+            W.update({"denoiser1." + k: v for k, v in sd.items()})
+            s = Sampler(d_latent=16, d_ff=32, d_layers=2, d_heads=H, single_only=True, max_batch=1, max_frames=16)
+        else:
+            from mixermdm_amd.synthetic import synthetic_state_dict
+            W = synthetic_state_dict(d_latent=16, d_ff=32, d_layers=2, m_latent=16, m_ff=32, m_layers=2)
+            W.update({"denoiser2." + k: v for k, v in sd.items()})
+            s = Sampler(d_latent=16, d_ff=32, d_layers=2, d_heads=H, m_latent=16, m_ff=32, m_layers=2, m_heads=2, model2_kind=kind,
+                        max_batch=1, max_frames=16)
+            s.set_norm_stats(*[np.ones(262, np.float32)] * 4)
+        s.load_state_dict(W)
+        s.prepare()
+        ref = t(key[:-1] + ":out")
+        for row, tt in enumerate(g["t"]):
+            x = t(xk)[row:row + 1].repeat(2, 1, 1)
+            c = t(ck)[row:row + 1].repeat(2, 1)
+            out = s.module_forward(which, x, c, int(tt))
+            assert_close(out[0], ref[row], atol=2e-5, rtol=1e-4, what=f"{key} row {row}")
+        s.close()
+
+
+def test_ddim_step_and_loop_vs_reference_golden(golden):
+    """Teacher-forced DDIM steps (i = 32 and i = 0) and the full ddim50 / ddim20 loops against the reference."""
+    s, g, t = golden_sampler(golden)
+    B = t("cfg_x").shape[0]
+    sch = s.set_schedule("ddim50")
+    for i in [32, 0]:
+        s.begin(t("cfg_cond"), t("cfg_x"))
+        st = s.state()
+        st["x2"].copy_(t("cfg_x2").to(dev()))
+        # jump to respaced index i: run S-1-i steps is not teacher-forced, so poke the device step word instead
+        _set_step(s, i)
+        s.run(1, use_graph=False)
+        st = s.state()
+        for k, nm in [("sample", "x"), ("sample2", "x2"), ("pred_xstart", "pred_xstart"), ("pred_xstart2", "pred_xstart2")]:
+            assert_close(st[nm], t(f"ddim:i{i}:{k}"), what=f"i={i} {k}", **STEP_TOL)
+    for strat in ["ddim50", "ddim20"]:
+        s.set_schedule(strat)
+        out, hist = s.sample(t("cfg_cond"), t(f"loop:{strat}:x_T"), use_graph=True,
+                             history=("influence_i1", "influence_i2", "out1", "out2", "out_influenced"))
+        ref = g[f"loop:{strat}:output"]
+        d = np.abs(out.cpu().numpy() - ref)
+        # same distributional bound the CPU oracle meets against the reference (tests/test_oracle_golden.py::test_mixer_loop)
+        assert d.mean() <= 2e-3 and np.percentile(d, 99) <= 3e-2, (strat, d.mean(), d.max())
+        n = int(g[f"loop:{strat}:nsteps"])
+        for name in ["influence_i1", "influence_i2", "out1", "out2", "out_influenced"]:
+            assert hist[name].shape[0] == n and hist[name].shape[1] == 2 * B
+            sums = hist[name].double().abs().sum(dim=(1, 2, 3)).cpu().numpy()
+            np.testing.assert_allclose(sums[:-1], g[f"loop:{strat}:{name}:abssum"][:-1], rtol=2e-3)
+            if strat == "ddim50":
+                assert_close(hist[name][0], t(f"loop:{strat}:{name}:0"), what=name + "[0]", **STEP_TOL)
+    s.close()
+
+
+def _set_step(s, i):
+    """Test helper: overwrite the device-side (step_idx, loop_pos) words through a 1-step-per-index schedule walk."""
+    # run (S-1-i) no-op-free alternative: re-begin and run until index i would be slow; instead use the C ABI directly
+    import ctypes as C
+    S = s.schedule.num_timesteps
+    # walk: begin() leaves step = S-1; run_step decrements. For teacher forcing keep x/x2 and only move the index:
+    x, x2 = s.state()["x"].clone(), s.state()["x2"].clone()
+    if S - 1 - i > 0:
+        s.run(S - 1 - i, use_graph=False)
+        st = s.state()
+        st["x"].copy_(x)
+        st["x2"].copy_(x2)
+        torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------
+# real model dimensions vs the oracle
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full():
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_stats, FULL_DIMS
+    sd = synthetic_state_dict(seed=0, std=0.02, bias_std=0.02, **FULL_DIMS)
+    stats = synthetic_stats()
+    s = Sampler(d_heads=8, m_heads=8, max_batch=2, max_frames=64, **FULL_DIMS)
+    s.load_state_dict(sd)
+    s.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+    s.prepare()
+    W = dict(sd)
+    W["sequence_pos_encoder.pe"] = pe_table(512)
+    W["denoiser1.sequence_pos_encoder.pe"] = pe_table(1024)
+    W["denoiser2.sequence_pos_encoder.pe"] = pe_table(1024)
+    ostats = (stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+    yield s, W, ostats
+    s.close()
+
+
+def test_full_size_denoisers_vs_oracle(full):
+    s, W, _ = full
+    n, T, t = 2, 48, 777
+    x1, x2 = rnd(80, n, T, 262), rnd(81, n, T, 524)
+    c1, c3 = rnd(82, n, 768), rnd(83, n, 3 * 768)
+    ts = torch.full((n,), t, dtype=torch.long)
+    ref = DN.in2in_denoiser(W, "denoiser1.", "individual", x1, ts, c1, 8)
+    assert_close(s.module_forward(0, x1, c1, t), ref, atol=1e-4, rtol=1e-3, what="denoiser1 full size")
+    ref = DN.in2in_denoiser(W, "denoiser2.", "interaction", x2, ts, c3, 8)
+    assert_close(s.module_forward(1, x2, c3, t), ref, atol=1e-4, rtol=1e-3, what="denoiser2 full size")
+
+
+def test_full_size_step_vs_oracle(full):
+    s, W, ostats = full
+    from mixermdm_amd.synthetic import synthetic_inputs
+    B, T = 2, 40
+    cond, xT = synthetic_inputs(B, T)
+    spec = MX.MixerSpec(d_heads=8, m_heads=8)
+    osch = OS.make_schedule("cosine", 1000, "ddim50")
+    s.set_schedule("ddim50")
+    s.begin(cond, xT)
+    s.run(1, use_graph=False)
+    st = s.state()
+    rx, rx2, p1, p2 = MX.mixer_ddim_step(W, spec, ostats, osch, 3.5, 49, xT, xT, cond)
+    for nm, ref in [("x", rx), ("x2", rx2), ("pred_xstart", p1), ("pred_xstart2", p2)]:
+        assert_close(st[nm], ref, what="full-size step " + nm, **STEP_TOL)
+    # second step from the oracle's state (teacher forced) exercises chains that differ
+    st["x"].copy_(rx.to(dev()))
+    st["x2"].copy_(rx2.to(dev()))
+    torch.cuda.synchronize()
+    s.run(1, use_graph=False)
+    st = s.state()
+    rx, rx2, p1, p2 = MX.mixer_ddim_step(W, spec, ostats, osch, 3.5, 48, rx, rx2, cond)
+    for nm, ref in [("x", rx), ("x2", rx2)]:
+        assert_close(st[nm], ref, what="full-size step 2 " + nm, **STEP_TOL)
+
+
+def test_graph_replay_equals_eager_and_is_deterministic(full):
+    s, W, _ = full
+    from mixermdm_amd.synthetic import synthetic_inputs
+    cond, xT = synthetic_inputs(2, 32)
+    s.set_schedule("ddim20")
+    a = s.sample(cond, xT, use_graph=False)
+    b = s.sample(cond, xT, use_graph=True)
+    c = s.sample(cond, xT, use_graph=True)
+    assert torch.equal(a, b) and torch.equal(b, c)
+    assert torch.isfinite(a).all()
+
+
+def test_batch_rows_are_independent(full):
+    """Sharding property: sample k of a batch == the same sample run alone (bitwise) -> multi-GPU shards
+    reproduce the single-GPU result without any cross-GPU math."""
+    s, W, _ = full
+    from mixermdm_amd.synthetic import synthetic_inputs
+    cond, xT = synthetic_inputs(2, 24)
+    s.set_schedule("ddim20")
+    both = s.sample(cond, xT)
+    for k in range(2):
+        one = s.sample(cond[k:k + 1], xT[k:k + 1])
+        assert torch.equal(one[0], both[k]), k
+
+
+def test_history_stride_and_slots(full):
+    s, W, _ = full
+    from mixermdm_amd.synthetic import synthetic_inputs
+    cond, xT = synthetic_inputs(1, 16)
+    s.set_schedule("ddim20")
+    out, h1 = s.sample(cond, xT, history=("influence_i1", "out_influenced"), history_every=1)
+    out2, h4 = s.sample(cond, xT, history=("influence_i1", "out_influenced"), history_every=4)
+    assert torch.equal(out, out2)
+    assert h1["influence_i1"].shape == (20, 2, 16, 262) and h4["influence_i1"].shape == (5, 2, 16, 262)
+    for k in range(5):
+        assert torch.equal(h4["influence_i1"][k], h1["influence_i1"][4 * k])
+        assert torch.equal(h4["out_influenced"][k], h1["out_influenced"][4 * k])
+    w = h1["influence_i1"]
+    assert (w >= 0).all() and (w <= 1).all()
+
+
+def test_single_chain_vs_reference_golden(golden):
+    from mixermdm_amd.sampler import Sampler
+    g, w, t = golden("single")
+    s = Sampler(d_latent=16, d_ff=32, d_layers=2, d_heads=int(g["H"]), single_only=True, cfg_scale=float(g["cfg_scale"]), max_batch=2, max_frames=16)
+    s.load_state_dict({"denoiser1." + k: v for k, v in w("ind.").items()})
+    s.prepare()
+    for strat in ["ddim50", "ddim20"]:
+        s.set_schedule(strat)
+        out = s.sample(t("cond"), t("x_T"))
+        d = np.abs(out.cpu().numpy() - g[f"loop:{strat}:output"])
+        assert d.mean() <= 1e-4 and d.max() <= 1e-2, (d.mean(), d.max())
+    s.close()
+
+
+def test_errors_are_loud(golden):
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd import MMDMError
+    from mixermdm_amd.synthetic import synthetic_state_dict
+    dims = dict(d_latent=16, d_ff=32, d_layers=1, m_latent=16, m_ff=32, m_layers=1)
+    s = Sampler(d_heads=2, m_heads=2, max_batch=1, max_frames=8, **dims)
+    sd = synthetic_state_dict(**dims)
+    with pytest.raises(MMDMError, match="Unexpected key"):
+        s.load_state_dict({"nonsense.weight": torch.zeros(2, 2)})
+    with pytest.raises(MMDMError, match="size mismatch"):
+        s.load_state_dict({"motion_embed.weight": torch.zeros(16, 100)})
+    missing = dict(sd)
+    missing.pop("influence.out.weight")
+    s.load_state_dict(missing)
+    s.set_norm_stats(*[np.ones(262, np.float32)] * 4)
+    with pytest.raises(MMDMError, match="Missing key"):
+        s.prepare()
+    s.load_state_dict(sd)
+    s.prepare()
+    s.set_schedule("ddim20")
+    with pytest.raises(MMDMError, match="exceed"):
+        s.begin(torch.zeros(2, 8 * 768), torch.zeros(2, 8, 524))
+    s.begin(torch.zeros(1, 8 * 768), torch.zeros(1, 8, 524))
+    with pytest.raises(MMDMError, match="left in the schedule"):
+        s.run(21)
+    with pytest.raises(ValueError, match="Mode not recognized"):
+        Sampler(d_heads=2, m_heads=2, max_batch=1, max_frames=8, mixing_mode=9, **dims)
+    s.close()
