@@ -59,6 +59,11 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm ships its own libamdhip64.so (soname libamdhip64.so.7) and finds it by file name through an RPATH.
+    # Load torch FIRST so that this library's NEEDED libamdhip64.so.7 binds to the runtime torch uses (one HIP runtime
+    # per process: device pointers and streams are shared with torch).  Loaded the other way round, two runtimes
+    # coexist and every HIP call from here reports "no ROCm-capable device".
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise MMDMError(f"{path} not found: build it with `python -m mixermdm_amd.build` (hipcc, gfx950). "

@@ -605,6 +605,7 @@ extern "C" int mmdm_set_schedule(mmdm_handle h, const int* timestep_map, const f
         HIPCHK(hipMemcpyAsync(h->d_coef + (size_t)k * S, coef + (size_t)k * S, S * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));   // host buffers may be transient
     h->S = S;
+    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // S is a kernel argument baked into the graph
     Ctx c{h, st};
     const bool pon = h->prof.on;
     h->prof.on = false;
@@ -718,6 +719,7 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
     const int S_keep = h->S;
     h->S = 1;
     h->begun = false;
+    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     int rc = MMDM_OK;
     HIPCHK(hipMemcpyAsync(h->d_tmap, &t, sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
