@@ -1,0 +1,331 @@
+"""Host-side mirror of the reference's `src/models` operator API for the denoising path, backed by libmmdm_hip.so.
+
+Reference surface mirrored:
+  * ``MixerMDM(cfg, num_frames=300, sampling_strategy="ddim50", store_influence=True, align=True)`` with
+    ``forward(batch)`` / ``forward_test(batch)`` / ``load_state_dict`` and the knobs ``.mixing.mode``,
+    ``.mixing.force_influence_val``, ``.mixing_mode``, ``.sampling_strategy``, ``.cfg_mixing_weight``
+    (src/models/mixermdm.py:18-19, 490-602);
+  * the inner callables: ``Mixer(x1, timesteps, cond, mask, x2)`` (mixermdm.py:660), denoisers
+    ``f(x, timesteps, cond=, mask=)`` (in2in.py:401), ``ClassifierFreeSampleModelX2`` (cfg_sampler.py:31-56) and
+    ``MixerDiffusion.ddim_sample_loop`` (gaussian_diffusion.py:1769-1820).
+
+Python only moves pointers: parameters live in torch tensors under the reference's state_dict key names and are copied
+into the HIP handle's packed layout; every arithmetic op of the loop is a HIP kernel.  Text encoding (CLIP tower +
+clipTransEncoder, mixermdm.py:283-356) is upstream of this path: pass ``batch["cond"]`` ([B, 8*768], layout
+mixermdm.py:342-354) or register ``text_encoder``.
+"""
+import os
+import numpy as np
+import torch
+from torch import nn
+
+from .configs import get_config
+from .sampler import Sampler, pe_table
+from .schedule import get_named_beta_schedule, space_timesteps, RespacedSchedule
+from .synthetic import mixer_shapes, synthetic_state_dict, synthetic_stats
+
+# state_dict prefixes of the reference's MixerMDM that are NOT on the denoising path (CLIP tower, sub-model facades,
+# training-only discriminators); accepted and ignored by load_state_dict.
+OFF_PATH_PREFIXES = ("model1.", "model2.", "denoiser1.", "denoiser2.", "discriminator_i.", "discriminator_I.", "clipTransEncoder.", "clip_ln.",
+                     "token_embedding.", "clip_transformer.", "positional_embedding", "ln_final.")
+
+HISTORY_BUDGET_BYTES = 32 << 30
+
+
+def _holder_tree(root, name, tensor):
+    """Register `tensor` as parameter `name` ("a.b.0.weight") on nested container modules so that state_dict() yields the
+    reference's key names."""
+    parts = name.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class _Callable(nn.Module):
+    """Base of the inner callables: shares the owner's sampler."""
+
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)
+
+    @staticmethod
+    def _uniform_t(timesteps):
+        t = timesteps.reshape(-1)
+        if not bool((t == t[0]).all()):
+            raise NotImplementedError("the HIP path runs one timestep per call (the sampler always passes t = [i]*B: gaussian_diffusion.py:1872)")
+        return int(t[0])
+
+
+class DenoiserHandle(_Callable):
+    """in2INDenoiser / InterDenoiser protocol: f(x [n,T,nf*k], timesteps [n], cond=[n,.], mask=None) -> [n,T,nf*k]."""
+
+    def __init__(self, owner, which):
+        super().__init__(owner)
+        self.which = which
+        self.text_dim = 768
+
+    def forward(self, x, timesteps, mask=None, cond=None):
+        if mask is not None:
+            raise NotImplementedError("key_padding masks are not used on the inference path (mask=None: mixermdm.py:533)")
+        n = x.shape[0]
+        if n % 2:
+            raise ValueError("the HIP denoiser works on the CFG-doubled batch (even number of rows)")
+        smp = self._owner._sampler_for(n // 2, x.shape[1])
+        return smp.module_forward(self.which, x, cond, self._uniform_t(timesteps))
+
+
+class Mixer(_Callable):
+    """Mixer.forward protocol (mixermdm.py:660): out_influenced for the CFG-doubled batch.  Holds the reference's knobs."""
+
+    def __init__(self, owner, mixing_mode, store_influence, force_influence_val, mode="train", align=True):
+        super().__init__(owner)
+        self.mixing_mode = mixing_mode
+        self.store_influence = store_influence
+        self.force_influence_val = force_influence_val
+        self.mode = mode
+        self.align = align
+        self.history_influence_i1, self.history_influence_i2 = [], []
+        self.history_out1, self.history_out2, self.history_out_influenced = [], [], []
+
+    def forward(self, x1, timesteps, cond=None, mask=None, x2=None):
+        if mask is not None:
+            raise NotImplementedError("mask must be None on the inference path")
+        if self.mixing_mode not in (1, 2, 3, 4):
+            raise ValueError("Mixing mode not recognized")
+        smp = self._owner._sampler_for(x1.shape[0] // 2, x1.shape[1])
+        return smp.module_forward(2, x1, cond, self._uniform_t(timesteps), x2=x2)
+
+
+class ClassifierFreeSampleModelX2(nn.Module):
+    """cfg_sampler.py:31-56: the doubling and the s*cond + (1-s)*uncond combine happen inside the HIP step."""
+
+    def __init__(self, model, cfg_scale):
+        super().__init__()
+        self.model = model
+        self.s = cfg_scale
+
+
+class MixerDiffusion:
+    """Two-chain DDIM sampler (gaussian_diffusion.py:1434-1463, 1769-1965): schedule tables on the host, loop on the GPU."""
+
+    def __init__(self, use_timesteps, align=True, *, betas, **kwargs):
+        self.align = align
+        self.schedule = RespacedSchedule(betas, use_timesteps)
+        self.timestep_map = self.schedule.timestep_map
+        self.num_timesteps = self.schedule.num_timesteps
+        self.original_num_steps = self.schedule.original_num_steps
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                         device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None, randomize_class=False,
+                         cond_fn_with_grad=False, dump_steps=None, const_noise=False, x_start=None):
+        if dump_steps is not None or const_noise:
+            raise NotImplementedError()                                   # gaussian_diffusion.py:1794-1797
+        if clip_denoised or denoised_fn is not None or cond_fn is not None or eta != 0.0 or skip_timesteps or init_image is not None \
+                or randomize_class or cond_fn_with_grad or x_start is not None:
+            raise NotImplementedError("HIP sampler implements the configuration MixerMDM.forward uses: clip_denoised=False, eta=0, no guidance fn")
+        mixer = model.model if isinstance(model, ClassifierFreeSampleModelX2) else model
+        owner = mixer._owner
+        model_kwargs = model_kwargs or {}
+        if model_kwargs.get("mask") is not None:
+            raise NotImplementedError("mask must be None")
+        cond = model_kwargs["cond"]
+        B, T, _ = shape
+        dev = owner.device
+        x_T = noise if noise is not None else torch.randn(*shape, device=dev)
+        return owner._run_loop(self, cond, x_T, cfg_scale=getattr(model, "s", owner.cfg_mixing_weight))
+
+
+class MixerMDM(nn.Module):
+    def __init__(self, cfg, num_frames=300, sampling_strategy="ddim50", store_influence=True, align=True, config_root=None):
+        super().__init__()
+        self.cfg = cfg
+        root = config_root or os.getcwd()
+        self.cfg_model1 = get_config(os.path.join(root, cfg.MODEL1) if not os.path.isabs(cfg.MODEL1) else cfg.MODEL1)
+        self.cfg_model2 = get_config(os.path.join(root, cfg.MODEL2) if not os.path.isabs(cfg.MODEL2) else cfg.MODEL2)
+        if self.cfg_model1.NAME != "in2INind":
+            raise NotImplementedError(f"MODEL1.NAME={self.cfg_model1.NAME}: only in2INind is built so far (MDM: SURVEY 8f-3)")
+        if self.cfg_model2.NAME not in ("in2IN", "InterGen"):
+            raise NotImplementedError(f"MODEL2.NAME={self.cfg_model2.NAME}")
+        self.align = align
+        self.store_influence = store_influence
+        self.num_frames = num_frames
+        g = cfg.GENERATOR if "GENERATOR" in cfg else cfg
+        self.nfeats = g.INPUT_DIM
+        self.dims = dict(d_latent=self.cfg_model1.LATENT_DIM, d_ff=self.cfg_model1.FF_SIZE, d_layers=self.cfg_model1.NUM_LAYERS,
+                         m_latent=g.LATENT_DIM, m_ff=g.FF_SIZE, m_layers=g.NUM_LAYERS)
+        self.d_heads, self.m_heads = self.cfg_model1.NUM_HEADS, g.NUM_HEADS
+        for k in ("LATENT_DIM", "FF_SIZE", "NUM_LAYERS", "NUM_HEADS"):
+            if self.cfg_model1[k] != self.cfg_model2[k]:
+                raise NotImplementedError("denoiser1 and denoiser2 must share dimensions (as configs/models/{individual,in2IN}.yaml do)")
+        self.cfg_mixing_weight = cfg.CFG_WEIGHT
+        self.text_dim = 768
+        self.mixing_mode = cfg.MIXING_MODE
+        self.diffusion_steps = cfg.DIFFUSION_STEPS
+        self.beta_scheduler = cfg.BETA_SCHEDULER
+        self.sampling_strategy = sampling_strategy
+        self.betas = get_named_beta_schedule(self.beta_scheduler, self.diffusion_steps)
+        self.history_every = 1
+        self.text_encoder = None            # callable(batch) -> cond [B, 8*768]; upstream of the hot path
+        self.mixing = Mixer(self, self.mixing_mode, store_influence, cfg.FORCE_INFLUENCE_VAL, align=align)
+        self.mixing.add_module("denoiser1", DenoiserHandle(self, 0))
+        self.mixing.add_module("denoiser2", DenoiserHandle(self, 1))
+        # the reference also exposes them as .denoiser1/.denoiser2 (mixermdm.py:67-68); plain attributes here, not re-registered
+        object.__setattr__(self, "denoiser1", self.mixing.denoiser1)
+        object.__setattr__(self, "denoiser2", self.mixing.denoiser2)
+        # parameters under the reference's key names (mixing.*), zero-initialised until loaded
+        for k, shp in mixer_shapes(mixing_mode=self.mixing_mode, **self.dims).items():
+            _holder_tree(self, "mixing." + k, torch.zeros(shp))
+        self._sampler = None
+        self._dirty = True
+        self._stats = None
+        self._try_load_norm_stats()
+
+    # ---- weights / stats -----------------------------------------------------------------------------
+    def _try_load_norm_stats(self):
+        """MotionNormalizerTorch{,HML3D}.__init__ paths (src/utils/utils.py:46-47, 66-67)."""
+        paths = ["./data/HumanML3D/mean_ih_new.npy", "./data/HumanML3D/std_ih_new.npy", "./data/global_mean.npy", "./data/global_std.npy"]
+        if all(os.path.exists(p) for p in paths):
+            self.set_norm_stats(*[np.load(p) for p in paths])
+
+    def set_norm_stats(self, mean_hml, std_hml, mean_ih, std_ih):
+        self._stats = [np.asarray(a, dtype=np.float32).reshape(262) for a in (mean_hml, std_hml, mean_ih, std_ih)]
+        self._dirty = True
+
+    def init_synthetic(self, seed=0, std=0.02, bias_std=0.0, stats_seed=3):
+        """Random-init weights of the reference architecture + synthetic normaliser stats (no checkpoints offline)."""
+        sd = synthetic_state_dict(seed=seed, std=std, bias_std=bias_std, mixing_mode=self.mixing_mode, **self.dims)
+        self.load_state_dict({"mixing." + k: v for k, v in sd.items()})
+        st = synthetic_stats(stats_seed)
+        self.set_norm_stats(st["mean_hml"], st["std_hml"], st["mean_ih"], st["std_ih"])
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        own = {k for k, _ in self.named_parameters()}
+        mine, unexpected = {}, []
+        for k, v in state_dict.items():
+            if k in own:
+                mine[k] = v
+            elif k.endswith("sequence_pos_encoder.pe") or k.startswith(OFF_PATH_PREFIXES):
+                continue                       # regenerated tables / off-path modules of the reference's checkpoint
+            else:
+                unexpected.append(k)
+        missing = sorted(own - set(mine))
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict for MixerMDM:\n\tMissing key(s): %s\n\tUnexpected key(s): %s" % (missing[:8], unexpected[:8]))
+        params = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, v in mine.items():
+                if tuple(v.shape) != tuple(params[k].shape):
+                    raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)}, the shape in current model is {tuple(params[k].shape)}")
+                params[k].copy_(v)
+        self._dirty = True
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def _apply(self, fn, recurse=True):
+        self._dirty = True
+        return super()._apply(fn, recurse)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def _sampler_for(self, B, T):
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("MixerMDM runs on an MI355X only: call .to('cuda:N') first (no CPU path)")
+        m = self.mixing
+        key = (str(dev), m.mixing_mode, bool(m.align), m.force_influence_val, self.cfg_model2.NAME)
+        s = self._sampler
+        if s is None or s._key != key or B > s.cfg.max_batch or T > s.cfg.max_frames:
+            if s is not None:
+                s.close()
+            s = Sampler(d_heads=self.d_heads, m_heads=self.m_heads, mixing_mode=m.mixing_mode, align=m.align, xstart_align=True,
+                        model2_kind=1 if self.cfg_model2.NAME == "InterGen" else 0, force_influence_val=m.force_influence_val,
+                        cfg_scale=self.cfg_mixing_weight, max_batch=max(B, s.cfg.max_batch if s else 1),
+                        max_frames=max(T, self.num_frames), device=dev, **self.dims)
+            s._key = key
+            self._sampler, self._dirty = s, True
+        if self._dirty:
+            if self._stats is None:
+                raise RuntimeError("normaliser statistics missing: ./data/global_{mean,std}.npy and ./data/HumanML3D/{mean,std}_ih_new.npy "
+                                   "not found (src/utils/utils.py:46-47,66-67); call set_norm_stats(...)")
+            s.load_state_dict({k[len("mixing."):]: p.data for k, p in self.named_parameters()})
+            s.set_norm_stats(*self._stats)
+            s.prepare()
+            s._strategy = None
+            self._dirty = False
+        return s
+
+    # ---- conditioning -------------------------------------------------------------------------------
+    def generate_cond(self, batch):
+        if "cond" in batch:
+            return batch["cond"]
+        if self.text_encoder is None:
+            raise NotImplementedError("text encoding (CLIP ViT-L/14 tower + clipTransEncoder, mixermdm.py:283-356) is upstream of the HIP path: "
+                                      "pass batch['cond'] [B, 8*768] or set model.text_encoder")
+        return self.text_encoder(batch)
+
+    # ---- sampling -----------------------------------------------------------------------------------
+    def _run_loop(self, diffusion, cond, x_T, cfg_scale=None):
+        B, T = x_T.shape[:2]
+        smp = self._sampler_for(B, T)
+        if cfg_scale is not None and float(cfg_scale) != float(smp.cfg.cfg_scale):
+            self.cfg_mixing_weight = cfg_scale
+            smp.close()
+            self._sampler = None
+            smp = self._sampler_for(B, T)
+        sch = diffusion.schedule
+        if getattr(smp, "_strategy", None) is not sch:
+            import ctypes as C
+            from ._lib import check
+            tmap = np.ascontiguousarray(np.array(sch.timestep_map, dtype=np.int32))
+            coef = np.ascontiguousarray(sch.device_coefficients())
+            with torch.cuda.device(smp.device):
+                check(smp.lib.mmdm_set_schedule(smp.h, tmap.ctypes.data_as(C.c_void_p), coef.ctypes.data_as(C.c_void_p), sch.num_timesteps, smp._s()), smp.h)
+            smp.schedule, smp._strategy = sch, sch
+        m = self.mixing
+        names = []
+        if m.store_influence:
+            names += ["influence_i1", "influence_i2"]
+        if m.mode == "eval":
+            names += ["out1", "out2", "out_influenced"]
+        slots = (sch.num_timesteps + self.history_every - 1) // self.history_every
+        need = slots * 2 * B * T * 4 * sum(262 if n.startswith("influence") else 524 for n in names)
+        if need > HISTORY_BUDGET_BYTES:
+            raise MemoryError(f"history side outputs need {need / 2**30:.1f} GiB for {sch.num_timesteps} steps (the reference keeps every step: "
+                              "mixermdm.py:794-808); set model.history_every = k to keep every k-th step, or store_influence=False / forward_test")
+        smp.begin(cond, x_T)
+        hist = smp.set_history(names, self.history_every) if names else {}
+        smp.run(None, use_graph=True)
+        out = smp.state()["pred_xstart2"].clone()
+        torch.cuda.current_stream(smp.device).wait_stream(smp.stream)
+        as_list = lambda n: list(hist[n].unbind(0)) if n in hist else []
+        m.history_influence_i1, m.history_influence_i2 = as_list("influence_i1"), as_list("influence_i2")
+        m.history_out1, m.history_out2, m.history_out_influenced = as_list("out1"), as_list("out2"), as_list("out_influenced")
+        return out
+
+    def _sample(self, batch, mode):
+        self.mixing.mode = mode
+        cond = self.generate_cond(batch)
+        B = cond.shape[0]
+        T = int(batch["motion_lens"][0])
+        self.diffusion_test = MixerDiffusion(use_timesteps=space_timesteps(self.diffusion_steps, self.sampling_strategy), betas=self.betas)
+        self.cfg_model = ClassifierFreeSampleModelX2(self.mixing, self.cfg_mixing_weight)
+        return self.diffusion_test.ddim_sample_loop(self.cfg_model, (B, T, self.nfeats * 2), noise=batch.get("x_T"), clip_denoised=False,
+                                                    progress=True, model_kwargs={"mask": None, "cond": cond}, x_start=None)
+
+    def forward(self, batch):
+        """mixermdm.py:490-548."""
+        output = self._sample(batch, "eval")
+        m = self.mixing
+        return {"output": output, "influence_i1": m.history_influence_i1, "influence_i2": m.history_influence_i2,
+                "out1": m.history_out1, "out2": m.history_out2, "out_influenced": m.history_out_influenced}
+
+    def forward_test(self, batch):
+        """mixermdm.py:550-602."""
+        output = self._sample(batch, "eval_intermediate")
+        m = self.mixing
+        return {"output": output, "influence_i1": m.history_influence_i1, "influence_i2": m.history_influence_i2}

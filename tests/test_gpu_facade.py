@@ -1,0 +1,84 @@
+"""GPU: the reference-API mirror (mixermdm_amd.models.MixerMDM) end to end on the reference's golden loop."""
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_model(tmp_path, golden, strategy="ddim50", **kw):
+    from mixermdm_amd.configs import CfgNode
+    from mixermdm_amd.models import MixerMDM
+    g, w, t = golden("mixer")
+    sub = dict(NUM_LAYERS=2, NUM_HEADS=int(g["d_heads"]), DROPOUT=0.1, INPUT_DIM=262, LATENT_DIM=16, FF_SIZE=32)
+    for name, nm in [("individual.yaml", "in2INind"), ("in2IN.yaml", "in2IN")]:
+        yaml.safe_dump(dict(NAME=nm, **sub), open(tmp_path / name, "w"))
+    cfg = CfgNode(dict(NAME="MixerMDM", GENERATOR=dict(sub, NUM_HEADS=int(g["m_heads"])), DISCRIMINATOR=dict(sub), ACTIVATION="gelu",
+                       DIFFUSION_STEPS=1000, BETA_SCHEDULER="cosine", SAMPLER="uniform", MOTION_REP="global", CFG_WEIGHT=float(g["cfg_scale"]),
+                       MIXING_MODE=4, FORCE_INFLUENCE_VAL="None", MODEL1="individual.yaml", MODEL2="in2IN.yaml"))
+    m = MixerMDM(cfg, num_frames=16, sampling_strategy=strategy, config_root=str(tmp_path), **kw)
+    sd = {"mixing." + k: v for k, v in w("mix.").items()}
+    sd["model1.decoder.net_individual.out.linear.bias"] = torch.zeros(262)      # an off-path key of the real checkpoint
+    m.load_state_dict(sd, strict=True)
+    m.set_norm_stats(g["mean_hml"], g["std_hml"], g["mean_ih"], g["std_ih"])
+    return m.to("cuda:0").eval(), g, t
+
+
+def test_forward_matches_reference_loop_and_history_contract(tmp_path, golden):
+    m, g, t = tiny_model(tmp_path, golden)
+    B, T = t("loop:ddim50:x_T").shape[:2]
+    batch = {"cond": t("cfg_cond").cuda(), "x_T": t("loop:ddim50:x_T").cuda(), "motion_lens": torch.tensor([[T]] * B)}
+    out = m(batch)
+    assert set(out) == {"output", "influence_i1", "influence_i2", "out1", "out2", "out_influenced"}
+    assert out["output"].shape == (B, T, 524) and out["output"].is_cuda
+    d = np.abs(out["output"].cpu().numpy() - g["loop:ddim50:output"])
+    assert d.mean() <= 2e-3 and np.percentile(d, 99) <= 3e-2, (d.mean(), d.max())
+    assert len(out["influence_i1"]) == 50 and out["influence_i1"][0].shape == (2 * B, T, 262)
+    assert len(out["out1"]) == 50 and out["out_influenced"][0].shape == (2 * B, T, 524)
+    assert m.mixing.mode == "eval"
+    np.testing.assert_allclose(out["influence_i1"][0].cpu().numpy(), g["loop:ddim50:influence_i1:0"], atol=2e-4, rtol=2e-4)
+
+    out_t = m.forward_test(batch)
+    assert set(out_t) == {"output", "influence_i1", "influence_i2"} and m.mixing.mode == "eval_intermediate"
+    assert torch.equal(out_t["output"], out["output"])
+
+    m.sampling_strategy = "ddim20"                       # knob used by the eval scripts
+    batch["x_T"] = t("loop:ddim20:x_T").cuda()
+    out20 = m.forward_test(batch)
+    d = np.abs(out20["output"].cpu().numpy() - g["loop:ddim20:output"])
+    assert d.mean() <= 2e-3 and len(out20["influence_i1"]) == 20
+
+
+def test_knobs_force_influence_and_inner_callables(tmp_path, golden):
+    m, g, t = tiny_model(tmp_path, golden)
+    x1, x2, cond = t("x1").cuda(), t("x2").cuda(), t("cond").cuda()
+    ts = t("t").long().cuda()
+    ref = g["fwd:m4:a1:fNone"]
+    got = m.mixing(x1, ts, cond=cond, mask=None, x2=x2)
+    bad = np.abs(got.cpu().numpy() - ref) > 2e-4 + 2e-4 * np.abs(ref)
+    assert bad.mean() <= 5e-4
+    m.mixing.force_influence_val = 1.0                   # src/evaluation/datasets.py:301,323 flips this between runs
+    got = m.mixing(x1, ts, cond=cond, mask=None, x2=x2)
+    ref = g["fwd:m4:a1:f1.0"]
+    bad = np.abs(got.cpu().numpy() - ref) > 2e-4 + 2e-4 * np.abs(ref)
+    assert bad.mean() <= 5e-4
+    with pytest.raises(NotImplementedError):
+        m.mixing(x1, torch.tensor([1, 2, 3, 4]).cuda(), cond=cond, mask=None, x2=x2)
+    o = m.denoiser1(x1[..., :262], ts, cond=cond[:, 3 * 768:4 * 768], mask=None)
+    assert o.shape == (4, x1.shape[1], 262) and torch.isfinite(o).all()
+    m.mixing.mixing_mode = 9
+    with pytest.raises(ValueError, match="Mixing mode not recognized"):
+        m.mixing(x1, ts, cond=cond, mask=None, x2=x2)
+
+
+def test_history_budget_is_enforced(tmp_path, golden, monkeypatch):
+    import mixermdm_amd.models as M
+    m, g, t = tiny_model(tmp_path, golden, strategy="ddim1000")
+    monkeypatch.setattr(M, "HISTORY_BUDGET_BYTES", 2 << 20)
+    batch = {"cond": t("cfg_cond").cuda(), "motion_lens": torch.tensor([[8]])}
+    with pytest.raises(MemoryError, match="history_every"):
+        m(batch)
+    m.history_every = 250
+    out = m(batch)
+    assert len(out["influence_i1"]) == 4 and torch.isfinite(out["output"]).all()
