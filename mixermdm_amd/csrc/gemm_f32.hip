@@ -12,16 +12,13 @@
 // Global->LDS staging is register-staged (global_load_dwordx4 -> ds_write_b128): the padded image rules out LDS-DMA.
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles that share A rows.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BM = 128, BN = 128, BK = 32, LDP = 36;
-constexpr int TILE_FLOATS = BM * LDP;                 // one operand, one buffer
-constexpr int SMEM_BYTES = 4 * TILE_FLOATS * 4;       // A,B x 2 buffers = 73,728 B -> 2 workgroups / CU
 
 struct GemmArgs {
     const float* A; const float* W; const float* bias; float* C; const float* extra;
@@ -30,8 +27,9 @@ struct GemmArgs {
     int mt, nt;
 };
 
-template <int VEC>
+template <int VEC, bool FULL>
 __device__ __forceinline__ f32x4 load4(const float* __restrict__ base, int ld, int row, int nrows, int k, int K) {
+    if (FULL) return *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + k);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (row < nrows) {
         const float* p = base + (size_t)row * ld + k;
@@ -50,11 +48,28 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ base, int ld, i
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
-template <int AVEC, int WVEC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
+// Tile configuration: the workgroup is WGM x WGN waves (encoded as TM = 10*WGM + tiles, TN likewise: TM=22 -> 2 waves x 2 tiles),
+// each wave owns (TM%10) x (TN%10) MFMA tiles of 32x32; K step BK.
+template <int TM_, int TN_, int BK_>
+struct Cfg {
+    static constexpr int WGM = TM_ >= 10 ? TM_ / 10 : 2, WGN = TN_ >= 10 ? TN_ / 10 : 2;
+    static constexpr int TM = TM_ % 10, TN = TN_ % 10;
+    static constexpr int THREADS = 64 * WGM * WGN;
+    static constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = BK_, LDP = BK_ + 4;
+    static constexpr int A_FLOATS = BM * LDP, B_FLOATS = BN * LDP;
+    static constexpr int SMEM_BYTES = 2 * (A_FLOATS + B_FLOATS) * 4;
+    static constexpr int F4_PER_ROW = BK_ / 4, ROWS_PER_PASS = THREADS / F4_PER_ROW;
+    static constexpr int PA = BM / ROWS_PER_PASS, PB = BN / ROWS_PER_PASS;
+    static constexpr int G = BK_ / 8;                       // groups of 8 k (4 MFMA k-steps) per K step
+};
+
+template <int TM_, int TN_, int BK_, int AVEC, int WVEC, bool FULL>
+__global__ __launch_bounds__((Cfg<TM_, TN_, BK_>::THREADS)) void gemm_f32_kernel(GemmArgs p) {
+    using C_ = Cfg<TM_, TN_, BK_>;
+    constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, LDP = C_::LDP, TM = C_::TM, TN = C_::TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                      // [2][BM*LDP]
-    float* Bs = smem + 2 * TILE_FLOATS;    // [2][BN*LDP]
+    float* As = smem;                          // [2][BM*LDP]
+    float* Bs = smem + 2 * C_::A_FLOATS;       // [2][BN*LDP]
 
     // XCD-aware remap (bijective for any grid size): blocks b and b+8 share an XCD; give each XCD a contiguous tile range.
     const int nwg = p.mt * p.nt;
@@ -66,36 +81,50 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / C_::WGN, wn = wave % C_::WGN;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // staging map: 128 rows x 8 float4 per tile; thread -> rows (tid>>3) + 32j, float4 column tid&7
-    const int sr = tid >> 3, sc = (tid & 7) * 4;
+    // staging map: thread -> rows (tid / F4_PER_ROW) + ROWS_PER_PASS*j, float4 column tid % F4_PER_ROW
+    const int sr = tid / C_::F4_PER_ROW, sc = (tid % C_::F4_PER_ROW) * 4;
 
-    f32x16 acc[2][2];
+    // Accumulators start as bias (+ residual / + PE row): the epilogue's extra reads are issued here, where their latency
+    // overlaps the first operand loads and the co-resident workgroups' MFMAs, instead of after the last MFMA.
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (32 * TN) + j * 32 + l31;
+            const bool cok = FULL || col < p.N;
+            const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                float v = bv;
+                if (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) {
+                    const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (cok && (FULL || row < p.M)) {
+                        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+                        v += p.extra[(size_t)er * p.ld_extra + col];
+                    }
+                }
+                acc[i][j][e] = v;
+            }
+        }
 
     const int nkt = (p.K + BK - 1) / BK;
-    f32x4 ra[4], rb[4];
+    f32x4 ra[C_::PA], rb[C_::PB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        ra[j] = load4<AVEC>(p.A, p.lda, m0 + sr + 32 * j, p.M, sc, p.K);
-        rb[j] = load4<WVEC>(p.W, p.ldw, n0 + sr + 32 * j, p.N, sc, p.Kw);
-    }
+    for (int j = 0; j < C_::PA; ++j) ra[j] = load4<AVEC, FULL>(p.A, p.lda, m0 + sr + C_::ROWS_PER_PASS * j, p.M, sc, p.K);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<f32x4*>(&As[(sr + 32 * j) * LDP + sc]) = ra[j];
-        *reinterpret_cast<f32x4*>(&Bs[(sr + 32 * j) * LDP + sc]) = rb[j];
-    }
+    for (int j = 0; j < C_::PB; ++j) rb[j] = load4<WVEC, FULL>(p.W, p.ldw, n0 + sr + C_::ROWS_PER_PASS * j, p.N, sc, p.Kw);
+#pragma unroll
+    for (int j = 0; j < C_::PA; ++j) *reinterpret_cast<f32x4*>(&As[(sr + C_::ROWS_PER_PASS * j) * LDP + sc]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < C_::PB; ++j) *reinterpret_cast<f32x4*>(&Bs[(sr + C_::ROWS_PER_PASS * j) * LDP + sc]) = rb[j];
     __syncthreads();
 
-    const int a_off = (wm * 64 + l31) * LDP + 4 * lh;
-    const int b_off = (wn * 64 + l31) * LDP + 4 * lh;
+    const int a_off = (wm * (32 * TM) + l31) * LDP + 4 * lh;
+    const int b_off = (wn * (32 * TN) + l31) * LDP + 4 * lh;
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
@@ -103,77 +132,103 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
         if (more) {
             const int k0 = (kt + 1) * BK + sc;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ra[j] = load4<AVEC>(p.A, p.lda, m0 + sr + 32 * j, p.M, k0, p.K);
-                rb[j] = load4<WVEC>(p.W, p.ldw, n0 + sr + 32 * j, p.N, k0, p.Kw);
-            }
+            for (int j = 0; j < C_::PA; ++j) ra[j] = load4<AVEC, FULL>(p.A, p.lda, m0 + sr + C_::ROWS_PER_PASS * j, p.M, k0, p.K);
+#pragma unroll
+            for (int j = 0; j < C_::PB; ++j) rb[j] = load4<WVEC, FULL>(p.W, p.ldw, n0 + sr + C_::ROWS_PER_PASS * j, p.N, k0, p.Kw);
         }
-        const float* Ac = As + cur * TILE_FLOATS + a_off;
-        const float* Bc = Bs + cur * TILE_FLOATS + b_off;
+        const float* Ac = As + cur * C_::A_FLOATS + a_off;
+        const float* Bc = Bs + cur * C_::B_FLOATS + b_off;
+        // fragments of group g+1 are fetched before the MFMAs of group g (register double buffering)
+        f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ac + g * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ac + 32 * LDP + g * 8);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bc + g * 8);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Bc + 32 * LDP + g * 8);
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LDP);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDP);
+#pragma unroll
+        for (int g = 0; g < C_::G; ++g) {
+            const int cb = g & 1, nb = cb ^ 1;
+            if (g + 1 < C_::G) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[nb][i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * LDP + (g + 1) * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[nb][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * LDP + (g + 1) * 8);
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i][s], bf[cb][j][s], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            float* An = As + (cur ^ 1) * TILE_FLOATS;
-            float* Bn = Bs + (cur ^ 1) * TILE_FLOATS;
+            float* An = As + (cur ^ 1) * C_::A_FLOATS;
+            float* Bn = Bs + (cur ^ 1) * C_::B_FLOATS;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<f32x4*>(&An[(sr + 32 * j) * LDP + sc]) = ra[j];
-                *reinterpret_cast<f32x4*>(&Bn[(sr + 32 * j) * LDP + sc]) = rb[j];
-            }
+            for (int j = 0; j < C_::PA; ++j) *reinterpret_cast<f32x4*>(&An[(sr + C_::ROWS_PER_PASS * j) * LDP + sc]) = ra[j];
+#pragma unroll
+            for (int j = 0; j < C_::PB; ++j) *reinterpret_cast<f32x4*>(&Bn[(sr + C_::ROWS_PER_PASS * j) * LDP + sc]) = rb[j];
         }
         __syncthreads();
     }
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l31;
-            if (col >= p.N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (32 * TN) + j * 32 + l31;
+            if (!FULL && col >= p.N) continue;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (row >= p.M) continue;
-                float v = acc[i][j][e] + bv;
-                switch (p.epilogue) {
-                    case MMDM_EPI_BIAS_GELU: v = gelu_erf(v); break;
-                    case MMDM_EPI_BIAS_RESID: v += p.extra[(size_t)row * p.ld_extra + col]; break;
-                    case MMDM_EPI_BIAS_PE: v += p.extra[(size_t)(row % p.period) * p.ld_extra + col]; break;
-                    case MMDM_EPI_BIAS_SILU: v = silu(v); break;
-                    default: break;
-                }
+                const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (!FULL && row >= p.M) continue;
+                float v = acc[i][j][e];
+                if (p.epilogue == MMDM_EPI_BIAS_GELU) v = gelu_erf(v);
+                else if (p.epilogue == MMDM_EPI_BIAS_SILU) v = silu(v);
                 p.C[(size_t)row * p.ldc + col] = v;
             }
         }
     }
 }
 
-template <int AVEC, int WVEC>
+template <int TM, int TN, int BK, int AVEC, int WVEC, bool FULL>
 int set_attr() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<AVEC, WVEC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN, BK, AVEC, WVEC, FULL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<TM, TN, BK>::SMEM_BYTES);
     if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
     return MMDM_OK;
 }
 
-template <int AVEC, int WVEC>
-int launch(const GemmArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((gemm_f32_kernel<AVEC, WVEC>), dim3(a.mt * a.nt), dim3(256), SMEM_BYTES, st, a);
+template <int TM, int TN, int BK, int AVEC, int WVEC, bool FULL>
+int launch(GemmArgs a, hipStream_t st) {
+    using C_ = Cfg<TM, TN, BK>;
+    a.mt = (a.M + C_::BM - 1) / C_::BM;
+    a.nt = (a.N + C_::BN - 1) / C_::BN;
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, AVEC, WVEC, FULL>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_f32");
+}
+
+// tile variants (selected per call; MMDM_GEMM_CFG overrides for benchmarking)
+template <int TM, int TN, int BK>
+int launch_cfg(const GemmArgs& a, bool av, bool wv, hipStream_t st) {
+    using C_ = Cfg<TM, TN, BK>;
+    const bool full = av && wv && (a.M % C_::BM == 0) && (a.N % C_::BN == 0) && (a.K % C_::BK == 0) && a.Kw == a.K;
+    if (full) return launch<TM, TN, BK, 4, 4, true>(a, st);
+    if (av && wv) return launch<TM, TN, BK, 4, 4, false>(a, st);
+    if (!av && wv) return launch<TM, TN, BK, 1, 4, false>(a, st);
+    if (av && !wv) return launch<TM, TN, BK, 4, 1, false>(a, st);
+    return launch<TM, TN, BK, 1, 1, false>(a, st);
+}
+
+template <int TM, int TN, int BK>
+int set_attr_cfg() {
+    int rc;
+    if ((rc = set_attr<TM, TN, BK, 4, 4, true>())) return rc;
+    if ((rc = set_attr<TM, TN, BK, 4, 4, false>())) return rc;
+    if ((rc = set_attr<TM, TN, BK, 1, 4, false>())) return rc;
+    if ((rc = set_attr<TM, TN, BK, 4, 1, false>())) return rc;
+    return set_attr<TM, TN, BK, 1, 1, false>();
 }
 
 inline bool vec_ok(const float* p, int ld, int K) {
@@ -182,13 +237,23 @@ inline bool vec_ok(const float* p, int ld, int K) {
 
 }  // namespace
 
+int g_gemm_cfg = -1;
+
 int mmdm_gemm_init(void) {
     int rc;
-    if ((rc = set_attr<4, 4>())) return rc;
-    if ((rc = set_attr<1, 4>())) return rc;
-    if ((rc = set_attr<4, 1>())) return rc;
-    return set_attr<1, 1>();
+    if ((rc = set_attr_cfg<22, 22, 32>())) return rc;
+    if ((rc = set_attr_cfg<22, 22, 16>())) return rc;
+    if ((rc = set_attr_cfg<22, 12, 16>())) return rc;
+    if ((rc = set_attr_cfg<22, 22, 8>())) return rc;
+    if ((rc = set_attr_cfg<42, 22, 16>())) return rc;
+    if ((rc = set_attr_cfg<22, 42, 16>())) return rc;
+    const char* e = getenv("MMDM_GEMM_CFG");
+    g_gemm_cfg = e ? atoi(e) : -1;
+    return MMDM_OK;
 }
+
+// tuning hook for scratch/gemm_bench.py (not part of the public ABI): force a tile configuration, -1 = automatic
+extern "C" void mmdmx_set_gemm_cfg(int cfg) { g_gemm_cfg = cfg; }
 
 extern "C" int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                                int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
@@ -213,11 +278,16 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     a.A = A; a.W = W; a.bias = bias; a.C = C; a.extra = extra;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
     a.M = M; a.N = N; a.K = K; a.Kw = Kw; a.epilogue = epilogue; a.period = period > 0 ? period : 1;
-    a.mt = (M + BM - 1) / BM; a.nt = (N + BN - 1) / BN;
+    a.mt = a.nt = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool av = vec_ok(A, lda, K), wv = vec_ok(W, ldw, Kw);
-    if (av && wv) return launch<4, 4>(a, st);
-    if (!av && wv) return launch<1, 4>(a, st);
-    if (av && !wv) return launch<4, 1>(a, st);
-    return launch<1, 1>(a, st);
+    switch (g_gemm_cfg) {
+        case 0: return launch_cfg<22, 22, 32>(a, av, wv, st);
+        case 2: return launch_cfg<22, 12, 16>(a, av, wv, st);
+        case 3: return launch_cfg<22, 22, 8>(a, av, wv, st);
+        case 4: return launch_cfg<42, 22, 16>(a, av, wv, st);
+        case 5: return launch_cfg<22, 42, 16>(a, av, wv, st);
+        case 1: return launch_cfg<22, 22, 16>(a, av, wv, st);
+        default: return launch_cfg<42, 22, 16>(a, av, wv, st);
+    }
 }

@@ -1,0 +1,30 @@
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, math, statistics
+from mixermdm_amd import ops, load_library
+lib = load_library()
+d = torch.device("cuda:0")
+shapes = [(19200,3072,1024,"qkv"),(19200,1024,1024,"out"),(19200,2048,1024,"ffn1"),(19200,1024,2048,"ffn2"),
+          (19200,1536,512,"m.qkv"),(19200,512,512,"m.out"),(19200,1024,512,"m.ffn1"),(19200,512,1024,"m.ffn2"),(4096,4096,4096,"sq4k")]
+cfgs = [int(c) for c in os.environ.get("CFGS","0,1,4").split(",")]
+only = sys.argv[1:]
+rounds, reps = 7, 4
+for M,N,K,name in shapes:
+    if only and name not in only: continue
+    x = torch.randn(M,K,device=d); w = torch.randn(N,K,device=d)/math.sqrt(K); b = torch.randn(N,device=d)
+    out = torch.empty(M,N,device=d)
+    epi = {"qkv":"bias","out":"resid","ffn1":"gelu","ffn2":"resid","m.qkv":"bias","m.out":"resid","m.ffn1":"gelu","m.ffn2":"resid","sq4k":"bias"}[name]
+    extra = out if epi=="resid" else None
+    res = {c: [] for c in cfgs}
+    for r in range(rounds):
+        for c in cfgs:
+            lib.mmdmx_set_gemm_cfg(c)
+            ops.linear(x,w,b,epi,extra,out=out)
+            e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps): ops.linear(x,w,b,epi,extra,out=out)
+            e1.record(); torch.cuda.synchronize()
+            res[c].append(e0.elapsed_time(e1)/reps)
+    line = f"{name:7s} {M}x{N}x{K} {epi:5s}"
+    for c in cfgs:
+        ms = statistics.median(res[c]); line += f" | cfg{c}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:6.1f}TF (min {2*M*N*K/min(res[c])/1e9:5.1f}..{2*M*N*K/max(res[c])/1e9:5.1f})"
+    print(line, flush=True)

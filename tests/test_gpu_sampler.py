@@ -16,7 +16,10 @@ from oracle import schedule as OS         # noqa: E402
 from oracle.layers import pe_table        # noqa: E402
 from test_gpu_kernels import assert_close, rnd, dev   # noqa: E402
 
-STEP_TOL = dict(atol=2e-4, rtol=2e-4, frac=5e-4, hard=5e-2)
+# frac: the golden inputs are N(0,1) noise, so a few rot6d vectors are nearly collinear and their Gram-Schmidt /
+# quaternion round trip amplifies 1e-7 rounding differences to 1e-3 (the CPU oracle shows the same handful of outliers
+# against the reference: tests/test_oracle_golden.py::close_frac); everything else must agree to 2e-4.
+STEP_TOL = dict(atol=2e-4, rtol=2e-4, frac=2e-3, hard=5e-2)
 
 
 def golden_sampler(golden, mode=4, align=True, force=None, model2_kind=0, max_batch=2, out1=False):
