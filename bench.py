@@ -116,7 +116,7 @@ def main():
         a_ms, a_n, a_fl = smp.profile_read(1)
         smp.profile(False)
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+        roof = {"bound": "mfma", "kernel": "gemm_glds_kernel<22,22> (v_mfma_f32_32x32x2_f32, LDS-DMA staged)", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                 "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
                 "gflop_per_launch": round(g_fl / g_n / 1e9, 3), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),

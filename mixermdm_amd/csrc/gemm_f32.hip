@@ -25,6 +25,7 @@ struct GemmArgs {
     int lda, ldw, ldc, ld_extra;
     int M, N, K, Kw, epilogue, period;   // Kw >= K: readable columns of W (zero beyond K)
     int mt, nt;
+    int ablate;                          // timing experiments only (scratch/gemm_bench.py); 0 in production
 };
 
 template <int VEC, bool FULL>
@@ -129,15 +130,15 @@ __global__ __launch_bounds__((Cfg<TM_, TN_, BK_>::THREADS)) void gemm_f32_kernel
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1) < nkt;
-        if (more) {
+        if (more && p.ablate < 1) {
             const int k0 = (kt + 1) * BK + sc;
 #pragma unroll
             for (int j = 0; j < C_::PA; ++j) ra[j] = load4<AVEC, FULL>(p.A, p.lda, m0 + sr + C_::ROWS_PER_PASS * j, p.M, k0, p.K);
 #pragma unroll
             for (int j = 0; j < C_::PB; ++j) rb[j] = load4<WVEC, FULL>(p.W, p.ldw, n0 + sr + C_::ROWS_PER_PASS * j, p.N, k0, p.Kw);
         }
-        const float* Ac = As + cur * C_::A_FLOATS + a_off;
-        const float* Bc = Bs + cur * C_::B_FLOATS + b_off;
+        const float* Ac = As + (p.ablate >= 1 ? 0 : cur) * C_::A_FLOATS + a_off;
+        const float* Bc = Bs + (p.ablate >= 1 ? 0 : cur) * C_::B_FLOATS + b_off;
         // fragments of group g+1 are fetched before the MFMAs of group g (register double buffering)
         f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
@@ -161,7 +162,7 @@ __global__ __launch_bounds__((Cfg<TM_, TN_, BK_>::THREADS)) void gemm_f32_kernel
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i][s], bf[cb][j][s], acc[i][j], 0, 0, 0);
         }
-        if (more) {
+        if (more && p.ablate < 1) {
             float* An = As + (cur ^ 1) * C_::A_FLOATS;
             float* Bn = Bs + (cur ^ 1) * C_::B_FLOATS;
 #pragma unroll
@@ -169,7 +170,7 @@ __global__ __launch_bounds__((Cfg<TM_, TN_, BK_>::THREADS)) void gemm_f32_kernel
 #pragma unroll
             for (int j = 0; j < C_::PB; ++j) *reinterpret_cast<f32x4*>(&Bn[(sr + C_::ROWS_PER_PASS * j) * LDP + sc]) = rb[j];
         }
-        __syncthreads();
+        if (p.ablate < 2) __syncthreads();
     }
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -190,6 +191,181 @@ __global__ __launch_bounds__((Cfg<TM_, TN_, BK_>::THREADS)) void gemm_f32_kernel
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (the production path when K % 16 == 0 and operands are 16-byte aligned).
+// Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write): each wave-instruction
+// lands 1 KiB = 16 rows x 64 B contiguously, so the LDS image is unpadded [row][16 floats]; bank conflicts of the
+// ds_read_b128 fragment reads are removed by an XOR swizzle applied on the per-lane SOURCE address and again on the
+// read (16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3)): a 16-lane read group then covers 16 distinct
+// 16-byte bank slots.  Rows past M / N are clamped on load (their results are never stored).
+// ---------------------------------------------------------------------------------------------------------
+template <int TM_, int TN_>
+struct GCfg {
+    static constexpr int WGM = TM_ / 10, WGN = TN_ / 10, TM = TM_ % 10, TN = TN_ % 10;
+    static constexpr int NWAVES = WGM * WGN, THREADS = 64 * NWAVES;
+    static constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 16;
+    static constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK;
+    static constexpr int NBUF = 2;
+    static constexpr int SMEM_BYTES = NBUF * (A_FLOATS + B_FLOATS) * 4;
+    static constexpr int NA = BM / 16, NB = BN / 16;                 // 1-KiB pieces per operand tile
+    static constexpr int NI = (NA + NB + NWAVES - 1) / NWAVES;       // pieces per wave
+};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int TM_, int TN_>
+__global__ __launch_bounds__((GCfg<TM_, TN_>::THREADS)) void gemm_glds_kernel(GemmArgs p) {
+    using C_ = GCfg<TM_, TN_>;
+    constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                   // [NBUF][BM*16]
+    float* Bs = smem + C_::NBUF * C_::A_FLOATS;         // [NBUF][BN*16]
+
+    const int nwg = p.mt * p.nt;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (swz / p.nt) * BM;
+    const int n0 = (swz % p.nt) * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C_::WGN, wn = wave % C_::WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // staging pieces of this wave: piece id pq = wave + NWAVES*u; pq < NA -> A rows 16pq.., else W rows 16(pq-NA)..
+    const float* src[C_::NI];
+    int dst[C_::NI];                                    // LDS float offset of the piece inside buffer 0 (wave-uniform)
+#pragma unroll
+    for (int u = 0; u < C_::NI; ++u) {
+        const int pq = wave + C_::NWAVES * u;
+        const int prow = lane >> 2, pc = lane & 3;
+        const int gch = pc ^ ((prow >> 2) & 3);        // source chunk stored at LDS chunk pc of this row
+        if (pq < C_::NA) {
+            int grow = m0 + 16 * pq + prow;
+            grow = grow < p.M ? grow : p.M - 1;
+            src[u] = p.A + (size_t)grow * p.lda + 4 * gch;
+            dst[u] = 16 * pq * BK;
+        } else {
+            int grow = n0 + 16 * (pq - C_::NA) + prow;
+            grow = grow < p.N ? grow : p.N - 1;
+            src[u] = p.W + (size_t)grow * p.ldw + 4 * gch;
+            dst[u] = C_::NBUF * C_::A_FLOATS + 16 * (pq - C_::NA) * BK;
+        }
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < C_::NI; ++u) {
+            const int pq = wave + C_::NWAVES * u;
+            if (pq < C_::NA + C_::NB) {
+                const int boff = pq < C_::NA ? buf * C_::A_FLOATS : buf * C_::B_FLOATS;
+                __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + dst[u] + boff), 16, 0, 0);
+                src[u] += BK;
+            }
+        }
+    };
+
+    // accumulators start as bias (+ residual / + PE row)
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (32 * TN) + j * 32 + l31;
+            const bool cok = col < p.N;
+            const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = bv;
+                if (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) {
+                    const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (cok && row < p.M) {
+                        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+                        v += p.extra[(size_t)er * p.ld_extra + col];
+                    }
+                }
+                acc[i][j][e] = v;
+            }
+        }
+
+    const int nkt = p.K / BK;
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // fragment read offsets (floats): row*16 + 4*((2g + lh) ^ sw), sw = (row >> 2) & 3 = (l31 >> 2) & 3
+    const int sw = (l31 >> 2) & 3;
+    const int c0 = 4 * (lh ^ sw), c1 = 4 * ((2 + lh) ^ sw);
+    const int a_row = (wm * (32 * TM) + l31) * BK;
+    const int b_row = (wn * (32 * TN) + l31) * BK;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) stage(cur ^ 1);
+        const float* Ac = As + cur * C_::A_FLOATS + a_row;
+        const float* Bc = Bs + cur * C_::B_FLOATS + b_row;
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            af[0][i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * BK + c0);
+            af[1][i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * BK + c1);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bf[0][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * BK + c0);
+            bf[1][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * BK + c1);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i][s], bf[g][j][s], acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (32 * TN) + j * 32 + l31;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (row >= p.M) continue;
+                float v = acc[i][j][e];
+                if (p.epilogue == MMDM_EPI_BIAS_GELU) v = gelu_erf(v);
+                else if (p.epilogue == MMDM_EPI_BIAS_SILU) v = silu(v);
+                p.C[(size_t)row * p.ldc + col] = v;
+            }
+        }
+    }
+}
+
+template <int TM_, int TN_>
+int launch_glds(GemmArgs a, hipStream_t st) {
+    using C_ = GCfg<TM_, TN_>;
+    a.mt = (a.M + C_::BM - 1) / C_::BM;
+    a.nt = (a.N + C_::BN - 1) / C_::BN;
+    hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+    return mmdm_check_launch("gemm_glds");
+}
+
+template <int TM_, int TN_>
+int set_attr_glds() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<TM_, TN_>::SMEM_BYTES);
+    if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_glds): %s", hipGetErrorString(e));
+    return MMDM_OK;
 }
 
 template <int TM, int TN, int BK, int AVEC, int WVEC, bool FULL>
@@ -238,6 +414,7 @@ inline bool vec_ok(const float* p, int ld, int K) {
 }  // namespace
 
 int g_gemm_cfg = -1;
+int g_gemm_ablate = 0;
 
 int mmdm_gemm_init(void) {
     int rc;
@@ -247,6 +424,8 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_cfg<22, 22, 8>())) return rc;
     if ((rc = set_attr_cfg<42, 22, 16>())) return rc;
     if ((rc = set_attr_cfg<22, 42, 16>())) return rc;
+    if ((rc = set_attr_glds<42, 22>())) return rc;
+    if ((rc = set_attr_glds<22, 22>())) return rc;
     const char* e = getenv("MMDM_GEMM_CFG");
     g_gemm_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
@@ -254,6 +433,7 @@ int mmdm_gemm_init(void) {
 
 // tuning hook for scratch/gemm_bench.py (not part of the public ABI): force a tile configuration, -1 = automatic
 extern "C" void mmdmx_set_gemm_cfg(int cfg) { g_gemm_cfg = cfg; }
+extern "C" void mmdmx_set_gemm_ablate(int a) { g_gemm_ablate = a; }
 
 extern "C" int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                                int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
@@ -279,15 +459,22 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
     a.M = M; a.N = N; a.K = K; a.Kw = Kw; a.epilogue = epilogue; a.period = period > 0 ? period : 1;
     a.mt = a.nt = 0;
+    a.ablate = g_gemm_ablate;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool av = vec_ok(A, lda, K), wv = vec_ok(W, ldw, Kw);
+    const bool glds_ok = av && wv && (K % 16 == 0) && Kw == K;
+    // production choice: LDS-DMA kernel, 128x128 tile / 4 waves (5 workgroups per CU) whenever the operands allow it
+    switch (g_gemm_cfg) {
+        case 10: if (glds_ok) return launch_glds<42, 22>(a, st); break;
+        case 11: case -1: if (glds_ok) return launch_glds<22, 22>(a, st); break;
+        default: break;
+    }
     switch (g_gemm_cfg) {
         case 0: return launch_cfg<22, 22, 32>(a, av, wv, st);
         case 2: return launch_cfg<22, 12, 16>(a, av, wv, st);
         case 3: return launch_cfg<22, 22, 8>(a, av, wv, st);
-        case 4: return launch_cfg<42, 22, 16>(a, av, wv, st);
         case 5: return launch_cfg<22, 42, 16>(a, av, wv, st);
-        case 1: return launch_cfg<22, 22, 16>(a, av, wv, st);
-        default: return launch_cfg<42, 22, 16>(a, av, wv, st);
+        case 4: return launch_cfg<42, 22, 16>(a, av, wv, st);
+        default: return launch_cfg<22, 22, 16>(a, av, wv, st);
     }
 }

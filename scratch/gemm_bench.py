@@ -6,6 +6,7 @@ d = torch.device("cuda:0")
 shapes = [(19200,3072,1024,"qkv"),(19200,1024,1024,"out"),(19200,2048,1024,"ffn1"),(19200,1024,2048,"ffn2"),
           (19200,1536,512,"m.qkv"),(19200,512,512,"m.out"),(19200,1024,512,"m.ffn1"),(19200,512,1024,"m.ffn2"),(4096,4096,4096,"sq4k")]
 cfgs = [int(c) for c in os.environ.get("CFGS","0,1,4").split(",")]
+lib.mmdmx_set_gemm_ablate(int(os.environ.get('ABL','0')))
 only = sys.argv[1:]
 rounds, reps = 7, 4
 for M,N,K,name in shapes:
