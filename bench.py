@@ -58,30 +58,20 @@ def main():
 
     from mixermdm_amd.sampler import Sampler
     from mixermdm_amd.synthetic import synthetic_state_dict, mixer_shapes, synthetic_stats, synthetic_inputs, FULL_DIMS
+    from mixermdm_amd.distributed import broadcast_state_dict
 
     B, T, S = args.batch, args.frames, 1000
-    # weights: rank 0 draws them on the host, one RCCL broadcast of the packed vector over xGMI (no other collective on the path)
+    # weights: rank 0 draws them on the host, ONE RCCL broadcast of the packed 1.46 GB vector over xGMI (no other collective on the path)
     shapes = mixer_shapes(**FULL_DIMS)
-    total = sum(int(torch.Size(s).numel()) for s in shapes.values())
-    flat = torch.empty(total, device=device, dtype=torch.float32)
-    sd_cpu = None
-    if rank == 0:
-        sd_cpu = synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, **FULL_DIMS)
-        flat.copy_(torch.cat([sd_cpu[k].reshape(-1) for k in shapes]))
-    if world > 1:
-        dist.broadcast(flat, 0)
-    sd, off = {}, 0
-    for k, shp in shapes.items():
-        n = int(torch.Size(shp).numel())
-        sd[k] = flat[off:off + n].view(shp)
-        off += n
+    sd_cpu = synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, **FULL_DIMS) if rank == 0 else None
+    sd = broadcast_state_dict(sd_cpu, shapes, src=0, device=device)
     stats = synthetic_stats()
     smp = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, **FULL_DIMS)
     smp.load_state_dict(sd)
     smp.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
     smp.prepare()
     smp.set_schedule("ddim1000")
-    del flat, sd
+    del sd
     cond, xT = synthetic_inputs(B, T, seed_cond=1 + 1000 * rank, seed_x=2 + 1000 * rank)   # each rank = its own shard of the batch
     cond, xT = cond.to(device), xT.to(device)
     use_graph = not args.no_graph
@@ -167,6 +157,17 @@ def cpu_baseline(sd_cpu, stats, T, nsteps):
     cond, xT = synthetic_inputs(1, T)
     x, x2 = xT.clone(), xT.clone()
     with torch.no_grad():
+        # thread-count calibration (one untimed step each): B=1 GEMMs are small, all cores is not always the fastest
+        ncpu = os.cpu_count() or 1
+        best = (None, 1e30)
+        for nt in sorted({min(ncpu, c) for c in (16, 32, 64, ncpu)}):
+            torch.set_num_threads(nt)
+            t0 = time.perf_counter()
+            MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 999, x, x2, cond)
+            dt1 = time.perf_counter() - t0
+            if dt1 < best[1]:
+                best = (nt, dt1)
+        torch.set_num_threads(best[0])
         x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 999, x, x2, cond)
         t0 = time.perf_counter()
         for k in range(nsteps):

@@ -305,9 +305,9 @@ __global__ __launch_bounds__((GCfg<TM_, TN_>::THREADS)) void gemm_glds_kernel(Ge
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) stage(cur ^ 1);
-        const float* Ac = As + cur * C_::A_FLOATS + a_row;
-        const float* Bc = Bs + cur * C_::B_FLOATS + b_row;
+        if (kt + 1 < nkt && p.ablate < 1) stage(cur ^ 1);
+        const float* Ac = As + (p.ablate >= 1 ? 0 : cur) * C_::A_FLOATS + a_row;
+        const float* Bc = Bs + (p.ablate >= 1 ? 0 : cur) * C_::B_FLOATS + b_row;
         f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -329,8 +329,9 @@ __global__ __launch_bounds__((GCfg<TM_, TN_>::THREADS)) void gemm_glds_kernel(Ge
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i][s], bf[g][j][s], acc[i][j], 0, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (p.ablate < 2) __syncthreads();
     }
+    if (p.ablate >= 3) return;
 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {

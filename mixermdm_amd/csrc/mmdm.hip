@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <unordered_map>
@@ -93,6 +94,10 @@ struct ModuleW {         // denoiser or mixer front/back ends
     float *time_tab = nullptr;                   // [S, D] = time_embed(pe[timestep_map])  (built by set_schedule)
 };
 
+struct Scratch {          // transformer-stack work buffers (one set per concurrently running stack)
+    float *h = nullptr, *xn = nullptr, *qkv = nullptr, *kv = nullptr, *att = nullptr, *f1 = nullptr;
+};
+
 struct Prof {
     bool on = false;
     std::vector<hipEvent_t> ev[2];               // pairs (start, stop) per launch, per class
@@ -128,7 +133,7 @@ struct mmdm_handle_s {
     bool begun = false;
 
     // workspace
-    float *h = nullptr, *xn = nullptr, *qkv = nullptr, *kv = nullptr, *att = nullptr, *f1 = nullptr;   // stack scratch
+    Scratch sa, sb;                                        // sa: denoiser1 + Influence, sb: denoiser2 (runs concurrently)
     float *mI = nullptr;                                   // Influence CA source  [R, Dm]
     float *o1 = nullptr, *o2 = nullptr, *out1 = nullptr, *out2 = nullptr;   // [n,T,524]
     float *w23 = nullptr, *hpool = nullptr;
@@ -145,8 +150,12 @@ struct mmdm_handle_s {
 
     // graph
     hipGraphExec_t gexec = nullptr;
-    int gB = 0, gT = 0;
-    bool g_hist = false;
+
+    // denoiser1 || denoiser2 on two streams: the two stacks are independent until the mixer (mixermdm.py:685-687), so the
+    // tail of one model's kernels overlaps the other's and the HBM-bound kernels hide under MFMA-bound ones.
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true;
 
     Prof prof;
 };
@@ -257,6 +266,7 @@ int build_module(mmdm_handle h, ModuleW& m, const std::string& pfx, const std::s
 struct Ctx {
     mmdm_handle h;
     hipStream_t st;
+    const Scratch* s;
 };
 
 int prof_begin(const Ctx& c, int cls, double flops) {
@@ -312,34 +322,34 @@ struct StackRun {
 
 // h [nseq*T, D] is updated in place through the L blocks (TransformerBlockDoubleCond / TransformerBlock / InfluenceBlockCross).
 int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
-    mmdm_handle H = c.h;
+    const Scratch& S = *c.s;
     const int D = w.D, F = w.F, R = r.nseq * r.T, dh = D / w.H;
     for (int l = 0; l < w.L; ++l) {
         const LayerW& lw = w.layers[l];
         auto ss_at = [&](int slot, int row0) { return r.ss + (size_t)row0 * r.ss_ld + ((size_t)l * w.n_ada + slot) * 2 * D; };
         // --- self attention (layers.py:36-45)
-        RC(mmdm_adaln_f32(hbuf, ss_at(0, r.sa_row0), r.ss_ld, r.sa_rows, H->xn, r.nseq, r.T, D, c.st));
-        RC(linear(c, H->xn, D, lw.sa_in_w, D, lw.sa_in_b, H->qkv, 3 * D, R, 3 * D, D));
-        RC(attention(c, H->qkv, 3 * D, H->qkv + D, 3 * D, H->qkv + 2 * D, 3 * D, H->att, D, r.nseq, r.T, r.T, w.H, dh, 0));
+        RC(mmdm_adaln_f32(hbuf, ss_at(0, r.sa_row0), r.ss_ld, r.sa_rows, S.xn, r.nseq, r.T, D, c.st));
+        RC(linear(c, S.xn, D, lw.sa_in_w, D, lw.sa_in_b, S.qkv, 3 * D, R, 3 * D, D));
+        RC(attention(c, S.qkv, 3 * D, S.qkv + D, 3 * D, S.qkv + 2 * D, 3 * D, S.att, D, r.nseq, r.T, r.T, w.H, dh, 0));
         if (r.ca_mode) {
             // keys/values of the cross attention come from the layer INPUT of the other stream (or a fixed source):
             // project them before the residual below overwrites h.
             const float* src = r.ca_mode == 1 ? hbuf : r.kv_src;
-            RC(mmdm_adaln_f32(src, ss_at(2, r.ca_row0), r.ss_ld, r.ca_rows, H->xn, r.nseq, r.T, D, c.st));
-            RC(linear(c, H->xn, D, lw.ca_in_w + (size_t)D * D, D, lw.ca_in_b + D, H->kv, 2 * D, R, 2 * D, D));
+            RC(mmdm_adaln_f32(src, ss_at(2, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, r.nseq, r.T, D, c.st));
+            RC(linear(c, S.xn, D, lw.ca_in_w + (size_t)D * D, D, lw.ca_in_b + D, S.kv, 2 * D, R, 2 * D, D));
         }
-        RC(linear(c, H->att, D, lw.sa_out_w, D, lw.sa_out_b, hbuf, D, R, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+        RC(linear(c, S.att, D, lw.sa_out_w, D, lw.sa_out_b, hbuf, D, R, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         // --- cross attention (layers.py:77-88)
         if (r.ca_mode) {
-            RC(mmdm_adaln_f32(hbuf, ss_at(1, r.ca_row0), r.ss_ld, r.ca_rows, H->xn, r.nseq, r.T, D, c.st));
-            RC(linear(c, H->xn, D, lw.ca_in_w, D, lw.ca_in_b, H->qkv, D, R, D, D));
-            RC(attention(c, H->qkv, D, H->kv, 2 * D, H->kv + D, 2 * D, H->att, D, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
-            RC(linear(c, H->att, D, lw.ca_out_w, D, lw.ca_out_b, hbuf, D, R, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+            RC(mmdm_adaln_f32(hbuf, ss_at(1, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, r.nseq, r.T, D, c.st));
+            RC(linear(c, S.xn, D, lw.ca_in_w, D, lw.ca_in_b, S.qkv, D, R, D, D));
+            RC(attention(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
+            RC(linear(c, S.att, D, lw.ca_out_w, D, lw.ca_out_b, hbuf, D, R, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         }
         // --- FFN (layers.py:99-106)
-        RC(mmdm_adaln_f32(hbuf, ss_at(w.has_ca ? 3 : 1, r.ffn_row0), r.ss_ld, r.ffn_rows, H->xn, r.nseq, r.T, D, c.st));
-        RC(linear(c, H->xn, D, lw.f1_w, D, lw.f1_b, H->f1, F, R, F, D, MMDM_EPI_BIAS_GELU));
-        RC(linear(c, H->f1, F, lw.f2_w, F, lw.f2_b, hbuf, D, R, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
+        RC(mmdm_adaln_f32(hbuf, ss_at(w.has_ca ? 3 : 1, r.ffn_row0), r.ss_ld, r.ffn_rows, S.xn, r.nseq, r.T, D, c.st));
+        RC(linear(c, S.xn, D, lw.f1_w, D, lw.f1_b, S.f1, F, R, F, D, MMDM_EPI_BIAS_GELU));
+        RC(linear(c, S.f1, F, lw.f2_w, F, lw.f2_b, hbuf, D, R, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
     }
     return MMDM_OK;
 }
@@ -366,7 +376,7 @@ int run_denoiser(const Ctx& c, const ModuleW& m, bool interaction, const float* 
     // embed: `x` holds xb samples (xb == n, or xb == n/2 when cond/uncond halves share the same x: cfg_sampler.py:41-42)
     for (int p = 0; p < npers; ++p)
         for (int rep = 0; rep < n / xb; ++rep)
-            RC(embed(c, m, x + (size_t)p * NF, ldx, H->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
+            RC(embed(c, m, x + (size_t)p * NF, ldx, c.s->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
     StackRun r;
     r.nseq = npers * n; r.T = T; r.ss = ss; r.ss_ld = ss_ld;
     r.sa_row0 = 0; r.sa_rows = npers * n;
@@ -374,9 +384,9 @@ int run_denoiser(const Ctx& c, const ModuleW& m, bool interaction, const float* 
     r.ca_row0 = 2 * n; r.ca_rows = n;
     r.ca_mode = interaction ? 1 : 0;
     r.kv_src = nullptr;
-    RC(run_stack(c, m.st, H->h, r));
+    RC(run_stack(c, m.st, c.s->h, r));
     for (int p = 0; p < npers; ++p)   // FinalLayer (layers.py:109-116), per person, concatenated on the channel axis (in2in.py:455-461)
-        RC(linear(c, H->h + (size_t)p * n * T * D, D, m.out_w, D, m.out_b, out + (size_t)p * NF, ldo, n * T, NF, D));
+        RC(linear(c, c.s->h + (size_t)p * n * T * D, D, m.out_w, D, m.out_b, out + (size_t)p * NF, ldo, n * T, NF, D));
     return MMDM_OK;
 }
 
@@ -394,7 +404,7 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     RC(mmdm_mixer_pre_f32(H->o1, H->o2, H->d_stats, H->out1, H->out2, n, T, cf.align, c.st));
     // motion_embed + PE of the four streams (mixermdm.py:722-732); seq = p*n + b
     for (int p = 0; p < 2; ++p) {
-        RC(embed(c, H->mx, H->out1 + (size_t)p * NF, NF2, H->h + (size_t)p * n * T * Dm, n, T));
+        RC(embed(c, H->mx, H->out1 + (size_t)p * NF, NF2, c.s->h + (size_t)p * n * T * Dm, n, T));
         RC(embed(c, H->mx, H->out2 + (size_t)p * NF, NF2, H->mI + (size_t)p * n * T * Dm, n, T));
     }
     StackRun r;
@@ -403,13 +413,13 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     r.ca_row0 = 2 * n; r.ca_rows = n;          // cond_I
     r.ffn_row0 = 2 * n; r.ffn_rows = n;        // FFN is conditioned on cond_I (influence.py:46)
     r.ca_mode = 2; r.kv_src = H->mI;
-    RC(run_stack(c, H->mx.st, H->h, r));
+    RC(run_stack(c, H->mx.st, c.s->h, r));
     const int mode = cf.mixing_mode;
     if (mode == 1 || mode == 3) {
-        RC(mmdm_mean_time_f32(H->h, H->hpool, 2 * n, T, Dm, c.st));
+        RC(mmdm_mean_time_f32(c.s->h, H->hpool, 2 * n, T, Dm, c.st));
         RC(mmdm_influence_head_f32(H->hpool, H->mx.out_w, H->mx.out_b, H->w23, 2 * n, Dm, H->nw, c.st));
     } else {
-        RC(mmdm_influence_head_f32(H->h, H->mx.out_w, H->mx.out_b, H->w23, 2 * n * T, Dm, H->nw, c.st));
+        RC(mmdm_influence_head_f32(c.s->h, H->mx.out_w, H->mx.out_b, H->w23, 2 * n * T, Dm, H->nw, c.st));
     }
     const int* lp = dyn_hist ? H->d_step + 1 : nullptr;
     RC(mmdm_blend_cfg_dyn(H->out1, H->out2, H->w23, mode, cf.use_force, cf.force_val, cf.cfg_scale, H->model_out,
@@ -435,8 +445,19 @@ int run_step(const Ctx& c) {
     RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n));
     RC(cond_vectors(c, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n));
     RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n));
-    RC(run_denoiser(c, H->d1, false, H->x, B, 2, NF2, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF2));
-    RC(run_denoiser(c, H->d2, true, H->x2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
+    if (H->overlap && !H->prof.on) {
+        // fork: denoiser2 on the auxiliary stream with its own scratch, denoiser1 on the caller's stream; join before the mixer
+        Ctx c2{H, H->st2, &H->sb};
+        HIPCHK(hipEventRecord(H->ev_fork, c.st));
+        HIPCHK(hipStreamWaitEvent(H->st2, H->ev_fork, 0));
+        RC(run_denoiser(c2, H->d2, true, H->x2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
+        RC(run_denoiser(c, H->d1, false, H->x, B, 2, NF2, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF2));
+        HIPCHK(hipEventRecord(H->ev_join, H->st2));
+        HIPCHK(hipStreamWaitEvent(c.st, H->ev_join, 0));
+    } else {
+        RC(run_denoiser(c, H->d1, false, H->x, B, 2, NF2, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF2));
+        RC(run_denoiser(c, H->d2, true, H->x2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
+    }
     RC(mixer_core(c, B, T, true));
     RC(mmdm_xstart_ddim_f32(H->model_out, H->d_stats, H->d_coef, H->S, H->d_step, H->x, H->x2, H->px1, H->px2, H->floor_ws,
                             B, T, H->cfg.xstart_align, c.st));
@@ -507,12 +528,17 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     const int npers = c.single_only ? 1 : 2;
     const size_t R = (size_t)npers * n * T;
     const size_t Dx = max2(D, Dm), Fx = max2(F, Fm);
-    float** bufs[] = {&h->h, &h->xn, &h->att};
-    for (float** b : bufs)
-        if ((rc = dalloc(h, b, R * Dx))) return fail(rc);
-    if ((rc = dalloc(h, &h->qkv, R * 3 * Dx))) return fail(rc);
-    if ((rc = dalloc(h, &h->kv, R * 2 * Dx))) return fail(rc);
-    if ((rc = dalloc(h, &h->f1, R * Fx))) return fail(rc);
+    for (Scratch* sc : {&h->sa, &h->sb}) {
+        if (sc == &h->sb && c.single_only) break;
+        const size_t d = sc == &h->sa ? Dx : (size_t)D, f = sc == &h->sa ? Fx : (size_t)F;
+        if ((rc = dalloc(h, &sc->h, R * d)) || (rc = dalloc(h, &sc->xn, R * d)) || (rc = dalloc(h, &sc->att, R * d)) ||
+            (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f)))
+            return fail(rc);
+    }
+    if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+        return fail(mmdm_set_error(MMDM_ERR_HIP, "mmdm_create: stream/event creation failed"));
+    h->overlap = getenv("MMDM_NO_OVERLAP") == nullptr;
     const size_t PT = (size_t)n * T * (c.single_only ? NF : NF2);
     if ((rc = dalloc(h, &h->o1, PT))) return fail(rc);
     if ((rc = dalloc(h, &h->x, PT / 2)) || (rc = dalloc(h, &h->px1, PT / 2))) return fail(rc);
@@ -546,6 +572,9 @@ extern "C" void mmdm_destroy(mmdm_handle h) {
     if (!h) return;
     (void)hipDeviceSynchronize();
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->st2) (void)hipStreamDestroy(h->st2);
     for (int k = 0; k < 2; ++k)
         for (hipEvent_t e : h->prof.ev[k]) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
@@ -606,7 +635,7 @@ extern "C" int mmdm_set_schedule(mmdm_handle h, const int* timestep_map, const f
     HIPCHK(hipStreamSynchronize(st));   // host buffers may be transient
     h->S = S;
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // S is a kernel argument baked into the graph
-    Ctx c{h, st};
+    Ctx c{h, st, &h->sa};
     const bool pon = h->prof.on;
     h->prof.on = false;
     int rc = build_time_tab(c, h->d1);
@@ -623,7 +652,7 @@ extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, in
     if (B <= 0 || B > h->cfg.max_batch || T <= 0 || T > h->cfg.max_frames)
         return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_begin: B=%d T=%d exceed the handle's max_batch=%d / max_frames=%d", B, T, h->cfg.max_batch, h->cfg.max_frames));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    Ctx c{h, st};
+    Ctx c{h, st, &h->sa};
     const int n = 2 * B, td = h->cfg.text_dim;
     const bool pon = h->prof.on;
     h->prof.on = false;
@@ -669,7 +698,7 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
     if (nsteps < 0 || nsteps > h->host_step + 1)
         return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: %d steps requested, %d left in the schedule", nsteps, h->host_step + 1));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    Ctx c{h, st};
+    Ctx c{h, st, &h->sa};
     if (use_graph && !h->prof.on) {
         if (!st) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: graph capture needs a non-default stream"));
         if (!h->gexec) {
@@ -713,7 +742,7 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
     if (t < 0 || t >= 5000) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: timestep %d out of range", t));
     if (which < 0 || which > 2 || (h->cfg.single_only && which != 0)) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: bad module %d", which));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    Ctx c{h, st};
+    Ctx c{h, st, &h->sa};
     const int td = h->cfg.text_dim;
     // a one-entry schedule at slot 0 of the tables: time_tab[0] = time_embed(pe[t]); restored by the next set_schedule
     const int S_keep = h->S;
