@@ -20,9 +20,11 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X fp32 matrix peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
 
 
-def algorithmic_flops_per_motion_step(T, D=1024, F=2048, L=8, Dm=512, Fm=1024, Lm=4):
-    """478.4 GFLOP at T=300."""
+def algorithmic_flops_per_motion_step(T, D=1024, F=2048, L=8, Dm=512, Fm=1024, Lm=4, single=False):
+    """478.4 GFLOP at T=300 (2-person); single-person 2*d1 + AdaLN = 55.7 GFLOP at T=196."""
     d1 = 2 * T * (L * (4 * D * D + 2 * D * F + 2 * (T + 1) * D) + 2 * 262 * D)
+    if single:
+        return 2 * d1 + 2 * L * 2 * 2 * D * D * 2
     d2 = 4 * T * (L * (8 * D * D + 2 * D * F + 4 * (T + 1) * D) + 2 * 262 * D)
     inf = 2 * T * (Lm * (8 * Dm * Dm + 2 * Dm * Fm + 4 * (T + 1) * Dm) + 23 * Dm)
     ada = 2 * L * 2 * 2 * D * D * 4 + 2 * L * 4 * 2 * 2 * D * D * 2 + 2 * Lm * 4 * 2 * Dm * Dm * 4
@@ -34,8 +36,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="motions per GPU (weak scaling)")
-    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--workload", choices=["mixer", "single"], default="mixer",
+                    help="mixer = BASELINE configs[2] (2-person MixerMDM, the headline metric); single = configs[1] (single-person in2IN, T=196, B=32)")
+    ap.add_argument("--batch", type=int, default=None, help="motions per GPU (weak scaling); default 16 (mixer) / 32 (single)")
+    ap.add_argument("--frames", type=int, default=None, help="default 300 (mixer) / 196 (single)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -60,19 +64,23 @@ def main():
     from mixermdm_amd.synthetic import synthetic_state_dict, mixer_shapes, synthetic_stats, synthetic_inputs, FULL_DIMS
     from mixermdm_amd.distributed import broadcast_state_dict
 
-    B, T, S = args.batch, args.frames, 1000
+    single = args.workload == "single"
+    B = args.batch or (32 if single else 16)
+    T = args.frames or (196 if single else 300)
+    S = 1000
     # weights: rank 0 draws them on the host, ONE RCCL broadcast of the packed 1.46 GB vector over xGMI (no other collective on the path)
-    shapes = mixer_shapes(**FULL_DIMS)
-    sd_cpu = synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, **FULL_DIMS) if rank == 0 else None
+    shapes = mixer_shapes(single_only=single, **FULL_DIMS)
+    sd_cpu = synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, single_only=single, **FULL_DIMS) if rank == 0 else None
     sd = broadcast_state_dict(sd_cpu, shapes, src=0, device=device)
     stats = synthetic_stats()
-    smp = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, **FULL_DIMS)
+    smp = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, single_only=single, **FULL_DIMS)
     smp.load_state_dict(sd)
-    smp.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+    if not single:
+        smp.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
     smp.prepare()
     smp.set_schedule("ddim1000")
     del sd
-    cond, xT = synthetic_inputs(B, T, seed_cond=1 + 1000 * rank, seed_x=2 + 1000 * rank)   # each rank = its own shard of the batch
+    cond, xT = synthetic_inputs(B, T, seed_cond=1 + 1000 * rank, seed_x=2 + 1000 * rank, single=single)   # each rank = its own shard of the batch
     cond, xT = cond.to(device), xT.to(device)
     use_graph = not args.no_graph
     if args.warmup + args.steps > S:
@@ -117,17 +125,19 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sd_cpu, stats, T, args.cpu_steps)
+        cpu = cpu_baseline(sd_cpu, stats, T, args.cpu_steps, single)
 
     if rank == 0:
-        flops = algorithmic_flops_per_motion_step(T)
+        flops = algorithmic_flops_per_motion_step(T, single=single)
         value = world * B / (ms_per_step * 1e-3 * S)
+        wl = ("BASELINE configs[1]: single-person in2IN (individual denoiser, CFG 3.5), T=%d, ddim1000 (eta=0), batch %d per GPU, fp32, random-init weights" % (T, B)) if single else \
+             ("BASELINE configs[2]: 2-person MixerMDM (in2IN individual + in2IN interaction + Mixer mode 4, align, CFG 3.5), "
+              "T=%d, ddim1000 (eta=0), batch %d per GPU, fp32, random-init weights" % (T, B))
         line = {
-            "metric": "generated motions/sec (1000-step DDPM, T=300, 2-person)", "value": round(value, 5), "unit": "motions/s",
+            "metric": "generated motions/sec (1000-step DDPM, T=%d, %s)" % (T, "single-person" if single else "2-person"), "value": round(value, 5), "unit": "motions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 2-person MixerMDM (in2IN individual + in2IN interaction + Mixer mode 4, align, CFG 3.5), "
-                                   "T=%d, ddim1000 (eta=0), batch %d per GPU, fp32, random-init weights" % (T, B),
+            "config": {"workload": wl,
                        "batch_per_gpu": B, "frames": T, "sampler_steps": S, "hipgraph": use_graph, "parallelism": "batch-sharded x%d, no in-loop collective" % world},
             "achieved_tflops_algorithmic": round(flops * B * world / (ms_per_step * 1e-3) / 1e12, 2),
             "frac_of_f32_mfma_peak": round(flops * B / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
@@ -140,13 +150,15 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(sd_cpu, stats, T, nsteps):
+def cpu_baseline(sd_cpu, stats, T, nsteps, single=False):
     """The oracle (a PyTorch-CPU port of the reference path, parity-pinned by tests/golden) timed on this host's cores:
     `nsteps` consecutive DDIM steps at B=1 after one untimed step, extrapolated to the 1000-step loop."""
     import torch
     from oracle import mixer as MX, schedule as OS
     from oracle.layers import pe_table
     from mixermdm_amd.synthetic import synthetic_inputs
+    if single:
+        return cpu_baseline_single(sd_cpu, T, nsteps)
     W = dict(sd_cpu)
     W["sequence_pos_encoder.pe"] = pe_table(512)
     W["denoiser1.sequence_pos_encoder.pe"] = pe_table(1024)
@@ -176,6 +188,27 @@ def cpu_baseline(sd_cpu, stats, T, nsteps):
     return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d consecutive DDIM steps (i=998..) of the same workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), "
                       "%.3f s/step, extrapolated x1000 steps" % (nsteps, T, torch.__version__, dt),
+            "s_per_step_b1": round(dt, 4)}
+
+
+def cpu_baseline_single(sd_cpu, T, nsteps):
+    import torch
+    from oracle import mixer as MX, schedule as OS
+    from oracle.layers import pe_table
+    from mixermdm_amd.synthetic import synthetic_inputs
+    W = dict(sd_cpu)
+    W["denoiser1.sequence_pos_encoder.pe"] = pe_table(1024)
+    sch = OS.make_schedule("cosine", 1000, "ddim1000")
+    cond, x = synthetic_inputs(1, T, single=True)
+    step = lambda i, x: MX.ddim_update(sch, i, x, MX.cfg_single(W, "denoiser1.", "individual", 3.5, x, torch.full((1,), sch.timestep_map[i], dtype=torch.long), cond, 8))
+    with torch.no_grad():
+        x = step(999, x)
+        t0 = time.perf_counter()
+        for k in range(nsteps):
+            x = step(998 - k, x)
+        dt = (time.perf_counter() - t0) / nsteps
+    return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d consecutive DDIM steps of the single-person workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), %.3f s/step, extrapolated x1000 steps" % (nsteps, T, torch.__version__, dt),
             "s_per_step_b1": round(dt, 4)}
 
 

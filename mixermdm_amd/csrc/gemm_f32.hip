@@ -201,28 +201,35 @@ __global__ __launch_bounds__((Cfg<TM_, TN_, BK_>::THREADS)) void gemm_f32_kernel
 // read (16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3)): a 16-lane read group then covers 16 distinct
 // 16-byte bank slots.  Rows past M / N are clamped on load (their results are never stored).
 // ---------------------------------------------------------------------------------------------------------
-template <int TM_, int TN_>
+template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2>
 struct GCfg {
     static constexpr int WGM = TM_ / 10, WGN = TN_ / 10, TM = TM_ % 10, TN = TN_ % 10;
     static constexpr int NWAVES = WGM * WGN, THREADS = 64 * NWAVES;
-    static constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 16;
+    static constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = BK_;
     static constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK;
-    static constexpr int NBUF = 2;
+    static constexpr int NBUF = NBUF_;
     static constexpr int SMEM_BYTES = NBUF * (A_FLOATS + B_FLOATS) * 4;
-    static constexpr int NA = BM / 16, NB = BN / 16;                 // 1-KiB pieces per operand tile
-    static constexpr int NI = (NA + NB + NWAVES - 1) / NWAVES;       // pieces per wave
+    static constexpr int CPR = BK / 4;                               // 16-byte chunks per row (4 or 8)
+    static constexpr int RPP = 64 / CPR;                             // rows per 1-KiB piece (16 or 8)
+    static constexpr int NA = BM / RPP, NB = BN / RPP;               // pieces per operand tile
+    static constexpr int NI = (NA + NB) / NWAVES;                    // pieces per wave (exact)
+    static_assert((NA + NB) % NWAVES == 0, "pieces must divide evenly over the waves (counted vmcnt)");
+    static constexpr int G = BK / 8;                                 // groups of 8 k per K step
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int TM_, int TN_>
-__global__ __launch_bounds__((GCfg<TM_, TN_>::THREADS)) void gemm_glds_kernel(GemmArgs p) {
-    using C_ = GCfg<TM_, TN_>;
-    constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
+// swizzle: 16-byte chunk c of tile row r is stored at chunk position c ^ swz(r)
+template <int CPR> __device__ __forceinline__ int swz_of(int r) { return CPR == 4 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
+
+template <int TM_, int TN_, int BK_, int NBUF_>
+__global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_glds_kernel(GemmArgs p) {
+    using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
+    constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN, CPR = C_::CPR, RPP = C_::RPP, NBUF = C_::NBUF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                   // [NBUF][BM*16]
-    float* Bs = smem + C_::NBUF * C_::A_FLOATS;         // [NBUF][BN*16]
+    float* As = smem;                                   // [NBUF][BM*BK]
+    float* Bs = smem + NBUF * C_::A_FLOATS;             // [NBUF][BN*BK]
 
     const int nwg = p.mt * p.nt;
     const int bid = blockIdx.x;
@@ -237,35 +244,35 @@ __global__ __launch_bounds__((GCfg<TM_, TN_>::THREADS)) void gemm_glds_kernel(Ge
     const int wm = wave / C_::WGN, wn = wave % C_::WGN;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // staging pieces of this wave: piece id pq = wave + NWAVES*u; pq < NA -> A rows 16pq.., else W rows 16(pq-NA)..
+    // staging pieces of this wave: piece id pq = wave + NWAVES*u; pq < NA -> A rows RPP*pq.., else W rows RPP*(pq-NA)..
     const float* src[C_::NI];
     int dst[C_::NI];                                    // LDS float offset of the piece inside buffer 0 (wave-uniform)
+    bool isa[C_::NI];
 #pragma unroll
     for (int u = 0; u < C_::NI; ++u) {
         const int pq = wave + C_::NWAVES * u;
-        const int prow = lane >> 2, pc = lane & 3;
-        const int gch = pc ^ ((prow >> 2) & 3);        // source chunk stored at LDS chunk pc of this row
-        if (pq < C_::NA) {
-            int grow = m0 + 16 * pq + prow;
+        const int prow = lane / CPR, pc = lane % CPR;
+        isa[u] = pq < C_::NA;
+        const int trow = (isa[u] ? RPP * pq : RPP * (pq - C_::NA)) + prow;      // row inside the operand tile
+        const int gch = pc ^ swz_of<CPR>(trow);                                  // source chunk stored at LDS chunk pc of this row
+        if (isa[u]) {
+            int grow = m0 + trow;
             grow = grow < p.M ? grow : p.M - 1;
             src[u] = p.A + (size_t)grow * p.lda + 4 * gch;
-            dst[u] = 16 * pq * BK;
+            dst[u] = RPP * pq * BK;
         } else {
-            int grow = n0 + 16 * (pq - C_::NA) + prow;
+            int grow = n0 + trow;
             grow = grow < p.N ? grow : p.N - 1;
             src[u] = p.W + (size_t)grow * p.ldw + 4 * gch;
-            dst[u] = C_::NBUF * C_::A_FLOATS + 16 * (pq - C_::NA) * BK;
+            dst[u] = NBUF * C_::A_FLOATS + RPP * (pq - C_::NA) * BK;
         }
     }
     auto stage = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < C_::NI; ++u) {
-            const int pq = wave + C_::NWAVES * u;
-            if (pq < C_::NA + C_::NB) {
-                const int boff = pq < C_::NA ? buf * C_::A_FLOATS : buf * C_::B_FLOATS;
-                __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + dst[u] + boff), 16, 0, 0);
-                src[u] += BK;
-            }
+            const int boff = isa[u] ? buf * C_::A_FLOATS : buf * C_::B_FLOATS;
+            __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + dst[u] + boff), 16, 0, 0);
+            src[u] += BK;
         }
     };
 
@@ -293,43 +300,49 @@ __global__ __launch_bounds__((GCfg<TM_, TN_>::THREADS)) void gemm_glds_kernel(Ge
         }
 
     const int nkt = p.K / BK;
-    stage(0);
+    // the accumulator-init loads above must not be counted by the pipeline's vmcnt arithmetic
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    stage(0);
+    if (NBUF == 3 && nkt > 1) stage(1);
 
-    // fragment read offsets (floats): row*16 + 4*((2g + lh) ^ sw), sw = (row >> 2) & 3 = (l31 >> 2) & 3
-    const int sw = (l31 >> 2) & 3;
-    const int c0 = 4 * (lh ^ sw), c1 = 4 * ((2 + lh) ^ sw);
+    // fragment read offsets (floats): row*BK + 4*((2g + lh) ^ sw)
+    const int sw = swz_of<CPR>(l31);
     const int a_row = (wm * (32 * TM) + l31) * BK;
     const int b_row = (wn * (32 * TN) + l31) * BK;
 
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt && p.ablate < 1) stage(cur ^ 1);
+        const int cur = NBUF == 3 ? kt % 3 : (kt & 1);
+        if (NBUF == 3) {
+            // tile kt has landed once at most the NI loads of tile kt+1 are still in flight
+            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C_::NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // raw barrier: __syncthreads() would drain vmcnt(0) while LDS-DMA is in flight and serialise the pipeline
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // everyone done reading buffer (kt+2)%3 (tile kt-1)
+            if (kt + 2 < nkt && p.ablate < 1) stage((kt + 2) % 3);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nkt && p.ablate < 1) stage(cur ^ 1);
+        }
         const float* Ac = As + (p.ablate >= 1 ? 0 : cur) * C_::A_FLOATS + a_row;
         const float* Bc = Bs + (p.ablate >= 1 ? 0 : cur) * C_::B_FLOATS + b_row;
-        f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            af[0][i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * BK + c0);
-            af[1][i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * BK + c1);
-        }
+        for (int g = 0; g < C_::G; ++g) {
+            const int cg = 4 * ((2 * g + lh) ^ sw);
+            f32x4 af[TM], bf[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            bf[0][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * BK + c0);
-            bf[1][j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * BK + c1);
-        }
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * BK + cg);
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * BK + cg);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i][s], bf[g][j][s], acc[i][j], 0, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (p.ablate < 2) __syncthreads();
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
     }
     if (p.ablate >= 3) return;
 
@@ -352,19 +365,19 @@ __global__ __launch_bounds__((GCfg<TM_, TN_>::THREADS)) void gemm_glds_kernel(Ge
     }
 }
 
-template <int TM_, int TN_>
+template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2>
 int launch_glds(GemmArgs a, hipStream_t st) {
-    using C_ = GCfg<TM_, TN_>;
+    using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
     a.mt = (a.M + C_::BM - 1) / C_::BM;
     a.nt = (a.N + C_::BN - 1) / C_::BN;
-    hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_glds");
 }
 
-template <int TM_, int TN_>
+template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2>
 int set_attr_glds() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<TM_, TN_>::SMEM_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<TM_, TN_, BK_, NBUF_>::SMEM_BYTES);
     if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_glds): %s", hipGetErrorString(e));
     return MMDM_OK;
 }
@@ -427,6 +440,9 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_cfg<22, 42, 16>())) return rc;
     if ((rc = set_attr_glds<42, 22>())) return rc;
     if ((rc = set_attr_glds<22, 22>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 16, 3>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 32, 2>())) return rc;
+    if ((rc = set_attr_glds<42, 22, 16, 3>())) return rc;
     const char* e = getenv("MMDM_GEMM_CFG");
     g_gemm_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
@@ -468,6 +484,9 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     switch (g_gemm_cfg) {
         case 10: if (glds_ok) return launch_glds<42, 22>(a, st); break;
         case 11: case -1: if (glds_ok) return launch_glds<22, 22>(a, st); break;
+        case 12: if (glds_ok) return launch_glds<22, 22, 16, 3>(a, st); break;
+        case 13: if (glds_ok && K % 32 == 0) return launch_glds<22, 22, 32, 2>(a, st); break;
+        case 14: if (glds_ok) return launch_glds<42, 22, 16, 3>(a, st); break;
         default: break;
     }
     switch (g_gemm_cfg) {
