@@ -6,7 +6,9 @@
 // The extra key has logit 0 and value 0, so it is folded in as the INITIAL online-softmax state (m=0, l=1, O=0).
 //
 // Structure: one 256-thread workgroup = 4 waves = 64 queries of one (sequence, head); each wave owns 16 queries.
-// Keys/values stream through LDS in chunks of 64.  QK^T is computed swapped (S^T = K Q^T) so that each lane holds
+// Keys/values stream through LDS in stages of 16 keys, double-buffered by LDS-DMA (global_load_lds_dwordx4: the next stage
+// is in flight while the current one is consumed; unpadded rows, XOR-swizzled on the DMA source address and on the read).
+// QK^T is computed swapped (S^T = K Q^T) so that each lane holds
 // four keys of ONE query column (C/D map: col = lane&15 = query, row = 4*(lane>>4)+reg = key): the row max / row sum
 // are 4 local values + two xor-shuffles (16, 32), and the exponentiated tile is already the A operand of the
 // P.V MFMA (k index = lane group) with no cross-lane movement or LDS round trip.  The d (reduction) order of
@@ -18,38 +20,60 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
+// hipcc (ROCm 7.2) pads the MFMA -> VALU read-after-write hazard only inside a basic block: when a (wave-uniform) branch
+// follows the last v_mfma of a chain and the branch target starts with a VALU read of the accumulator, no wait states are
+// emitted on the taken path and the VALU can read the accumulator before the MFMA has written it (seen here as a run-to-run
+// different running max once two waves shared a SIMD).  MFMA_SETTLE(x) is an opaque asm statement that takes the accumulator
+// as a read-write operand -- so the compiler keeps it behind the MFMAs that produce x and ahead of every consumer -- and
+// supplies the wait states itself (24 >= the 18 a 16-pass MFMA needs).
+#define MFMA_SETTLE(x) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(x))
 
-constexpr int KC = 64;   // keys per LDS chunk
+constexpr int KC = 16;   // keys per LDS stage (two stages in flight)
 constexpr int QW = 16;   // queries per wave
 constexpr int QB = 64;   // queries per workgroup
 
 struct AttnArgs {
     const float* Q; const float* K; const float* V; float* O;
     int ldq, ldk, ldv, ldo;
-    int nseq, Tq, Tk, H, shift, qtiles;
-    float scale;
+    int nseq, Tq, Tk, H, shift, qtiles, pairs_per_xcd;
+    float scale, scale2;
 };
 
+// LDS image of one stage (KC keys): K rows and V rows are DH floats, unpadded (LDS-DMA writes 1 KiB contiguous pieces);
+// bank conflicts are avoided by XOR swizzles applied on the per-lane SOURCE address of the DMA and again on the read:
+//   K: 16-byte chunk c of key row r is stored at chunk (c ^ (r & 15))      (conflict-free ds_read_b128 fragment reads)
+//   V: 16-byte chunk c of key row r is stored at chunk (c ^ (4 * ((r >> 2) & 1)))  (conflict-free ds_read_b32 operand reads)
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
-    constexpr int LDK = DH + 4;                 // padded LDS row (floats): 16-byte reads spread over bank slots
     constexpr int NJ = DH / 16;                 // d groups of 16 (QK^T) == 16-wide output column tiles (PV)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                           // [KC][LDK]
-    float* Vs = smem + KC * LDK;                // [KC][LDK]
+    constexpr int NKT = KC / 16;                // 16-key tiles per stage
+    constexpr int CPR = DH / 4;                 // 16-byte chunks per row
+    constexpr int RPP = 64 / CPR;               // rows per 1-KiB DMA piece
+    constexpr int NPIECE = 2 * KC / RPP;        // pieces per stage (K then V)
+    constexpr int NI = NPIECE / 4;              // pieces per wave
+    constexpr int STAGE = 2 * KC * DH;          // floats per stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 stages][K: KC*DH | V: KC*DH]
 
+    // XCD-aware mapping: blocks b and b+8 share an XCD (private L2), so all query tiles of one (sequence, head) are given to
+    // blocks of the same residue mod 8 -- its K/V is then fetched into one L2 once instead of into up to `qtiles` L2s.
     const int bid = blockIdx.x;
-    const int qt = bid % p.qtiles;
-    const int sh = bid / p.qtiles;
+    const int local = bid >> 3, xcd = bid & 7;
+    const int qt = local % p.qtiles;
+    const int sh = xcd * p.pairs_per_xcd + local / p.qtiles;
+    if (sh >= p.nseq * p.H) return;
     const int head = sh % p.H;
     const int seq = sh / p.H;
     const int kvseq = (seq + p.shift) % p.nseq;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 15, g = lane >> 4;
     const int q0 = qt * QB + wave * QW;
 
-    // Q fragment (B operand of S^T = K Q^T): lane (q = lq, g) holds Q[q][16j + 4g + s], pre-scaled.
+    // Q fragment (B operand of S^T = K Q^T): lane (q = lq, g) holds Q[q][16j + 4g + s], pre-scaled into the log2 domain.
     f32x4 qf[NJ];
     {
         int qrow = q0 + lq;
@@ -58,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             f32x4 v = *reinterpret_cast<const f32x4*>(qp + 16 * j);
-            qf[j] = v * p.scale;
+            qf[j] = v * p.scale2;
         }
     }
 
@@ -70,61 +94,78 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     const float* Kg = p.K + (size_t)kvseq * p.Tk * p.ldk + head * DH;
     const float* Vg = p.V + (size_t)kvseq * p.Tk * p.ldv + head * DH;
 
-    for (int c0 = 0; c0 < p.Tk; c0 += KC) {
-        __syncthreads();                        // previous chunk fully consumed
-        // stage K and V chunk: KC rows x DH floats each; zero-fill rows past Tk
-        constexpr int F4_PER_ROW = DH / 4;
-        constexpr int F4_TOTAL = KC * F4_PER_ROW;
+    // DMA pieces of this wave: piece pq = wave + 4u; pq < NPIECE/2 -> K rows RPP*pq.., else V rows.  Rows past Tk are clamped
+    // (their scores are masked to -inf below, so the values never matter).
+    auto stage = [&](int c0, int buf) {
 #pragma unroll
-        for (int i = tid; i < F4_TOTAL; i += 256) {
-            const int row = i / F4_PER_ROW, c4 = (i % F4_PER_ROW) * 4;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (c0 + row < p.Tk) {
-                kv = *reinterpret_cast<const f32x4*>(Kg + (size_t)(c0 + row) * p.ldk + c4);
-                vv = *reinterpret_cast<const f32x4*>(Vg + (size_t)(c0 + row) * p.ldv + c4);
-            }
-            *reinterpret_cast<f32x4*>(&Ks[row * LDK + c4]) = kv;
-            *reinterpret_cast<f32x4*>(&Vs[row * LDK + c4]) = vv;
+        for (int u = 0; u < NI; ++u) {
+            const int pq = wave + 4 * u;
+            const bool isk = pq < NPIECE / 2;
+            const int trow = RPP * (isk ? pq : pq - NPIECE / 2) + lane / CPR;
+            const int pos = lane % CPR;
+            const int src_chunk = isk ? (pos ^ (trow & 15)) : (pos ^ (4 * ((trow >> 2) & 1)));
+            int krow = c0 + trow;
+            krow = krow < p.Tk ? krow : p.Tk - 1;
+            const float* src = (isk ? Kg + (size_t)krow * p.ldk : Vg + (size_t)krow * p.ldv) + 4 * src_chunk;
+            float* dst = smem + buf * STAGE + (isk ? 0 : KC * DH) + RPP * (isk ? pq : pq - NPIECE / 2) * DH;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
         }
-        __syncthreads();
+    };
 
-        // S^T tiles: st[kt][reg] = score(key = c0 + 16kt + 4g + reg, query = lq)
-        f32x4 st[4];
+    const int nchunks = (p.Tk + KC - 1) / KC;
+    stage(0, 0);
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int c0 = ci * KC, cur = ci & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk ci have landed
+        __syncthreads();                                        // ... everyone's; and chunk ci-1 is fully consumed
+        if (ci + 1 < nchunks) stage(c0 + KC, cur ^ 1);         // prefetch into the other stage while computing this one
+        const float* Ks = smem + cur * STAGE;
+        const float* Vs = Ks + KC * DH;
+
+        // S^T tiles: st[kt][reg] = score(key = c0 + 16kt + 4g + reg, query = lq); K fragments double-buffered in registers
+        f32x4 st[NKT];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < NKT; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 kf[2][NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) kf[0][kt] = *reinterpret_cast<const f32x4*>(&Ks[(16 * kt + lq) * DH + 4 * (g ^ lq)]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            f32x4 kf[4];
+            const int cb = j & 1;
+            if (j + 1 < NJ) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-                kf[kt] = *reinterpret_cast<const f32x4*>(&Ks[(16 * kt + lq) * LDK + 16 * j + 4 * g]);
+                for (int kt = 0; kt < NKT; ++kt)
+                    kf[cb ^ 1][kt] = *reinterpret_cast<const f32x4*>(&Ks[(16 * kt + lq) * DH + 4 * ((4 * (j + 1) + g) ^ lq)]);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-                    st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][s], qf[j][s], st[kt], 0, 0, 0);
+                for (int kt = 0; kt < NKT; ++kt)
+                    st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[cb][kt][s], qf[j][s], st[kt], 0, 0, 0);
         }
 
-        // mask keys past Tk, chunk max for this lane's query
-        float cmax = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < NKT; ++kt) MFMA_SETTLE(st[kt]);
+        if (c0 + KC > p.Tk) {                  // only the last chunk can hold keys past Tk (wave-uniform branch)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = c0 + 16 * kt + 4 * g + r;
-                if (key >= p.Tk) st[kt][r] = -INFINITY;
-                cmax = fmaxf(cmax, st[kt][r]);
-            }
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + 16 * kt + 4 * g + r >= p.Tk) st[kt][r] = -INFINITY;
+        }
+        float cmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+#pragma unroll
+        for (int kt = 1; kt < NKT; ++kt) cmax = fmaxf(cmax, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
         const float m_new = fmaxf(m_run, cmax);
-        const float alpha = expf(m_run - m_new);
+        const float alpha = EXP2(m_run - m_new);
         float lsum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                st[kt][r] = expf(st[kt][r] - m_new);
+                st[kt][r] = EXP2(st[kt][r] - m_new);
                 lsum += st[kt][r];
             }
         lsum += __shfl_xor(lsum, 16);
@@ -139,21 +180,34 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];
+            for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];       // (the PV MFMAs of the previous chunk retired long ago: barrier + QK^T in between)
 
         // O[q][n] += sum_key P[q][key] V[key][n]:  A = P (lane-local: st[kt][r] is P[q=lq][key=16kt+4g+r]),
-        // B = V[key = 16kt + 4g + r][n = 16j + lq]
+        // B = V[key = 16kt + 4g + r][n = 16j + lq]; key rows 4g+r with g odd are stored with the column chunk index ^ 4 (n ^ 16).
+        const int vsw = 16 * (g & 1);
+        float vb[2][NJ];
+        {
+            const float* vrow = &Vs[(4 * g) * DH + lq];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+            for (int j = 0; j < NJ; ++j) vb[0][j] = vrow[(16 * j) ^ vsw];
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* vrow = &Vs[(16 * kt + 4 * g + r) * LDK + lq];
+        for (int idx = 0; idx < 4 * NKT; ++idx) {
+            const int kt = idx >> 2, r = idx & 3, cb = idx & 1;
+            if (idx + 1 < 4 * NKT) {
+                const int kt1 = (idx + 1) >> 2, r1 = (idx + 1) & 3;
+                const float* vrow = &Vs[(16 * kt1 + 4 * g + r1) * DH + lq];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vrow[16 * j], o[j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) vb[cb ^ 1][j] = vrow[(16 * j) ^ vsw];
             }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vb[cb][j], o[j], 0, 0, 0);
+        }
     }
 
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
     // normalise and store: accumulator element (j, r) is O[query q0 + 4g + r][16j + lq]
     float lr[4];
 #pragma unroll
@@ -204,11 +258,11 @@ __global__ void attn_small_kernel(AttnArgs p) {
 }
 
 template <int DH>
-constexpr int attn_smem() { return 2 * KC * (DH + 4) * 4; }
+constexpr int attn_smem() { return 2 * 2 * KC * DH * 4; }
 
 template <int DH>
 int launch_mfma(const AttnArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((attn_mfma_kernel<DH>), dim3(a.nseq * a.H * a.qtiles), dim3(256), attn_smem<DH>(), st, a);
+    hipLaunchKernelGGL((attn_mfma_kernel<DH>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), attn_smem<DH>(), st, a);
     return mmdm_check_launch("attn_mfma");
 }
 
@@ -244,7 +298,9 @@ extern "C" int mmdm_attention_f32(const float* Q, int ldq, const float* K, int l
     a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
+    a.pairs_per_xcd = (nseq * H + 7) / 8;
     a.scale = 1.0f / sqrtf((float)dh);
+    a.scale2 = a.scale * 1.4426950408889634f;     // scores kept in the log2 domain: softmax via v_exp_f32 (2^x)
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dh == 128 || dh == 64) {
         const bool al = ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V)) & 15) == 0 &&

@@ -345,6 +345,11 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
         }
     }
     if (p.ablate >= 3) return;
+    // MFMA -> VALU hazard across the loop-exit branch: see MFMA_SETTLE in attn_f32.hip
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
