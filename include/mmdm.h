@@ -114,6 +114,11 @@ int mmdm_xstart_ddim_f32(const float* model_out, const float* stats, const float
 int mmdm_cfg_ddim_f32(const float* m, const float* coef, int S, const int* step_idx, float cfg_scale,
                       float* x, float* pred_xstart, int B, int T, int C, void* stream);
 
+/* Temporal smoothing of generated motions: out[b,t,c] = sum_k w[k+radius] * x[b, clamp(t+k, 0, T-1), c], accumulated in
+ * double.  `weights` is a DEVICE array of 2*radius+1 doubles (the normalised gaussian of scipy's _gaussian_kernel1d).
+ * Replaces scipy.ndimage.gaussian_filter1d(motion, 1, axis=0, mode='nearest')  src/scripts/infer/mixermdm.py:130. */
+int mmdm_gaussian_filter1d_f32(const float* x, float* out, const double* weights, int radius, int n, int T, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 2. The sampler handle: weights + workspace + captured step graph.
  * ---------------------------------------------------------------------------------------------- */

@@ -37,6 +37,7 @@ SYMBOLS = {
     "mmdm_blend_cfg_f32": (_I, [_VP, _VP, _VP, _I, _I, C.c_float, C.c_float, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "mmdm_xstart_ddim_f32": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "mmdm_cfg_ddim_f32": (_I, [_VP, _VP, _I, _VP, C.c_float, _VP, _VP, _I, _I, _I, _VP]),
+    "mmdm_gaussian_filter1d_f32": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "mmdm_create": (_I, [C.POINTER(Config), C.POINTER(_VP)]),
     "mmdm_destroy": (None, [_VP]),
     "mmdm_handle_error": (C.c_char_p, [_VP]),

@@ -319,14 +319,14 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
             // raw barrier: __syncthreads() would drain vmcnt(0) while LDS-DMA is in flight and serialise the pipeline
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // everyone done reading buffer (kt+2)%3 (tile kt-1)
-            if (kt + 2 < nkt && p.ablate < 1) stage((kt + 2) % 3);
+            if (kt + 2 < nkt && (p.ablate & 7) < 1) stage((kt + 2) % 3);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 1 < nkt && p.ablate < 1) stage(cur ^ 1);
+            if (kt + 1 < nkt && (p.ablate & 7) < 1) stage(cur ^ 1);
         }
-        const float* Ac = As + (p.ablate >= 1 ? 0 : cur) * C_::A_FLOATS + a_row;
-        const float* Bc = Bs + (p.ablate >= 1 ? 0 : cur) * C_::B_FLOATS + b_row;
+        const float* Ac = As + ((p.ablate & 7) >= 1 ? 0 : cur) * C_::A_FLOATS + a_row;
+        const float* Bc = Bs + ((p.ablate & 7) >= 1 ? 0 : cur) * C_::B_FLOATS + b_row;
 #pragma unroll
         for (int g = 0; g < C_::G; ++g) {
             const int cg = 4 * ((2 * g + lh) ^ sw);
@@ -335,6 +335,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * BK + cg);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * BK + cg);
+            if (p.ablate & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -342,9 +343,10 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            if (p.ablate & 8) __builtin_amdgcn_s_setprio(0);
         }
     }
-    if (p.ablate >= 3) return;
+    if ((p.ablate & 7) >= 3) return;
     // MFMA -> VALU hazard across the loop-exit branch: see MFMA_SETTLE in attn_f32.hip
 #pragma unroll
     for (int i = 0; i < TM; ++i)

@@ -96,7 +96,34 @@ __global__ __launch_bounds__(256) void influence_head_kernel(const float* __rest
     }
 }
 
+// scipy.ndimage.gaussian_filter1d(x, sigma, axis=time, mode="nearest") on [n, T, C]: correlate with a symmetric kernel of
+// radius r, indices clamped to [0, T-1]; weights and accumulation in double (scipy's correlate1d accumulates in double).
+__global__ void gauss1d_kernel(const float* __restrict__ x, float* __restrict__ out, const double* __restrict__ w, int radius, int n, int T, int C) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * T * C) return;
+    const int c = (int)(idx % C);
+    const int t = (int)((idx / C) % T);
+    const size_t b = idx / ((size_t)C * T);
+    const float* xb = x + b * T * C + c;
+    double acc = 0.0;
+    for (int k = -radius; k <= radius; ++k) {
+        int tt = t + k;
+        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+        acc += w[k + radius] * (double)xb[(size_t)tt * C];
+    }
+    out[idx] = (float)acc;
+}
+
 }  // namespace
+
+extern "C" int mmdm_gaussian_filter1d_f32(const float* x, float* out, const double* weights, int radius, int n, int T, int C, void* stream) {
+    if (n == 0 || T == 0 || C == 0) return MMDM_OK;
+    if (!x || !out || !weights || radius < 0 || n < 0 || T < 0 || C < 0 || x == out)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_gaussian_filter1d_f32: bad arguments (in-place is not supported)");
+    const size_t total = (size_t)n * T * C;
+    hipLaunchKernelGGL(gauss1d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, weights, radius, n, T, C);
+    return mmdm_check_launch("gauss1d");
+}
 
 extern "C" int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss_rows, float* out, int nseq, int T, int D, void* stream) {
     if (nseq == 0 || T == 0) return MMDM_OK;

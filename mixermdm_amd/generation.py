@@ -1,0 +1,80 @@
+"""Callers on either side of the denoising loop, mirroring the reference's harnesses:
+
+  * ``generate_one_sample`` = LitGenModel.generate_loop + the save layout of generate_one_sample
+    (src/scripts/infer/mixermdm.py:57-144): model(batch) -> output[0] as [T, 2, 262] -> gaussian_filter1d(sigma=1, time axis,
+    mode="nearest") -> ``<name>_motion.npy`` / ``_influence{1,2}.npy``;
+  * ``generate_for_evaluation`` = the generation loop of EvaluationDataset* (src/evaluation/datasets.py:71-163): per item a
+    ``forward_test`` on B = 1 (or mm_num_repeats) motions of that item's length, reshape to [B, T, 2, 262], optional
+    de-normalisation, zero padding to ``max_length``.
+
+Smoothing runs on the GPU (``ops.gaussian_filter1d``, bit-compatible with scipy's double-accumulating correlate1d);
+file writing and list bookkeeping stay on the host, as in the reference.  Plots / viewers are out of scope.
+"""
+import copy
+import os
+import numpy as np
+import torch
+
+from . import ops
+
+
+def generate_loop(model, batch, window_size):
+    """LitGenModel.generate_loop (infer/mixermdm.py:102-144).  `batch` may carry 'cond'/'x_T' instead of prompts."""
+    batch = copy.copy(batch)
+    batch["motion_lens"] = torch.full((1, 1), int(window_size), dtype=torch.long)
+    for src, dst in (("prompt_individual1", "text_individual1"), ("prompt_individual2", "text_individual2"), ("prompt_interaction", "text_interaction")):
+        if src in batch:
+            batch[dst] = [batch[src]]
+    out = model(batch)
+    motion = out["output"][0].reshape(out["output"][0].shape[0], 2, -1)          # [T, 2, 262]
+    motion = ops.gaussian_filter1d(motion.reshape(1, motion.shape[0], -1), 1.0).reshape(motion.shape)
+    return (motion.cpu().numpy(), out["influence_i1"], out["influence_i2"], out["out1"], out["out2"], out["out_influenced"])
+
+
+def generate_one_sample(model, batch, name, save_folder, window_size=299):
+    """infer/mixermdm.py:57-99 without the plotting: writes <name>_motion.npy, _influence1.npy, _influence2.npy."""
+    motion, i1, i2, _, _, _ = generate_loop(model, batch, window_size)
+    os.makedirs(save_folder, exist_ok=True)
+    path = os.path.join(save_folder, name)
+    np.save(path + "_motion.npy", motion)
+    np.save(path + "_influence1.npy", np.array([t.cpu().numpy() for t in i1]))
+    np.save(path + "_influence2.npy", np.array([t.cpu().numpy() for t in i2]))
+    return motion
+
+
+def generate_for_evaluation(model, items, max_length=300, mm_idxs=(), mm_num_repeats=1, normalizer=None, extended=True):
+    """Generation loop of the evaluation datasets (datasets.py:71-163).
+
+    items: iterable of dicts with 'text' (tuple/list of str), 'motion_lens' (LongTensor [1]), optionally
+    'text_individual1/2', and -- since the CLIP tower is upstream -- optionally a precomputed 'cond' [1, 8*768].
+    Returns (generated_motions, mm_generated_motions) with the reference's dictionary keys.
+    """
+    generated, mm_generated = [], []
+    mm_idxs = set(mm_idxs)
+    with torch.no_grad():
+        for i, data in enumerate(items):
+            rep = mm_num_repeats if i in mm_idxs else 1
+            batch = {"text": list(data["text"]) * rep, "motion_lens": data["motion_lens"]}
+            if extended:
+                batch["text_individual1"] = list(data["text_individual1"]) * rep
+                batch["text_individual2"] = list(data["text_individual2"]) * rep
+            if "cond" in data:
+                batch["cond"] = data["cond"].repeat(rep, 1)
+            out = model.forward_test(batch)["output"]
+            motions = out.reshape(out.shape[0], out.shape[1], 2, -1).cpu().numpy()
+            if normalizer is not None:
+                motions = normalizer.backward(motions)
+            B, T = motions.shape[:2]
+            if T < max_length:
+                motions = np.concatenate((motions, np.zeros((B, max_length - T, 2, motions.shape[-1]))), axis=1)
+            assert motions.shape[1] == max_length
+            sub = {"motion1": motions[0, :, 0], "motion2": motions[0, :, 1], "motion_lens": data["motion_lens"][0], "text": data["text"][0]}
+            if extended:
+                sub.update(text_individual1=data["text_individual1"][0], text_individual2=data["text_individual2"][0])
+            generated.append(sub)
+            if i in mm_idxs:
+                mm = {"mm_motions": motions, "motion_lens": data["motion_lens"][0], "text": data["text"][0]}
+                if extended:
+                    mm.update(text_individual1=data["text_individual1"][0], text_individual2=data["text_individual2"][0])
+                mm_generated.append(mm)
+    return generated, mm_generated

@@ -135,3 +135,20 @@ def cfg_ddim(m, coef, step_idx, cfg_scale, x):
     p = torch.empty_like(x)
     check(load_library().mmdm_cfg_ddim_f32(_p(m.contiguous()), _p(coef), coef.shape[1], _p(step_idx), float(cfg_scale), _p(x), _p(p), B, T, Cc, _stream()))
     return p
+
+
+def gaussian_filter1d(x, sigma=1.0, truncate=4.0):
+    """scipy.ndimage.gaussian_filter1d(x, sigma, axis=-2, mode="nearest") for x [..., T, C] on the GPU."""
+    import numpy as np
+    _chk(x)
+    x = x.contiguous()
+    T, Cc = x.shape[-2], x.shape[-1]
+    n = x.numel() // (T * Cc) if x.numel() else 0
+    radius = int(truncate * float(sigma) + 0.5)            # scipy: lw = int(truncate * sd + 0.5)
+    k = np.arange(-radius, radius + 1)
+    w = np.exp(-0.5 / (sigma * sigma) * k ** 2)            # scipy.ndimage._filters._gaussian_kernel1d, order 0
+    w = w / w.sum()
+    wd = torch.from_numpy(w).to(x.device)
+    out = torch.empty_like(x)
+    check(load_library().mmdm_gaussian_filter1d_f32(_p(x), _p(out), C.c_void_p(wd.data_ptr()), radius, n, T, Cc, _stream()))
+    return out

@@ -82,3 +82,36 @@ def test_history_budget_is_enforced(tmp_path, golden, monkeypatch):
     m.history_every = 250
     out = m(batch)
     assert len(out["influence_i1"]) == 4 and torch.isfinite(out["output"]).all()
+
+
+def test_gaussian_filter_matches_scipy():
+    from scipy.ndimage import gaussian_filter1d
+    from mixermdm_amd import ops
+    x = torch.randn(3, 37, 524, generator=torch.Generator().manual_seed(5))
+    for sigma in [1.0, 2.5]:
+        ref = gaussian_filter1d(x.numpy(), sigma, axis=1, mode="nearest")
+        got = ops.gaussian_filter1d(x.cuda(), sigma).cpu().numpy()
+        np.testing.assert_allclose(got, ref, atol=1e-6, rtol=1e-6)
+    one = torch.randn(1, 1, 8).cuda()                         # T = 1: every tap clamps to the only frame
+    np.testing.assert_allclose(ops.gaussian_filter1d(one).cpu().numpy(), one.cpu().numpy(), atol=1e-6)
+
+
+def test_generation_harnesses(tmp_path, golden):
+    """infer-script and eval-dataset callers: file layout, smoothing, per-item T, padding, mm repeats."""
+    from scipy.ndimage import gaussian_filter1d
+    from mixermdm_amd.generation import generate_one_sample, generate_for_evaluation
+    m, g, t = tiny_model(tmp_path, golden, strategy="ddim20")
+    cond = t("cfg_cond")[:1].cuda()
+    xT = torch.randn(1, 12, 524, generator=torch.Generator().manual_seed(9)).cuda()
+    motion = generate_one_sample(m, {"cond": cond, "x_T": xT}, "s0", str(tmp_path / "out"), window_size=12)
+    assert motion.shape == (12, 2, 262)
+    raw = m({"cond": cond, "x_T": xT, "motion_lens": torch.tensor([[12]])})["output"][0].reshape(12, 2, 262).cpu().numpy()
+    np.testing.assert_allclose(motion, gaussian_filter1d(raw, 1, axis=0, mode="nearest"), atol=1e-6, rtol=1e-6)
+    saved = np.load(tmp_path / "out" / "s0_motion.npy")
+    assert np.array_equal(saved, motion)
+    assert np.load(tmp_path / "out" / "s0_influence1.npy").shape == (20, 2, 12, 262)
+    items = [dict(text=("a",), text_individual1=("b",), text_individual2=("c",), motion_lens=torch.tensor([T]), cond=cond) for T in (8, 16, 10)]
+    gen, mm = generate_for_evaluation(m, items, max_length=16, mm_idxs=[1], mm_num_repeats=2)
+    assert len(gen) == 3 and len(mm) == 1
+    assert gen[0]["motion1"].shape == (16, 262) and np.all(gen[0]["motion1"][8:] == 0) and np.any(gen[0]["motion1"][:8] != 0)
+    assert mm[0]["mm_motions"].shape == (2, 16, 2, 262) and gen[1]["text_individual2"] == "c"
