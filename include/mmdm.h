@@ -119,6 +119,11 @@ int mmdm_cfg_ddim_f32(const float* m, const float* coef, int S, const int* step_
  * Replaces scipy.ndimage.gaussian_filter1d(motion, 1, axis=0, mode='nearest')  src/scripts/infer/mixermdm.py:130. */
 int mmdm_gaussian_filter1d_f32(const float* x, float* out, const double* weights, int radius, int n, int T, int C, void* stream);
 
+/* 4-way CFG + single-chain DDIM: x0 = s*m[0:B] + s_int*m[B:2B] + s_ind*m[2B:3B] + (1-(s+s_int+s_ind))*m[3B:4B]; m [4B,T,C].
+ * Replaces ClassifierFreeSampleModelMultiple combine + GaussianDiffusion.ddim_sample  cfg_sampler.py:90-98, gaussian_diffusion.py:799-849. */
+int mmdm_cfg4_ddim_f32(const float* m, const float* coef, int S, const int* step_idx, float s, float s_int, float s_ind,
+                       float* x, float* pred_xstart, int B, int T, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 2. The sampler handle: weights + workspace + captured step graph.
  * ---------------------------------------------------------------------------------------------- */
@@ -141,7 +146,10 @@ typedef struct {
     float cfg_scale;   /* CFG_WEIGHT */
     int max_batch;     /* B (before CFG doubling) the workspace is sized for */
     int max_frames;    /* T */
-    int single_only;   /* 1: only denoiser1 is used (single-person configs 1-2); mixer/denoiser2 weights not required */
+    int single_only;   /* 0: two-chain MixerMDM.  1: single chain, denoiser1 only (individual in2IN, 2-way CFG; configs 1-2).
+                        * 2: single chain, denoiser2 only (stand-alone interaction in2IN/InterGen, 4-way CFG of
+                        *    ClassifierFreeSampleModelMultiple  src/models/utils/cfg_sampler.py:59-98; in2in.py:330-341) */
+    float cfg_scale_interaction, cfg_scale_individual;   /* CFG_WEIGHT_INTERACTION / CFG_WEIGHT_INDIVIDUAL (single_only == 2) */
 } mmdm_config;
 
 int mmdm_create(const mmdm_config* cfg, mmdm_handle* out);

@@ -19,7 +19,8 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("d_latent", "d_ff", "d_layers", "d_heads", "m_latent", "m_ff", "m_layers", "m_heads",
                                         "nfeats", "text_dim", "mixing_mode", "align", "xstart_align", "model2_kind", "use_force")] + \
                [("force_val", C.c_float), ("cfg_scale", C.c_float)] + \
-               [(n, C.c_int) for n in ("max_batch", "max_frames", "single_only")]
+               [(n, C.c_int) for n in ("max_batch", "max_frames", "single_only")] + \
+               [("cfg_scale_interaction", C.c_float), ("cfg_scale_individual", C.c_float)]
 
 
 # every symbol include/mmdm.h declares: name -> (restype, argtypes)
@@ -38,6 +39,7 @@ SYMBOLS = {
     "mmdm_xstart_ddim_f32": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "mmdm_cfg_ddim_f32": (_I, [_VP, _VP, _I, _VP, C.c_float, _VP, _VP, _I, _I, _I, _VP]),
     "mmdm_gaussian_filter1d_f32": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "mmdm_cfg4_ddim_f32": (_I, [_VP, _VP, _I, _VP, C.c_float, C.c_float, C.c_float, _VP, _VP, _I, _I, _I, _VP]),
     "mmdm_create": (_I, [C.POINTER(Config), C.POINTER(_VP)]),
     "mmdm_destroy": (None, [_VP]),
     "mmdm_handle_error": (C.c_char_p, [_VP]),

@@ -339,6 +339,17 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* __restrict__
     if (px) px[idx] = x0;
 }
 
+__global__ __launch_bounds__(256) void cfg4_ddim_kernel(const float* __restrict__ m, const float* __restrict__ coef, int S, const int* __restrict__ step_idx,
+                                                         float s, float si, float sd, float* __restrict__ x, float* __restrict__ px, size_t per_batch_total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per_batch_total) return;
+    const int i = *step_idx;
+    // (s*full) + (s_int*interaction-only) + (s_ind*individuals-only) + ((1-(s+s_int+s_ind))*uncond)   cfg_sampler.py:97
+    const float x0 = (s * m[idx]) + (si * m[per_batch_total + idx]) + (sd * m[2 * per_batch_total + idx]) + ((1.0f - (s + si + sd)) * m[3 * per_batch_total + idx]);
+    x[idx] = ddim(x[idx], x0, coef[i], coef[S + i], coef[2 * S + i], coef[3 * S + i]);
+    if (px) px[idx] = x0;
+}
+
 __global__ void step_dec_kernel(int* step_idx, int* loop_pos) { *step_idx -= 1; *loop_pos += 1; }
 __global__ void set_step_kernel(int* step_idx, int* loop_pos, int s, int l) { *step_idx = s; *loop_pos = l; }
 
@@ -434,6 +445,16 @@ extern "C" int mmdm_cfg_ddim_f32(const float* m, const float* coef, int S, const
     hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        m, coef, S, step_idx, cfg_scale, x, pred_xstart, total);
     return mmdm_check_launch("cfg_ddim");
+}
+
+extern "C" int mmdm_cfg4_ddim_f32(const float* m, const float* coef, int S, const int* step_idx, float s, float s_int, float s_ind,
+                                  float* x, float* pred_xstart, int B, int T, int C, void* stream) {
+    if (B == 0 || T == 0) return MMDM_OK;
+    if (!m || !coef || !step_idx || !x || S <= 0 || B < 0 || T < 0 || C <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_cfg4_ddim_f32: bad arguments");
+    const size_t total = (size_t)B * T * C;
+    hipLaunchKernelGGL(cfg4_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       m, coef, S, step_idx, s, s_int, s_ind, x, pred_xstart, total);
+    return mmdm_check_launch("cfg4_ddim");
 }
 
 int mmdm_step_dec(int* step_idx, int* loop_pos, hipStream_t st) {

@@ -436,10 +436,18 @@ int ss_ld_of(const ModuleW& m) { return m.st.L * m.st.n_ada * 2 * m.st.D; }
 int run_step(const Ctx& c) {
     mmdm_handle H = c.h;
     const int B = H->B, T = H->T, n = 2 * B;
-    if (H->cfg.single_only) {
+    if (H->cfg.single_only == 1) {
         RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, n));
         RC(run_denoiser(c, H->d1, false, H->x, B, 1, NF, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF));
         RC(mmdm_cfg_ddim_f32(H->o1, H->d_coef, H->S, H->d_step, H->cfg.cfg_scale, H->x, H->px1, B, T, NF, c.st));
+        return mmdm_step_dec(H->d_step, H->d_step + 1, c.st);
+    }
+    if (H->cfg.single_only == 2) {   // stand-alone interaction denoiser, 4 CFG copies of x (cfg_sampler.py:70-71)
+        const int n4 = 4 * B;
+        RC(cond_vectors(c, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n4));
+        RC(run_denoiser(c, H->d2, true, H->x, B, 2, NF2, n4, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
+        RC(mmdm_cfg4_ddim_f32(H->o2, H->d_coef, H->S, H->d_step, H->cfg.cfg_scale, H->cfg.cfg_scale_interaction, H->cfg.cfg_scale_individual,
+                              H->x, H->px1, B, T, NF2, c.st));
         return mmdm_step_dec(H->d_step, H->d_step + 1, c.st);
     }
     RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n));
@@ -518,14 +526,17 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     h->nw = (c.mixing_mode >= 3) ? 23 : 1;
     int rc = MMDM_OK;
     auto fail = [&](int code) { mmdm_destroy(h); return code; };
-    const int D = c.d_latent, F = c.d_ff, B = c.max_batch, T = c.max_frames, n = 2 * B, td = c.text_dim;
+    if (c.single_only < 0 || c.single_only > 2) return fail(mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: single_only must be 0, 1 or 2"));
+    const int D = c.d_latent, F = c.d_ff, B = c.max_batch, T = c.max_frames, n = (c.single_only == 2 ? 4 : 2) * B, td = c.text_dim;
     const int Dm = c.single_only ? 4 : c.m_latent, Fm = c.single_only ? 4 : c.m_ff;
-    if ((rc = build_module(h, h->d1, "denoiser1.", "denoiser1.", D, F, c.d_layers, c.d_heads, false, true, "denoiser1.out.linear", NF))) return fail(rc);
+    if (c.single_only != 2 &&
+        (rc = build_module(h, h->d1, "denoiser1.", "denoiser1.", D, F, c.d_layers, c.d_heads, false, true, "denoiser1.out.linear", NF))) return fail(rc);
+    if (c.single_only != 1 &&
+        (rc = build_module(h, h->d2, "denoiser2.", "denoiser2.", D, F, c.d_layers, c.d_heads, true, false, "denoiser2.out.linear", NF))) return fail(rc);
     if (!c.single_only) {
-        if ((rc = build_module(h, h->d2, "denoiser2.", "denoiser2.", D, F, c.d_layers, c.d_heads, true, false, "denoiser2.out.linear", NF))) return fail(rc);
         if ((rc = build_module(h, h->mx, "", "influence.", Dm, Fm, c.m_layers, c.m_heads, true, false, "influence.out", h->nw))) return fail(rc);
     }
-    const int npers = c.single_only ? 1 : 2;
+    const int npers = c.single_only == 1 ? 1 : 2;
     const size_t R = (size_t)npers * n * T;
     const size_t Dx = max2(D, Dm), Fx = max2(F, Fm);
     for (Scratch* sc : {&h->sa, &h->sb}) {
@@ -539,16 +550,23 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
         return fail(mmdm_set_error(MMDM_ERR_HIP, "mmdm_create: stream/event creation failed"));
     h->overlap = getenv("MMDM_NO_OVERLAP") == nullptr;
-    const size_t PT = (size_t)n * T * (c.single_only ? NF : NF2);
-    if ((rc = dalloc(h, &h->o1, PT))) return fail(rc);
-    if ((rc = dalloc(h, &h->x, PT / 2)) || (rc = dalloc(h, &h->px1, PT / 2))) return fail(rc);
-    if ((rc = dalloc(h, &h->txt_d1, (size_t)npers * n * D)) || (rc = dalloc(h, &h->se_d1, (size_t)npers * n * D)) ||
-        (rc = dalloc(h, &h->ss_d1, (size_t)npers * n * ss_ld_of(h->d1))))
-        return fail(rc);
+    const size_t PT = (size_t)n * T * (c.single_only == 1 ? NF : NF2);
+    const size_t PB = (size_t)B * T * (c.single_only == 1 ? NF : NF2);
+    if ((rc = dalloc(h, &h->x, PB)) || (rc = dalloc(h, &h->px1, PB))) return fail(rc);
+    if (c.single_only != 2) {
+        if ((rc = dalloc(h, &h->o1, PT))) return fail(rc);
+        if ((rc = dalloc(h, &h->txt_d1, (size_t)npers * n * D)) || (rc = dalloc(h, &h->se_d1, (size_t)npers * n * D)) ||
+            (rc = dalloc(h, &h->ss_d1, (size_t)npers * n * ss_ld_of(h->d1))))
+            return fail(rc);
+    } else {
+        if ((rc = dalloc(h, &h->o2, PT)) || (rc = dalloc(h, &h->txt_d2, (size_t)3 * n * D)) || (rc = dalloc(h, &h->se_d2, (size_t)3 * n * D)) ||
+            (rc = dalloc(h, &h->ss_d2, (size_t)3 * n * ss_ld_of(h->d2))))
+            return fail(rc);
+    }
     if (!c.single_only) {
         if ((rc = dalloc(h, &h->mI, R * Dm)) || (rc = dalloc(h, &h->o2, PT)) || (rc = dalloc(h, &h->out1, PT)) || (rc = dalloc(h, &h->out2, PT)) ||
             (rc = dalloc(h, &h->w23, (size_t)2 * n * T * 23)) || (rc = dalloc(h, &h->hpool, (size_t)2 * n * Dm)) ||
-            (rc = dalloc(h, &h->model_out, PT / 2)) || (rc = dalloc(h, &h->x2, PT / 2)) || (rc = dalloc(h, &h->px2, PT / 2)) ||
+            (rc = dalloc(h, &h->model_out, PB)) || (rc = dalloc(h, &h->x2, PB)) || (rc = dalloc(h, &h->px2, PB)) ||
             (rc = dalloc(h, &h->floor_ws, (size_t)2 * B)) ||
             (rc = dalloc(h, &h->txt_d2, (size_t)3 * n * D)) || (rc = dalloc(h, &h->se_d2, (size_t)3 * n * D)) ||
             (rc = dalloc(h, &h->ss_d2, (size_t)3 * n * ss_ld_of(h->d2))) ||
@@ -638,8 +656,8 @@ extern "C" int mmdm_set_schedule(mmdm_handle h, const int* timestep_map, const f
     Ctx c{h, st, &h->sa};
     const bool pon = h->prof.on;
     h->prof.on = false;
-    int rc = build_time_tab(c, h->d1);
-    if (!rc && !h->cfg.single_only) rc = build_time_tab(c, h->d2);
+    int rc = h->cfg.single_only != 2 ? build_time_tab(c, h->d1) : MMDM_OK;
+    if (!rc && h->cfg.single_only != 1) rc = build_time_tab(c, h->d2);
     if (!rc && !h->cfg.single_only) rc = build_time_tab(c, h->mx);
     h->prof.on = pon;
     h->begun = false;
@@ -657,7 +675,20 @@ extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, in
     const bool pon = h->prof.on;
     h->prof.on = false;
     int rc = MMDM_OK;
-    if (h->cfg.single_only) {
+    if (h->cfg.single_only == 2) {
+        // 4 CFG copies of cond [B, 3*td]: full | interaction only (first td columns) | individuals only (columns td..) | zeros
+        const int n4 = 4 * B, ldc = 3 * td;
+        HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n4 * ldc * sizeof(float), st));
+        HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * ldc * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpy2DAsync(h->cond_cat + (size_t)B * ldc, ldc * sizeof(float), cond, ldc * sizeof(float), td * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpy2DAsync(h->cond_cat + (size_t)2 * B * ldc + td, ldc * sizeof(float), cond + td, ldc * sizeof(float), 2 * td * sizeof(float), B,
+                                hipMemcpyDeviceToDevice, st));
+        const bool ig = h->cfg.model2_kind == 1;
+        rc = text_rows(c, h->d2, h->cond_cat, ldc, ig ? 0 : td, h->txt_d2, 0, n4);
+        if (!rc) rc = text_rows(c, h->d2, h->cond_cat, ldc, ig ? 0 : 2 * td, h->txt_d2, n4, n4);
+        if (!rc) rc = text_rows(c, h->d2, h->cond_cat, ldc, 0, h->txt_d2, 2 * n4, n4);
+        HIPCHK(hipMemcpyAsync(h->x, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else if (h->cfg.single_only) {
         HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n * td * sizeof(float), st));
         HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * td * sizeof(float), hipMemcpyDeviceToDevice, st));
         rc = linear(c, h->cond_cat, td, h->d1.te_w, td, h->d1.te_b, h->txt_d1, h->d1.st.D, n, h->d1.st.D, td);
@@ -737,10 +768,10 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
                                    float* out, int n, int T, void* stream) {
     if (!h || !x || !cond || !out) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: null argument");
     if (!h->prepared) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_module_forward: call mmdm_prepare first"));
-    if (n <= 0 || (n & 1) || n / 2 > h->cfg.max_batch || T <= 0 || T > h->cfg.max_frames)
+    if (n <= 0 || (n & 1) || n / 2 > h->cfg.max_batch * (h->cfg.single_only == 2 ? 2 : 1) || T <= 0 || T > h->cfg.max_frames)
         return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: n=%d (even, <= 2*max_batch) T=%d out of range", n, T));
     if (t < 0 || t >= 5000) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: timestep %d out of range", t));
-    if (which < 0 || which > 2 || (h->cfg.single_only && which != 0)) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: bad module %d", which));
+    if (which < 0 || which > 2 || (h->cfg.single_only == 1 && which != 0) || (h->cfg.single_only == 2 && which != 1)) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: bad module %d", which));
     hipStream_t st = static_cast<hipStream_t>(stream);
     Ctx c{h, st, &h->sa};
     const int td = h->cfg.text_dim;

@@ -29,15 +29,17 @@ class Sampler:
 
     def __init__(self, *, d_latent, d_ff, d_layers, d_heads, m_latent=0, m_ff=0, m_layers=0, m_heads=1, mixing_mode=4, align=True,
                  xstart_align=True, model2_kind=0, force_influence_val=None, cfg_scale=3.5, max_batch=1, max_frames=300,
-                 single_only=False, text_dim=768, device=None):
+                 single_only=False, text_dim=768, device=None, cfg_scale_interaction=0.0, cfg_scale_individual=0.0):
+        """single_only: False/0 = two-chain MixerMDM; True/1 = individual denoiser alone (2-way CFG);
+        2 = interaction denoiser alone with the 4-way CFG of ClassifierFreeSampleModelMultiple."""
         if not torch.cuda.is_available():
             raise RuntimeError("mixermdm_amd.Sampler needs an MI355X (HIP device); there is no CPU path")
         self.lib = load_library()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.cfg = Config(d_latent, d_ff, d_layers, d_heads, m_latent, m_ff, m_layers, m_heads, 262, text_dim, mixing_mode, int(align),
                           int(xstart_align), model2_kind, int(force_influence_val is not None), float(force_influence_val or 0.0),
-                          float(cfg_scale), max_batch, max_frames, int(single_only))
-        self.single_only = single_only
+                          float(cfg_scale), max_batch, max_frames, int(single_only), float(cfg_scale_interaction), float(cfg_scale_individual))
+        self.single_only = int(single_only)
         self.h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.lib.mmdm_create(C.byref(self.cfg), C.byref(self.h)))
@@ -66,9 +68,13 @@ class Sampler:
         keys raise in prepare().  pe buffers are regenerated if absent."""
         sd = dict(sd)
         D, Dm = self.cfg.d_latent, self.cfg.m_latent
-        pes = [("denoiser1.sequence_pos_encoder.pe", D)]
+        pes = []
+        if self.single_only != 2:
+            pes.append(("denoiser1.sequence_pos_encoder.pe", D))
+        if self.single_only != 1:
+            pes.append(("denoiser2.sequence_pos_encoder.pe", D))
         if not self.single_only:
-            pes += [("denoiser2.sequence_pos_encoder.pe", D), ("sequence_pos_encoder.pe", Dm)]
+            pes.append(("sequence_pos_encoder.pe", Dm))
         for k, d in pes:
             if k not in sd:
                 sd[k] = pe_table(d)
@@ -149,7 +155,7 @@ class Sampler:
         ptrs = [C.c_void_p() for _ in range(5)]
         check(self.lib.mmdm_get_state(self.h, *[C.byref(p) for p in ptrs]), self.h)
         self.stream.synchronize()
-        Cc = 262 if self.single_only else 524
+        Cc = 262 if self.single_only == 1 else 524
         shape = (self.B, self.T, Cc)
         out = {}
         for nm, p in zip(("x", "x2", "pred_xstart", "pred_xstart2", "model_out"), ptrs):
@@ -173,7 +179,7 @@ class Sampler:
         cond = cond.to(self.device, torch.float32).contiguous()
         x2c = x2.to(self.device, torch.float32).contiguous() if x2 is not None else None
         n, T = x.shape[:2]
-        out = torch.empty(n, T, 262 if which == 0 else 524, device=self.device, dtype=torch.float32)
+        out = torch.empty(n, T, 262 if which == 0 else 524, device=self.device, dtype=torch.float32)   # which 1 with single_only=2: n = 4B rows
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.device(self.device):
             check(self.lib.mmdm_module_forward(self.h, which, C.c_void_p(x.data_ptr()), C.c_void_p(x2c.data_ptr() if x2c is not None else 0),

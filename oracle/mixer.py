@@ -181,3 +181,31 @@ def single_ddim_loop(W, p, mode, sched, s, x_T, cond, num_heads, first_steps=Non
         x0 = cfg_single(W, p, mode, s, x, ts, cond, num_heads)
         x = ddim_update(sched, i, x, x0)
     return x0, x
+
+
+def cfg_multiple(W, p, s, s_int, s_ind, x, timesteps, cond, num_heads, model2="in2IN"):
+    """ClassifierFreeSampleModelMultiple.forward -- cfg_sampler.py:67-98 (4 copies: full | interaction-only | individuals-only | zeros)."""
+    B = x.shape[0]
+    c_int = torch.zeros_like(cond)
+    c_int[:, :768] = cond[:, :768]
+    c_ind = torch.zeros_like(cond)
+    c_ind[:, 768:] = cond[:, 768:]
+    cc = torch.cat([cond, c_int, c_ind, torch.zeros_like(cond)], dim=0)
+    xx, tt = torch.cat([x] * 4), torch.cat([timesteps] * 4)
+    out = inter_denoiser(W, p, xx, tt, cc, num_heads) if model2 == "InterGen" else in2in_denoiser(W, p, "interaction", xx, tt, cc, num_heads)
+    return (s * out[:B]) + (s_int * out[B:2 * B]) + (s_ind * out[2 * B:3 * B]) + ((1 - (s + s_int + s_ind)) * out[3 * B:])
+
+
+def interaction_ddim_loop(W, p, sched, s, s_int, s_ind, x_T, cond, num_heads, first_steps=None):
+    """in2INDiffusion.forward, mode "interaction" (in2in.py:330-341) on MotionDiffusion's single-chain DDIM loop."""
+    x = x_T.clone()
+    B = x.shape[0]
+    x0 = None
+    idx = list(range(sched.num_timesteps))[::-1]
+    if first_steps is not None:
+        idx = idx[:first_steps]
+    for i in idx:
+        ts = torch.full((B,), sched.timestep_map[i], dtype=torch.long)
+        x0 = cfg_multiple(W, p, s, s_int, s_ind, x, ts, cond, num_heads)
+        x = ddim_update(sched, i, x, x0)
+    return x0, x

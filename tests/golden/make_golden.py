@@ -64,7 +64,7 @@ from models.utils.influence import Influence, InfluenceBlockCross  # noqa: E402
 from models.utils.layers import AdaLN, VanillaSelfAttention, VanillaCrossAttention, FFN  # noqa: E402
 from models.utils.blocks import TransformerBlock, TransformerBlockDoubleCond  # noqa: E402
 from models.utils.utils import PositionalEncoding  # noqa: E402
-from models.utils.cfg_sampler import ClassifierFreeSampleModel, ClassifierFreeSampleModelX2  # noqa: E402
+from models.utils.cfg_sampler import ClassifierFreeSampleModel, ClassifierFreeSampleModelX2, ClassifierFreeSampleModelMultiple  # noqa: E402
 from models.utils import gaussian_diffusion as gd  # noqa: E402
 from utils import alignment as al  # noqa: E402
 from utils import rotation_conversions as rc  # noqa: E402
@@ -342,7 +342,26 @@ def g_single():
     save("single", **out)
 
 
+# ---- G12 stand-alone interaction sampler (4-way CFG) -----------------------------------------------------
+def g_interaction():
+    B, T = 2, 12
+    m = reinit(in2INDenoiser(262, mode="interaction", **DEN), 31)
+    cfg = ClassifierFreeSampleModelMultiple(m, 3, 3, 1)          # configs/models/in2IN.yaml CFG_WEIGHT{,_INTERACTION,_INDIVIDUAL}
+    out = dict(sd(m, "int."))
+    out.update(H=DEN["num_heads"], s=3.0, s_int=3.0, s_ind=1.0)
+    xT, c = rnd(95, B, T, 524), rnd(96, B, 3 * 768)
+    out.update(x_T=xT, cond=c)
+    out["cfg:out"] = cfg(xT, torch.full((B,), 500, dtype=torch.long), cond=c, mask=None)
+    diff = gd.MotionDiffusion(use_timesteps=gd.space_timesteps(1000, "ddim20"), motion_rep="global", mode="interaction",
+                              betas=gd.get_named_beta_schedule("cosine", 1000),
+                              model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                              loss_type=gd.LossType.MSE, rescale_timesteps=False)
+    out["loop:ddim20:output"] = diff.ddim_sample_loop(cfg, (B, T, 524), noise=xT.clone(), clip_denoised=False, progress=False,
+                                                      model_kwargs={"mask": None, "cond": c})
+    save("interaction", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "pe", "layers", "denoisers", "influence", "geometry", "mixer", "single"]
+    which = sys.argv[1:] or ["schedule", "pe", "layers", "denoisers", "influence", "geometry", "mixer", "single", "interaction"]
     for w in which:
         globals()["g_" + w]()

@@ -273,3 +273,19 @@ def test_errors_are_loud(golden):
     with pytest.raises(ValueError, match="Mode not recognized"):
         Sampler(d_heads=2, m_heads=2, max_batch=1, max_frames=8, mixing_mode=9, **dims)
     s.close()
+
+
+def test_interaction_standalone_4way_cfg_vs_reference_golden(golden):
+    """single_only=2: in2IN interaction denoiser alone with ClassifierFreeSampleModelMultiple (cfg_sampler.py:59-98)."""
+    from mixermdm_amd.sampler import Sampler
+    g, w, t = golden("interaction")
+    s = Sampler(d_latent=16, d_ff=32, d_layers=2, d_heads=int(g["H"]), single_only=2, cfg_scale=float(g["s"]),
+                cfg_scale_interaction=float(g["s_int"]), cfg_scale_individual=float(g["s_ind"]), max_batch=2, max_frames=16)
+    s.load_state_dict({"denoiser2." + k: v for k, v in w("int.").items()})
+    s.prepare()
+    s.set_schedule("ddim20")
+    for graph in (False, True):
+        out = s.sample(t("cond"), t("x_T"), use_graph=graph)
+        d = np.abs(out.cpu().numpy() - g["loop:ddim20:output"])
+        assert out.shape == (2, 12, 524) and d.mean() <= 1e-4 and d.max() <= 1e-2, (d.mean(), d.max())
+    s.close()

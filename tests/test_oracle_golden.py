@@ -229,3 +229,17 @@ def test_single_chain(golden):
         out, _ = MX.single_ddim_loop(W, "", "individual", S.make_schedule("cosine", 1000, strat), s, t("x_T"), t("cond"), H)
         d = np.abs(out.numpy() - g[f"loop:{strat}:output"])
         assert d.mean() <= 1e-4 and d.max() <= 1e-2, (d.mean(), d.max())
+
+
+# ---- G12 ----------------------------------------------------------------------------------------
+def test_interaction_standalone_4way_cfg(golden):
+    g, w, t = golden("interaction")
+    W = w("int.", [("sequence_pos_encoder.pe", 16)])
+    H = int(g["H"])
+    s, si, sd = float(g["s"]), float(g["s_int"]), float(g["s_ind"])
+    B = t("x_T").shape[0]
+    out = MX.cfg_multiple(W, "", s, si, sd, t("x_T"), torch.full((B,), 500, dtype=torch.long), t("cond"), H)
+    close(out, g["cfg:out"], atol=5e-5, rtol=1e-4)
+    out, _ = MX.interaction_ddim_loop(W, "", S.make_schedule("cosine", 1000, "ddim20"), s, si, sd, t("x_T"), t("cond"), H)
+    d = np.abs(out.numpy() - g["loop:ddim20:output"])
+    assert d.mean() <= 1e-4 and d.max() <= 1e-2, (d.mean(), d.max())
