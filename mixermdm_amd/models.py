@@ -329,3 +329,105 @@ class MixerMDM(nn.Module):
         output = self._sample(batch, "eval_intermediate")
         m = self.mixing
         return {"output": output, "influence_i1": m.history_influence_i1, "influence_i2": m.history_influence_i2}
+
+
+class in2INDiffusion(nn.Module):
+    """Stand-alone sub-model sampler: in2INDiffusion.forward (src/models/in2in.py:285-356), modes "individual"
+    (ClassifierFreeSampleModel, [B,T,262]) and "interaction" (ClassifierFreeSampleModelMultiple, [B,T,524]); output stays in
+    the model's normalised space, as in the reference (callers de-normalise: src/scripts/infer/in2IN.py:101-105)."""
+
+    def __init__(self, cfg, mode, sampling_strategy="ddim50"):
+        super().__init__()
+        if mode not in ("individual", "interaction"):
+            raise NotImplementedError(f"in2IN mode {mode!r}: 'dual' (DualMDM sampler) is not built (SURVEY 8f-4)")
+        self.cfg, self.mode = cfg, mode
+        self.nfeats = cfg.INPUT_DIM
+        self.dims = dict(d_latent=cfg.LATENT_DIM, d_ff=cfg.FF_SIZE, d_layers=cfg.NUM_LAYERS)
+        self.num_heads = cfg.NUM_HEADS
+        self.cfg_weight = cfg.CFG_WEIGHT
+        self.cfg_weight_interaction = cfg.CFG_WEIGHT_INTERACTION if "CFG_WEIGHT_INTERACTION" in cfg else 0.0
+        self.cfg_weight_individual = cfg.CFG_WEIGHT_INDIVIDUAL if "CFG_WEIGHT_INDIVIDUAL" in cfg else 0.0
+        self.diffusion_steps = cfg.DIFFUSION_STEPS
+        self.betas = get_named_beta_schedule(cfg.BETA_SCHEDULER, self.diffusion_steps)
+        self.sampling_strategy = sampling_strategy
+        self._net = "net_individual" if mode == "individual" else "net_interaction"
+        from .synthetic import denoiser_shapes
+        for k, shp in denoiser_shapes(self._net + ".", self.dims["d_latent"], self.dims["d_ff"], self.dims["d_layers"]).items():
+            _holder_tree(self, k, torch.zeros(shp))
+        self._sampler, self._dirty = None, True
+
+    def _apply(self, fn, recurse=True):
+        self._dirty = True
+        return super()._apply(fn, recurse)
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("sequence_pos_encoder.pe")}
+        self._dirty = True
+        return super().load_state_dict(sd, strict=strict)
+
+    def _get_sampler(self, B, T):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("in2IN runs on an MI355X only: call .to('cuda:N') first (no CPU path)")
+        s = self._sampler
+        if s is None or B > s.cfg.max_batch or T > s.cfg.max_frames or s.device != dev:
+            if s is not None:
+                s.close()
+            kind = 1 if self.mode == "individual" else 2
+            s = Sampler(d_heads=self.num_heads, single_only=kind, cfg_scale=self.cfg_weight, cfg_scale_interaction=self.cfg_weight_interaction,
+                        cfg_scale_individual=self.cfg_weight_individual, max_batch=B, max_frames=max(T, 300), device=dev, **self.dims)
+            self._sampler, self._dirty = s, True
+        if self._dirty:
+            pfx = "denoiser1." if self.mode == "individual" else "denoiser2."
+            s.load_state_dict({pfx + k[len(self._net) + 1:]: p.data for k, p in self.named_parameters()})
+            s.prepare()
+            s._strategy = None
+            self._dirty = False
+        return s
+
+    def forward(self, batch):
+        if self.mode == "interaction":
+            cond = torch.cat([batch["cond_interaction"], batch["cond_interaction_individual1"], batch["cond_interaction_individual2"]], dim=1)
+        else:
+            cond = torch.cat([batch["cond_individual_individual1"]], dim=1)
+        B, T = cond.shape[0], int(batch["motion_lens"][0])
+        s = self._get_sampler(B, T)
+        if s._strategy != self.sampling_strategy:
+            s.set_schedule(self.sampling_strategy, self.cfg.BETA_SCHEDULER, self.diffusion_steps)
+            s._strategy = self.sampling_strategy
+        width = self.nfeats * (2 if self.mode == "interaction" else 1)
+        x_T = batch["x_T"] if "x_T" in batch else torch.randn(B, T, width, device=s.device)
+        return {"output": s.sample(cond, x_T)}
+
+
+class in2IN(nn.Module):
+    """in2IN(cfg, mode) facade (src/models/in2in.py:14-135) around the stand-alone sampler; text encoding is upstream (pass the
+    encoded ``cond_*`` entries in the batch or register ``text_encoder(batch) -> batch``)."""
+
+    def __init__(self, cfg, mode):
+        super().__init__()
+        self.cfg, self.mode = cfg, mode
+        self.decoder = in2INDiffusion(cfg, mode, sampling_strategy=cfg.STRATEGY)
+        self.text_encoder = None
+
+    def text_process(self, batch, mode=None, text_name="text", out_name="cond"):
+        if out_name in batch:
+            return batch
+        if self.text_encoder is None:
+            raise NotImplementedError("text encoding (CLIP tower + clipTransEncoder, in2in.py:109-135) is upstream of the HIP path: "
+                                      f"put the encoded '{out_name}' in the batch or set model.text_encoder")
+        return self.text_encoder(batch, mode, text_name, out_name)
+
+    def decode_motion(self, batch):
+        batch.update(self.decoder(batch))
+        return batch
+
+    def forward_test(self, batch):
+        if self.mode == "interaction":
+            batch = self.text_process(batch, "interaction", out_name="cond_interaction")
+            batch = self.text_process(batch, "interaction", "text_individual1", "cond_interaction_individual1")
+            batch = self.text_process(batch, "interaction", "text_individual2", "cond_interaction_individual2")
+        else:
+            batch = self.text_process(batch, "individual", out_name="cond_individual_individual1")
+        batch.update(self.decode_motion(batch))
+        return batch

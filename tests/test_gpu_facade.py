@@ -115,3 +115,30 @@ def test_generation_harnesses(tmp_path, golden):
     assert len(gen) == 3 and len(mm) == 1
     assert gen[0]["motion1"].shape == (16, 262) and np.all(gen[0]["motion1"][8:] == 0) and np.any(gen[0]["motion1"][:8] != 0)
     assert mm[0]["mm_motions"].shape == (2, 16, 2, 262) and gen[1]["text_individual2"] == "c"
+
+
+def test_in2in_standalone_facades(golden):
+    """in2IN(cfg, mode).forward_test for both shipped sub-model configs (tiny dims), against the reference goldens."""
+    from mixermdm_amd.configs import CfgNode
+    from mixermdm_amd.models import in2IN
+    base = dict(NUM_LAYERS=2, DROPOUT=0.1, INPUT_DIM=262, LATENT_DIM=16, FF_SIZE=32, DIFFUSION_STEPS=1000, BETA_SCHEDULER="cosine", STRATEGY="ddim20")
+    g, w, t = golden("single")
+    m = in2IN(CfgNode(dict(base, NAME="in2INind", NUM_HEADS=int(g["H"]), CFG_WEIGHT=float(g["cfg_scale"]))), "individual")
+    m.decoder.load_state_dict({"net_individual." + k: v for k, v in w("ind.").items()})
+    m = m.to("cuda:0")
+    out = m.forward_test({"cond_individual_individual1": t("cond").cuda(), "x_T": t("x_T").cuda(), "motion_lens": torch.tensor([12, 12])})
+    d = np.abs(out["output"].cpu().numpy() - g["loop:ddim20:output"])
+    assert out["output"].shape == (2, 12, 262) and d.mean() <= 1e-4 and d.max() <= 1e-2
+    with pytest.raises(NotImplementedError, match="upstream of the HIP path"):
+        m.forward_test({"text": ["walk"], "motion_lens": torch.tensor([12])})
+
+    g, w, t = golden("interaction")
+    m = in2IN(CfgNode(dict(base, NAME="in2IN", NUM_HEADS=int(g["H"]), CFG_WEIGHT=float(g["s"]), CFG_WEIGHT_INTERACTION=float(g["s_int"]),
+                           CFG_WEIGHT_INDIVIDUAL=float(g["s_ind"]))), "interaction")
+    m.decoder.load_state_dict({"net_interaction." + k: v for k, v in w("int.").items()})
+    m = m.to("cuda:0")
+    c = t("cond").cuda()
+    out = m.forward_test({"cond_interaction": c[:, :768], "cond_interaction_individual1": c[:, 768:1536], "cond_interaction_individual2": c[:, 1536:],
+                          "x_T": t("x_T").cuda(), "motion_lens": torch.tensor([12, 12])})
+    d = np.abs(out["output"].cpu().numpy() - g["loop:ddim20:output"])
+    assert out["output"].shape == (2, 12, 524) and d.mean() <= 1e-4 and d.max() <= 1e-2
