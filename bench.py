@@ -110,12 +110,13 @@ def main():
     if rank == 0 and args.profile_steps > 0 and args.warmup + args.steps + args.profile_steps <= S:
         smp.profile(True)
         smp.run(args.profile_steps, use_graph=False)
-        g_ms, g_n, g_fl = smp.profile_read(0)
-        a_ms, a_n, a_fl = smp.profile_read(1)
+        g_ms, g_n, g_fl, g_by = smp.profile_read(0)
+        a_ms, a_n, a_fl, _ = smp.profile_read(1)
         smp.profile(False)
         ach = g_fl / (g_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "gemm_glds_kernel<22,22> (v_mfma_f32_32x32x2_f32, LDS-DMA staged)", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(single),
+                "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1),
                 "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
                 "gflop_per_launch": round(g_fl / g_n / 1e9, 3), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
                 "attention": {"achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a_ms / args.profile_steps, 3),
@@ -148,6 +149,17 @@ def main():
     smp.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(single):
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this workload (profiles/r01_gemm_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane
+    streams on gfx950).  bench.py cannot collect PMC counters itself; null when the artefact is absent or for another workload."""
+    path = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    if single or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
 
 
 def cpu_baseline(sd_cpu, stats, T, nsteps, single=False):

@@ -199,7 +199,7 @@ int mmdm_module_forward(mmdm_handle h, int which, const float* x, const float* x
 /* Live kernel timing for bench.py: wraps hipEvents on `stream` around every launch of the kernel class `which`
  * (0 = linear/GEMM, 1 = attention) during mmdm_run(use_graph=0) and accumulates. */
 int mmdm_profile_enable(mmdm_handle h, int on);
-int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launches, double* flops);
+int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launches, double* flops, double* algorithmic_bytes);
 
 #ifdef __cplusplus
 }

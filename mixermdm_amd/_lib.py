@@ -53,7 +53,7 @@ SYMBOLS = {
     "mmdm_get_state": (_I, [_VP] + [C.POINTER(_VP)] * 5),
     "mmdm_module_forward": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _VP]),
     "mmdm_profile_enable": (_I, [_VP, _I]),
-    "mmdm_profile_read": (_I, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "mmdm_profile_read": (_I, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 

@@ -103,6 +103,7 @@ struct Prof {
     std::vector<hipEvent_t> ev[2];               // pairs (start, stop) per launch, per class
     size_t used[2] = {0, 0};
     double flops[2] = {0, 0};
+    double bytes[2] = {0, 0};                    // algorithmic bytes (operands read once + result written once)
     double ms[2] = {0, 0};
     int64_t launches[2] = {0, 0};
 };
@@ -269,7 +270,7 @@ struct Ctx {
     const Scratch* s;
 };
 
-int prof_begin(const Ctx& c, int cls, double flops) {
+int prof_begin(const Ctx& c, int cls, double flops, double bytes = 0) {
     Prof& p = c.h->prof;
     if (!p.on) return MMDM_OK;
     if (p.used[cls] + 2 > p.ev[cls].size()) {
@@ -280,6 +281,7 @@ int prof_begin(const Ctx& c, int cls, double flops) {
         }
     }
     p.flops[cls] += flops;
+    p.bytes[cls] += bytes;
     HIPCHK(hipEventRecord(p.ev[cls][p.used[cls]], c.st));
     return MMDM_OK;
 }
@@ -294,14 +296,14 @@ int prof_end(const Ctx& c, int cls) {
 
 int linear(const Ctx& c, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
            int epi = MMDM_EPI_BIAS, const float* extra = nullptr, int ld_extra = 0, int period = 0, int Kw = 0) {
-    RC(prof_begin(c, 0, 2.0 * M * N * K));
+    RC(prof_begin(c, 0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1))));
     RC(mmdm_linear_f32_ex(A, lda, W, ldw, Kw ? Kw : K, bias, C, ldc, M, N, K, epi, extra, ld_extra, period, c.st));
     return prof_end(c, 0);
 }
 
 int attention(const Ctx& c, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
               int nseq, int Tq, int Tk, int H, int dh, int shift) {
-    RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh));
+    RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh, 4.0 * nseq * H * dh * (2.0 * Tq + 2.0 * Tk)));
     RC(mmdm_attention_f32(Q, ldq, K, ldk, V, ldv, O, ldo, nseq, Tq, Tk, H, dh, shift, c.st));
     return prof_end(c, 1);
 }
@@ -824,11 +826,11 @@ extern "C" int mmdm_profile_enable(mmdm_handle h, int on) {
     if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_profile_enable: null handle");
     h->prof.on = on != 0;
     if (on)
-        for (int k = 0; k < 2; ++k) { h->prof.used[k] = 0; h->prof.flops[k] = 0; h->prof.ms[k] = 0; h->prof.launches[k] = 0; }
+        for (int k = 0; k < 2; ++k) { h->prof.used[k] = 0; h->prof.flops[k] = 0; h->prof.bytes[k] = 0; h->prof.ms[k] = 0; h->prof.launches[k] = 0; }
     return MMDM_OK;
 }
 
-extern "C" int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launches, double* flops) {
+extern "C" int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launches, double* flops, double* bytes) {
     if (!h || which < 0 || which > 1) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_profile_read: bad argument");
     Prof& p = h->prof;
     HIPCHK(hipDeviceSynchronize());
@@ -841,5 +843,6 @@ extern "C" int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int
     if (total_ms) *total_ms = ms;
     if (launches) *launches = (int64_t)(p.used[which] / 2);
     if (flops) *flops = p.flops[which];
+    if (bytes) *bytes = p.bytes[which];
     return MMDM_OK;
 }

@@ -193,9 +193,9 @@ class Sampler:
         check(self.lib.mmdm_profile_enable(self.h, int(on)), self.h)
 
     def profile_read(self, which):
-        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
-        check(self.lib.mmdm_profile_read(self.h, which, C.byref(ms), C.byref(n), C.byref(fl)), self.h)
-        return ms.value, n.value, fl.value
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        check(self.lib.mmdm_profile_read(self.h, which, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), self.h)
+        return ms.value, n.value, fl.value, by.value
 
 
 def _from_ptr(ptr, shape, device):
