@@ -289,3 +289,41 @@ def test_interaction_standalone_4way_cfg_vs_reference_golden(golden):
         d = np.abs(out.cpu().numpy() - g["loop:ddim20:output"])
         assert out.shape == (2, 12, 524) and d.mean() <= 1e-4 and d.max() <= 1e-2, (d.mean(), d.max())
     s.close()
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (2, 17), (1, 299), (5, 33), (3, 20)])
+def test_ragged_shapes_match_oracle_one_step(full_small, B, T):
+    """Edge shapes (single frame, odd lengths, the infer script's T=299, B=3 -- where the reference's dim-less torch.cross
+    (alignment.py:198) is wrong but the intended dim=-1 math is what both oracle and kernels implement)."""
+    s, W, ostats = full_small
+    from mixermdm_amd.synthetic import synthetic_inputs
+    cond, xT = synthetic_inputs(B, T, seed_cond=11, seed_x=12)
+    spec = MX.MixerSpec(d_heads=4, m_heads=4)
+    osch = OS.make_schedule("cosine", 1000, "ddim20")
+    s.set_schedule("ddim20")
+    s.begin(cond, xT)
+    s.run(1, use_graph=True)
+    st = s.state()
+    rx, rx2, p1, p2 = MX.mixer_ddim_step(W, spec, ostats, osch, 3.5, 19, xT, xT, cond)
+    for nm, ref in [("x", rx), ("x2", rx2), ("pred_xstart2", p2)]:
+        assert_close(st[nm], ref, what=f"B={B} T={T} {nm}", **STEP_TOL)
+
+
+@pytest.fixture(scope="module")
+def full_small():
+    """Reduced-depth model at real head dims (dh = 128 / 64) for shape sweeps the oracle can follow quickly."""
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_stats
+    dims = dict(d_latent=512, d_ff=1024, d_layers=2, m_latent=256, m_ff=512, m_layers=2)
+    sd = synthetic_state_dict(seed=4, std=0.03, bias_std=0.02, **dims)
+    stats = synthetic_stats()
+    s = Sampler(d_heads=4, m_heads=4, max_batch=5, max_frames=300, **dims)
+    s.load_state_dict(sd)
+    s.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+    s.prepare()
+    W = dict(sd)
+    W["sequence_pos_encoder.pe"] = pe_table(256)
+    W["denoiser1.sequence_pos_encoder.pe"] = pe_table(512)
+    W["denoiser2.sequence_pos_encoder.pe"] = pe_table(512)
+    yield s, W, (stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+    s.close()
