@@ -114,7 +114,7 @@ def main():
         a_ms, a_n, a_fl, _ = smp.profile_read(1)
         smp.profile(False)
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_glds_kernel<22,22> (v_mfma_f32_32x32x2_f32, LDS-DMA staged)", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+        roof = {"bound": "mfma", "kernel": "gemm_glds_kernel (v_mfma_f32_32x32x2_f32, LDS-DMA staged; 128x128 tiles, 128x64 when N <= 512)", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(single),
                 "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1),
                 "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),

@@ -518,6 +518,9 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_glds<22, 22, 16, 3>())) return rc;
     if ((rc = set_attr_glds<22, 22, 32, 2>())) return rc;
     if ((rc = set_attr_glds<42, 22, 16, 3>())) return rc;
+    if ((rc = set_attr_glds<22, 12>())) return rc;
+    if ((rc = set_attr_glds<12, 22>())) return rc;
+    if ((rc = set_attr_glds<22, 21>())) return rc;
     const char* e = getenv("MMDM_GEMM_CFG");
     g_gemm_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
@@ -558,10 +561,20 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     // production choice: LDS-DMA kernel, 128x128 tile / 4 waves (5 workgroups per CU) whenever the operands allow it
     switch (g_gemm_cfg) {
         case 10: if (glds_ok) return launch_glds<42, 22>(a, st); break;
-        case 11: case -1: if (glds_ok) return launch_glds<22, 22>(a, st); break;
+        case -1:
+            if (glds_ok) {
+                // few 128x128 tiles (< ~4 per CU): halve the tile along N so that more workgroups hide each other's latencies
+                const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+                return tiles < 1000 ? launch_glds<22, 21>(a, st) : launch_glds<22, 22>(a, st);
+            }
+            break;
+        case 11: if (glds_ok) return launch_glds<22, 22>(a, st); break;
         case 12: if (glds_ok) return launch_glds<22, 22, 16, 3>(a, st); break;
         case 13: if (glds_ok && K % 32 == 0) return launch_glds<22, 22, 32, 2>(a, st); break;
         case 14: if (glds_ok) return launch_glds<42, 22, 16, 3>(a, st); break;
+        case 15: if (glds_ok) return launch_glds<22, 12>(a, st); break;     // 128 x 64 tile, 2 waves
+        case 16: if (glds_ok) return launch_glds<12, 22>(a, st); break;     // 64 x 128 tile, 2 waves
+        case 17: if (glds_ok) return launch_glds<22, 21>(a, st); break;     // 128 x 64 tile, 4 waves (64 x 32 per wave)
         default: break;
     }
     switch (g_gemm_cfg) {
