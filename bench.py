@@ -17,6 +17,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (same guide)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X fp32 matrix peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
 
 
@@ -40,6 +41,8 @@ def main():
                     help="mixer = BASELINE configs[2] (2-person MixerMDM, the headline metric); single = configs[1] (single-person in2IN, T=196, B=32)")
     ap.add_argument("--batch", type=int, default=None, help="motions per GPU (weak scaling); default 16 (mixer) / 32 (single)")
     ap.add_argument("--frames", type=int, default=None, help="default 300 (mixer) / 196 (single)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = the parity path and the headline metric; bf16 = BASELINE configs[4]-style path (bf16 GEMM operands, fp32 accumulate)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -73,7 +76,7 @@ def main():
     sd_cpu = synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, single_only=single, **FULL_DIMS) if rank == 0 else None
     sd = broadcast_state_dict(sd_cpu, shapes, src=0, device=device)
     stats = synthetic_stats()
-    smp = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, single_only=single, **FULL_DIMS)
+    smp = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, single_only=single, precision=args.precision, **FULL_DIMS)
     smp.load_state_dict(sd)
     if not single:
         smp.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
@@ -114,8 +117,10 @@ def main():
         a_ms, a_n, a_fl, _ = smp.profile_read(1)
         smp.profile(False)
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_glds_kernel (v_mfma_f32_32x32x2_f32, LDS-DMA staged; 128x128 tiles, 128x64 when N <= 512)", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(single),
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        roof = {"bound": "mfma", "kernel": "gemm_glds_kernel (v_mfma_f32_32x32x2_f32, LDS-DMA staged; 128x128 tiles, 128x64 when N <= 512)" if args.precision == "fp32"
+                          else "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, LDS-DMA staged, 256x128 tiles)", "achieved": round(ach, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(single) if args.precision == "fp32" else None,
                 "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1),
                 "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
                 "gflop_per_launch": round(g_fl / g_n / 1e9, 3), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
@@ -131,17 +136,17 @@ def main():
     if rank == 0:
         flops = algorithmic_flops_per_motion_step(T, single=single)
         value = world * B / (ms_per_step * 1e-3 * S)
-        wl = ("BASELINE configs[1]: single-person in2IN (individual denoiser, CFG 3.5), T=%d, ddim1000 (eta=0), batch %d per GPU, fp32, random-init weights" % (T, B)) if single else \
+        wl = ("BASELINE configs[1]: single-person in2IN (individual denoiser, CFG 3.5), T=%d, ddim1000 (eta=0), batch %d per GPU, %s, random-init weights" % (T, B, args.precision)) if single else \
              ("BASELINE configs[2]: 2-person MixerMDM (in2IN individual + in2IN interaction + Mixer mode 4, align, CFG 3.5), "
-              "T=%d, ddim1000 (eta=0), batch %d per GPU, fp32, random-init weights" % (T, B))
+              "T=%d, ddim1000 (eta=0), batch %d per GPU, %s, random-init weights" % (T, B, "fp32" if args.precision == "fp32" else "bf16 GEMM operands / fp32 accumulate (configs[4]-style)"))
         line = {
             "metric": "generated motions/sec (1000-step DDPM, T=%d, %s)" % (T, "single-person" if single else "2-person"), "value": round(value, 5), "unit": "motions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": wl,
                        "batch_per_gpu": B, "frames": T, "sampler_steps": S, "hipgraph": use_graph, "parallelism": "batch-sharded x%d, no in-loop collective" % world},
             "achieved_tflops_algorithmic": round(flops * B * world / (ms_per_step * 1e-3) / 1e12, 2),
-            "frac_of_f32_mfma_peak": round(flops * B / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "frac_of_f32_mfma_peak": round(flops * B / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if args.precision == "fp32" else None,
             "outputs_finite": finite,
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -55,10 +55,20 @@ enum {
 int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                     int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
 
+/* bf16-operand variant (BASELINE configs[4]): A [M,K] and W [N,K] are bf16 (16-byte aligned rows, K % 32 == 0), accumulation
+ * fp32 (v_mfma_f32_32x32x16_bf16), bias / residual / PE fp32, C fp32 (out_bf16 = 0) or bf16 (out_bf16 = 1); N % 4 == 0. */
+int mmdm_linear_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16,
+                     int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
+/* Round-to-nearest-even fp32 -> bf16 conversion of n contiguous elements. */
+int mmdm_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+
 /* AdaLN apply: out[s,t,:] = LN_{eps=1e-6,no affine}(h[s,t,:]) * (1 + ss[row(s), 0:D]) + ss[row(s), D:2D],
  * row(s) = s % ss_rows.  ss is the output of Linear(SiLU(emb)) (scale first, shift second), row stride ss_ld.
  * Replaces AdaLN.forward  src/models/utils/layers.py:15-25. */
 int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss_rows, float* out, int nseq, int T, int D, void* stream);
+
+/* Same with a selectable output type: out_bf16 != 0 writes `out` as bf16 (operand of the next bf16 GEMM). */
+int mmdm_adaln_ex(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, int nseq, int T, int D, void* stream);
 
 /* Multi-head attention core with add_zero_attn (one extra key, logit 0, value 0), no masks, scale 1/sqrt(dh).
  * Q/K/V/O are [nseq, T*, H*dh] views with row strides ld*; the K/V sequence for query sequence s is
@@ -66,6 +76,10 @@ int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss_rows, floa
  * Replaces the SDPA inside nn.MultiheadAttention  src/models/utils/layers.py:33-44, 74-87. */
 int mmdm_attention_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                        int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
+
+/* Same with a selectable output type (fp32 Q/K/V in, fp32 softmax and accumulation; O fp32 or bf16). */
+int mmdm_attention_ex(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O, int ldo, int out_bf16,
+                      int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
 
 /* out[r,:] = silu(time_row[:] + txt[r,:]) for r < rows; time_row = time_tab + (*step_idx) * D.
  * Replaces `embed_timestep(t) + text_embed(c)` followed by AdaLN's SiLU  in2in.py:415-422, layers.py:9-10. */
@@ -150,6 +164,9 @@ typedef struct {
                         * 2: single chain, denoiser2 only (stand-alone interaction in2IN/InterGen, 4-way CFG of
                         *    ClassifierFreeSampleModelMultiple  src/models/utils/cfg_sampler.py:59-98; in2in.py:330-341) */
     float cfg_scale_interaction, cfg_scale_individual;   /* CFG_WEIGHT_INTERACTION / CFG_WEIGHT_INDIVIDUAL (single_only == 2) */
+    int precision;     /* 0: exact fp32 everywhere (the parity path).  1: bf16 operands for the transformer-stack GEMMs (weights
+                        *    converted once at mmdm_prepare; AdaLN / attention / GELU outputs written as bf16), fp32 accumulation,
+                        *    residual stream, softmax, geometry, DDIM and embeddings (BASELINE configs[4], "bf16 path") */
 } mmdm_config;
 
 int mmdm_create(const mmdm_config* cfg, mmdm_handle* out);

@@ -20,7 +20,7 @@ class Config(C.Structure):
                                         "nfeats", "text_dim", "mixing_mode", "align", "xstart_align", "model2_kind", "use_force")] + \
                [("force_val", C.c_float), ("cfg_scale", C.c_float)] + \
                [(n, C.c_int) for n in ("max_batch", "max_frames", "single_only")] + \
-               [("cfg_scale_interaction", C.c_float), ("cfg_scale_individual", C.c_float)]
+               [("cfg_scale_interaction", C.c_float), ("cfg_scale_individual", C.c_float), ("precision", C.c_int)]
 
 
 # every symbol include/mmdm.h declares: name -> (restype, argtypes)
@@ -29,7 +29,11 @@ SYMBOLS = {
     "mmdm_last_error": (C.c_char_p, []),
     "mmdm_version": (C.c_char_p, []),
     "mmdm_linear_f32": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
+    "mmdm_linear_bf16": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
+    "mmdm_f32_to_bf16": (_I, [_VP, _VP, C.c_int64, _VP]),
     "mmdm_adaln_f32": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _I, _VP]),
+    "mmdm_adaln_ex": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _I, _I, _VP]),
+    "mmdm_attention_ex": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "mmdm_attention_f32": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "mmdm_cond_silu_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP]),
     "mmdm_mixer_pre_f32": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),

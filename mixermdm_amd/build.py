@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmdm_hip.so")
-SOURCES = ["mmdm.hip", "gemm_f32.hip", "attn_f32.hip", "rowops.hip", "geometry.hip"]
+SOURCES = ["mmdm.hip", "gemm_f32.hip", "gemm_bf16.hip", "attn_f32.hip", "rowops.hip", "geometry.hip"]
 
 
 def needs_build():

@@ -40,6 +40,7 @@ struct AttnArgs {
     int ldq, ldk, ldv, ldo;
     int nseq, Tq, Tk, H, shift, qtiles, pairs_per_xcd;
     float scale, scale2;
+    int out_bf16;      // O written as bf16 (feeds the bf16 out-projection GEMM)
 };
 
 // LDS image of one stage (KC keys): K rows and V rows are DH floats, unpadded (LDS-DMA writes 1 KiB contiguous pieces);
@@ -217,9 +218,16 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         const int qrow = q0 + 4 * g + r;
         if (qrow >= p.Tq) continue;
         const float inv = 1.0f / lr[r];
-        float* op = p.O + ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH + lq;
+        const size_t off = ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH + lq;
+        if (p.out_bf16) {
+            __bf16* op = reinterpret_cast<__bf16*>(p.O) + off;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) op[16 * j] = o[j][r] * inv;
+            for (int j = 0; j < NJ; ++j) op[16 * j] = (__bf16)(o[j][r] * inv);
+        } else {
+            float* op = p.O + off;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) op[16 * j] = o[j][r] * inv;
+        }
     }
 }
 
@@ -251,10 +259,13 @@ __global__ void attn_small_kernel(AttnArgs p) {
         for (int d = 0; d < DH; ++d) acc[d] = acc[d] * a + e * vp[d];
         m = mn;
     }
-    float* op = p.O + ((size_t)seq * p.Tq + q) * p.ldo + head * DH;
+    const size_t off = ((size_t)seq * p.Tq + q) * p.ldo + head * DH;
     const float inv = 1.0f / l;
 #pragma unroll
-    for (int d = 0; d < DH; ++d) op[d] = acc[d] * inv;
+    for (int d = 0; d < DH; ++d) {
+        if (p.out_bf16) reinterpret_cast<__bf16*>(p.O)[off + d] = (__bf16)(acc[d] * inv);
+        else p.O[off + d] = acc[d] * inv;
+    }
 }
 
 template <int DH>
@@ -287,6 +298,12 @@ int mmdm_attn_init(void) {
 
 extern "C" int mmdm_attention_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                                   int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
+    return mmdm_attention_ex(Q, ldq, K, ldk, V, ldv, O, ldo, 0, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);
+}
+
+extern "C" int mmdm_attention_ex(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* Ov, int ldo, int out_bf16,
+                                 int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
+    float* O = static_cast<float*>(Ov);
     if (nseq == 0 || Tq == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
     if (!Q || !K || !V || !O || nseq < 0 || Tq < 0 || Tk <= 0 || H <= 0 || dh <= 0)
@@ -295,7 +312,7 @@ extern "C" int mmdm_attention_f32(const float* Q, int ldq, const float* K, int l
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_f32: row strides must cover H*dh=%d", H * dh);
     AttnArgs a;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
-    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H;
+    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
     a.pairs_per_xcd = (nseq * H + 7) / 8;

@@ -1,0 +1,256 @@
+// bf16-operand linear layer for gfx950 (BASELINE configs[4] "bf16 path"): C = A W^T + b, A and W bf16, fp32 accumulate on
+// v_mfma_f32_32x32x16_bf16, fused epilogues, fp32 or bf16 output.
+//
+// Same structure as gemm_glds_kernel (gemm_f32.hip): a 64-byte LDS row holds 32 bf16 instead of 16 floats, so the LDS image,
+// the 1-KiB LDS-DMA pieces and the XOR swizzle (16-byte chunk c of row r at c ^ ((r >> 2) & 3)) are byte-for-byte the same;
+// one ds_read_b128 per operand now feeds ONE MFMA of K = 16 (lane (r, h) holds k = 8h .. 8h+7 of MFMA k-block kb: chunk 2kb + h).
+// Operands are swapped (D^T = W A^T) so that the output row sits on the lane and four consecutive columns in consecutive
+// accumulator registers: bias / residual loads and result stores are 16-byte (fp32) or 8-byte (bf16) accesses.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include "kernels.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct BArgs {
+    const __bf16* A; const __bf16* W; const float* bias; void* C; const float* extra;
+    int lda, ldw, ldc, ld_extra;          // element strides
+    int M, N, K, epilogue, period, out_bf16;
+    int mt, nt;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+template <int TM_, int TN_>
+struct BCfg {
+    static constexpr int WGM = TM_ / 10, WGN = TN_ / 10, TM = TM_ % 10, TN = TN_ % 10;
+    static constexpr int NWAVES = WGM * WGN, THREADS = 64 * NWAVES;
+    static constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 32;          // K step in bf16 elements (64 bytes)
+    static constexpr int A_FLOATS = BM * 16, B_FLOATS = BN * 16;                  // LDS sizes in 4-byte units
+    static constexpr int SMEM_BYTES = 2 * (A_FLOATS + B_FLOATS) * 4;
+    static constexpr int NA = BM / 16, NB = BN / 16;                              // 1-KiB pieces (16 rows x 64 B)
+    static constexpr int NI = (NA + NB) / NWAVES;
+    static_assert((NA + NB) % NWAVES == 0, "pieces must divide evenly over the waves");
+};
+
+template <int TM_, int TN_>
+__global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BArgs p) {
+    using C_ = BCfg<TM_, TN_>;
+    constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                              // [2][BM*16] (4-byte units)
+    float* Bs = smem + 2 * C_::A_FLOATS;
+
+    const int nwg = p.mt * p.nt;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (swz / p.nt) * BM;
+    const int n0 = (swz % p.nt) * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C_::WGN, wn = wave % C_::WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const char* src[C_::NI];
+    int dst[C_::NI];
+    bool isa[C_::NI];
+#pragma unroll
+    for (int u = 0; u < C_::NI; ++u) {
+        const int pq = wave + C_::NWAVES * u;
+        const int prow = lane >> 2, pc = lane & 3;
+        isa[u] = pq < C_::NA;
+        const int trow = 16 * (isa[u] ? pq : pq - C_::NA) + prow;
+        const int gch = pc ^ ((trow >> 2) & 3);
+        if (isa[u]) {
+            int grow = m0 + trow;
+            grow = grow < p.M ? grow : p.M - 1;
+            src[u] = reinterpret_cast<const char*>(p.A + (size_t)grow * p.lda) + 16 * gch;
+            dst[u] = 16 * pq * 16;
+        } else {
+            int grow = n0 + trow;
+            grow = grow < p.N ? grow : p.N - 1;
+            src[u] = reinterpret_cast<const char*>(p.W + (size_t)grow * p.ldw) + 16 * gch;
+            dst[u] = 2 * C_::A_FLOATS + 16 * (pq - C_::NA) * 16;
+        }
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < C_::NI; ++u) {
+            const int boff = isa[u] ? buf * C_::A_FLOATS : buf * C_::B_FLOATS;
+            __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + dst[u] + boff), 16, 0, 0);
+            src[u] += 64;
+        }
+    };
+
+    // accumulators start as bias (+ residual / + PE row); D^T map: lane&31 = row, register 4*qd + c = column 8*qd + 4*lh + c
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * (32 * TM) + i * 32 + l31;
+        const bool rok = row < p.M;
+        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+        const bool ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && rok;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (col < p.N) {
+                    if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + col);
+                    if (ext) v += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = v[c];
+            }
+    }
+
+    const int nkt = p.K / BK;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage(0);
+
+    const int sw = (l31 >> 2) & 3;
+    const int a_row = (wm * (32 * TM) + l31) * 16;
+    const int b_row = (wn * (32 * TN) + l31) * 16;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nkt) stage(cur ^ 1);
+        const float* Ac = As + cur * C_::A_FLOATS + a_row;
+        const float* Bc = Bs + cur * C_::B_FLOATS + b_row;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int cg = 4 * ((2 * kb + lh) ^ sw);
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ac + i * 32 * 16 + cg));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bc + j * 32 * 16 + cg));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    // MFMA -> VALU hazard across the loop-exit branch: see MFMA_SETTLE in attn_f32.hip
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * (32 * TM) + i * 32 + l31;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
+                if (col >= p.N) continue;
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float t = acc[i][j][4 * qd + c];
+                    if (p.epilogue == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
+                    else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
+                    v[c] = t;
+                }
+                if (p.out_bf16) {
+                    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col) = o;
+                } else {
+                    *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
+                }
+            }
+    }
+}
+
+template <int TM_, int TN_>
+int launch(BArgs a, hipStream_t st) {
+    using C_ = BCfg<TM_, TN_>;
+    a.mt = (a.M + C_::BM - 1) / C_::BM;
+    a.nt = (a.N + C_::BN - 1) / C_::BN;
+    hipLaunchKernelGGL((gemm_bf16_kernel<TM_, TN_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+    return mmdm_check_launch("gemm_bf16");
+}
+
+template <int TM_, int TN_>
+int set_attr() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM_, TN_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, BCfg<TM_, TN_>::SMEM_BYTES);
+    if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16): %s", hipGetErrorString(e));
+    return MMDM_OK;
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (__bf16)in[i];
+}
+
+int g_bf16_cfg = -1;
+
+}  // namespace
+
+int mmdm_gemm_bf16_init(void) {
+    int rc;
+    if ((rc = set_attr<22, 22>())) return rc;
+    if ((rc = set_attr<42, 22>())) return rc;
+    if ((rc = set_attr<42, 42>())) return rc;
+    if ((rc = set_attr<22, 21>())) return rc;
+    const char* e = getenv("MMDM_BF16_CFG");
+    g_bf16_cfg = e ? atoi(e) : -1;
+    return MMDM_OK;
+}
+
+extern "C" void mmdmx_set_bf16_cfg(int c) { g_bf16_cfg = c; }
+
+extern "C" int mmdm_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
+    if (n <= 0) return MMDM_OK;
+    if (!in || !out) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_f32_to_bf16: null argument");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), in, static_cast<__bf16*>(out), (size_t)n);
+    return mmdm_check_launch("f32_to_bf16");
+}
+
+extern "C" int mmdm_linear_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16,
+                                int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
+    if (M == 0 || N == 0) return MMDM_OK;
+    if (int rc = mmdm_kernels_init()) return rc;
+    if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < K || ldc < N)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_bf16: bad shape M=%d N=%d K=%d lda=%d ldw=%d ldc=%d", M, N, K, lda, ldw, ldc);
+    if (epilogue < MMDM_EPI_BIAS || epilogue > MMDM_EPI_BIAS_SILU) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_bf16: unknown epilogue %d", epilogue);
+    const bool ext = epilogue == MMDM_EPI_BIAS_RESID || epilogue == MMDM_EPI_BIAS_PE;
+    if (ext && (!extra || ld_extra < N)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_bf16: epilogue %d needs `extra` with ld >= N", epilogue);
+    if (epilogue == MMDM_EPI_BIAS_PE && period <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_bf16: PE epilogue needs period > 0");
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if ((K & 31) || (lda & 7) || (ldw & 7) || !al16(A) || !al16(W))
+        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16: needs K %% 32 == 0 and 16-byte aligned bf16 rows");
+    if ((N & 3) || (ldc & 3) || !al16(C) || (bias && !al16(bias)) || (ext && ((ld_extra & 3) || !al16(extra))))
+        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16: needs N %% 4 == 0 and 16-byte aligned output / bias / residual rows");
+    BArgs a;
+    a.A = static_cast<const __bf16*>(A); a.W = static_cast<const __bf16*>(W); a.bias = bias; a.C = C; a.extra = extra;
+    a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
+    a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_bf16 = out_bf16;
+    a.mt = a.nt = 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (g_bf16_cfg) {
+        case 0: return launch<22, 22>(a, st);
+        case 1: return launch<42, 22>(a, st);
+        case 2: return launch<42, 42>(a, st);
+        case 3: return launch<22, 21>(a, st);
+        default: return launch<42, 22>(a, st);
+    }
+}

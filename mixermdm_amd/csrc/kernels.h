@@ -11,6 +11,7 @@ int mmdm_check_launch(const char* what);
 // One-time per-process kernel attribute setup (dynamic LDS sizes); safe to call repeatedly, never during capture.
 int mmdm_kernels_init(void);
 int mmdm_gemm_init(void);
+int mmdm_gemm_bf16_init(void);
 
 constexpr int MMDM_NF = 262;      // pose features per person (src/models/in2in.py:426, INPUT_DIM)
 constexpr int MMDM_NJ = 22;       // joints

@@ -37,6 +37,7 @@ int mmdm_kernels_init(void) {
     static int state = -1;  // -1 not tried, 0 ok
     if (state == 0) return MMDM_OK;
     int rc = mmdm_gemm_init();
+    if (!rc) rc = mmdm_gemm_bf16_init();
     if (!rc) rc = mmdm_attn_init();
     if (!rc) state = 0;
     return rc;
@@ -77,11 +78,16 @@ struct LayerW {
     float *f1_w, *f1_b, *f2_w, *f2_b;
 };
 
+struct LayerWB {         // bf16 twins of the stack GEMM weights (precision == 1), converted at mmdm_prepare
+    void *sa_in_w = nullptr, *sa_out_w = nullptr, *ca_in_w = nullptr, *ca_out_w = nullptr, *f1_w = nullptr, *f2_w = nullptr;
+};
+
 struct StackW {          // a transformer stack: denoiser blocks or Influence blocks
     int D = 0, F = 0, L = 0, H = 0, n_ada = 0;
     bool has_ca = false;
     float *ada_w = nullptr, *ada_b = nullptr;   // [L*n_ada*2D, D], [L*n_ada*2D]  (slots: sa, [ca_q, ca_kv,] ffn)
     std::vector<LayerW> layers;
+    std::vector<LayerWB> layers_b;
 };
 
 struct ModuleW {         // denoiser or mixer front/back ends
@@ -205,9 +211,28 @@ int build_stack(mmdm_handle h, StackW& st, const std::string& pfx, int D, int F,
     RC(dalloc(h, &st.ada_w, (size_t)L * st.n_ada * 2 * D * D));
     RC(dalloc(h, &st.ada_b, (size_t)L * st.n_ada * 2 * D));
     st.layers.resize(L);
+    const bool bf = h->cfg.precision == 1;
+    if (bf) st.layers_b.resize(L);
+    auto twin = [&](void** p, size_t n) -> int {          // n bf16 elements
+        float* q = nullptr;
+        RC(dalloc(h, &q, (n + 1) / 2));
+        *p = q;
+        return MMDM_OK;
+    };
     for (int i = 0; i < L; ++i) {
         LayerW& lw = st.layers[i];
         memset(&lw, 0, sizeof(lw));
+        if (bf) {
+            LayerWB& b2 = st.layers_b[i];
+            RC(twin(&b2.sa_in_w, (size_t)3 * D * D));
+            RC(twin(&b2.sa_out_w, (size_t)D * D));
+            RC(twin(&b2.f1_w, (size_t)F * D));
+            RC(twin(&b2.f2_w, (size_t)D * F));
+            if (has_ca) {
+                RC(twin(&b2.ca_in_w, (size_t)3 * D * D));
+                RC(twin(&b2.ca_out_w, (size_t)D * D));
+            }
+        }
         const std::string b = pfx + "blocks." + std::to_string(i) + ".";
         auto ada = [&](const char* norm, int slot) {
             add_view(h, b + norm + ".emb_layers.1.weight", st.ada_w + ((size_t)i * st.n_ada + slot) * 2 * D * D, 2 * D, D);
@@ -323,35 +348,63 @@ struct StackRun {
 };
 
 // h [nseq*T, D] is updated in place through the L blocks (TransformerBlockDoubleCond / TransformerBlock / InfluenceBlockCross).
+// bf16-operand GEMM with the same accounting as linear()
+int linear_b(const Ctx& c, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16, int M, int N, int K,
+             int epi = MMDM_EPI_BIAS, const float* extra = nullptr, int ld_extra = 0) {
+    RC(prof_begin(c, 0, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + (out_bf16 ? 2.0 : 4.0) * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
+    RC(mmdm_linear_bf16(A, lda, W, ldw, bias, C, ldc, out_bf16, M, N, K, epi, extra, ld_extra, 0, c.st));
+    return prof_end(c, 0);
+}
+
+int attention_b(const Ctx& c, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O, int ldo, int out_bf16,
+                int nseq, int Tq, int Tk, int H, int dh, int shift) {
+    RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh, 4.0 * nseq * H * dh * (2.0 * Tq + 2.0 * Tk)));
+    RC(mmdm_attention_ex(Q, ldq, K, ldk, V, ldv, O, ldo, out_bf16, nseq, Tq, Tk, H, dh, shift, c.st));
+    return prof_end(c, 1);
+}
+
+// h [nseq*T, D] is updated in place through the L blocks (TransformerBlockDoubleCond / TransformerBlock / InfluenceBlockCross).
+// precision == 1: the GEMM operands xn / att / f1 are written as bf16 by their producers and the weights come from the bf16 twins;
+// the residual stream h, the Q/K/V projections, softmax and all accumulation stay fp32.
 int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     const Scratch& S = *c.s;
     const int D = w.D, F = w.F, R = r.nseq * r.T, dh = D / w.H;
+    const bool bf = c.h->cfg.precision == 1;
+    const int ob = bf ? 1 : 0;
+    auto bw = [](const void* base, size_t elems) { return static_cast<const void*>(static_cast<const uint16_t*>(base) + elems); };
+    // one GEMM of the stack: fp32 (A fp32, W fp32) or bf16 (A bf16 from the producer, W twin)
+    auto gemm = [&](const float* A, int lda, const float* Wf, const void* Wb, size_t woff, const float* bias, float* C, int ldc, int out_b, int N, int K,
+                    int epi, const float* extra, int ld_extra) -> int {
+        if (bf) return linear_b(c, A, lda, bw(Wb, woff), K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra);
+        return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra);
+    };
     for (int l = 0; l < w.L; ++l) {
         const LayerW& lw = w.layers[l];
+        const LayerWB lb = bf ? w.layers_b[l] : LayerWB();
         auto ss_at = [&](int slot, int row0) { return r.ss + (size_t)row0 * r.ss_ld + ((size_t)l * w.n_ada + slot) * 2 * D; };
         // --- self attention (layers.py:36-45)
-        RC(mmdm_adaln_f32(hbuf, ss_at(0, r.sa_row0), r.ss_ld, r.sa_rows, S.xn, r.nseq, r.T, D, c.st));
-        RC(linear(c, S.xn, D, lw.sa_in_w, D, lw.sa_in_b, S.qkv, 3 * D, R, 3 * D, D));
-        RC(attention(c, S.qkv, 3 * D, S.qkv + D, 3 * D, S.qkv + 2 * D, 3 * D, S.att, D, r.nseq, r.T, r.T, w.H, dh, 0));
+        RC(mmdm_adaln_ex(hbuf, ss_at(0, r.sa_row0), r.ss_ld, r.sa_rows, S.xn, ob, r.nseq, r.T, D, c.st));
+        RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+        RC(attention_b(c, S.qkv, 3 * D, S.qkv + D, 3 * D, S.qkv + 2 * D, 3 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, 0));
         if (r.ca_mode) {
             // keys/values of the cross attention come from the layer INPUT of the other stream (or a fixed source):
             // project them before the residual below overwrites h.
             const float* src = r.ca_mode == 1 ? hbuf : r.kv_src;
-            RC(mmdm_adaln_f32(src, ss_at(2, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, r.nseq, r.T, D, c.st));
-            RC(linear(c, S.xn, D, lw.ca_in_w + (size_t)D * D, D, lw.ca_in_b + D, S.kv, 2 * D, R, 2 * D, D));
+            RC(mmdm_adaln_ex(src, ss_at(2, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, ob, r.nseq, r.T, D, c.st));
+            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0));
         }
-        RC(linear(c, S.att, D, lw.sa_out_w, D, lw.sa_out_b, hbuf, D, R, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+        RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         // --- cross attention (layers.py:77-88)
         if (r.ca_mode) {
-            RC(mmdm_adaln_f32(hbuf, ss_at(1, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, r.nseq, r.T, D, c.st));
-            RC(linear(c, S.xn, D, lw.ca_in_w, D, lw.ca_in_b, S.qkv, D, R, D, D));
-            RC(attention(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
-            RC(linear(c, S.att, D, lw.ca_out_w, D, lw.ca_out_b, hbuf, D, R, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+            RC(mmdm_adaln_ex(hbuf, ss_at(1, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, ob, r.nseq, r.T, D, c.st));
+            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0));
+            RC(attention_b(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
+            RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         }
         // --- FFN (layers.py:99-106)
-        RC(mmdm_adaln_f32(hbuf, ss_at(w.has_ca ? 3 : 1, r.ffn_row0), r.ss_ld, r.ffn_rows, S.xn, r.nseq, r.T, D, c.st));
-        RC(linear(c, S.xn, D, lw.f1_w, D, lw.f1_b, S.f1, F, R, F, D, MMDM_EPI_BIAS_GELU));
-        RC(linear(c, S.f1, F, lw.f2_w, F, lw.f2_b, hbuf, D, R, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
+        RC(mmdm_adaln_ex(hbuf, ss_at(w.has_ca ? 3 : 1, r.ffn_row0), r.ss_ld, r.ffn_rows, S.xn, ob, r.nseq, r.T, D, c.st));
+        RC(gemm(S.xn, D, lw.f1_w, lb.f1_w, 0, lw.f1_b, S.f1, F, ob, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
+        RC(gemm(S.f1, F, lw.f2_w, lb.f2_w, 0, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
     }
     return MMDM_OK;
 }
@@ -521,6 +574,9 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     if (!cfg->single_only && (cfg->mixing_mode < 1 || cfg->mixing_mode > 4)) return mmdm_set_error(MMDM_ERR_ARG, "Mode not recognized");
     if (cfg->max_batch <= 0 || cfg->max_frames <= 0 || cfg->text_dim <= 0 || cfg->text_dim % 4)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: bad max_batch / max_frames / text_dim");
+    if (cfg->precision < 0 || cfg->precision > 1) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: precision must be 0 (fp32) or 1 (bf16 GEMM operands)");
+    if (cfg->precision == 1 && ((cfg->d_latent % 32) || (cfg->d_ff % 32) || (!cfg->single_only && ((cfg->m_latent % 32) || (cfg->m_ff % 32)))))
+        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: the bf16 path needs latent and ff sizes that are multiples of 32");
     RC(mmdm_kernels_init());
     mmdm_handle h = new mmdm_handle_s();
     h->cfg = *cfg;
@@ -638,6 +694,24 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
         }
     if (nmiss) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "Missing key(s) in state_dict (%d): %s%s", nmiss, missing.c_str(), nmiss > 4 ? ", ..." : ""));
     if (!h->cfg.single_only && !h->stats_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_prepare: normaliser stats not set"));
+    if (h->cfg.precision == 1) {
+        for (ModuleW* m : {&h->d1, &h->d2, &h->mx}) {
+            StackW& st = m->st;
+            for (size_t i = 0; i < st.layers_b.size(); ++i) {
+                const LayerW& lw = st.layers[i];
+                LayerWB& lb = st.layers_b[i];
+                const int64_t D = st.D, F = st.F;
+                int rc = mmdm_f32_to_bf16(lw.sa_in_w, lb.sa_in_w, 3 * D * D, nullptr);
+                if (!rc) rc = mmdm_f32_to_bf16(lw.sa_out_w, lb.sa_out_w, D * D, nullptr);
+                if (!rc) rc = mmdm_f32_to_bf16(lw.f1_w, lb.f1_w, F * D, nullptr);
+                if (!rc) rc = mmdm_f32_to_bf16(lw.f2_w, lb.f2_w, D * F, nullptr);
+                if (!rc && st.has_ca) rc = mmdm_f32_to_bf16(lw.ca_in_w, lb.ca_in_w, 3 * D * D, nullptr);
+                if (!rc && st.has_ca) rc = mmdm_f32_to_bf16(lw.ca_out_w, lb.ca_out_w, D * D, nullptr);
+                if (rc) return herr(h, rc);
+            }
+        }
+        HIPCHK(hipDeviceSynchronize());
+    }
     h->prepared = true;
     return MMDM_OK;
 }

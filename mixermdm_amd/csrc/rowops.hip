@@ -16,9 +16,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // out = LN(h) * (1 + scale) + shift ; one wave per row; row cached in registers (D <= 64*4*MAXV).
 // Reference: AdaLN.forward src/models/utils/layers.py:15-25 (LayerNorm eps 1e-6, biased variance, no affine).
-template <int MAXV>
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int MAXV, bool OBF>
 __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h, const float* __restrict__ ss, int ss_ld, int ss_rows,
-                                                     float* __restrict__ out, int rows, int T, int D) {
+                                                     void* __restrict__ outv, int rows, int T, int D) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -45,14 +47,19 @@ __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h,
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-6f);
     const float* sp = ss + (size_t)((row / T) % ss_rows) * ss_ld;
-    float* op = out + (size_t)row * D;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(sp + 4 * c);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(sp + D + 4 * c);
-            *reinterpret_cast<f32x4*>(op + 4 * c) = (v[i] - mean) * rstd * (1.0f + sc) + sh;
+            const f32x4 y = (v[i] - mean) * rstd * (1.0f + sc) + sh;
+            if (OBF) {
+                const bf16x4 o = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
+                *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(outv) + (size_t)row * D + 4 * c) = o;
+            } else {
+                *reinterpret_cast<f32x4*>(static_cast<float*>(outv) + (size_t)row * D + 4 * c) = y;
+            }
         }
     }
 }
@@ -126,6 +133,10 @@ extern "C" int mmdm_gaussian_filter1d_f32(const float* x, float* out, const doub
 }
 
 extern "C" int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss_rows, float* out, int nseq, int T, int D, void* stream) {
+    return mmdm_adaln_ex(h, ss, ss_ld, ss_rows, out, 0, nseq, T, D, stream);
+}
+
+extern "C" int mmdm_adaln_ex(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, int nseq, int T, int D, void* stream) {
     if (nseq == 0 || T == 0) return MMDM_OK;
     if (!h || !ss || !out || nseq < 0 || T < 0 || D <= 0 || ss_rows <= 0 || ss_ld < 2 * D)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_adaln_f32: bad arguments nseq=%d T=%d D=%d ss_ld=%d ss_rows=%d", nseq, T, D, ss_ld, ss_rows);
@@ -135,10 +146,16 @@ extern "C" int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss
     const int rows = nseq * T;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((rows + 3) / 4), block(256);
-    if (D <= 256) hipLaunchKernelGGL(adaln_kernel<1>, grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);
-    else if (D <= 512) hipLaunchKernelGGL(adaln_kernel<2>, grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);
-    else if (D <= 1024) hipLaunchKernelGGL(adaln_kernel<4>, grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);
-    else hipLaunchKernelGGL(adaln_kernel<8>, grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);
+#define ADALN_LAUNCH(V)                                                                                                   \
+    do {                                                                                                                  \
+        if (out_bf16) hipLaunchKernelGGL((adaln_kernel<V, true>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);  \
+        else hipLaunchKernelGGL((adaln_kernel<V, false>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);          \
+    } while (0)
+    if (D <= 256) ADALN_LAUNCH(1);
+    else if (D <= 512) ADALN_LAUNCH(2);
+    else if (D <= 1024) ADALN_LAUNCH(4);
+    else ADALN_LAUNCH(8);
+#undef ADALN_LAUNCH
     return mmdm_check_launch("adaln");
 }
 

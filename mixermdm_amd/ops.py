@@ -152,3 +152,28 @@ def gaussian_filter1d(x, sigma=1.0, truncate=4.0):
     out = torch.empty_like(x)
     check(load_library().mmdm_gaussian_filter1d_f32(_p(x), _p(out), C.c_void_p(wd.data_ptr()), radius, n, T, Cc, _stream()))
     return out
+
+
+def to_bf16(x):
+    """fp32 -> bf16 (RNE) on the GPU; returns a torch.bfloat16 tensor of the same shape."""
+    _chk(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(load_library().mmdm_f32_to_bf16(_p(x), C.c_void_p(out.data_ptr()), x.numel(), _stream()))
+    return out
+
+
+def linear_bf16(x, weight, bias=None, epilogue="bias", extra=None, period=0, out_dtype=torch.float32):
+    """y = x @ weight.T + bias with bf16 operands (x, weight torch.bfloat16), fp32 accumulation; fp32 or bf16 result."""
+    for t in (x, weight):
+        if not t.is_cuda or t.dtype != torch.bfloat16:
+            raise TypeError("linear_bf16 expects CUDA torch.bfloat16 operands")
+    _chk(bias, extra)
+    K, N = x.shape[-1], weight.shape[0]
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    out = torch.empty(M, N, device=x.device, dtype=out_dtype)
+    check(load_library().mmdm_linear_bf16(C.c_void_p(x2.data_ptr()), x2.stride(0), C.c_void_p(weight.data_ptr()), weight.stride(0), _p(bias),
+                                          C.c_void_p(out.data_ptr()), out.stride(0), int(out_dtype == torch.bfloat16), M, N, K, EPI[epilogue],
+                                          _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
+    return out.reshape(*x.shape[:-1], N)

@@ -29,7 +29,7 @@ class Sampler:
 
     def __init__(self, *, d_latent, d_ff, d_layers, d_heads, m_latent=0, m_ff=0, m_layers=0, m_heads=1, mixing_mode=4, align=True,
                  xstart_align=True, model2_kind=0, force_influence_val=None, cfg_scale=3.5, max_batch=1, max_frames=300,
-                 single_only=False, text_dim=768, device=None, cfg_scale_interaction=0.0, cfg_scale_individual=0.0):
+                 single_only=False, text_dim=768, device=None, cfg_scale_interaction=0.0, cfg_scale_individual=0.0, precision="fp32"):
         """single_only: False/0 = two-chain MixerMDM; True/1 = individual denoiser alone (2-way CFG);
         2 = interaction denoiser alone with the 4-way CFG of ClassifierFreeSampleModelMultiple."""
         if not torch.cuda.is_available():
@@ -38,7 +38,8 @@ class Sampler:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.cfg = Config(d_latent, d_ff, d_layers, d_heads, m_latent, m_ff, m_layers, m_heads, 262, text_dim, mixing_mode, int(align),
                           int(xstart_align), model2_kind, int(force_influence_val is not None), float(force_influence_val or 0.0),
-                          float(cfg_scale), max_batch, max_frames, int(single_only), float(cfg_scale_interaction), float(cfg_scale_individual))
+                          float(cfg_scale), max_batch, max_frames, int(single_only), float(cfg_scale_interaction), float(cfg_scale_individual),
+                          {"fp32": 0, "bf16": 1}[precision])
         self.single_only = int(single_only)
         self.h = C.c_void_p()
         with torch.cuda.device(self.device):

@@ -1,0 +1,26 @@
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, math, statistics
+from mixermdm_amd import ops, load_library
+lib = load_library(); d = torch.device("cuda:0")
+shapes = [(19200,3072,1024,"qkv","bias"),(19200,1024,1024,"out","resid"),(19200,2048,1024,"ffn1","gelu"),(19200,1024,2048,"ffn2","resid"),(19200,512,512,"m.out","resid"),(8192,8192,8192,"sq8k","bias")]
+cfgs = [0,1,2,3]
+for M,N,K,name,epi in shapes:
+    x = torch.randn(M,K,device=d); w = torch.randn(N,K,device=d)/math.sqrt(K); b = torch.randn(N,device=d)
+    xb, wb = ops.to_bf16(x), ops.to_bf16(w)
+    extra = torch.randn(M,N,device=d) if epi=="resid" else None
+    # correctness vs fp32 matmul of the rounded operands
+    ref = torch.nn.functional.linear(xb.float(), wb.float(), b)
+    if epi=="gelu": ref = torch.nn.functional.gelu(ref)
+    if epi=="resid": ref = ref + extra
+    line=f"{name:6s} {M}x{N}x{K} {epi:5s}"
+    for c in cfgs:
+        lib.mmdmx_set_bf16_cfg(c)
+        out = ops.linear_bf16(xb,wb,b,epi,extra)
+        err=(out-ref).abs().max().item()
+        res=[]
+        for r in range(5):
+            e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e0.record()
+            for _ in range(4): ops.linear_bf16(xb,wb,b,epi,extra)
+            e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
+        ms=statistics.median(res); line+=f" | cfg{c}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:7.1f}TF err {err:.1e}"
+    print(line, flush=True)

@@ -327,3 +327,50 @@ def full_small():
     W["denoiser2.sequence_pos_encoder.pe"] = pe_table(512)
     yield s, W, (stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
     s.close()
+
+
+def test_bf16_path_tracks_the_fp32_path():
+    """precision="bf16" (BASELINE configs[4]-style: bf16 GEMM operands, fp32 accumulation / softmax / geometry / DDIM).
+    Tolerance (stated for bf16, 8 mantissa bits): after one step the model output agrees with the fp32 path to 3e-2 relative RMS,
+    the DDIM state to 2e-3 relative RMS; a ddim20 run stays finite and within 6e-2 relative RMS."""
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_stats, synthetic_inputs, FULL_DIMS
+    sd = synthetic_state_dict(seed=0, std=0.02, bias_std=0.02, **FULL_DIMS)
+    st = synthetic_stats()
+    B, T = 2, 48
+    cond, xT = synthetic_inputs(B, T)
+    res = {}
+    for prec in ("fp32", "bf16"):
+        s = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, precision=prec, **FULL_DIMS)
+        s.load_state_dict(sd)
+        s.set_norm_stats(st["mean_hml"], st["std_hml"], st["mean_ih"], st["std_ih"])
+        s.prepare()
+        s.set_schedule("ddim20")
+        s.begin(cond, xT)
+        s.run(1, use_graph=False)
+        one = {k: v.clone() for k, v in s.state().items()}
+        s.run(19, use_graph=True)
+        res[prec] = (one, s.state()["pred_xstart2"].clone())
+        s.close()
+    rel = lambda a, b: ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+    assert rel(res["bf16"][0]["model_out"], res["fp32"][0]["model_out"]) < 3e-2
+    assert rel(res["bf16"][0]["x"], res["fp32"][0]["x"]) < 2e-3 and rel(res["bf16"][0]["x2"], res["fp32"][0]["x2"]) < 2e-3
+    assert torch.isfinite(res["bf16"][1]).all() and rel(res["bf16"][1], res["fp32"][1]) < 6e-2
+    assert not torch.equal(res["bf16"][0]["x"], res["fp32"][0]["x"])        # the bf16 kernels really ran
+
+
+def test_bf16_linear_matches_rounded_operand_reference():
+    from mixermdm_amd import ops, MMDMError
+    import torch.nn.functional as F
+    M, N, K = 300, 512, 1024
+    x, w, b, r = rnd(90, M, K), rnd(91, N, K, scale=0.03), rnd(92, N), rnd(93, M, N)
+    xb, wb = ops.to_bf16(x.to(dev())), ops.to_bf16(w.to(dev()))
+    assert torch.equal(xb.cpu(), x.bfloat16())                               # RNE conversion == torch's
+    ref = F.linear(xb.float().cpu().double(), wb.float().cpu().double(), b.double())
+    assert_close(ops.linear_bf16(xb, wb, b.to(dev())), ref.float(), atol=2e-5, rtol=1e-5)
+    assert_close(ops.linear_bf16(xb, wb, b.to(dev()), "resid", r.to(dev())), (ref + r.double()).float(), atol=2e-5, rtol=1e-5)
+    g = ops.linear_bf16(xb, wb, b.to(dev()), "gelu", out_dtype=torch.bfloat16)
+    assert g.dtype == torch.bfloat16
+    assert_close(g.float(), F.gelu(ref).float(), atol=1e-2, rtol=1e-2)
+    with pytest.raises(MMDMError, match="K %% 32|K % 32"):
+        ops.linear_bf16(xb[:, :48].contiguous(), wb[:, :48].contiguous())
