@@ -45,7 +45,8 @@ enum {
     MMDM_EPI_BIAS_GELU = 1,  /* C = gelu_erf(A W^T + b)                         FFN.linear1+activation  src/models/utils/layers.py:104 */
     MMDM_EPI_BIAS_RESID = 2, /* C = A W^T + b + R   (R may alias C)             "+ x" residuals         src/models/utils/blocks.py:50-63 */
     MMDM_EPI_BIAS_PE = 3,    /* C = A W^T + b + pe[m % period]                  motion_embed + PositionalEncoding  src/models/in2in.py:426-431 */
-    MMDM_EPI_BIAS_SILU = 4   /* C = silu(A W^T + b)                             TimestepEmbedder time_embed.0+SiLU src/models/utils/utils.py:47-51 */
+    MMDM_EPI_BIAS_SILU = 4,  /* C = silu(A W^T + b)                             TimestepEmbedder time_embed.0+SiLU src/models/utils/utils.py:47-51 */
+    MMDM_EPI_BIAS_QUICKGELU = 5 /* C = z*sigmoid(1.702 z), z = A W^T + b            CLIP text tower MLP (clip==1.0 model.py QuickGELU; src/models/mixermdm.py:213) */
 };
 
 /* y = x W^T + b with a fused epilogue; exact fp32 (v_mfma_f32_32x32x2_f32).
@@ -80,6 +81,14 @@ int mmdm_attention_f32(const float* Q, int ldq, const float* K, int ldk, const f
 /* Same with a selectable output type (fp32 Q/K/V in, fp32 softmax and accumulation; O fp32 or bf16). */
 int mmdm_attention_ex(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O, int ldo, int out_bf16,
                       int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
+
+/* Same with options.  flags: MMDM_ATTN_NO_ZERO_KEY = plain softmax over the Tk keys (nn.MultiheadAttention default, as inside
+ * nn.TransformerEncoderLayer: MDMDenoiser.seqTransEncoder src/models/mdm.py:252-264, clipTransEncoder src/models/mixermdm.py:246-258);
+ * MMDM_ATTN_CAUSAL = keys <= query only (the CLIP text tower's attention mask; needs NO_ZERO_KEY and Tq == Tk).
+ * Head sizes 64 and 128 run on the MFMA kernel, 4..32 and any other size <= 256 on scalar fallbacks. */
+enum { MMDM_ATTN_NO_ZERO_KEY = 1, MMDM_ATTN_CAUSAL = 2 };
+int mmdm_attention_opts(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O, int ldo, int out_bf16,
+                        int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
 
 /* out[r,:] = silu(time_row[:] + txt[r,:]) for r < rows; time_row = time_tab + (*step_idx) * D.
  * Replaces `embed_timestep(t) + text_embed(c)` followed by AdaLN's SiLU  in2in.py:415-422, layers.py:9-10. */
@@ -138,6 +147,40 @@ int mmdm_gaussian_filter1d_f32(const float* x, float* out, const double* weights
 int mmdm_cfg4_ddim_f32(const float* m, const float* coef, int S, const int* step_idx, float s, float s_int, float s_ind,
                        float* x, float* pred_xstart, int B, int T, int C, void* stream);
 
+/* DualMDM composition + single-chain DDIM:  g_I = u_I + s_int (c_I - u_I),  g_i = u_i + s_ind (c_i - u_i)  (c = rows [0,B), u = rows
+ * [B,2B) of the two models' outputs m_int / m_ind [2B,T,C]);  x0 = g_I + w_table[*step_idx] (g_i - g_I).
+ * Replaces ClassifierFreeSampleDualMDM combine + GaussianDiffusion.ddim_sample  cfg_sampler.py:139-150, gaussian_diffusion.py:799-849. */
+int mmdm_dual_ddim_f32(const float* m_ind, const float* m_int, const float* coef, int S, const int* step_idx, const float* w_table,
+                       float s_ind, float s_int, float* x, float* pred_xstart, int B, int T, int C, void* stream);
+
+/* nn.LayerNorm with affine: out[r,:] = (x[r,:] - mean) / sqrt(var + eps) * gamma + beta (biased variance); in place allowed.
+ * Replaces norm1/norm2 of nn.TransformerEncoderLayer (src/models/mdm.py:252-264), clip_ln (src/models/mixermdm.py:259), ln_final. */
+int mmdm_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out, int rows, int D, float eps, void* stream);
+
+/* out[b,l,:] = table[tokens[b,l],:] + pos[l,:]; tokens: DEVICE int32 [n,L], clamped to [0, vocab).
+ * Replaces token_embedding(text) + positional_embedding  src/models/mixermdm.py:298-299. */
+int mmdm_token_embed_f32(const float* table, int vocab, const int* tokens, const float* pos, float* out, int n, int L, int D, void* stream);
+
+/* dst[i,:] = src[idx[i],:]; idx: DEVICE int32 [n].  Replaces out[arange(B), text.argmax(-1)] (EOT row)  src/models/mixermdm.py:311. */
+int mmdm_gather_rows_f32(const float* src, const int* idx, float* dst, int n, int D, void* stream);
+
+/* One nn.TransformerEncoderLayer(batch_first=True) on x [nseq, T, D] in place, eval mode, dh = D/H.
+ *   norm_first = 0 (torch default): x = LN1(x + SA(x)); x = LN2(x + W2 act(W1 x + b1) + b2)
+ *       -- MDMDenoiser.seqTransEncoder (src/models/mdm.py:252-264), clipTransEncoder text heads (src/models/mixermdm.py:246-258, in2in.py:24-52)
+ *   norm_first = 1: x += SA(LN1 x); x += W2 act(W1 LN2 x + b1) + b2 -- CLIP's ResidualAttentionBlock (clip==1.0 model.py; ln_1/ln_2 = norm1/norm2,
+ *       mlp.c_fc/c_proj = linear1/linear2), with causal = 1 and activation = MMDM_EPI_BIAS_QUICKGELU
+ * activation: MMDM_EPI_BIAS_GELU or MMDM_EPI_BIAS_QUICKGELU.  workspace: mmdm_encoder_layer_workspace(...) floats of device memory. */
+typedef struct {
+    const float *in_proj_weight, *in_proj_bias;     /* [3D, D], [3D]  (q, k, v order) */
+    const float *out_proj_weight, *out_proj_bias;   /* [D, D], [D] */
+    const float *linear1_weight, *linear1_bias;     /* [F, D], [F] */
+    const float *linear2_weight, *linear2_bias;     /* [D, F], [D] */
+    const float *norm1_weight, *norm1_bias, *norm2_weight, *norm2_bias;   /* [D] each */
+} mmdm_encoder_layer_weights;
+size_t mmdm_encoder_layer_workspace(int nseq, int T, int D, int F);
+int mmdm_encoder_layer_f32(float* x, const mmdm_encoder_layer_weights* w, int nseq, int T, int D, int H, int F, int norm_first,
+                           int activation, int causal, float eps, float* workspace, size_t workspace_floats, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 2. The sampler handle: weights + workspace + captured step graph.
  * ---------------------------------------------------------------------------------------------- */
@@ -160,13 +203,20 @@ typedef struct {
     float cfg_scale;   /* CFG_WEIGHT */
     int max_batch;     /* B (before CFG doubling) the workspace is sized for */
     int max_frames;    /* T */
-    int single_only;   /* 0: two-chain MixerMDM.  1: single chain, denoiser1 only (individual in2IN, 2-way CFG; configs 1-2).
+    int single_only;   /* 0: two-chain MixerMDM.  1: single chain, denoiser1 only (individual in2IN or MDM, 2-way CFG; configs 1-2).
                         * 2: single chain, denoiser2 only (stand-alone interaction in2IN/InterGen, 4-way CFG of
-                        *    ClassifierFreeSampleModelMultiple  src/models/utils/cfg_sampler.py:59-98; in2in.py:330-341) */
+                        *    ClassifierFreeSampleModelMultiple  src/models/utils/cfg_sampler.py:59-98; in2in.py:330-341)
+                        * 3: single chain, in2IN "dual": denoiser1 in "dual_individual" and denoiser2 in "dual_interaction" mode composed by
+                        *    ClassifierFreeSampleDualMDM  cfg_sampler.py:101-150, in2in.py:318-329; cond [B, 5*text_dim]; guidance scales
+                        *    cfg_scale_individual / cfg_scale_interaction; needs mmdm_set_dual_weights */
     float cfg_scale_interaction, cfg_scale_individual;   /* CFG_WEIGHT_INTERACTION / CFG_WEIGHT_INDIVIDUAL (single_only == 2) */
     int precision;     /* 0: exact fp32 everywhere (the parity path).  1: bf16 operands for the transformer-stack GEMMs (weights
                         *    converted once at mmdm_prepare; AdaLN / attention / GELU outputs written as bf16), fp32 accumulation,
                         *    residual stream, softmax, geometry, DDIM and embeddings (BASELINE configs[4], "bf16 path") */
+    int model1_kind;   /* 0 = in2IN individual denoiser, 1 = MDMDenoiser (post-norm nn.TransformerEncoder with a conditioning token,
+                        *    src/models/mdm.py:234-298; MODEL1.NAME == "MDM", src/models/mixermdm.py:32-40, 264-265).  Its cond slices are
+                        *    latent-sized (mdm.py:279), so the mixer's cond rows are [3*text_dim | 2*d1_latent | 3*text_dim] */
+    int d1_latent, d1_ff, d1_layers, d1_heads;   /* denoiser1's own sizes (MODEL1 is a separate config); 0 = same as d_* */
 } mmdm_config;
 
 int mmdm_create(const mmdm_config* cfg, mmdm_handle* out);
@@ -185,6 +235,10 @@ int mmdm_set_norm_stats(mmdm_handle h, const float* stats_host);
 /* Schedule (HOST pointers): S respaced steps; timestep_map[S] (original t the model sees, gaussian_diffusion.py:2200-2205);
  * coef [4*S] fp32 as in mmdm_xstart_ddim_f32.  Builds the per-step timestep-embedding tables. */
 int mmdm_set_schedule(mmdm_handle h, const int* timestep_map, const float* coef, int S, void* stream);
+
+/* Dual sampler only (single_only == 3): w[S] (HOST floats) = the composition weight s_composition(timestep_map[i]) of every respaced
+ * step (ClassifierFreeSampleDualMDM.weight, cfg_sampler.py:113-125).  Call after every mmdm_set_schedule. */
+int mmdm_set_dual_weights(mmdm_handle h, const float* w_host, int S);
 
 /* Check that every weight is present; allocate nothing afterwards. */
 int mmdm_prepare(mmdm_handle h);
@@ -209,6 +263,8 @@ int mmdm_get_state(mmdm_handle h, float** x, float** x2, float** pred_xstart, fl
  *   which: 0 = denoiser1 (individual; x [n,T,262], cond [n,text_dim]) -> out [n,T,262]
  *          1 = denoiser2 (interaction; x [n,T,524], cond [n,3*text_dim]) -> out [n,T,524]
  *          2 = Mixer.forward (x = x1 [n,T,524], x2 [n,T,524], cond [n,8*text_dim]) -> out [n,T,524] (out_influenced)
+ *          3 = denoiser1 in "dual_individual" mode (dual handle; x [n,T,524], cond [n,5*text_dim]) -> out [n,T,524]
+ *          (which = 0 with model1_kind = 1: MDMDenoiser.forward, cond [n, d1_latent])
  * t = original (remapped) timestep shared by all rows.  Replaces in2INDenoiser.forward / Mixer.forward. */
 int mmdm_module_forward(mmdm_handle h, int which, const float* x, const float* x2, const float* cond, int t,
                         float* out, int n, int T, void* stream);

@@ -20,7 +20,14 @@ class Config(C.Structure):
                                         "nfeats", "text_dim", "mixing_mode", "align", "xstart_align", "model2_kind", "use_force")] + \
                [("force_val", C.c_float), ("cfg_scale", C.c_float)] + \
                [(n, C.c_int) for n in ("max_batch", "max_frames", "single_only")] + \
-               [("cfg_scale_interaction", C.c_float), ("cfg_scale_individual", C.c_float), ("precision", C.c_int)]
+               [("cfg_scale_interaction", C.c_float), ("cfg_scale_individual", C.c_float), ("precision", C.c_int)] + \
+               [(n, C.c_int) for n in ("model1_kind", "d1_latent", "d1_ff", "d1_layers", "d1_heads")]
+
+
+class EncoderLayerWeights(C.Structure):
+    """mmdm_encoder_layer_weights (include/mmdm.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias", "linear1_weight", "linear1_bias",
+                                           "linear2_weight", "linear2_bias", "norm1_weight", "norm1_bias", "norm2_weight", "norm2_bias")]
 
 
 # every symbol include/mmdm.h declares: name -> (restype, argtypes)
@@ -44,6 +51,14 @@ SYMBOLS = {
     "mmdm_cfg_ddim_f32": (_I, [_VP, _VP, _I, _VP, C.c_float, _VP, _VP, _I, _I, _I, _VP]),
     "mmdm_gaussian_filter1d_f32": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "mmdm_cfg4_ddim_f32": (_I, [_VP, _VP, _I, _VP, C.c_float, C.c_float, C.c_float, _VP, _VP, _I, _I, _I, _VP]),
+    "mmdm_attention_opts": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "mmdm_dual_ddim_f32": (_I, [_VP, _VP, _VP, _I, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _I, _I, _I, _VP]),
+    "mmdm_layernorm_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I, C.c_float, _VP]),
+    "mmdm_token_embed_f32": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "mmdm_gather_rows_f32": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
+    "mmdm_encoder_layer_workspace": (C.c_size_t, [_I, _I, _I, _I]),
+    "mmdm_encoder_layer_f32": (_I, [_VP, C.POINTER(EncoderLayerWeights), _I, _I, _I, _I, _I, _I, _I, _I, C.c_float, _VP, C.c_size_t, _VP]),
+    "mmdm_set_dual_weights": (_I, [_VP, _VP, _I]),
     "mmdm_create": (_I, [C.POINTER(Config), C.POINTER(_VP)]),
     "mmdm_destroy": (None, [_VP]),
     "mmdm_handle_error": (C.c_char_p, [_VP]),

@@ -41,6 +41,7 @@ struct AttnArgs {
     int nseq, Tq, Tk, H, shift, qtiles, pairs_per_xcd;
     float scale, scale2;
     int out_bf16;      // O written as bf16 (feeds the bf16 out-projection GEMM)
+    int flags;         // MMDM_ATTN_NO_ZERO_KEY: plain softmax (nn.MultiheadAttention default); MMDM_ATTN_CAUSAL: key <= query only
 };
 
 // LDS image of one stage (KC keys): K rows and V rows are DH floats, unpadded (LDS-DMA writes 1 KiB contiguous pieces);
@@ -90,7 +91,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     f32x4 o[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = 0.f, l_run = 1.f;             // add_zero_attn: one key with logit 0, value 0 already absorbed
+    // add_zero_attn: one key with logit 0, value 0 already absorbed in the initial state; without it the state starts empty
+    // (m = -inf, l = 0: the first chunk always holds a visible key, so alpha = 2^(-inf) = 0 and no NaN can form).
+    const bool nozero = (p.flags & MMDM_ATTN_NO_ZERO_KEY) != 0, causal = (p.flags & MMDM_ATTN_CAUSAL) != 0;
+    float m_run = nozero ? -INFINITY : 0.f, l_run = nozero ? 0.f : 1.f;
 
     const float* Kg = p.K + (size_t)kvseq * p.Tk * p.ldk + head * DH;
     const float* Vg = p.V + (size_t)kvseq * p.Tk * p.ldv + head * DH;
@@ -113,7 +117,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         }
     };
 
-    const int nchunks = (p.Tk + KC - 1) / KC;
+    int nchunks = (p.Tk + KC - 1) / KC;
+    if (causal) {                               // keys past the workgroup's last query are never visible (same count for all 4 waves: barriers)
+        const int last_q = min(qt * QB + QB - 1, p.Tq - 1);
+        nchunks = min(nchunks, last_q / KC + 1);
+    }
     stage(0, 0);
     for (int ci = 0; ci < nchunks; ++ci) {
         const int c0 = ci * KC, cur = ci & 1;
@@ -147,12 +155,13 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) MFMA_SETTLE(st[kt]);
-        if (c0 + KC > p.Tk) {                  // only the last chunk can hold keys past Tk (wave-uniform branch)
+        if (c0 + KC > p.Tk || (causal && c0 + KC - 1 > q0)) {   // keys past Tk (last chunk) or above the diagonal (wave-uniform branch)
+            const int kmax = causal ? min(p.Tk - 1, q0 + lq) : p.Tk - 1;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (c0 + 16 * kt + 4 * g + r >= p.Tk) st[kt][r] = -INFINITY;
+                    if (c0 + 16 * kt + 4 * g + r > kmax) st[kt][r] = -INFINITY;
         }
         float cmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
 #pragma unroll
@@ -245,8 +254,10 @@ __global__ void attn_small_kernel(AttnArgs p) {
     const float* qp = p.Q + ((size_t)seq * p.Tq + q) * p.ldq + head * DH;
 #pragma unroll
     for (int d = 0; d < DH; ++d) { qv[d] = qp[d] * p.scale; acc[d] = 0.f; }
-    float m = 0.f, l = 1.f;
-    for (int k = 0; k < p.Tk; ++k) {
+    const bool nozero = (p.flags & MMDM_ATTN_NO_ZERO_KEY) != 0;
+    float m = nozero ? -INFINITY : 0.f, l = nozero ? 0.f : 1.f;
+    const int kend = (p.flags & MMDM_ATTN_CAUSAL) ? min(p.Tk, q + 1) : p.Tk;
+    for (int k = 0; k < kend; ++k) {
         const float* kp = p.K + ((size_t)kvseq * p.Tk + k) * p.ldk + head * DH;
         const float* vp = p.V + ((size_t)kvseq * p.Tk + k) * p.ldv + head * DH;
         float s = 0.f;
@@ -265,6 +276,60 @@ __global__ void attn_small_kernel(AttnArgs p) {
     for (int d = 0; d < DH; ++d) {
         if (p.out_bf16) reinterpret_cast<__bf16*>(p.O)[off + d] = (__bf16)(acc[d] * inv);
         else p.O[off + d] = acc[d] * inv;
+    }
+}
+
+// Any-head-size fallback (dh <= 256, e.g. the 96-wide heads of the 768/8 clipTransEncoder text heads): one wavefront per
+// (sequence, head, query), lanes over the head dimension, one wave reduction per key.  Only the short text sequences use it.
+__global__ __launch_bounds__(256) void attn_wave_kernel(AttnArgs p, int dh) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int total = p.nseq * p.H * p.Tq;
+    if (idx >= total) return;
+    const int lane = threadIdx.x & 63;
+    const int q = idx % p.Tq;
+    const int head = (idx / p.Tq) % p.H;
+    const int seq = idx / (p.Tq * p.H);
+    const int kvseq = (seq + p.shift) % p.nseq;
+    float qv[4], acc[4];
+    const float* qp = p.Q + ((size_t)seq * p.Tq + q) * p.ldq + head * dh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = lane + 64 * i;
+        qv[i] = d < dh ? qp[d] * p.scale : 0.f;
+        acc[i] = 0.f;
+    }
+    const bool nozero = (p.flags & MMDM_ATTN_NO_ZERO_KEY) != 0;
+    float m = nozero ? -INFINITY : 0.f, l = nozero ? 0.f : 1.f;
+    const int kend = (p.flags & MMDM_ATTN_CAUSAL) ? min(p.Tk, q + 1) : p.Tk;
+    for (int k = 0; k < kend; ++k) {
+        const float* kp = p.K + ((size_t)kvseq * p.Tk + k) * p.ldk + head * dh;
+        const float* vp = p.V + ((size_t)kvseq * p.Tk + k) * p.ldv + head * dh;
+        float sdot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = lane + 64 * i;
+            if (d < dh) sdot += qv[i] * kp[d];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o);
+        const float mn = fmaxf(m, sdot);
+        const float a = expf(m - mn), e = expf(sdot - mn);
+        l = l * a + e;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = lane + 64 * i;
+            if (d < dh) acc[i] = acc[i] * a + e * vp[d];
+        }
+        m = mn;
+    }
+    const size_t off = ((size_t)seq * p.Tq + q) * p.ldo + head * dh;
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = lane + 64 * i;
+        if (d >= dh) continue;
+        if (p.out_bf16) reinterpret_cast<__bf16*>(p.O)[off + d] = (__bf16)(acc[i] * inv);
+        else p.O[off + d] = acc[i] * inv;
     }
 }
 
@@ -303,16 +368,24 @@ extern "C" int mmdm_attention_f32(const float* Q, int ldq, const float* K, int l
 
 extern "C" int mmdm_attention_ex(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* Ov, int ldo, int out_bf16,
                                  int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
+    return mmdm_attention_opts(Q, ldq, K, ldk, V, ldv, Ov, ldo, out_bf16, 0, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);
+}
+
+extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* Ov, int ldo, int out_bf16,
+                                   int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
     float* O = static_cast<float*>(Ov);
     if (nseq == 0 || Tq == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
     if (!Q || !K || !V || !O || nseq < 0 || Tq < 0 || Tk <= 0 || H <= 0 || dh <= 0)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_f32: bad shape nseq=%d Tq=%d Tk=%d H=%d dh=%d", nseq, Tq, Tk, H, dh);
+    if (flags & ~(MMDM_ATTN_NO_ZERO_KEY | MMDM_ATTN_CAUSAL)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_opts: unknown flags 0x%x", flags);
+    if ((flags & MMDM_ATTN_CAUSAL) && (Tq != Tk || !(flags & MMDM_ATTN_NO_ZERO_KEY)))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_opts: the causal mask needs Tq == Tk and no zero key");
     if (ldq < H * dh || ldk < H * dh || ldv < H * dh || ldo < H * dh)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_f32: row strides must cover H*dh=%d", H * dh);
     AttnArgs a;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
-    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16;
+    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
     a.pairs_per_xcd = (nseq * H + 7) / 8;
@@ -330,6 +403,10 @@ extern "C" int mmdm_attention_ex(const float* Q, int ldq, const float* K, int ld
         case 8: return launch_small<8>(a, st);
         case 16: return launch_small<16>(a, st);
         case 32: return launch_small<32>(a, st);
-        default: return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_attention_f32: head dim %d not supported (4,8,16,32,64,128)", dh);
+        default: break;
     }
+    if (dh > 256) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_attention_f32: head dim %d not supported (<= 256)", dh);
+    const int total = nseq * H * Tq;
+    hipLaunchKernelGGL(attn_wave_kernel, dim3((total + 3) / 4), dim3(256), 0, st, a, dh);
+    return mmdm_check_launch("attn_wave");
 }

@@ -350,6 +350,22 @@ __global__ __launch_bounds__(256) void cfg4_ddim_kernel(const float* __restrict_
     if (px) px[idx] = x0;
 }
 
+// ClassifierFreeSampleDualMDM.forward combine (cfg_sampler.py:139-150) + DDIM update: per-model guidance, then the
+// time-scheduled blend out_int + w[step] (out_ind - out_int).
+__global__ __launch_bounds__(256) void dual_ddim_kernel(const float* __restrict__ mi, const float* __restrict__ mI, const float* __restrict__ coef, int S,
+                                                         const int* __restrict__ step_idx, const float* __restrict__ wtab, float s_ind, float s_int,
+                                                         float* __restrict__ x, float* __restrict__ px, size_t per_batch_total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per_batch_total) return;
+    const int i = *step_idx;
+    const float ui = mi[per_batch_total + idx], uI = mI[per_batch_total + idx];
+    const float gI = uI + s_int * (mI[idx] - uI);
+    const float gi = ui + s_ind * (mi[idx] - ui);
+    const float x0 = gI + wtab[i] * (gi - gI);
+    x[idx] = ddim(x[idx], x0, coef[i], coef[S + i], coef[2 * S + i], coef[3 * S + i]);
+    if (px) px[idx] = x0;
+}
+
 __global__ void step_dec_kernel(int* step_idx, int* loop_pos) { *step_idx -= 1; *loop_pos += 1; }
 __global__ void set_step_kernel(int* step_idx, int* loop_pos, int s, int l) { *step_idx = s; *loop_pos = l; }
 
@@ -455,6 +471,23 @@ extern "C" int mmdm_cfg4_ddim_f32(const float* m, const float* coef, int S, cons
     hipLaunchKernelGGL(cfg4_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        m, coef, S, step_idx, s, s_int, s_ind, x, pred_xstart, total);
     return mmdm_check_launch("cfg4_ddim");
+}
+
+extern "C" int mmdm_dual_ddim_f32(const float* m_ind, const float* m_int, const float* coef, int S, const int* step_idx, const float* w_table,
+                                  float s_ind, float s_int, float* x, float* pred_xstart, int B, int T, int C, void* stream) {
+    if (B == 0 || T == 0) return MMDM_OK;
+    if (!m_ind || !m_int || !coef || !step_idx || !w_table || !x || S <= 0 || B < 0 || T < 0 || C <= 0)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_dual_ddim_f32: bad arguments");
+    const size_t total = (size_t)B * T * C;
+    hipLaunchKernelGGL(dual_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       m_ind, m_int, coef, S, step_idx, w_table, s_ind, s_int, x, pred_xstart, total);
+    return mmdm_check_launch("dual_ddim");
+}
+
+extern "C" int mmdm_gather_rows_f32(const float* src, const int* idx, float* dst, int n, int D, void* stream) {
+    if (n == 0) return MMDM_OK;
+    if (!src || !idx || !dst || n < 0 || D <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_gather_rows_f32: bad arguments");
+    return mmdm_gather_rows(src, idx, dst, n, D, static_cast<hipStream_t>(stream));
 }
 
 int mmdm_step_dec(int* step_idx, int* loop_pos, hipStream_t st) {

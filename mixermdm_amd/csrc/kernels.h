@@ -26,3 +26,6 @@ int mmdm_blend_cfg_dyn(const float* out1, const float* out2, const float* w, int
                        int B, int T, hipStream_t st);
 int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
+int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
+                  int nseq, int T, int D, hipStream_t st);
+int mmdm_mdm_unpack(const float* src, float* dst, int nseq, int T, int D, hipStream_t st);

@@ -90,8 +90,14 @@ struct StackW {          // a transformer stack: denoiser blocks or Influence bl
     std::vector<LayerWB> layers_b;
 };
 
+struct EncLayerW {       // one nn.TransformerEncoderLayer (post-norm): MDMDenoiser.seqTransEncoder.layers.{i}  src/models/mdm.py:252-264
+    float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_g, *n1_b, *n2_g, *n2_b;
+};
+
 struct ModuleW {         // denoiser or mixer front/back ends
     StackW st;
+    int kind = 0;                                // 0: AdaLN blocks (in2IN / InterGen / Influence); 1: MDMDenoiser (post-norm encoder + cond token)
+    std::vector<EncLayerW> enc;                  // kind == 1
     float *pe = nullptr;                         // [5000, D]
     float *me_w = nullptr, *me_b = nullptr;      // motion_embed [D, 262] stored with ld NFP
     float *te_w = nullptr, *te_b = nullptr;      // text_embed [D, text_dim]
@@ -150,6 +156,9 @@ struct mmdm_handle_s {
     float *se_d1 = nullptr, *se_d2 = nullptr, *se_mx = nullptr;         // silu(time + text)
     float *ss_d1 = nullptr, *ss_d2 = nullptr, *ss_mx = nullptr;         // AdaLN (scale|shift) for every layer/norm
     float *tt_tmp = nullptr, *tt_tmp2 = nullptr;           // [Smax, maxD] schedule scratch
+    float *dual_w = nullptr;                               // [Smax] DualMDM composition weight per respaced step (single_only == 3)
+    bool dual_w_set = false;
+    int td1 = 0, cond_w = 0;                               // denoiser1's cond width (text_dim, or the latent size for MDM) and the cond row width
 
     // history
     float *hist_i1 = nullptr, *hist_i2 = nullptr, *hist_o1 = nullptr, *hist_o2 = nullptr, *hist_mix = nullptr;
@@ -286,6 +295,41 @@ int build_module(mmdm_handle h, ModuleW& m, const std::string& pfx, const std::s
     return MMDM_OK;
 }
 
+// MDMDenoiser (src/models/mdm.py:234-298): pose embedding, cond token, post-norm nn.TransformerEncoder, pose head.
+int build_module_mdm(mmdm_handle h, ModuleW& m, const std::string& pfx, int D, int F, int L, int H) {
+    m.kind = 1;
+    m.st.D = D; m.st.F = F; m.st.L = L; m.st.H = H; m.st.n_ada = 0; m.st.has_ca = false;
+    RC(add_slot(h, pfx + "sequence_pos_encoder.pe", &m.pe, 5000, D));
+    add_ignored(h, pfx + "embed_timestep.sequence_pos_encoder.pe");
+    RC(add_slot(h, pfx + "input_process.poseEmbedding.weight", &m.me_w, D, NF, NFP));
+    RC(add_slot(h, pfx + "input_process.poseEmbedding.bias", &m.me_b, D, 1));
+    RC(add_slot(h, pfx + "embed_timestep.time_embed.0.weight", &m.t0_w, D, D));
+    RC(add_slot(h, pfx + "embed_timestep.time_embed.0.bias", &m.t0_b, D, 1));
+    RC(add_slot(h, pfx + "embed_timestep.time_embed.2.weight", &m.t2_w, D, D));
+    RC(add_slot(h, pfx + "embed_timestep.time_embed.2.bias", &m.t2_b, D, 1));
+    RC(add_slot(h, pfx + "output_process.poseFinal.weight", &m.out_w, NF, D));
+    RC(add_slot(h, pfx + "output_process.poseFinal.bias", &m.out_b, NF, 1));
+    m.enc.resize(L);
+    for (int i = 0; i < L; ++i) {
+        EncLayerW& e = m.enc[i];
+        const std::string b = pfx + "seqTransEncoder.layers." + std::to_string(i) + ".";
+        RC(add_slot(h, b + "self_attn.in_proj_weight", &e.in_w, 3 * D, D));
+        RC(add_slot(h, b + "self_attn.in_proj_bias", &e.in_b, 3 * D, 1));
+        RC(add_slot(h, b + "self_attn.out_proj.weight", &e.out_w, D, D));
+        RC(add_slot(h, b + "self_attn.out_proj.bias", &e.out_b, D, 1));
+        RC(add_slot(h, b + "linear1.weight", &e.l1_w, F, D));
+        RC(add_slot(h, b + "linear1.bias", &e.l1_b, F, 1));
+        RC(add_slot(h, b + "linear2.weight", &e.l2_w, D, F));
+        RC(add_slot(h, b + "linear2.bias", &e.l2_b, D, 1));
+        RC(add_slot(h, b + "norm1.weight", &e.n1_g, D, 1));
+        RC(add_slot(h, b + "norm1.bias", &e.n1_b, D, 1));
+        RC(add_slot(h, b + "norm2.weight", &e.n2_g, D, 1));
+        RC(add_slot(h, b + "norm2.bias", &e.n2_b, D, 1));
+    }
+    RC(dalloc(h, &m.time_tab, (size_t)h->Smax * D));
+    return MMDM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // profiled launches
 // ------------------------------------------------------------------------------------------------------
@@ -296,6 +340,7 @@ struct Ctx {
 };
 
 int prof_begin(const Ctx& c, int cls, double flops, double bytes = 0) {
+    if (!c.h) return MMDM_OK;                 // stateless C-ABI composites run without a handle
     Prof& p = c.h->prof;
     if (!p.on) return MMDM_OK;
     if (p.used[cls] + 2 > p.ev[cls].size()) {
@@ -312,6 +357,7 @@ int prof_begin(const Ctx& c, int cls, double flops, double bytes = 0) {
 }
 
 int prof_end(const Ctx& c, int cls) {
+    if (!c.h) return MMDM_OK;
     Prof& p = c.h->prof;
     if (!p.on) return MMDM_OK;
     HIPCHK(hipEventRecord(p.ev[cls][p.used[cls] + 1], c.st));
@@ -326,10 +372,10 @@ int linear(const Ctx& c, const float* A, int lda, const float* W, int ldw, const
     return prof_end(c, 0);
 }
 
-int attention(const Ctx& c, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
-              int nseq, int Tq, int Tk, int H, int dh, int shift) {
-    RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh, 4.0 * nseq * H * dh * (2.0 * Tq + 2.0 * Tk)));
-    RC(mmdm_attention_f32(Q, ldq, K, ldk, V, ldv, O, ldo, nseq, Tq, Tk, H, dh, shift, c.st));
+// plain self-attention of nn.TransformerEncoderLayer (no zero key)
+int attention_plain(const Ctx& c, const float* qkv, int ld, float* O, int ldo, int nseq, int T, int H, int dh, int flags) {
+    RC(prof_begin(c, 1, 4.0 * nseq * H * (double)T * T * dh, 4.0 * nseq * H * dh * 4.0 * T));
+    RC(mmdm_attention_opts(qkv, ld, qkv + H * dh, ld, qkv + 2 * H * dh, ld, O, ldo, 0, flags, nseq, T, T, H, dh, 0, c.st));
     return prof_end(c, 1);
 }
 
@@ -345,6 +391,7 @@ struct StackRun {
     int ffn_row0, ffn_rows; // ... by ffn.norm
     int ca_mode;            // 0 none; 1 keys/values = the other half of the layer INPUT (in2in.py:439-440); 2 = fixed `kv_src`
     const float* kv_src;
+    int l0 = 0;             // first block to run (the "dual_individual" quirk runs only the last block on person b)
 };
 
 // h [nseq*T, D] is updated in place through the L blocks (TransformerBlockDoubleCond / TransformerBlock / InfluenceBlockCross).
@@ -378,7 +425,7 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         if (bf) return linear_b(c, A, lda, bw(Wb, woff), K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra);
         return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra);
     };
-    for (int l = 0; l < w.L; ++l) {
+    for (int l = r.l0; l < w.L; ++l) {
         const LayerW& lw = w.layers[l];
         const LayerWB lb = bf ? w.layers_b[l] : LayerWB();
         auto ss_at = [&](int slot, int row0) { return r.ss + (size_t)row0 * r.ss_ld + ((size_t)l * w.n_ada + slot) * 2 * D; };
@@ -445,10 +492,76 @@ int run_denoiser(const Ctx& c, const ModuleW& m, bool interaction, const float* 
     return MMDM_OK;
 }
 
+// One nn.TransformerEncoderLayer on x [nseq*T, D] in place.  norm_first = 0 (torch default, MDM / clipTransEncoder):
+//   x = LN1(x + SA(x)); x = LN2(x + W2 act(W1 x)).   norm_first = 1 (CLIP ResidualAttentionBlock): x += SA(LN1 x); x += W2 act(W1 LN2 x).
+// ws: qkv [R,3D] | att [R,D] | tmp [R,D] | f1 [R,F].
+int encoder_layer(const Ctx& c, float* x, const EncLayerW& w, int nseq, int T, int D, int H, int F, bool norm_first, int act_epi, bool causal,
+                  float eps, float* qkv, float* att, float* tmp, float* f1) {
+    const int R = nseq * T, dh = D / H;
+    const int flags = MMDM_ATTN_NO_ZERO_KEY | (causal ? MMDM_ATTN_CAUSAL : 0);
+    if (norm_first) {
+        RC(mmdm_layernorm_f32(x, w.n1_g, w.n1_b, tmp, R, D, eps, c.st));
+        RC(linear(c, tmp, D, w.in_w, D, w.in_b, qkv, 3 * D, R, 3 * D, D));
+        RC(attention_plain(c, qkv, 3 * D, att, D, nseq, T, H, dh, flags));
+        RC(linear(c, att, D, w.out_w, D, w.out_b, x, D, R, D, D, MMDM_EPI_BIAS_RESID, x, D));
+        RC(mmdm_layernorm_f32(x, w.n2_g, w.n2_b, tmp, R, D, eps, c.st));
+        RC(linear(c, tmp, D, w.l1_w, D, w.l1_b, f1, F, R, F, D, act_epi));
+        return linear(c, f1, F, w.l2_w, F, w.l2_b, x, D, R, D, F, MMDM_EPI_BIAS_RESID, x, D);
+    }
+    RC(linear(c, x, D, w.in_w, D, w.in_b, qkv, 3 * D, R, 3 * D, D));
+    RC(attention_plain(c, qkv, 3 * D, att, D, nseq, T, H, dh, flags));
+    RC(linear(c, att, D, w.out_w, D, w.out_b, tmp, D, R, D, D, MMDM_EPI_BIAS_RESID, x, D));
+    RC(mmdm_layernorm_f32(tmp, w.n1_g, w.n1_b, x, R, D, eps, c.st));
+    RC(linear(c, x, D, w.l1_w, D, w.l1_b, f1, F, R, F, D, act_epi));
+    RC(linear(c, f1, F, w.l2_w, F, w.l2_b, tmp, D, R, D, F, MMDM_EPI_BIAS_RESID, x, D));
+    return mmdm_layernorm_f32(tmp, w.n2_g, w.n2_b, x, R, D, eps, c.st);
+}
+
+// MDMDenoiser.forward (mdm.py:273-298) on the CFG-doubled batch: `cond` rows are [n, ldc] with person p's latent-sized slice at
+// column p*D; sequence order person-major as in run_denoiser.
+int run_denoiser_mdm(const Ctx& c, const ModuleW& m, const float* x, int xb, int npers, int ldx, int n, int T, const float* cond, int ldc,
+                     float* out, int ldo) {
+    const Scratch& S = *c.s;
+    const int D = m.st.D, nseq = npers * n;
+    // pose embeddings + pe[1 + t] (token 0 is the conditioning token) into S.att, then assemble [nseq, T+1, D] in S.h
+    for (int p = 0; p < npers; ++p)
+        for (int rep = 0; rep < n / xb; ++rep)
+            RC(linear(c, x + (size_t)p * NF, ldx, m.me_w, NFP, m.me_b, S.att + ((size_t)p * n + (size_t)rep * xb) * T * D, D, xb * T, D, NF,
+                      MMDM_EPI_BIAS_PE, m.pe + D, D, T, NFP));
+    for (int p = 0; p < npers; ++p)
+        RC(mmdm_mdm_pack(S.att + (size_t)p * n * T * D, cond + (size_t)p * D, ldc, m.time_tab, c.h->d_step, m.pe,
+                         S.h + (size_t)p * n * (T + 1) * D, n, T, D, c.st));
+    for (int l = 0; l < m.st.L; ++l)
+        RC(encoder_layer(c, S.h, m.enc[l], nseq, T + 1, D, m.st.H, m.st.F, false, MMDM_EPI_BIAS_GELU, false, 1e-5f, S.qkv, S.att, S.xn, S.f1));
+    RC(mmdm_mdm_unpack(S.h, S.att, nseq, T, D, c.st));
+    for (int p = 0; p < npers; ++p)
+        RC(linear(c, S.att + (size_t)p * n * T * D, D, m.out_w, D, m.out_b, out + (size_t)p * NF, ldo, n * T, NF, D));
+    return MMDM_OK;
+}
+
 // text_embed of cond slices (in2in.py:415-417, mixermdm.py:677-682): txt[row0 + r] = te(cond[r, col0 : col0+td])
 int text_rows(const Ctx& c, const ModuleW& m, const float* cond, int ldc, int col0, float* txt, int row0, int n) {
     const int td = c.h->cfg.text_dim;
     return linear(c, cond + col0, ldc, m.te_w, td, m.te_b, txt + (size_t)row0 * m.st.D, m.st.D, n, m.st.D, td);
+}
+
+// in2INDenoiser "dual_individual" (in2in.py:420-422, 441-451): person a runs all blocks; person b's state is never advanced between
+// blocks in the reference, so its output is the LAST block applied once to the embedded input.
+int run_dual_individual(const Ctx& c, const ModuleW& m, const float* x, int xb, int n, int T, const float* ss, int ss_ld, float* out) {
+    const int D = m.st.D;
+    for (int p = 0; p < 2; ++p)
+        for (int rep = 0; rep < n / xb; ++rep)
+            RC(embed(c, m, x + (size_t)p * NF, NF2, c.s->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
+    StackRun r;
+    r.nseq = n; r.T = T; r.ss = ss; r.ss_ld = ss_ld;
+    r.ca_row0 = 0; r.ca_rows = n; r.ca_mode = 0; r.kv_src = nullptr;
+    r.sa_row0 = r.ffn_row0 = 0; r.sa_rows = r.ffn_rows = n; r.l0 = 0;
+    RC(run_stack(c, m.st, c.s->h, r));
+    r.sa_row0 = r.ffn_row0 = n; r.l0 = m.st.L - 1;
+    RC(run_stack(c, m.st, c.s->h + (size_t)n * T * D, r));
+    for (int p = 0; p < 2; ++p)
+        RC(linear(c, c.s->h + (size_t)p * n * T * D, D, m.out_w, D, m.out_b, out + (size_t)p * NF, NF2, n * T, NF, D));
+    return MMDM_OK;
 }
 
 int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
@@ -492,8 +605,12 @@ int run_step(const Ctx& c) {
     mmdm_handle H = c.h;
     const int B = H->B, T = H->T, n = 2 * B;
     if (H->cfg.single_only == 1) {
-        RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, n));
-        RC(run_denoiser(c, H->d1, false, H->x, B, 1, NF, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF));
+        if (H->d1.kind == 1) {
+            RC(run_denoiser_mdm(c, H->d1, H->x, B, 1, NF, n, T, H->cond_cat, H->td1, H->o1, NF));
+        } else {
+            RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, n));
+            RC(run_denoiser(c, H->d1, false, H->x, B, 1, NF, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF));
+        }
         RC(mmdm_cfg_ddim_f32(H->o1, H->d_coef, H->S, H->d_step, H->cfg.cfg_scale, H->x, H->px1, B, T, NF, c.st));
         return mmdm_step_dec(H->d_step, H->d_step + 1, c.st);
     }
@@ -505,21 +622,34 @@ int run_step(const Ctx& c) {
                               H->x, H->px1, B, T, NF2, c.st));
         return mmdm_step_dec(H->d_step, H->d_step + 1, c.st);
     }
-    RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n));
+    const bool dual = H->cfg.single_only == 3;
+    // the individual model on both persons: in2IN blocks, the "dual_individual" variant of them, or MDMDenoiser
+    auto model1 = [&](const Ctx& cc) -> int {
+        if (H->d1.kind == 1) return run_denoiser_mdm(cc, H->d1, H->x, B, 2, NF2, n, T, H->cond_cat + 3 * H->cfg.text_dim, H->cond_w, H->o1, NF2);
+        if (dual) return run_dual_individual(cc, H->d1, H->x, B, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1);
+        return run_denoiser(cc, H->d1, false, H->x, B, 2, NF2, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF2);
+    };
+    const float* xin2 = dual ? H->x : H->x2;       // DualMDM feeds the same x to both models (cfg_sampler.py:141-142)
+    if (H->d1.kind == 0) RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n));
     RC(cond_vectors(c, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n));
-    RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n));
+    if (!dual) RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n));
     if (H->overlap && !H->prof.on) {
         // fork: denoiser2 on the auxiliary stream with its own scratch, denoiser1 on the caller's stream; join before the mixer
         Ctx c2{H, H->st2, &H->sb};
         HIPCHK(hipEventRecord(H->ev_fork, c.st));
         HIPCHK(hipStreamWaitEvent(H->st2, H->ev_fork, 0));
-        RC(run_denoiser(c2, H->d2, true, H->x2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
-        RC(run_denoiser(c, H->d1, false, H->x, B, 2, NF2, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF2));
+        RC(run_denoiser(c2, H->d2, true, xin2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
+        RC(model1(c));
         HIPCHK(hipEventRecord(H->ev_join, H->st2));
         HIPCHK(hipStreamWaitEvent(c.st, H->ev_join, 0));
     } else {
-        RC(run_denoiser(c, H->d1, false, H->x, B, 2, NF2, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF2));
-        RC(run_denoiser(c, H->d2, true, H->x2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
+        RC(model1(c));
+        RC(run_denoiser(c, H->d2, true, xin2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
+    }
+    if (dual) {
+        RC(mmdm_dual_ddim_f32(H->o1, H->o2, H->d_coef, H->S, H->d_step, H->dual_w, H->cfg.cfg_scale_individual, H->cfg.cfg_scale_interaction,
+                              H->x, H->px1, B, T, NF2, c.st));
+        return mmdm_step_dec(H->d_step, H->d_step + 1, c.st);
     }
     RC(mixer_core(c, B, T, true));
     RC(mmdm_xstart_ddim_f32(H->model_out, H->d_stats, H->d_coef, H->S, H->d_step, H->x, H->x2, H->px1, H->px2, H->floor_ws,
@@ -530,19 +660,22 @@ int run_step(const Ctx& c) {
 // text embeddings of the three modules from a CFG-doubled cond [n, 8*td] (rows B.. are zero: cfg_sampler.py:45-46)
 int text_all(const Ctx& c, const float* cond, int n) {
     mmdm_handle H = c.h;
-    const int td = H->cfg.text_dim, ldc = 8 * td;
-    // denoiser1: person 1 <- ind_ind1, person 2 <- ind_ind2 (mixermdm.py:672-673)
-    RC(text_rows(c, H->d1, cond, ldc, 3 * td, H->txt_d1, 0, n));
-    RC(text_rows(c, H->d1, cond, ldc, 4 * td, H->txt_d1, n, n));
+    const int td = H->cfg.text_dim, td1 = H->td1, ldc = H->cond_w, base = 3 * td + 2 * td1;
+    // denoiser1: person 1 <- ind_ind1, person 2 <- ind_ind2 (mixermdm.py:672-673); MDMDenoiser consumes its slices directly
+    if (H->d1.kind == 0) {
+        RC(text_rows(c, H->d1, cond, ldc, 3 * td, H->txt_d1, 0, n));
+        RC(text_rows(c, H->d1, cond, ldc, 3 * td + td1, H->txt_d1, n, n));
+    }
     // denoiser2 rows: [emb_individual1 | emb_individual2 | emb(interaction)] (in2in.py:415-417); InterGen shares one emb (intergen.py:270)
     const bool ig = H->cfg.model2_kind == 1;
     RC(text_rows(c, H->d2, cond, ldc, ig ? 0 : 1 * td, H->txt_d2, 0, n));
     RC(text_rows(c, H->d2, cond, ldc, ig ? 0 : 2 * td, H->txt_d2, n, n));
     RC(text_rows(c, H->d2, cond, ldc, 0, H->txt_d2, 2 * n, n));
+    if (H->cfg.single_only == 3) return MMDM_OK;       // dual: cond is [n, 5*td], no mixer
     // mixer rows: [cond_i1 | cond_i2 | cond_I] (mixermdm.py:677-682)
-    RC(text_rows(c, H->mx, cond, ldc, 6 * td, H->txt_mx, 0, n));
-    RC(text_rows(c, H->mx, cond, ldc, 7 * td, H->txt_mx, n, n));
-    RC(text_rows(c, H->mx, cond, ldc, 5 * td, H->txt_mx, 2 * n, n));
+    RC(text_rows(c, H->mx, cond, ldc, base + td, H->txt_mx, 0, n));
+    RC(text_rows(c, H->mx, cond, ldc, base + 2 * td, H->txt_mx, n, n));
+    RC(text_rows(c, H->mx, cond, ldc, base, H->txt_mx, 2 * n, n));
     return MMDM_OK;
 }
 
@@ -567,16 +700,28 @@ extern "C" const char* mmdm_handle_error(mmdm_handle h) { return h ? h->err : "n
 extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     if (!cfg || !out) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: null argument");
     if (cfg->nfeats != NF) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: nfeats must be 262");
-    if (cfg->d_latent <= 0 || cfg->d_heads <= 0 || cfg->d_latent % cfg->d_heads || cfg->d_latent % 4 || cfg->d_ff % 4)
+    const int so = cfg->single_only;
+    if (so < 0 || so > 3) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: single_only must be 0, 1, 2 or 3");
+    const bool has_d1 = so != 2, has_d2 = so != 1, has_mx = so == 0, two_models = so == 0 || so == 3;
+    if (cfg->model1_kind < 0 || cfg->model1_kind > 1) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: model1_kind must be 0 (in2IN individual) or 1 (MDM)");
+    const bool mdm = has_d1 && cfg->model1_kind == 1;
+    if (mdm && so == 3) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: the dual sampler composes two in2IN denoisers (model1_kind must be 0)");
+    // denoiser1 may have its own sizes (MODEL1 and MODEL2 are separate configs: src/models/mixermdm.py:32-40); 0 = same as denoiser2
+    const int D = cfg->d_latent, F = cfg->d_ff;
+    const int D1 = cfg->d1_latent ? cfg->d1_latent : D, F1 = cfg->d1_ff ? cfg->d1_ff : F;
+    const int L1 = cfg->d1_layers ? cfg->d1_layers : cfg->d_layers, H1 = cfg->d1_heads ? cfg->d1_heads : cfg->d_heads;
+    if (D <= 0 || cfg->d_heads <= 0 || D % cfg->d_heads || D % 4 || F <= 0 || F % 4 || cfg->d_layers <= 0 ||
+        D1 <= 0 || H1 <= 0 || D1 % H1 || D1 % 4 || F1 <= 0 || F1 % 4 || L1 <= 0)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: bad denoiser dims");
-    if (!cfg->single_only && (cfg->m_latent <= 0 || cfg->m_heads <= 0 || cfg->m_latent % cfg->m_heads || cfg->m_latent % 4 || cfg->m_ff % 4))
+    if (has_mx && (cfg->m_latent <= 0 || cfg->m_heads <= 0 || cfg->m_latent % cfg->m_heads || cfg->m_latent % 4 || cfg->m_ff <= 0 || cfg->m_ff % 4 || cfg->m_layers <= 0))
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: bad mixer dims");
-    if (!cfg->single_only && (cfg->mixing_mode < 1 || cfg->mixing_mode > 4)) return mmdm_set_error(MMDM_ERR_ARG, "Mode not recognized");
+    if (has_mx && (cfg->mixing_mode < 1 || cfg->mixing_mode > 4)) return mmdm_set_error(MMDM_ERR_ARG, "Mode not recognized");
     if (cfg->max_batch <= 0 || cfg->max_frames <= 0 || cfg->text_dim <= 0 || cfg->text_dim % 4)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: bad max_batch / max_frames / text_dim");
     if (cfg->precision < 0 || cfg->precision > 1) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: precision must be 0 (fp32) or 1 (bf16 GEMM operands)");
-    if (cfg->precision == 1 && ((cfg->d_latent % 32) || (cfg->d_ff % 32) || (!cfg->single_only && ((cfg->m_latent % 32) || (cfg->m_ff % 32)))))
+    if (cfg->precision == 1 && ((D % 32) || (F % 32) || (D1 % 32) || (F1 % 32) || (has_mx && ((cfg->m_latent % 32) || (cfg->m_ff % 32)))))
         return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: the bf16 path needs latent and ff sizes that are multiples of 32");
+    if (cfg->precision == 1 && mdm) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: the bf16 path does not cover MDMDenoiser");
     RC(mmdm_kernels_init());
     mmdm_handle h = new mmdm_handle_s();
     h->cfg = *cfg;
@@ -584,21 +729,22 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     h->nw = (c.mixing_mode >= 3) ? 23 : 1;
     int rc = MMDM_OK;
     auto fail = [&](int code) { mmdm_destroy(h); return code; };
-    if (c.single_only < 0 || c.single_only > 2) return fail(mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: single_only must be 0, 1 or 2"));
-    const int D = c.d_latent, F = c.d_ff, B = c.max_batch, T = c.max_frames, n = (c.single_only == 2 ? 4 : 2) * B, td = c.text_dim;
-    const int Dm = c.single_only ? 4 : c.m_latent, Fm = c.single_only ? 4 : c.m_ff;
-    if (c.single_only != 2 &&
-        (rc = build_module(h, h->d1, "denoiser1.", "denoiser1.", D, F, c.d_layers, c.d_heads, false, true, "denoiser1.out.linear", NF))) return fail(rc);
-    if (c.single_only != 1 &&
-        (rc = build_module(h, h->d2, "denoiser2.", "denoiser2.", D, F, c.d_layers, c.d_heads, true, false, "denoiser2.out.linear", NF))) return fail(rc);
-    if (!c.single_only) {
-        if ((rc = build_module(h, h->mx, "", "influence.", Dm, Fm, c.m_layers, c.m_heads, true, false, "influence.out", h->nw))) return fail(rc);
+    const int B = c.max_batch, T = c.max_frames, n = (so == 2 ? 4 : 2) * B, td = c.text_dim;
+    const int Dm = has_mx ? c.m_latent : 4, Fm = has_mx ? c.m_ff : 4;
+    h->td1 = mdm ? D1 : td;                                  // MDMDenoiser adds its cond slice to the timestep embedding: latent-sized (mdm.py:279)
+    h->cond_w = so == 0 ? 6 * td + 2 * h->td1 : so == 1 ? h->td1 : so == 2 ? 3 * td : 5 * td;
+    if (has_d1) {
+        rc = mdm ? build_module_mdm(h, h->d1, "denoiser1.", D1, F1, L1, H1)
+                 : build_module(h, h->d1, "denoiser1.", "denoiser1.", D1, F1, L1, H1, false, true, "denoiser1.out.linear", NF);
+        if (rc) return fail(rc);
     }
-    const int npers = c.single_only == 1 ? 1 : 2;
-    const size_t R = (size_t)npers * n * T;
-    const size_t Dx = max2(D, Dm), Fx = max2(F, Fm);
+    if (has_d2 && (rc = build_module(h, h->d2, "denoiser2.", "denoiser2.", D, F, c.d_layers, c.d_heads, true, false, "denoiser2.out.linear", NF))) return fail(rc);
+    if (has_mx && (rc = build_module(h, h->mx, "", "influence.", Dm, Fm, c.m_layers, c.m_heads, true, false, "influence.out", h->nw))) return fail(rc);
+    const int npers = so == 1 ? 1 : 2;
+    const size_t R = (size_t)npers * n * (T + 1);            // + 1: MDMDenoiser's conditioning token
+    const size_t Dx = max2(max2(has_d1 ? D1 : 4, has_d2 ? D : 4), Dm), Fx = max2(max2(has_d1 ? F1 : 4, has_d2 ? F : 4), Fm);
     for (Scratch* sc : {&h->sa, &h->sb}) {
-        if (sc == &h->sb && c.single_only) break;
+        if (sc == &h->sb && !two_models) break;
         const size_t d = sc == &h->sa ? Dx : (size_t)D, f = sc == &h->sa ? Fx : (size_t)F;
         if ((rc = dalloc(h, &sc->h, R * d)) || (rc = dalloc(h, &sc->xn, R * d)) || (rc = dalloc(h, &sc->att, R * d)) ||
             (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f)))
@@ -608,33 +754,32 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
         return fail(mmdm_set_error(MMDM_ERR_HIP, "mmdm_create: stream/event creation failed"));
     h->overlap = getenv("MMDM_NO_OVERLAP") == nullptr;
-    const size_t PT = (size_t)n * T * (c.single_only == 1 ? NF : NF2);
-    const size_t PB = (size_t)B * T * (c.single_only == 1 ? NF : NF2);
+    const size_t PT = (size_t)n * T * (so == 1 ? NF : NF2);
+    const size_t PB = (size_t)B * T * (so == 1 ? NF : NF2);
     if ((rc = dalloc(h, &h->x, PB)) || (rc = dalloc(h, &h->px1, PB))) return fail(rc);
-    if (c.single_only != 2) {
+    if (has_d1) {
         if ((rc = dalloc(h, &h->o1, PT))) return fail(rc);
-        if ((rc = dalloc(h, &h->txt_d1, (size_t)npers * n * D)) || (rc = dalloc(h, &h->se_d1, (size_t)npers * n * D)) ||
-            (rc = dalloc(h, &h->ss_d1, (size_t)npers * n * ss_ld_of(h->d1))))
+        if (!mdm && ((rc = dalloc(h, &h->txt_d1, (size_t)npers * n * D1)) || (rc = dalloc(h, &h->se_d1, (size_t)npers * n * D1)) ||
+                     (rc = dalloc(h, &h->ss_d1, (size_t)npers * n * ss_ld_of(h->d1)))))
             return fail(rc);
-    } else {
+    }
+    if (has_d2) {
         if ((rc = dalloc(h, &h->o2, PT)) || (rc = dalloc(h, &h->txt_d2, (size_t)3 * n * D)) || (rc = dalloc(h, &h->se_d2, (size_t)3 * n * D)) ||
             (rc = dalloc(h, &h->ss_d2, (size_t)3 * n * ss_ld_of(h->d2))))
             return fail(rc);
     }
-    if (!c.single_only) {
-        if ((rc = dalloc(h, &h->mI, R * Dm)) || (rc = dalloc(h, &h->o2, PT)) || (rc = dalloc(h, &h->out1, PT)) || (rc = dalloc(h, &h->out2, PT)) ||
+    if (has_mx) {
+        if ((rc = dalloc(h, &h->mI, R * Dm)) || (rc = dalloc(h, &h->out1, PT)) || (rc = dalloc(h, &h->out2, PT)) ||
             (rc = dalloc(h, &h->w23, (size_t)2 * n * T * 23)) || (rc = dalloc(h, &h->hpool, (size_t)2 * n * Dm)) ||
             (rc = dalloc(h, &h->model_out, PB)) || (rc = dalloc(h, &h->x2, PB)) || (rc = dalloc(h, &h->px2, PB)) ||
             (rc = dalloc(h, &h->floor_ws, (size_t)2 * B)) ||
-            (rc = dalloc(h, &h->txt_d2, (size_t)3 * n * D)) || (rc = dalloc(h, &h->se_d2, (size_t)3 * n * D)) ||
-            (rc = dalloc(h, &h->ss_d2, (size_t)3 * n * ss_ld_of(h->d2))) ||
             (rc = dalloc(h, &h->txt_mx, (size_t)3 * n * Dm)) || (rc = dalloc(h, &h->se_mx, (size_t)3 * n * Dm)) ||
             (rc = dalloc(h, &h->ss_mx, (size_t)3 * n * ss_ld_of(h->mx))))
             return fail(rc);
     }
-    if ((rc = dalloc(h, &h->cond_cat, (size_t)n * 8 * td))) return fail(rc);
+    if ((rc = dalloc(h, &h->cond_cat, (size_t)n * h->cond_w))) return fail(rc);
     if ((rc = dalloc(h, &h->tt_tmp, (size_t)h->Smax * Dx)) || (rc = dalloc(h, &h->tt_tmp2, (size_t)h->Smax * Dx))) return fail(rc);
-    if ((rc = dalloc(h, &h->d_coef, (size_t)4 * h->Smax)) || (rc = dalloc(h, &h->d_stats, 4 * NF))) return fail(rc);
+    if ((rc = dalloc(h, &h->d_coef, (size_t)4 * h->Smax)) || (rc = dalloc(h, &h->d_stats, 4 * NF)) || (rc = dalloc(h, &h->dual_w, h->Smax))) return fail(rc);
     float* tmp = nullptr;
     if ((rc = dalloc(h, &tmp, h->Smax))) return fail(rc);
     h->d_tmap = reinterpret_cast<int*>(tmp);
@@ -693,7 +838,7 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
             ++nmiss;
         }
     if (nmiss) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "Missing key(s) in state_dict (%d): %s%s", nmiss, missing.c_str(), nmiss > 4 ? ", ..." : ""));
-    if (!h->cfg.single_only && !h->stats_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_prepare: normaliser stats not set"));
+    if (h->cfg.single_only == 0 && !h->stats_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_prepare: normaliser stats not set"));
     if (h->cfg.precision == 1) {
         for (ModuleW* m : {&h->d1, &h->d2, &h->mx}) {
             StackW& st = m->st;
@@ -728,16 +873,26 @@ extern "C" int mmdm_set_schedule(mmdm_handle h, const int* timestep_map, const f
         HIPCHK(hipMemcpyAsync(h->d_coef + (size_t)k * S, coef + (size_t)k * S, S * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));   // host buffers may be transient
     h->S = S;
+    h->dual_w_set = false;
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // S is a kernel argument baked into the graph
     Ctx c{h, st, &h->sa};
     const bool pon = h->prof.on;
     h->prof.on = false;
     int rc = h->cfg.single_only != 2 ? build_time_tab(c, h->d1) : MMDM_OK;
     if (!rc && h->cfg.single_only != 1) rc = build_time_tab(c, h->d2);
-    if (!rc && !h->cfg.single_only) rc = build_time_tab(c, h->mx);
+    if (!rc && h->cfg.single_only == 0) rc = build_time_tab(c, h->mx);
     h->prof.on = pon;
     h->begun = false;
     return herr(h, rc);
+}
+
+extern "C" int mmdm_set_dual_weights(mmdm_handle h, const float* w_host, int S) {
+    if (!h || !w_host) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_dual_weights: null argument");
+    if (h->cfg.single_only != 3) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_set_dual_weights: the handle is not a dual sampler (single_only != 3)"));
+    if (S != h->S || S <= 0) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_dual_weights: S=%d does not match the schedule (%d steps)", S, h->S));
+    HIPCHK(hipMemcpy(h->dual_w, w_host, (size_t)S * sizeof(float), hipMemcpyHostToDevice));
+    h->dual_w_set = true;
+    return MMDM_OK;
 }
 
 extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, int B, int T, void* stream) {
@@ -764,17 +919,22 @@ extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, in
         if (!rc) rc = text_rows(c, h->d2, h->cond_cat, ldc, ig ? 0 : 2 * td, h->txt_d2, n4, n4);
         if (!rc) rc = text_rows(c, h->d2, h->cond_cat, ldc, 0, h->txt_d2, 2 * n4, n4);
         HIPCHK(hipMemcpyAsync(h->x, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    } else if (h->cfg.single_only) {
-        HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n * td * sizeof(float), st));
-        HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * td * sizeof(float), hipMemcpyDeviceToDevice, st));
-        rc = linear(c, h->cond_cat, td, h->d1.te_w, td, h->d1.te_b, h->txt_d1, h->d1.st.D, n, h->d1.st.D, td);
+    } else if (h->cfg.single_only == 1) {
+        const int cw = h->cond_w;                            // text_dim, or the latent size for MDMDenoiser (cond is added to the timestep embedding)
+        HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n * cw * sizeof(float), st));
+        HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * cw * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (h->d1.kind == 0) rc = linear(c, h->cond_cat, td, h->d1.te_w, td, h->d1.te_b, h->txt_d1, h->d1.st.D, n, h->d1.st.D, td);
         HIPCHK(hipMemcpyAsync(h->x, x_T, (size_t)B * T * NF * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
-        HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n * 8 * td * sizeof(float), st));
-        HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * 8 * td * sizeof(float), hipMemcpyDeviceToDevice, st));
+        // mixer: cond [B, 6*td + 2*td1] (mixermdm.py:342-354); dual: cond [B, 5*td] (in2in.py:299-305) -- same column order for the
+        // first five slices, so text_all serves both
+        if (h->cfg.single_only == 3 && !h->dual_w_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_begin: call mmdm_set_dual_weights after mmdm_set_schedule"));
+        const int cw = h->cond_w;
+        HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n * cw * sizeof(float), st));
+        HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * cw * sizeof(float), hipMemcpyDeviceToDevice, st));
         rc = text_all(c, h->cond_cat, n);
         HIPCHK(hipMemcpyAsync(h->x, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(h->x2, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));   // img2 = img.clone()
+        if (h->x2) HIPCHK(hipMemcpyAsync(h->x2, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));   // img2 = img.clone()
     }
     h->prof.on = pon;
     if (rc) return herr(h, rc);
@@ -847,7 +1007,8 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
     if (n <= 0 || (n & 1) || n / 2 > h->cfg.max_batch * (h->cfg.single_only == 2 ? 2 : 1) || T <= 0 || T > h->cfg.max_frames)
         return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: n=%d (even, <= 2*max_batch) T=%d out of range", n, T));
     if (t < 0 || t >= 5000) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: timestep %d out of range", t));
-    if (which < 0 || which > 2 || (h->cfg.single_only == 1 && which != 0) || (h->cfg.single_only == 2 && which != 1)) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: bad module %d", which));
+    const int so_ = h->cfg.single_only;
+    if (which < 0 || which > 3 || (so_ == 1 && which != 0) || (so_ == 2 && which != 1) || (so_ == 3 && (which == 2 || which == 0)) || (so_ != 3 && which == 3)) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: bad module %d", which));
     hipStream_t st = static_cast<hipStream_t>(stream);
     Ctx c{h, st, &h->sa};
     const int td = h->cfg.text_dim;
@@ -861,6 +1022,19 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
     HIPCHK(hipStreamSynchronize(st));
     RC(mmdm_set_step(h->d_step, h->d_step + 1, 0, 0, st));
     auto done = [&](int code) { h->S = 0; (void)S_keep; return herr(h, code); };   // schedule must be set again
+    if (which == 3) {                         // in2INDenoiser "dual_individual": x [n,T,524], cond [n, 5*td]
+        if ((rc = build_time_tab(c, h->d1))) return done(rc);
+        if ((rc = text_rows(c, h->d1, cond, 5 * td, 3 * td, h->txt_d1, 0, n))) return done(rc);
+        if ((rc = text_rows(c, h->d1, cond, 5 * td, 4 * td, h->txt_d1, n, n))) return done(rc);
+        if ((rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, 2 * n))) return done(rc);
+        rc = run_dual_individual(c, h->d1, x, n, n, T, h->ss_d1, ss_ld_of(h->d1), out);
+        return done(rc);
+    }
+    if (which == 0 && h->d1.kind == 1) {      // MDMDenoiser.forward: cond [n, latent]
+        if ((rc = build_time_tab(c, h->d1))) return done(rc);
+        rc = run_denoiser_mdm(c, h->d1, x, n, 1, NF, n, T, cond, h->td1, out, NF);
+        return done(rc);
+    }
     if (which == 0) {
         if ((rc = build_time_tab(c, h->d1))) return done(rc);
         if ((rc = linear(c, cond, td, h->d1.te_w, td, h->d1.te_b, h->txt_d1, h->d1.st.D, n, h->d1.st.D, td))) return done(rc);
@@ -882,10 +1056,12 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
     if (!x2) return done(mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: Mixer.forward needs x2"));
     if ((rc = build_time_tab(c, h->d1)) || (rc = build_time_tab(c, h->d2)) || (rc = build_time_tab(c, h->mx))) return done(rc);
     if ((rc = text_all(c, cond, n))) return done(rc);
-    if ((rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, 2 * n))) return done(rc);
+    if (h->d1.kind == 0 && (rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, 2 * n))) return done(rc);
     if ((rc = cond_vectors(c, h->d2, h->txt_d2, h->se_d2, h->ss_d2, 3 * n))) return done(rc);
     if ((rc = cond_vectors(c, h->mx, h->txt_mx, h->se_mx, h->ss_mx, 3 * n))) return done(rc);
-    if ((rc = run_denoiser(c, h->d1, false, x, n, 2, NF2, n, T, h->ss_d1, ss_ld_of(h->d1), h->o1, NF2))) return done(rc);
+    rc = h->d1.kind == 1 ? run_denoiser_mdm(c, h->d1, x, n, 2, NF2, n, T, cond + 3 * td, h->cond_w, h->o1, NF2)
+                         : run_denoiser(c, h->d1, false, x, n, 2, NF2, n, T, h->ss_d1, ss_ld_of(h->d1), h->o1, NF2);
+    if (rc) return done(rc);
     if ((rc = run_denoiser(c, h->d2, true, x2, n, 2, NF2, n, T, h->ss_d2, ss_ld_of(h->d2), h->o2, NF2))) return done(rc);
     // Mixer.forward returns out_influenced for the whole CFG-doubled batch: reuse the blend kernel's history output.
     h->hist_i1 = h->hist_i2 = h->hist_o1 = h->hist_o2 = nullptr;
@@ -894,6 +1070,38 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
     rc = mixer_core(c, n / 2, T, true);
     h->hist_mix = nullptr;
     return done(rc);
+}
+
+extern "C" size_t mmdm_encoder_layer_workspace(int nseq, int T, int D, int F) {
+    if (nseq <= 0 || T <= 0 || D <= 0 || F <= 0) return 0;
+    return (size_t)nseq * T * ((size_t)5 * D + F);
+}
+
+extern "C" int mmdm_encoder_layer_f32(float* x, const mmdm_encoder_layer_weights* w, int nseq, int T, int D, int H, int F, int norm_first,
+                                      int activation, int causal, float eps, float* workspace, size_t workspace_floats, void* stream) {
+    if (nseq == 0 || T == 0) return MMDM_OK;
+    if (!x || !w || !workspace || nseq < 0 || T < 0 || D <= 0 || H <= 0 || D % H || F <= 0)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_encoder_layer_f32: bad arguments nseq=%d T=%d D=%d H=%d F=%d", nseq, T, D, H, F);
+    if (activation != MMDM_EPI_BIAS_GELU && activation != MMDM_EPI_BIAS_QUICKGELU)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_encoder_layer_f32: activation must be MMDM_EPI_BIAS_GELU or MMDM_EPI_BIAS_QUICKGELU");
+    if (workspace_floats < mmdm_encoder_layer_workspace(nseq, T, D, F))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_encoder_layer_f32: workspace too small (%zu < %zu floats)", workspace_floats, mmdm_encoder_layer_workspace(nseq, T, D, F));
+    for (const float* q : {w->in_proj_weight, w->in_proj_bias, w->out_proj_weight, w->out_proj_bias, w->linear1_weight, w->linear1_bias,
+                           w->linear2_weight, w->linear2_bias, w->norm1_weight, w->norm1_bias, w->norm2_weight, w->norm2_bias})
+        if (!q) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_encoder_layer_f32: null weight pointer");
+    RC(mmdm_kernels_init());
+    const size_t R = (size_t)nseq * T;
+    float* qkv = workspace;
+    float* att = qkv + R * 3 * D;
+    float* tmp = att + R * D;
+    float* f1 = tmp + R * D;
+    EncLayerW e;
+    auto nc = [](const float* q) { return const_cast<float*>(q); };
+    e.in_w = nc(w->in_proj_weight); e.in_b = nc(w->in_proj_bias); e.out_w = nc(w->out_proj_weight); e.out_b = nc(w->out_proj_bias);
+    e.l1_w = nc(w->linear1_weight); e.l1_b = nc(w->linear1_bias); e.l2_w = nc(w->linear2_weight); e.l2_b = nc(w->linear2_bias);
+    e.n1_g = nc(w->norm1_weight); e.n1_b = nc(w->norm1_bias); e.n2_g = nc(w->norm2_weight); e.n2_b = nc(w->norm2_bias);
+    Ctx c{nullptr, static_cast<hipStream_t>(stream), nullptr};
+    return encoder_layer(c, x, e, nseq, T, D, H, F, norm_first != 0, activation, causal != 0, eps, qkv, att, tmp, f1);
 }
 
 extern "C" int mmdm_profile_enable(mmdm_handle h, int on) {

@@ -64,6 +64,82 @@ __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h,
     }
 }
 
+// out = LN_{eps}(x) * gamma + beta (nn.LayerNorm with affine); one wave per row, row cached in registers, in place allowed.
+// Reference: norm1 / norm2 of nn.TransformerEncoderLayer (src/models/mdm.py:252-264, src/models/mixermdm.py:246-259), clip_ln, ln_final.
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ out, int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xp = x + (size_t)row * D;
+    const int nv = D >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) v[i] = *reinterpret_cast<const f32x4*>(xp + 4 * c);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 d = v[i] - mean;
+            q += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c);
+            *reinterpret_cast<f32x4*>(out + (size_t)row * D + 4 * c) = (v[i] - mean) * rstd * g + b;
+        }
+    }
+}
+
+// MDMDenoiser sequence assembly (src/models/mdm.py:279-294): dst [nseq, T+1, D];
+//   dst[s, 0, :]   = (cond[s, :] + time_tab[*step, :]) + pe[0, :]         (the conditioning token; cond row stride ldc)
+//   dst[s, 1+t, :] = src[s, t, :]                                          (pose embeddings, already + pe[1+t])
+__global__ void mdm_pack_kernel(const float* __restrict__ src, const float* __restrict__ cond, int ldc, const float* __restrict__ time_tab,
+                                const int* __restrict__ step_idx, const float* __restrict__ pe, float* __restrict__ dst, int nseq, int T, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nseq * (T + 1) * D) return;
+    const int d = (int)(i % D);
+    const size_t row = i / D;
+    const int t = (int)(row % (T + 1));
+    const size_t s = row / (T + 1);
+    dst[i] = t == 0 ? (cond[s * ldc + d] + time_tab[(size_t)(*step_idx) * D + d]) + pe[d] : src[(s * T + (t - 1)) * D + d];
+}
+
+// dst[s, t, :] = src[s, 1+t, :]   (drop the conditioning token: mdm.py:296)
+__global__ void mdm_unpack_kernel(const float* __restrict__ src, float* __restrict__ dst, int nseq, int T, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nseq * T * D) return;
+    const int d = (int)(i % D);
+    const size_t row = i / D;
+    dst[i] = src[(row + row / T + 1) * D + d];
+}
+
+// out[b, l, :] = table[tokens[b, l], :] + pos[l, :]   (CLIP token + positional embedding: src/models/mixermdm.py:298-299)
+__global__ void token_embed_kernel(const float* __restrict__ table, const int* __restrict__ tokens, const float* __restrict__ pos,
+                                   float* __restrict__ out, int n, int L, int D, int vocab) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * L * D) return;
+    const int d = (int)(i % D);
+    const size_t row = i / D;
+    int tok = tokens[row];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    out[i] = table[(size_t)tok * D + d] + pos[(row % L) * D + d];
+}
+
 __global__ void cond_silu_kernel(const float* __restrict__ time_tab, const int* __restrict__ step_idx, const float* __restrict__ txt,
                                  float* __restrict__ out, int rows, int D) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,6 +233,44 @@ extern "C" int mmdm_adaln_ex(const float* h, const float* ss, int ss_ld, int ss_
     else ADALN_LAUNCH(8);
 #undef ADALN_LAUNCH
     return mmdm_check_launch("adaln");
+}
+
+extern "C" int mmdm_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out, int rows, int D, float eps, void* stream) {
+    if (rows == 0) return MMDM_OK;
+    if (!x || !gamma || !beta || !out || rows < 0 || D <= 0 || !(eps > 0.f)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_layernorm_f32: bad arguments rows=%d D=%d", rows, D);
+    if ((D & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(out)) & 15))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_layernorm_f32: D must be a multiple of 4 and pointers 16-byte aligned");
+    if (D > 64 * 4 * 8) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_layernorm_f32: D=%d > 2048", D);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((rows + 3) / 4), block(256);
+    if (D <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, st, x, gamma, beta, out, rows, D, eps);
+    else if (D <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, st, x, gamma, beta, out, rows, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, st, x, gamma, beta, out, rows, D, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, st, x, gamma, beta, out, rows, D, eps);
+    return mmdm_check_launch("layernorm");
+}
+
+int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
+                  int nseq, int T, int D, hipStream_t st) {
+    const size_t n = (size_t)nseq * (T + 1) * D;
+    if (n == 0) return MMDM_OK;
+    hipLaunchKernelGGL(mdm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, cond, ldc, time_tab, step_idx, pe, dst, nseq, T, D);
+    return mmdm_check_launch("mdm_pack");
+}
+
+int mmdm_mdm_unpack(const float* src, float* dst, int nseq, int T, int D, hipStream_t st) {
+    const size_t n = (size_t)nseq * T * D;
+    if (n == 0) return MMDM_OK;
+    hipLaunchKernelGGL(mdm_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, nseq, T, D);
+    return mmdm_check_launch("mdm_unpack");
+}
+
+extern "C" int mmdm_token_embed_f32(const float* table, int vocab, const int* tokens, const float* pos, float* out, int n, int L, int D, void* stream) {
+    if (n == 0 || L == 0) return MMDM_OK;
+    if (!table || !tokens || !pos || !out || n < 0 || L < 0 || D <= 0 || vocab <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_token_embed_f32: bad arguments");
+    const size_t total = (size_t)n * L * D;
+    hipLaunchKernelGGL(token_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), table, tokens, pos, out, n, L, D, vocab);
+    return mmdm_check_launch("token_embed");
 }
 
 extern "C" int mmdm_cond_silu_f32(const float* time_tab, const int* step_idx, const float* txt, float* out, int rows, int D, void* stream) {

@@ -145,8 +145,8 @@ class MixerMDM(nn.Module):
         root = config_root or os.getcwd()
         self.cfg_model1 = get_config(os.path.join(root, cfg.MODEL1) if not os.path.isabs(cfg.MODEL1) else cfg.MODEL1)
         self.cfg_model2 = get_config(os.path.join(root, cfg.MODEL2) if not os.path.isabs(cfg.MODEL2) else cfg.MODEL2)
-        if self.cfg_model1.NAME != "in2INind":
-            raise NotImplementedError(f"MODEL1.NAME={self.cfg_model1.NAME}: only in2INind is built so far (MDM: SURVEY 8f-3)")
+        if self.cfg_model1.NAME not in ("in2INind", "MDM"):
+            raise NotImplementedError(f"MODEL1.NAME={self.cfg_model1.NAME}")
         if self.cfg_model2.NAME not in ("in2IN", "InterGen"):
             raise NotImplementedError(f"MODEL2.NAME={self.cfg_model2.NAME}")
         self.align = align
@@ -154,12 +154,12 @@ class MixerMDM(nn.Module):
         self.num_frames = num_frames
         g = cfg.GENERATOR if "GENERATOR" in cfg else cfg
         self.nfeats = g.INPUT_DIM
-        self.dims = dict(d_latent=self.cfg_model1.LATENT_DIM, d_ff=self.cfg_model1.FF_SIZE, d_layers=self.cfg_model1.NUM_LAYERS,
-                         m_latent=g.LATENT_DIM, m_ff=g.FF_SIZE, m_layers=g.NUM_LAYERS)
-        self.d_heads, self.m_heads = self.cfg_model1.NUM_HEADS, g.NUM_HEADS
-        for k in ("LATENT_DIM", "FF_SIZE", "NUM_LAYERS", "NUM_HEADS"):
-            if self.cfg_model1[k] != self.cfg_model2[k]:
-                raise NotImplementedError("denoiser1 and denoiser2 must share dimensions (as configs/models/{individual,in2IN}.yaml do)")
+        c1, c2 = self.cfg_model1, self.cfg_model2
+        # MODEL1 and MODEL2 are separate configs (mixermdm.py:32-40): denoiser1 carries its own sizes (d1_*), denoiser2 the d_* ones
+        self.dims = dict(d_latent=c2.LATENT_DIM, d_ff=c2.FF_SIZE, d_layers=c2.NUM_LAYERS, m_latent=g.LATENT_DIM, m_ff=g.FF_SIZE, m_layers=g.NUM_LAYERS,
+                         d1_latent=c1.LATENT_DIM, d1_ff=c1.FF_SIZE, d1_layers=c1.NUM_LAYERS)
+        self.d_heads, self.d1_heads, self.m_heads = c2.NUM_HEADS, c1.NUM_HEADS, g.NUM_HEADS
+        self.model1_kind = 1 if c1.NAME == "MDM" else 0
         self.cfg_mixing_weight = cfg.CFG_WEIGHT
         self.text_dim = 768
         self.mixing_mode = cfg.MIXING_MODE
@@ -168,15 +168,21 @@ class MixerMDM(nn.Module):
         self.sampling_strategy = sampling_strategy
         self.betas = get_named_beta_schedule(self.beta_scheduler, self.diffusion_steps)
         self.history_every = 1
-        self.text_encoder = None            # callable(batch) -> cond [B, 8*768]; upstream of the hot path
+        self.text_encoder = None            # optional callable(batch) -> cond [B, 8*768] overriding the built-in text stage
+        self._text_sd, self._text_enc = None, None
         self.mixing = Mixer(self, self.mixing_mode, store_influence, cfg.FORCE_INFLUENCE_VAL, align=align)
         self.mixing.add_module("denoiser1", DenoiserHandle(self, 0))
+        if self.model1_kind == 1:
+            # MDMDenoiser.text_dim is hard-coded to 256 (mdm.py:238) while its cond is added to the latent-sized timestep embedding
+            # (mdm.py:279): the cond slice width is the latent size (they coincide for the reference's MDM, LATENT_DIM = 256).
+            self.mixing.denoiser1.text_dim = c1.LATENT_DIM
         self.mixing.add_module("denoiser2", DenoiserHandle(self, 1))
         # the reference also exposes them as .denoiser1/.denoiser2 (mixermdm.py:67-68); plain attributes here, not re-registered
         object.__setattr__(self, "denoiser1", self.mixing.denoiser1)
         object.__setattr__(self, "denoiser2", self.mixing.denoiser2)
         # parameters under the reference's key names (mixing.*), zero-initialised until loaded
-        for k, shp in mixer_shapes(mixing_mode=self.mixing_mode, **self.dims).items():
+        self._model1 = "MDM" if self.model1_kind else "in2INind"
+        for k, shp in mixer_shapes(mixing_mode=self.mixing_mode, model1=self._model1, **self.dims).items():
             _holder_tree(self, "mixing." + k, torch.zeros(shp))
         self._sampler = None
         self._dirty = True
@@ -196,7 +202,7 @@ class MixerMDM(nn.Module):
 
     def init_synthetic(self, seed=0, std=0.02, bias_std=0.0, stats_seed=3):
         """Random-init weights of the reference architecture + synthetic normaliser stats (no checkpoints offline)."""
-        sd = synthetic_state_dict(seed=seed, std=std, bias_std=bias_std, mixing_mode=self.mixing_mode, **self.dims)
+        sd = synthetic_state_dict(seed=seed, std=std, bias_std=bias_std, mixing_mode=self.mixing_mode, model1=self._model1, **self.dims)
         self.load_state_dict({"mixing." + k: v for k, v in sd.items()})
         st = synthetic_stats(stats_seed)
         self.set_norm_stats(st["mean_hml"], st["std_hml"], st["mean_ih"], st["std_ih"])
@@ -222,6 +228,14 @@ class MixerMDM(nn.Module):
                     raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)}, the shape in current model is {tuple(params[k].shape)}")
                 params[k].copy_(v)
         self._dirty = True
+        # text-conditioning stage: when the checkpoint carries the CLIP tower and the three clipTransEncoder heads
+        # (mixermdm.py:212-259), generate_cond runs on the GPU too; built lazily on the model's device
+        need = ("token_embedding.weight", "positional_embedding", "ln_final.weight", "clipTransEncoder.layers.0.linear1.weight", "clip_ln.weight")
+        if all(k in state_dict for k in need):
+            pre = ("token_embedding.", "positional_embedding", "clip_transformer.", "ln_final.", "clipTransEncoder.", "clip_ln.",
+                   "model1.clipTransEncoder", "model1.clip_ln", "model2.clipTransEncoder", "model2.clip_ln", "model1.clip_model.", "model1.embed_text.")
+            self._text_sd = {k: v for k, v in state_dict.items() if k.startswith(pre)}
+            self._text_enc = None
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def _apply(self, fn, recurse=True):
@@ -237,12 +251,13 @@ class MixerMDM(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("MixerMDM runs on an MI355X only: call .to('cuda:N') first (no CPU path)")
         m = self.mixing
-        key = (str(dev), m.mixing_mode, bool(m.align), m.force_influence_val, self.cfg_model2.NAME)
+        key = (str(dev), m.mixing_mode, bool(m.align), m.force_influence_val, self.cfg_model2.NAME, self.cfg_model1.NAME)
         s = self._sampler
         if s is None or s._key != key or B > s.cfg.max_batch or T > s.cfg.max_frames:
             if s is not None:
                 s.close()
-            s = Sampler(d_heads=self.d_heads, m_heads=self.m_heads, mixing_mode=m.mixing_mode, align=m.align, xstart_align=True,
+            s = Sampler(d_heads=self.d_heads, d1_heads=self.d1_heads, model1_kind=self.model1_kind, m_heads=self.m_heads,
+                        mixing_mode=m.mixing_mode, align=m.align, xstart_align=True,
                         model2_kind=1 if self.cfg_model2.NAME == "InterGen" else 0, force_influence_val=m.force_influence_val,
                         cfg_scale=self.cfg_mixing_weight, max_batch=max(B, s.cfg.max_batch if s else 1),
                         max_frames=max(T, self.num_frames), device=dev, **self.dims)
@@ -263,6 +278,13 @@ class MixerMDM(nn.Module):
     def generate_cond(self, batch):
         if "cond" in batch:
             return batch["cond"]
+        if self.text_encoder is None and getattr(self, "_text_sd", None) is not None:
+            if self._text_enc is None or self._text_enc.tower.table.device != self.device:
+                from .text import MixerTextEncoder
+                heads = self._text_sd["clip_transformer.resblocks.0.attn.in_proj_weight"].shape[1] // 64 if "clip_transformer.resblocks.0.attn.in_proj_weight" in self._text_sd else 12
+                self._text_enc = MixerTextEncoder(self._text_sd, clip_heads=heads, head_heads=8, device=self.device, model2=self.cfg_model2.NAME,
+                                                  model1=self.cfg_model1.NAME)
+            return self._text_enc.generate_cond(batch)
         if self.text_encoder is None:
             raise NotImplementedError("text encoding (CLIP ViT-L/14 tower + clipTransEncoder, mixermdm.py:283-356) is upstream of the HIP path: "
                                       "pass batch['cond'] [B, 8*768] or set model.text_encoder")
@@ -333,27 +355,32 @@ class MixerMDM(nn.Module):
 
 class in2INDiffusion(nn.Module):
     """Stand-alone sub-model sampler: in2INDiffusion.forward (src/models/in2in.py:285-356), modes "individual"
-    (ClassifierFreeSampleModel, [B,T,262]) and "interaction" (ClassifierFreeSampleModelMultiple, [B,T,524]); output stays in
-    the model's normalised space, as in the reference (callers de-normalise: src/scripts/infer/in2IN.py:101-105)."""
+    (ClassifierFreeSampleModel, [B,T,262]), "interaction" (ClassifierFreeSampleModelMultiple, [B,T,524]) and "dual"
+    (ClassifierFreeSampleDualMDM over net_individual + net_interaction, [B,T,524]); output stays in the model's normalised
+    space, as in the reference (callers de-normalise: src/scripts/infer/in2IN.py:101-105)."""
 
     def __init__(self, cfg, mode, sampling_strategy="ddim50"):
         super().__init__()
-        if mode not in ("individual", "interaction"):
-            raise NotImplementedError(f"in2IN mode {mode!r}: 'dual' (DualMDM sampler) is not built (SURVEY 8f-4)")
+        if mode not in ("individual", "interaction", "dual"):
+            raise ValueError(f"in2IN mode {mode!r} not recognized")
         self.cfg, self.mode = cfg, mode
         self.nfeats = cfg.INPUT_DIM
         self.dims = dict(d_latent=cfg.LATENT_DIM, d_ff=cfg.FF_SIZE, d_layers=cfg.NUM_LAYERS)
         self.num_heads = cfg.NUM_HEADS
-        self.cfg_weight = cfg.CFG_WEIGHT
+        self.cfg_weight = cfg.CFG_WEIGHT if "CFG_WEIGHT" in cfg else 0.0
         self.cfg_weight_interaction = cfg.CFG_WEIGHT_INTERACTION if "CFG_WEIGHT_INTERACTION" in cfg else 0.0
         self.cfg_weight_individual = cfg.CFG_WEIGHT_INDIVIDUAL if "CFG_WEIGHT_INDIVIDUAL" in cfg else 0.0
+        if mode == "dual":                          # in2in.py:158-162
+            self.cfg_composition_weight_func, self.cfg_composition_weight_value = cfg.W_FUNC, cfg.W_VALUE
         self.diffusion_steps = cfg.DIFFUSION_STEPS
         self.betas = get_named_beta_schedule(cfg.BETA_SCHEDULER, self.diffusion_steps)
         self.sampling_strategy = sampling_strategy
-        self._net = "net_individual" if mode == "individual" else "net_interaction"
+        self._nets = {"individual": [("net_individual", "denoiser1.")], "interaction": [("net_interaction", "denoiser2.")],
+                      "dual": [("net_individual", "denoiser1."), ("net_interaction", "denoiser2.")]}[mode]
         from .synthetic import denoiser_shapes
-        for k, shp in denoiser_shapes(self._net + ".", self.dims["d_latent"], self.dims["d_ff"], self.dims["d_layers"]).items():
-            _holder_tree(self, k, torch.zeros(shp))
+        for net, _ in self._nets:
+            for k, shp in denoiser_shapes(net + ".", self.dims["d_latent"], self.dims["d_ff"], self.dims["d_layers"]).items():
+                _holder_tree(self, k, torch.zeros(shp))
         self._sampler, self._dirty = None, True
 
     def _apply(self, fn, recurse=True):
@@ -373,20 +400,25 @@ class in2INDiffusion(nn.Module):
         if s is None or B > s.cfg.max_batch or T > s.cfg.max_frames or s.device != dev:
             if s is not None:
                 s.close()
-            kind = 1 if self.mode == "individual" else 2
+            kind = {"individual": 1, "interaction": 2, "dual": 3}[self.mode]
             s = Sampler(d_heads=self.num_heads, single_only=kind, cfg_scale=self.cfg_weight, cfg_scale_interaction=self.cfg_weight_interaction,
                         cfg_scale_individual=self.cfg_weight_individual, max_batch=B, max_frames=max(T, 300), device=dev, **self.dims)
             self._sampler, self._dirty = s, True
         if self._dirty:
-            pfx = "denoiser1." if self.mode == "individual" else "denoiser2."
-            s.load_state_dict({pfx + k[len(self._net) + 1:]: p.data for k, p in self.named_parameters()})
+            sd = {}
+            for net, pfx in self._nets:
+                sd.update({pfx + k[len(net) + 1:]: p.data for k, p in self.named_parameters() if k.startswith(net + ".")})
+            s.load_state_dict(sd)
             s.prepare()
             s._strategy = None
             self._dirty = False
         return s
 
     def forward(self, batch):
-        if self.mode == "interaction":
+        if self.mode == "dual":                      # in2in.py:299-305
+            cond = torch.cat([batch["cond_interaction"], batch["cond_interaction_individual1"], batch["cond_interaction_individual2"],
+                              batch["cond_individual_individual1"], batch["cond_individual_individual2"]], dim=1)
+        elif self.mode == "interaction":
             cond = torch.cat([batch["cond_interaction"], batch["cond_interaction_individual1"], batch["cond_interaction_individual2"]], dim=1)
         else:
             cond = torch.cat([batch["cond_individual_individual1"]], dim=1)
@@ -394,8 +426,10 @@ class in2INDiffusion(nn.Module):
         s = self._get_sampler(B, T)
         if s._strategy != self.sampling_strategy:
             s.set_schedule(self.sampling_strategy, self.cfg.BETA_SCHEDULER, self.diffusion_steps)
+            if self.mode == "dual":
+                s.set_dual_weights(self.cfg_composition_weight_func, self.cfg_composition_weight_value)
             s._strategy = self.sampling_strategy
-        width = self.nfeats * (2 if self.mode == "interaction" else 1)
+        width = self.nfeats * (1 if self.mode == "individual" else 2)
         x_T = batch["x_T"] if "x_T" in batch else torch.randn(B, T, width, device=s.device)
         return {"output": s.sample(cond, x_T)}
 
@@ -423,11 +457,14 @@ class in2IN(nn.Module):
         return batch
 
     def forward_test(self, batch):
-        if self.mode == "interaction":
+        if self.mode in ("interaction", "dual"):
             batch = self.text_process(batch, "interaction", out_name="cond_interaction")
             batch = self.text_process(batch, "interaction", "text_individual1", "cond_interaction_individual1")
             batch = self.text_process(batch, "interaction", "text_individual2", "cond_interaction_individual2")
-        else:
+        if self.mode == "dual":
+            batch = self.text_process(batch, "individual", "text_individual1", "cond_individual_individual1")
+            batch = self.text_process(batch, "individual", "text_individual2", "cond_individual_individual2")
+        elif self.mode == "individual":
             batch = self.text_process(batch, "individual", out_name="cond_individual_individual1")
         batch.update(self.decode_motion(batch))
         return batch

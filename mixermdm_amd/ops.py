@@ -6,9 +6,10 @@ tensor.  No function here computes anything in Python: a non-CUDA tensor raises.
 import ctypes as C
 import torch
 
-from ._lib import load_library, check
+from ._lib import load_library, check, EncoderLayerWeights
 
-EPI = {"bias": 0, "gelu": 1, "resid": 2, "pe": 3, "silu": 4}
+EPI = {"bias": 0, "gelu": 1, "resid": 2, "pe": 3, "silu": 4, "quickgelu": 5}
+ATTN_NO_ZERO_KEY, ATTN_CAUSAL = 1, 2
 
 
 def _p(t):
@@ -55,17 +56,70 @@ def adaln(h, ss, ss_rows=None):
     return out
 
 
-def attention(q, k, v, num_heads, kv_seq_shift=0):
-    """q [nseq, Tq, H*dh], k/v [nseq, Tk, H*dh] (may be column slices of a packed projection); add_zero_attn semantics."""
+def attention(q, k, v, num_heads, kv_seq_shift=0, zero_key=True, causal=False):
+    """q [nseq, Tq, H*dh], k/v [nseq, Tk, H*dh] (may be column slices of a packed projection); add_zero_attn semantics by default,
+    plain softmax with zero_key=False (optionally causal)."""
     _chk(q, k, v)
     nseq, Tq, HD = q.shape
     Tk = k.shape[1]
     for t in (q, k, v):
         assert t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1), "rows must be uniformly strided"
     out = torch.empty(nseq, Tq, HD, device=q.device, dtype=torch.float32)
-    check(load_library().mmdm_attention_f32(_p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(out), HD,
-                                            nseq, Tq, Tk, num_heads, HD // num_heads, kv_seq_shift, _stream()))
+    flags = (0 if zero_key else ATTN_NO_ZERO_KEY) | (ATTN_CAUSAL if causal else 0)
+    check(load_library().mmdm_attention_opts(_p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(out), HD, 0, flags,
+                                             nseq, Tq, Tk, num_heads, HD // num_heads, kv_seq_shift, _stream()))
     return out
+
+
+def layernorm(x, weight, bias, eps=1e-5):
+    """nn.LayerNorm over the last dimension with affine parameters."""
+    _chk(x, weight, bias)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    D = x.shape[-1]
+    check(load_library().mmdm_layernorm_f32(_p(x), _p(weight), _p(bias), _p(out), x.numel() // D, D, float(eps), _stream()))
+    return out
+
+
+def token_embed(table, tokens, pos):
+    """table[tokens] + pos[:L]; tokens int32 [n, L] on the device."""
+    _chk(table, tokens, pos)
+    assert tokens.dtype == torch.int32 and tokens.is_contiguous() and table.is_contiguous() and pos.is_contiguous()
+    n, L = tokens.shape
+    D = table.shape[1]
+    assert pos.shape[0] >= L and pos.shape[1] == D
+    out = torch.empty(n, L, D, device=table.device, dtype=torch.float32)
+    check(load_library().mmdm_token_embed_f32(_p(table), table.shape[0], _p(tokens), _p(pos), _p(out), n, L, D, _stream()))
+    return out
+
+
+def gather_rows(src, idx):
+    """src [R, D][idx] with idx int32 [n] on the device."""
+    _chk(src, idx)
+    assert idx.dtype == torch.int32 and src.is_contiguous() and src.dim() == 2
+    out = torch.empty(idx.shape[0], src.shape[1], device=src.device, dtype=torch.float32)
+    check(load_library().mmdm_gather_rows_f32(_p(src), _p(idx), _p(out), idx.shape[0], src.shape[1], _stream()))
+    return out
+
+
+def encoder_layer_(x, w, num_heads, norm_first=False, activation="gelu", causal=False, eps=1e-5, workspace=None):
+    """One nn.TransformerEncoderLayer on x [nseq, T, D] IN PLACE.  w: dict with in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias,
+    linear1.weight/bias, linear2.weight/bias, norm1.weight/bias, norm2.weight/bias (contiguous fp32 device tensors)."""
+    names = ("in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias", "linear1.weight", "linear1.bias",
+             "linear2.weight", "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+    ts = [w[k] for k in names]
+    _chk(x, *ts)
+    assert x.is_contiguous() and all(t.is_contiguous() for t in ts)
+    nseq, T, D = x.shape
+    F = w["linear1.weight"].shape[0]
+    lib = load_library()
+    need = lib.mmdm_encoder_layer_workspace(nseq, T, D, F)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=x.device, dtype=torch.float32)
+    cw = EncoderLayerWeights(*[t.data_ptr() for t in ts])
+    check(lib.mmdm_encoder_layer_f32(_p(x), C.byref(cw), nseq, T, D, num_heads, F, int(norm_first), EPI[activation], int(causal), float(eps),
+                                     _p(workspace), workspace.numel(), _stream()))
+    return x
 
 
 def cond_silu(time_tab, step_idx, txt):

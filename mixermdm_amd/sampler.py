@@ -29,9 +29,12 @@ class Sampler:
 
     def __init__(self, *, d_latent, d_ff, d_layers, d_heads, m_latent=0, m_ff=0, m_layers=0, m_heads=1, mixing_mode=4, align=True,
                  xstart_align=True, model2_kind=0, force_influence_val=None, cfg_scale=3.5, max_batch=1, max_frames=300,
-                 single_only=False, text_dim=768, device=None, cfg_scale_interaction=0.0, cfg_scale_individual=0.0, precision="fp32"):
+                 single_only=False, text_dim=768, device=None, cfg_scale_interaction=0.0, cfg_scale_individual=0.0, precision="fp32",
+                 model1_kind=0, d1_latent=0, d1_ff=0, d1_layers=0, d1_heads=0):
         """single_only: False/0 = two-chain MixerMDM; True/1 = individual denoiser alone (2-way CFG);
-        2 = interaction denoiser alone with the 4-way CFG of ClassifierFreeSampleModelMultiple."""
+        2 = interaction denoiser alone with the 4-way CFG of ClassifierFreeSampleModelMultiple;
+        3 = in2IN "dual": both denoisers composed by ClassifierFreeSampleDualMDM (call set_dual_weights after set_schedule).
+        model1_kind: 0 = in2IN individual, 1 = MDMDenoiser; d1_*: denoiser1's own sizes (0 = same as d_*)."""
         if not torch.cuda.is_available():
             raise RuntimeError("mixermdm_amd.Sampler needs an MI355X (HIP device); there is no CPU path")
         self.lib = load_library()
@@ -39,7 +42,7 @@ class Sampler:
         self.cfg = Config(d_latent, d_ff, d_layers, d_heads, m_latent, m_ff, m_layers, m_heads, 262, text_dim, mixing_mode, int(align),
                           int(xstart_align), model2_kind, int(force_influence_val is not None), float(force_influence_val or 0.0),
                           float(cfg_scale), max_batch, max_frames, int(single_only), float(cfg_scale_interaction), float(cfg_scale_individual),
-                          {"fp32": 0, "bf16": 1}[precision])
+                          {"fp32": 0, "bf16": 1}[precision], int(model1_kind), d1_latent, d1_ff, d1_layers, d1_heads)
         self.single_only = int(single_only)
         self.h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -71,10 +74,10 @@ class Sampler:
         D, Dm = self.cfg.d_latent, self.cfg.m_latent
         pes = []
         if self.single_only != 2:
-            pes.append(("denoiser1.sequence_pos_encoder.pe", D))
+            pes.append(("denoiser1.sequence_pos_encoder.pe", self.cfg.d1_latent or D))
         if self.single_only != 1:
             pes.append(("denoiser2.sequence_pos_encoder.pe", D))
-        if not self.single_only:
+        if self.single_only == 0:
             pes.append(("sequence_pos_encoder.pe", Dm))
         for k, d in pes:
             if k not in sd:
@@ -111,6 +114,25 @@ class Sampler:
             check(self.lib.mmdm_set_schedule(self.h, tmap.ctypes.data_as(C.c_void_p), coef.ctypes.data_as(C.c_void_p), sch.num_timesteps, self._s()), self.h)
         self.schedule = sch
         return sch
+
+    def set_dual_weights(self, func, value):
+        """Composition weight of ClassifierFreeSampleDualMDM (cfg_sampler.py:113-125) evaluated in float64 on the model-side
+        timestep of every respaced step, exactly as the reference's lambdas do, then handed over as a float32 table."""
+        t = np.asarray(self.schedule.timestep_map, dtype=np.int64)
+        if func == "exp":
+            w = np.exp(-value * (1000 - t))
+        elif func == "exp-inv":
+            w = 1 - np.exp(-value * (1000 - t))
+        elif func == "lin":
+            w = 1 - ((1000 - t) / 1000)
+        elif func == "const":
+            w = np.full(t.shape, value, dtype=np.float64)
+        else:
+            raise ValueError("Unknown function")
+        w = np.ascontiguousarray(w.astype(np.float32))
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_set_dual_weights(self.h, w.ctypes.data_as(C.c_void_p), len(w)), self.h)
+        return w
 
     # ---- sampling ---------------------------------------------------------------------------------
     def begin(self, cond, x_T):
@@ -175,12 +197,13 @@ class Sampler:
 
     # ---- teacher-forced module forwards (tests / swappable inner protocol) ----------------------------
     def module_forward(self, which, x, cond, t, x2=None):
-        """which: 0 denoiser1, 1 denoiser2, 2 Mixer.forward; inputs are the CFG-doubled batch.  Invalidates the schedule."""
+        """which: 0 denoiser1, 1 denoiser2, 2 Mixer.forward, 3 denoiser1 in "dual_individual" mode; inputs are the CFG-doubled batch.
+        Invalidates the schedule."""
         x = x.to(self.device, torch.float32).contiguous()
         cond = cond.to(self.device, torch.float32).contiguous()
         x2c = x2.to(self.device, torch.float32).contiguous() if x2 is not None else None
         n, T = x.shape[:2]
-        out = torch.empty(n, T, 262 if which == 0 else 524, device=self.device, dtype=torch.float32)   # which 1 with single_only=2: n = 4B rows
+        out = torch.empty(n, T, 262 if which == 0 else 524, device=self.device, dtype=torch.float32)   # which 1 with single_only=2: n = 4B rows; 3 = dual_individual
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.device(self.device):
             check(self.lib.mmdm_module_forward(self.h, which, C.c_void_p(x.data_ptr()), C.c_void_p(x2c.data_ptr() if x2c is not None else 0),

@@ -41,8 +41,28 @@ def denoiser_shapes(prefix, D, F, L, text_dim=768, nfeats=262):
     return {prefix + k: v for k, v in sh.items()}
 
 
-def mixer_shapes(d_latent, d_ff, d_layers, m_latent, m_ff, m_layers, mixing_mode=4, text_dim=768, nfeats=262, single_only=False):
-    sh = denoiser_shapes("denoiser1.", d_latent, d_ff, d_layers, text_dim, nfeats)
+def mdm_denoiser_shapes(prefix, D, F, L, nfeats=262):
+    """MDMDenoiser parameters (src/models/mdm.py:234-271): pose embedding / head, timestep MLP, post-norm nn.TransformerEncoder layers.
+    LayerNorm weights are named *.norm{1,2}.weight (drawn like any other 1-d parameter: callers that want gamma ~ 1 add it)."""
+    sh = {
+        "input_process.poseEmbedding.weight": (D, nfeats), "input_process.poseEmbedding.bias": (D,),
+        "embed_timestep.time_embed.0.weight": (D, D), "embed_timestep.time_embed.0.bias": (D,),
+        "embed_timestep.time_embed.2.weight": (D, D), "embed_timestep.time_embed.2.bias": (D,),
+        "output_process.poseFinal.weight": (nfeats, D), "output_process.poseFinal.bias": (nfeats,),
+    }
+    for i in range(L):
+        q = f"seqTransEncoder.layers.{i}."
+        sh.update({q + "self_attn.in_proj_weight": (3 * D, D), q + "self_attn.in_proj_bias": (3 * D,),
+                   q + "self_attn.out_proj.weight": (D, D), q + "self_attn.out_proj.bias": (D,),
+                   q + "linear1.weight": (F, D), q + "linear1.bias": (F,), q + "linear2.weight": (D, F), q + "linear2.bias": (D,),
+                   q + "norm1.weight": (D,), q + "norm1.bias": (D,), q + "norm2.weight": (D,), q + "norm2.bias": (D,)})
+    return {prefix + k: v for k, v in sh.items()}
+
+
+def mixer_shapes(d_latent, d_ff, d_layers, m_latent, m_ff, m_layers, mixing_mode=4, text_dim=768, nfeats=262, single_only=False,
+                 model1="in2INind", d1_latent=0, d1_ff=0, d1_layers=0):
+    D1, F1, L1 = d1_latent or d_latent, d1_ff or d_ff, d1_layers or d_layers
+    sh = mdm_denoiser_shapes("denoiser1.", D1, F1, L1, nfeats) if model1 == "MDM" else denoiser_shapes("denoiser1.", D1, F1, L1, text_dim, nfeats)
     if single_only:
         return sh
     sh.update(denoiser_shapes("denoiser2.", d_latent, d_ff, d_layers, text_dim, nfeats))
@@ -65,7 +85,9 @@ def synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, **dims):
     g = torch.Generator().manual_seed(seed)
     sd = {}
     for k, shape in mixer_shapes(**dims).items():
-        if len(shape) == 1:
+        if len(shape) == 1 and (k.endswith("norm1.weight") or k.endswith("norm2.weight")):
+            sd[k] = 1 + torch.randn(shape, generator=g) * bias_std if bias_std else torch.ones(shape)      # LayerNorm gamma
+        elif len(shape) == 1:
             sd[k] = torch.randn(shape, generator=g) * bias_std if bias_std else torch.zeros(shape)
         else:
             sd[k] = torch.randn(shape, generator=g) * std

@@ -10,12 +10,14 @@ from . import layers as L
 
 
 def in2in_denoiser(W, p, mode, x, timesteps, cond, num_heads, nfeats=262):
-    """in2INDenoiser.forward, modes "individual" / "interaction" -- in2in.py:401-462.
+    """in2INDenoiser.forward, modes "individual" / "interaction" / "dual_interaction" / "dual_individual" -- in2in.py:401-462.
 
     W[p+"sequence_pos_encoder.pe"] is the [5000, D] table buffer (utils.py:24-35);
     the timestep embedding indexes the SAME table with the remapped t (utils.py:54-55).
     Interaction CA uses the other stream's previous-layer h for both updates (in2in.py:439-440).
     """
+    if mode not in ("individual", "interaction", "dual_interaction", "dual_individual"):
+        raise ValueError("Mode not recognized")
     pe = W[p + "sequence_pos_encoder.pe"]
     T = x.shape[1]
     te = L.timestep_embed(W, p + "embed_timestep", pe, timesteps)
@@ -28,13 +30,21 @@ def in2in_denoiser(W, p, mode, x, timesteps, cond, num_heads, nfeats=262):
         for i in range(num_layers):
             h_a = L.block_double_cond(W, f"{p}blocks.{i}", mode, h_a, None, emb1, None, num_heads)
         return L.linear(W, p + "out.linear", h_a)
-    if mode != "interaction":
-        raise ValueError("Mode not recognized")
+    x_b = x[..., nfeats:]
+    h_b = L.linear(W, p + "motion_embed", x_b) + pe[:T].unsqueeze(0)
+    if mode == "dual_individual":
+        # two persons, each through the individual blocks with its own text (cond columns 3*768.. and 4*768..) -- in2in.py:420-422, 441-443
+        emb1 = te + txt(cond[:, 768 * 3:768 * 4])
+        emb2 = te + txt(cond[:, 768 * 4:])
+        # QUIRK (in2in.py:448-451): h_b_prev is only advanced in the interaction modes, so in "dual_individual" every
+        # layer recomputes person b from the EMBEDDED input and the result is the LAST block applied once.
+        for i in range(num_layers):
+            h_a = L.block_double_cond(W, f"{p}blocks.{i}", mode, h_a, None, emb1, None, num_heads)
+        h_b = L.block_double_cond(W, f"{p}blocks.{num_layers - 1}", mode, h_b, None, emb2, None, num_heads)
+        return torch.cat([L.linear(W, p + "out.linear", h_a), L.linear(W, p + "out.linear", h_b)], dim=-1)
     emb = te + txt(cond[:, :768])
     emb1 = te + txt(cond[:, 768:768 * 2])
     emb2 = te + txt(cond[:, 768 * 2:768 * 3])
-    x_b = x[..., nfeats:]
-    h_b = L.linear(W, p + "motion_embed", x_b) + pe[:T].unsqueeze(0)
     for i in range(num_layers):
         n_a = L.block_double_cond(W, f"{p}blocks.{i}", mode, h_a, h_b, emb1, emb, num_heads)
         n_b = L.block_double_cond(W, f"{p}blocks.{i}", mode, h_b, h_a, emb2, emb, num_heads)

@@ -9,18 +9,20 @@ import torch
 from . import layers as L
 from . import geometry as G
 from .denoiser import in2in_denoiser, inter_denoiser, influence
+from .encoder import mdm_denoiser
 
 
 class MixerSpec:
     """Static description of a Mixer instance (what Mixer.__init__ stores -- mixermdm.py:606-657)."""
 
     def __init__(self, d_heads=8, m_heads=8, mixing_mode=4, align=True, force_influence_val=None,
-                 nfeats=262, text_dim=768, d1_text_dim=768, d2_text_dim=768, model2="in2IN"):
+                 nfeats=262, text_dim=768, d1_text_dim=768, d2_text_dim=768, model2="in2IN", model1="in2INind"):
         self.d_heads, self.m_heads = d_heads, m_heads
         self.mixing_mode, self.align, self.force = mixing_mode, align, force_influence_val
         self.nfeats, self.text_dim = nfeats, text_dim
         self.d1_text_dim, self.d2_text_dim = d1_text_dim, d2_text_dim
         self.model2 = model2
+        self.model1 = model1      # "in2INind" | "MDM" (mixermdm.py:32-40, 264-272); MDM: d1_text_dim = its latent size (mdm.py:279)
 
 
 def expand_influence(w, mode, T):
@@ -61,8 +63,12 @@ def mixer_forward(W, spec, stats, x1, timesteps, cond, x2, hist=None):
     cond_i1 = te + L.linear(W, "text_embed", cond[:, base + td2:base + 2 * td2])
     cond_i2 = te + L.linear(W, "text_embed", cond[:, base + 2 * td2:base + 3 * td2])
 
-    o11 = in2in_denoiser(W, "denoiser1.", "individual", x1[:, :, :nf], timesteps, cond1_1, spec.d_heads, nf)
-    o12 = in2in_denoiser(W, "denoiser1.", "individual", x1[:, :, nf:], timesteps, cond1_2, spec.d_heads, nf)
+    if spec.model1 == "MDM":
+        o11 = mdm_denoiser(W, "denoiser1.", x1[:, :, :nf], timesteps, cond1_1, spec.d_heads)
+        o12 = mdm_denoiser(W, "denoiser1.", x1[:, :, nf:], timesteps, cond1_2, spec.d_heads)
+    else:
+        o11 = in2in_denoiser(W, "denoiser1.", "individual", x1[:, :, :nf], timesteps, cond1_1, spec.d_heads, nf)
+        o12 = in2in_denoiser(W, "denoiser1.", "individual", x1[:, :, nf:], timesteps, cond1_2, spec.d_heads, nf)
     if spec.model2 == "InterGen":
         o2 = inter_denoiser(W, "denoiser2.", x2, timesteps, cond2, spec.d_heads, nf)
     else:
@@ -207,5 +213,51 @@ def interaction_ddim_loop(W, p, sched, s, s_int, s_ind, x_T, cond, num_heads, fi
     for i in idx:
         ts = torch.full((B,), sched.timestep_map[i], dtype=torch.long)
         x0 = cfg_multiple(W, p, s, s_int, s_ind, x, ts, cond, num_heads)
+        x = ddim_update(sched, i, x, x0)
+    return x0, x
+
+
+# ---- in2IN "dual" sampler (DualMDM composition) -------------------------------------------------
+
+def dual_weight(func, value, t):
+    """ClassifierFreeSampleDualMDM.weight -- cfg_sampler.py:113-125, evaluated on the (remapped) timestep t in float64."""
+    import numpy as np
+    x = np.asarray([t])
+    if func == "exp":
+        return np.exp(-value * (1000 - x))[0]
+    if func == "exp-inv":
+        return 1 - np.exp(-value * (1000 - x))[0]
+    if func == "lin":
+        return 1 - ((1000 - x) / 1000)[0]
+    if func == "const":
+        return value
+    raise ValueError("Unknown function")
+
+
+def cfg_dual(W, p_ind, p_int, s_ind, s_int, w, x, timesteps, cond, num_heads):
+    """ClassifierFreeSampleDualMDM.forward -- cfg_sampler.py:127-150: both denoisers on the CFG-doubled batch,
+    per-model guidance, then out_int + w (out_ind - out_int) with the time-scheduled scalar w."""
+    B = x.shape[0]
+    xx, tt = torch.cat([x, x]), torch.cat([timesteps, timesteps])
+    cc = torch.cat([cond, torch.zeros_like(cond)])
+    o_int = in2in_denoiser(W, p_int, "dual_interaction", xx, tt, cc, num_heads)
+    o_ind = in2in_denoiser(W, p_ind, "dual_individual", xx, tt, cc, num_heads)
+    g_int = o_int[B:] + s_int * (o_int[:B] - o_int[B:])
+    g_ind = o_ind[B:] + s_ind * (o_ind[:B] - o_ind[B:])
+    return g_int + float(w) * (g_ind - g_int)
+
+
+def dual_ddim_loop(W, p_ind, p_int, sched, s_ind, s_int, func, value, x_T, cond, num_heads, first_steps=None):
+    """in2INDiffusion.forward, mode "dual" (in2in.py:318-329) on MotionDiffusion's single-chain DDIM loop."""
+    x = x_T.clone()
+    B = x.shape[0]
+    x0 = None
+    idx = list(range(sched.num_timesteps))[::-1]
+    if first_steps is not None:
+        idx = idx[:first_steps]
+    for i in idx:
+        t = sched.timestep_map[i]
+        ts = torch.full((B,), t, dtype=torch.long)
+        x0 = cfg_dual(W, p_ind, p_int, s_ind, s_int, dual_weight(func, value, t), x, ts, cond, num_heads)
         x = ddim_update(sched, i, x, x0)
     return x0, x

@@ -64,7 +64,9 @@ from models.utils.influence import Influence, InfluenceBlockCross  # noqa: E402
 from models.utils.layers import AdaLN, VanillaSelfAttention, VanillaCrossAttention, FFN  # noqa: E402
 from models.utils.blocks import TransformerBlock, TransformerBlockDoubleCond  # noqa: E402
 from models.utils.utils import PositionalEncoding  # noqa: E402
-from models.utils.cfg_sampler import ClassifierFreeSampleModel, ClassifierFreeSampleModelX2, ClassifierFreeSampleModelMultiple  # noqa: E402
+from models.utils.cfg_sampler import (ClassifierFreeSampleModel, ClassifierFreeSampleModelX2, ClassifierFreeSampleModelMultiple,  # noqa: E402
+                                      ClassifierFreeSampleDualMDM)
+from models.mdm import MDMDenoiser  # noqa: E402
 from models.utils import gaussian_diffusion as gd  # noqa: E402
 from utils import alignment as al  # noqa: E402
 from utils import rotation_conversions as rc  # noqa: E402
@@ -361,7 +363,124 @@ def g_interaction():
     save("interaction", **out)
 
 
+# ---- G13 in2IN "dual" sampler (ClassifierFreeSampleDualMDM) ---------------------------------
+def g_dual():
+    B, T = 2, 12
+    m_ind = reinit(in2INDenoiser(262, mode="dual_individual", **DEN), 30)
+    m_int = reinit(in2INDenoiser(262, mode="dual_interaction", **DEN), 31)
+    out = dict(sd(m_ind, "ind."))
+    out.update(sd(m_int, "int."))
+    out.update(H=DEN["num_heads"], s_ind=2.0, s_int=3.0)
+    xT, c = rnd(97, B, T, 524), rnd(98, B, 5 * 768)
+    out.update(x_T=xT, cond=c)
+    out["fwd:dual_individual"] = m_ind(xT, torch.tensor([500, 20]), cond=c)
+    for func, value in [("exp", 0.004), ("lin", 0.0), ("const", 0.3), ("exp-inv", 0.002)]:
+        cfg = ClassifierFreeSampleDualMDM(m_ind, m_int, 2.0, 3.0, func, value)
+        out[f"cfg:{func}:out"] = cfg(xT, torch.full((B,), 500, dtype=torch.long), cond=c, mask=None)
+        out[f"cfg:{func}:value"] = value
+    for func, value in [("exp", 0.004), ("lin", 0.0)]:
+        cfg = ClassifierFreeSampleDualMDM(m_ind, m_int, 2.0, 3.0, func, value)
+        diff = gd.MotionDiffusion(use_timesteps=gd.space_timesteps(1000, "ddim20"), motion_rep="global", mode="dual",
+                                  betas=gd.get_named_beta_schedule("cosine", 1000),
+                                  model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                                  loss_type=gd.LossType.MSE, rescale_timesteps=False)
+        out[f"loop:{func}:ddim20:output"] = diff.ddim_sample_loop(cfg, (B, T, 524), noise=xT.clone(), clip_denoised=False, progress=False,
+                                                                  model_kwargs={"mask": None, "cond": c})
+    save("dual", **out)
+
+
+# ---- G14 MDMDenoiser as MODEL1 -------------------------------------------------------------
+def g_mdm():
+    B, T = 2, 12
+    D = DEN["latent_dim"]
+    mk = lambda: MDMDenoiser(None, 262, D, DEN["ff_size"], DEN["num_layers"], DEN["num_heads"], DEN["dropout"], "gelu")
+    m = reinit(mk(), 33)
+    out = dict(sd(m, "mdm."))
+    out.update(H=DEN["num_heads"], t=np.array([980, 0]))
+    x, c = rnd(24, B, T, 262), rnd(25, B, D)
+    out.update(x=x, cond=c)
+    out["mdm:out"] = m(x, torch.tensor([980, 0]), cond=c.clone())            # forward adds the timestep embedding to cond IN PLACE
+    # Mixer with MDM as denoiser1.  MDMDenoiser hard-codes text_dim = 256 (mdm.py:238) while cond must be latent-sized
+    # (mdm.py:279): the fixture uses the tiny latent and sets the attribute accordingly.
+    ref_mix = build_mixer(4, True, None)
+    d1 = mk()
+    d1.text_dim = D
+    d2 = in2INDenoiser(262, mode="interaction", **DEN)
+    mix = reinit(Mixer(d1, d2, nfeats=262, latent_dim=16, ff_size=32, text_dim=768, n_blocks=2, n_heads=2,
+                       mixing_mode=4, store_influence=True, force_influence_val=None, mode="eval", align=True), 100)
+    a, b = sd(ref_mix, "mix."), sd(mix, "mix.")
+    for k, v in b.items():
+        if ".denoiser1." in k:
+            out[k.replace("w:mix.", "w:mixmdm.")] = v
+        else:
+            assert np.array_equal(v, a[k]), k          # everything else is the mixer.npz weight set (name-seeded)
+    B2 = 2 * B
+    x1, x2 = rnd(80, B2, T, 524), rnd(81, B2, T, 524)
+    cond = rnd(87, B2, 6 * 768 + 2 * D)
+    cond[B:] = 0
+    t = torch.full((B2,), 640, dtype=torch.long)
+    out.update(mix_x1=x1, mix_x2=x2, mix_cond=cond.clone(), mix_t=t)
+    reset_hist(mix)
+    out["fwd:mixmdm"] = mix(x1, t, cond=cond, mask=None, x2=x2)
+    out["fwd:mixmdm:out1"] = mix.history_out1[0]
+    cfg = ClassifierFreeSampleModelX2(mix, 3.5)
+    xb, cb = rnd(88, B, T, 524), rnd(89, B, 6 * 768 + 2 * D)
+    out.update(loop_x_T=xb, loop_cond=cb)
+    reset_hist(mix)
+    out["loop:ddim20:output"] = make_diffusion("ddim20").ddim_sample_loop(cfg, (B, T, 524), noise=xb.clone(), clip_denoised=False,
+                                                                         progress=False, model_kwargs={"mask": None, "cond": cb})
+    save("mdm", **out)
+
+
+# ---- G15 text-conditioning stage -----------------------------------------------------------
+def g_text():
+    """text_process of MixerMDM / in2IN / InterGen, called UNBOUND on a stand-in ``self`` (their __init__ needs the CLIP
+    package and its weights).  The CLIP residual tower is third-party and absent, so ``clip_transformer`` is the identity
+    here: the fixture pins everything around it -- token + positional embedding, ln_final, the 2-layer post-norm
+    clipTransEncoder, clip_ln and the EOT (argmax) gather."""
+    import types
+    import torch.nn as nn
+    import clip as clip_stub
+    from models.mixermdm import MixerMDM
+    from models.in2in import in2IN
+    from models.intergen import InterGen
+    Dt, Hh, Ff, V, ctx, B = 32, 4, 64, 50, 10, 3
+    tokens = torch.tensor([[49, 3, 7, 48, 0, 0, 0, 0, 0, 0], [49, 5, 5, 5, 5, 5, 5, 5, 5, 48], [49, 48, 0, 0, 0, 0, 0, 0, 0, 0]])
+    clip_stub.tokenize = lambda raw, truncate=True: tokens
+    def enc():
+        return nn.TransformerEncoder(nn.TransformerEncoderLayer(d_model=Dt, nhead=Hh, dim_feedforward=Ff, dropout=0.1, activation="gelu",
+                                                                batch_first=True), num_layers=2)
+    fake = nn.Module()
+    fake.token_embedding = nn.Embedding(V, Dt)
+    fake.positional_embedding = nn.Parameter(torch.zeros(ctx, Dt))
+    fake.clip_transformer = nn.Linear(1, 1)        # only its device is read (text_process line 1); replaced by the identity below
+    fake.ln_final = nn.LayerNorm(Dt)
+    fake.clipTransEncoder, fake.clip_ln = enc(), nn.LayerNorm(Dt)
+    fake.clipTransEncoder_individual, fake.clip_ln_individual = enc(), nn.LayerNorm(Dt)
+    fake.clipTransEncoder_interaction, fake.clip_ln_interaction = enc(), nn.LayerNorm(Dt)
+    reinit(fake, 110)
+    fake.dtype = torch.float32
+    out = {k: v for k, v in sd(fake, "txt.").items() if "clip_transformer" not in k}
+    out.update(tokens=tokens, H=Hh)
+    class Tower(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = nn.Parameter(torch.zeros(1))
+        def forward(self, x):
+            return x
+    fake.clip_transformer = Tower()
+    batch = {"text": ["a", "b", "c"]}
+    MixerMDM.text_process(fake, batch, "text", "cond")
+    out["mixer:cond"] = batch["cond"]
+    for mode in ["individual", "interaction"]:
+        in2IN.text_process(fake, batch, mode, "text", "cond_" + mode)
+        out[f"in2in:{mode}:cond"] = batch["cond_" + mode]
+    InterGen.text_process(fake, batch, "interaction", "text", "cond_ig")
+    out["intergen:cond"] = batch["cond_ig"]
+    save("text", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "pe", "layers", "denoisers", "influence", "geometry", "mixer", "single", "interaction"]
+    which = sys.argv[1:] or ["schedule", "pe", "layers", "denoisers", "influence", "geometry", "mixer", "single", "interaction", "dual", "mdm", "text"]
     for w in which:
         globals()["g_" + w]()

@@ -22,14 +22,16 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_config_struct_matches_header_field_order():
-    from mixermdm_amd._lib import Config
+    from mixermdm_amd._lib import Config, EncoderLayerWeights
     hdr = open(os.path.join(ROOT, "include", "mmdm.h")).read()
-    body = hdr[hdr.index("typedef struct {"):hdr.index("} mmdm_config;")]
-    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    names = []
-    for decl in re.findall(r"(?:int|float)\s+([^;]+);", body):
-        names += [n.strip() for n in decl.split(",")]
-    assert names == [f[0] for f in Config._fields_]
+    for tail, cls in [("} mmdm_config;", Config), ("} mmdm_encoder_layer_weights;", EncoderLayerWeights)]:
+        end = hdr.index(tail)
+        body = hdr[hdr.rindex("typedef struct {", 0, end):end]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in re.findall(r"(?:const float|int|float)\s+([^;]+);", body):
+            names += [n.strip().lstrip("*") for n in decl.split(",")]
+        assert names == [f[0] for f in cls._fields_], tail
 
 
 def test_product_schedule_matches_reference_tables(golden):

@@ -142,3 +142,84 @@ def test_in2in_standalone_facades(golden):
                           "x_T": t("x_T").cuda(), "motion_lens": torch.tensor([12, 12])})
     d = np.abs(out["output"].cpu().numpy() - g["loop:ddim20:output"])
     assert out["output"].shape == (2, 12, 524) and d.mean() <= 1e-4 and d.max() <= 1e-2
+
+
+def test_in2in_dual_facade_vs_reference_golden(golden):
+    """in2IN(cfg, "dual"): net_individual + net_interaction composed by ClassifierFreeSampleDualMDM (in2in.py:318-329)."""
+    from mixermdm_amd.configs import CfgNode
+    from mixermdm_amd.models import in2IN
+    g, w, t = golden("dual")
+    cfg = CfgNode(dict(NAME="in2IN", NUM_LAYERS=2, NUM_HEADS=int(g["H"]), DROPOUT=0.1, INPUT_DIM=262, LATENT_DIM=16, FF_SIZE=32, DIFFUSION_STEPS=1000,
+                       BETA_SCHEDULER="cosine", STRATEGY="ddim20", CFG_WEIGHT_INDIVIDUAL=float(g["s_ind"]), CFG_WEIGHT_INTERACTION=float(g["s_int"]),
+                       W_FUNC="exp", W_VALUE=float(g["cfg:exp:value"])))
+    m = in2IN(cfg, "dual")
+    sd = {"net_individual." + k: v for k, v in w("ind.").items()}
+    sd.update({"net_interaction." + k: v for k, v in w("int.").items()})
+    m.decoder.load_state_dict(sd)
+    m = m.to("cuda:0")
+    c = t("cond").cuda()
+    sl = lambda i: c[:, 768 * i:768 * (i + 1)]
+    out = m.forward_test({"cond_interaction": sl(0), "cond_interaction_individual1": sl(1), "cond_interaction_individual2": sl(2),
+                          "cond_individual_individual1": sl(3), "cond_individual_individual2": sl(4), "x_T": t("x_T").cuda(),
+                          "motion_lens": torch.tensor([12, 12])})
+    d = np.abs(out["output"].cpu().numpy() - g["loop:exp:ddim20:output"])
+    assert out["output"].shape == (2, 12, 524) and d.mean() <= 1e-4 and d.max() <= 1e-2, (d.mean(), d.max())
+    with pytest.raises(ValueError):
+        in2IN(cfg, "trio")
+
+
+def test_mixermdm_facade_with_mdm_as_model1(tmp_path, golden):
+    """MODEL1.NAME == "MDM" (mixermdm.py:32-40): denoiser1 is an MDMDenoiser with its own sizes; cond rows [3*768 | 2*latent | 3*768]."""
+    from mixermdm_amd.configs import CfgNode
+    from mixermdm_amd.models import MixerMDM
+    gm, wm, _ = golden("mixer")
+    g, w, t = golden("mdm")
+    sub = dict(NUM_LAYERS=2, NUM_HEADS=2, DROPOUT=0.1, INPUT_DIM=262, LATENT_DIM=16, FF_SIZE=32)
+    for name, nm in [("mdm.yaml", "MDM"), ("in2IN.yaml", "in2IN")]:
+        yaml.safe_dump(dict(NAME=nm, **sub), open(tmp_path / name, "w"))
+    cfg = CfgNode(dict(NAME="MixerMDM", GENERATOR=dict(sub), DISCRIMINATOR=dict(sub), ACTIVATION="gelu", DIFFUSION_STEPS=1000, BETA_SCHEDULER="cosine",
+                       SAMPLER="uniform", MOTION_REP="global", CFG_WEIGHT=3.5, MIXING_MODE=4, FORCE_INFLUENCE_VAL="None", MODEL1="mdm.yaml", MODEL2="in2IN.yaml"))
+    m = MixerMDM(cfg, num_frames=16, sampling_strategy="ddim20", config_root=str(tmp_path))
+    sd = {"mixing." + k: v for k, v in wm("mix.").items() if not k.startswith("denoiser1.")}
+    sd.update({"mixing." + k: v for k, v in w("mixmdm.").items()})
+    m.load_state_dict(sd, strict=True)
+    m.set_norm_stats(gm["mean_hml"], gm["std_hml"], gm["mean_ih"], gm["std_ih"])
+    m = m.to("cuda:0").eval()
+    assert m.mixing.denoiser1.text_dim == 16
+    out = m.forward_test({"cond": t("loop_cond").cuda(), "x_T": t("loop_x_T").cuda(), "motion_lens": torch.tensor([[12]] * 2)})
+    d = np.abs(out["output"].cpu().numpy() - g["loop:ddim20:output"])
+    assert d.mean() <= 2e-3 and np.percentile(d, 99) <= 3e-2, (d.mean(), d.max())
+
+
+def test_facade_runs_the_text_stage_when_the_checkpoint_carries_it(tmp_path, golden):
+    """load_state_dict with token_embedding / clip_transformer / clipTransEncoder keys -> generate_cond runs on the GPU from token ids
+    and feeds forward_test (tiny 768-wide heads so the cond layout is the real [B, 8*768])."""
+    from oracle import encoder as EN
+    from test_gpu_extensions import clip_weights, enc_weights
+    from test_gpu_kernels import rnd
+    m, g, t = tiny_model(tmp_path, golden, strategy="ddim20")
+    V, ctx, D, H = 30, 12, 768, 12
+    W = clip_weights(900, V, ctx, D, 1, 64)
+    W.pop("text_projection")                # MixerMDM aliases the tower's modules only (mixermdm.py:213-216): no projection in its state dict
+    for j, (pfx, ln) in enumerate([("clipTransEncoder.", "clip_ln"), ("model1.clipTransEncoder_individual.", "model1.clip_ln_individual"),
+                                   ("model2.clipTransEncoder_interaction.", "model2.clip_ln_interaction")]):
+        for i in range(2):
+            for k, v in enc_weights(1000 + 50 * j + 10 * i, D, 64, std=0.03).items():
+                W[f"{pfx}layers.{i}.{k}"] = v
+        W[ln + ".weight"], W[ln + ".bias"] = 1 + rnd(1100 + j, D) * 0.1, rnd(1110 + j, D) * 0.1
+    sd = {k: p.detach().cpu() for k, p in m.named_parameters()}
+    sd.update(W)
+    m.load_state_dict(sd, strict=True)
+    gen = torch.Generator().manual_seed(3)
+    mk = lambda e: torch.cat([torch.randint(1, V - 1, (2, e), generator=gen), torch.full((2, 1), V - 1), torch.zeros(2, ctx - e - 1, dtype=torch.long)], 1)
+    t1, t2, tI = mk(3), mk(6), mk(9)
+    batch = {"tokens_text_individual1": t1, "tokens_text_individual2": t2, "tokens_text": tI, "motion_lens": torch.tensor([[8]] * 2)}
+    cond = m.generate_cond(batch)
+    assert cond.shape == (2, 8 * 768) and cond.is_cuda
+    cI = EN.clip_text_tower(W, "", tI, H)
+    ref_infl_I = EN.text_head(W, "clipTransEncoder.", "clip_ln", cI, tI, 8)
+    np.testing.assert_allclose(cond[:, 5 * 768:6 * 768].cpu().numpy(), ref_infl_I.numpy(), atol=2e-4, rtol=2e-4)
+    ref_int = EN.text_head(W, "model2.clipTransEncoder_interaction.", "model2.clip_ln_interaction", cI, tI, 8)
+    np.testing.assert_allclose(cond[:, :768].cpu().numpy(), ref_int.numpy(), atol=2e-4, rtol=2e-4)
+    out = m.forward_test(batch)
+    assert out["output"].shape == (2, 8, 524) and torch.isfinite(out["output"]).all()

@@ -240,9 +240,16 @@ def test_attention_and_linear_are_bitwise_reproducible_at_full_occupancy(dh):
 
 def test_attention_unsupported_head_dim():
     from mixermdm_amd import ops, MMDMError
-    x = torch.zeros(1, 4, 24, device=dev())
+    x = torch.zeros(1, 4, 300, device=dev())       # 4..32, 64, 128: dedicated kernels; any other size <= 256: wave-per-query fallback
     with pytest.raises(MMDMError, match="head dim"):
         ops.attention(x, x, x, 1)
+    x = torch.randn(2, 9, 2 * 24, device=dev())    # dh = 24 runs on the fallback, with the zero key
+    q, k, v = x.cpu().view(2, 9, 2, 24).transpose(1, 2).unbind(0)[0], None, None
+    ref = torch.nn.functional.scaled_dot_product_attention
+    xs = x.cpu().view(2, 9, 2, 24).transpose(1, 2)
+    z = torch.zeros(2, 2, 1, 24)
+    want = ref(xs, torch.cat([xs, z], 2), torch.cat([xs, z], 2)).transpose(1, 2).reshape(2, 9, 48)
+    assert_close(ops.attention(x, x, x, 2), want, atol=2e-5, rtol=1e-4, what="attention dh=24")
 
 
 # ---------------------------------------------------------------------------------------------------

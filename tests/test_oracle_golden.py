@@ -12,6 +12,7 @@ from oracle import layers as L
 from oracle import geometry as G
 from oracle import denoiser as DN
 from oracle import mixer as MX
+from oracle import encoder as EN
 
 torch.set_grad_enabled(False)
 
@@ -243,3 +244,66 @@ def test_interaction_standalone_4way_cfg(golden):
     out, _ = MX.interaction_ddim_loop(W, "", S.make_schedule("cosine", 1000, "ddim20"), s, si, sd, t("x_T"), t("cond"), H)
     d = np.abs(out.numpy() - g["loop:ddim20:output"])
     assert d.mean() <= 1e-4 and d.max() <= 1e-2, (d.mean(), d.max())
+
+
+# ---- G13 ----------------------------------------------------------------------------------------
+def test_dual_sampler(golden):
+    g, w, t = golden("dual")
+    W = w("ind.", [("sequence_pos_encoder.pe", 16)])
+    W = {"ind." + k: v for k, v in W.items()}
+    W.update({"int." + k: v for k, v in w("int.", [("sequence_pos_encoder.pe", 16)]).items()})
+    H, si, sI = int(g["H"]), float(g["s_ind"]), float(g["s_int"])
+    B = t("x_T").shape[0]
+    close(DN.in2in_denoiser(W, "ind.", "dual_individual", t("x_T"), torch.tensor([500, 20]), t("cond"), H), g["fwd:dual_individual"], atol=1e-5)
+    ts = torch.full((B,), 500, dtype=torch.long)
+    for func in ["exp", "lin", "const", "exp-inv"]:
+        wv = MX.dual_weight(func, float(g[f"cfg:{func}:value"]), 500)
+        close(MX.cfg_dual(W, "ind.", "int.", si, sI, wv, t("x_T"), ts, t("cond"), H), g[f"cfg:{func}:out"], atol=5e-5, rtol=1e-4)
+    with pytest.raises(ValueError):
+        MX.dual_weight("cos", 1.0, 10)
+    sched = S.make_schedule("cosine", 1000, "ddim20")
+    for func in ["exp", "lin"]:
+        out, _ = MX.dual_ddim_loop(W, "ind.", "int.", sched, si, sI, func, float(g[f"cfg:{func}:value"]), t("x_T"), t("cond"), H)
+        d = np.abs(out.numpy() - g[f"loop:{func}:ddim20:output"])
+        assert d.mean() <= 1e-4 and d.max() <= 1e-2, (d.mean(), d.max())
+
+
+# ---- G14 ----------------------------------------------------------------------------------------
+def _mixmdm_weights(golden):
+    gm, wm, _ = golden("mixer")
+    g, w, t = golden("mdm")
+    W = wm("mix.", [("sequence_pos_encoder.pe", 16), ("denoiser2.sequence_pos_encoder.pe", 16)])
+    W = {k: v for k, v in W.items() if not k.startswith("denoiser1.")}
+    W.update(w("mixmdm.", [("denoiser1.sequence_pos_encoder.pe", 16)]))
+    stats = tuple(torch.from_numpy(gm[k]) for k in ["mean_hml", "std_hml", "mean_ih", "std_ih"])
+    return g, t, W, stats
+
+
+def test_mdm_denoiser_and_mixer_with_mdm(golden):
+    g, w, t = golden("mdm")
+    W = w("mdm.", [("sequence_pos_encoder.pe", 16)])
+    H = int(g["H"])
+    cond = t("cond").clone()
+    close(EN.mdm_denoiser(W, "", t("x"), t("t").long(), cond, H), g["mdm:out"], atol=1e-5, rtol=1e-4)
+    assert torch.equal(cond, t("cond"))                      # the oracle does not reproduce the in-place add on the argument
+    g, t, W, stats = _mixmdm_weights(golden)
+    spec = MX.MixerSpec(d_heads=2, m_heads=2, model1="MDM", d1_text_dim=16)
+    hist = {}
+    out = MX.mixer_forward(W, spec, stats, t("mix_x1"), t("mix_t").long(), t("mix_cond"), t("mix_x2"), hist)
+    close_frac(hist["out1"][0], g["fwd:mixmdm:out1"], **MIX_TOL)
+    close_frac(out, g["fwd:mixmdm"], **MIX_TOL)
+    out, _, _ = MX.mixer_ddim_loop(W, spec, stats, S.make_schedule("cosine", 1000, "ddim20"), 3.5, t("loop_x_T"), t("loop_cond"))
+    d = np.abs(out.numpy() - g["loop:ddim20:output"])
+    assert d.mean() <= 2e-3 and np.percentile(d, 99) <= 3e-2, (d.mean(), d.max())
+
+
+# ---- G15 ----------------------------------------------------------------------------------------
+def test_text_heads(golden):
+    """Everything in text_process around the (third-party, identity here) CLIP residual tower."""
+    g, w, t = golden("text")
+    W = w("txt.")
+    H, tok = int(g["H"]), t("tokens").long()
+    clip_out = EN.clip_text_tower(W, "", tok, H)          # no resblocks keys in the fixture -> embedding + ln_final only
+    for enc, ln, key in [("clipTransEncoder.", "clip_ln", "mixer:cond"), ("clipTransEncoder_individual.", "clip_ln_individual", "in2in:individual:cond"),
+                         ("clipTransEncoder_interaction.", "clip_ln_interaction", "in2in:interaction:cond"), ("clipTransEncoder.", "clip_ln", "intergen:cond")]:
+        close(EN.text_head(W, enc, ln, clip_out, tok, H), g[key], atol=1e-5, rtol=1e-4)
