@@ -63,6 +63,17 @@ int mmdm_linear_bf16(const void* A, int lda, const void* W, int ldw, const float
 /* Round-to-nearest-even fp32 -> bf16 conversion of n contiguous elements. */
 int mmdm_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 
+/* fp32 linear layer on the bf16 matrix cores by exact 3-way operand splitting ("fp32-split" precision, mmdm_config.precision = 2):
+ * every fp32 x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (3 x 8 significand bits = fp32's 24);
+ * a*w is accumulated in fp32 as a1w1 + a1w2 + a2w1 + a1w3 + a3w1 + a2w2 (six v_mfma_f32_32x32x16_bf16; the three dropped terms are
+ * < 2^-32 |a||w|), i.e. to fp32 accuracy at 6/16 of the fp32-MFMA cost.  A and W are given as three bf16 planes [3][rows][K]
+ * (plane strides in elements, from mmdm_f32_split3 or a split-writing producer); C is fp32 [M,N], or three bf16 planes if out_split.
+ * Epilogues / extra / period as mmdm_linear_f32; K % 32 == 0, N % 4 == 0. */
+int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const void* W, int ldw, int64_t w_plane, const float* bias, void* C, int ldc,
+                      int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
+/* Exact split of n contiguous fp32 values into three bf16 planes out[0], out[plane_stride], out[2*plane_stride] (elements). */
+int mmdm_f32_split3(const float* in, void* out, int64_t n, int64_t plane_stride, void* stream);
+
 /* AdaLN apply: out[s,t,:] = LN_{eps=1e-6,no affine}(h[s,t,:]) * (1 + ss[row(s), 0:D]) + ss[row(s), D:2D],
  * row(s) = s % ss_rows.  ss is the output of Linear(SiLU(emb)) (scale first, shift second), row stride ss_ld.
  * Replaces AdaLN.forward  src/models/utils/layers.py:15-25. */
@@ -212,7 +223,10 @@ typedef struct {
     float cfg_scale_interaction, cfg_scale_individual;   /* CFG_WEIGHT_INTERACTION / CFG_WEIGHT_INDIVIDUAL (single_only == 2) */
     int precision;     /* 0: exact fp32 everywhere (the parity path).  1: bf16 operands for the transformer-stack GEMMs (weights
                         *    converted once at mmdm_prepare; AdaLN / attention / GELU outputs written as bf16), fp32 accumulation,
-                        *    residual stream, softmax, geometry, DDIM and embeddings (BASELINE configs[4], "bf16 path") */
+                        *    residual stream, softmax, geometry, DDIM and embeddings (BASELINE configs[4], "bf16 path")
+                        * 2: "fp32-split": fp32 results from the bf16 matrix cores -- the transformer-stack GEMM operands are exact 3-way
+                        *    bf16 splits (weights split at mmdm_prepare, AdaLN / attention / GELU outputs written as three planes) and each
+                        *    product is accumulated as six bf16 MFMAs (mmdm_linear_split); accuracy = fp32 MFMA, everything else as 0 */
     int model1_kind;   /* 0 = in2IN individual denoiser, 1 = MDMDenoiser (post-norm nn.TransformerEncoder with a conditioning token,
                         *    src/models/mdm.py:234-298; MODEL1.NAME == "MDM", src/models/mixermdm.py:32-40, 264-265).  Its cond slices are
                         *    latent-sized (mdm.py:279), so the mixer's cond rows are [3*text_dim | 2*d1_latent | 3*text_dim] */

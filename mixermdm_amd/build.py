@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmdm_hip.so")
-SOURCES = ["mmdm.hip", "gemm_f32.hip", "gemm_bf16.hip", "attn_f32.hip", "rowops.hip", "geometry.hip"]
+SOURCES = ["mmdm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "attn_f32.hip", "rowops.hip", "geometry.hip"]
 
 
 def needs_build():
@@ -22,14 +22,21 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    hdrs = [os.path.join(CSRC, "kernels.h"), os.path.join(HERE, "..", "include", "mmdm.h")]
+    objs, procs = [], []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [path] + hdrs):
+            continue                                  # object is newer than its source and the shared headers
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        procs.append((cmd, subprocess.Popen(cmd)))    # translation units are independent: compile them side by side
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

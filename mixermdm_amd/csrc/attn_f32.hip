@@ -40,7 +40,7 @@ struct AttnArgs {
     int ldq, ldk, ldv, ldo;
     int nseq, Tq, Tk, H, shift, qtiles, pairs_per_xcd;
     float scale, scale2;
-    int out_bf16;      // O written as bf16 (feeds the bf16 out-projection GEMM)
+    int out_bf16;      // 1: O written as bf16 (feeds the bf16 out-projection GEMM); 2: as three bf16 planes (exact split, plane stride nseq*Tq*ldo)
     int flags;         // MMDM_ATTN_NO_ZERO_KEY: plain softmax (nn.MultiheadAttention default); MMDM_ATTN_CAUSAL: key <= query only
 };
 
@@ -228,7 +228,20 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         if (qrow >= p.Tq) continue;
         const float inv = 1.0f / lr[r];
         const size_t off = ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH + lq;
-        if (p.out_bf16) {
+        if (p.out_bf16 == 2) {
+            __bf16* op = reinterpret_cast<__bf16*>(p.O) + off;
+            const size_t plane = (size_t)p.nseq * p.Tq * p.ldo;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float y = o[j][r] * inv;
+                const __bf16 b1 = (__bf16)y;
+                const float r1 = y - (float)b1;
+                const __bf16 b2 = (__bf16)r1;
+                op[16 * j] = b1;
+                op[plane + 16 * j] = b2;
+                op[2 * plane + 16 * j] = (__bf16)(r1 - (float)b2);
+            }
+        } else if (p.out_bf16) {
             __bf16* op = reinterpret_cast<__bf16*>(p.O) + off;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) op[16 * j] = (__bf16)(o[j][r] * inv);
@@ -237,6 +250,23 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) op[16 * j] = o[j][r] * inv;
         }
+    }
+}
+
+__device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y) {
+    if (p.out_bf16 == 2) {
+        __bf16* op = reinterpret_cast<__bf16*>(p.O) + idx;
+        const size_t plane = (size_t)p.nseq * p.Tq * p.ldo;
+        const __bf16 b1 = (__bf16)y;
+        const float r1 = y - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        op[0] = b1;
+        op[plane] = b2;
+        op[2 * plane] = (__bf16)(r1 - (float)b2);
+    } else if (p.out_bf16) {
+        reinterpret_cast<__bf16*>(p.O)[idx] = (__bf16)y;
+    } else {
+        p.O[idx] = y;
     }
 }
 
@@ -273,10 +303,7 @@ __global__ void attn_small_kernel(AttnArgs p) {
     const size_t off = ((size_t)seq * p.Tq + q) * p.ldo + head * DH;
     const float inv = 1.0f / l;
 #pragma unroll
-    for (int d = 0; d < DH; ++d) {
-        if (p.out_bf16) reinterpret_cast<__bf16*>(p.O)[off + d] = (__bf16)(acc[d] * inv);
-        else p.O[off + d] = acc[d] * inv;
-    }
+    for (int d = 0; d < DH; ++d) store_out(p, off + d, acc[d] * inv);
 }
 
 // Any-head-size fallback (dh <= 256, e.g. the 96-wide heads of the 768/8 clipTransEncoder text heads): one wavefront per
@@ -328,8 +355,7 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(AttnArgs p, int dh) {
     for (int i = 0; i < 4; ++i) {
         const int d = lane + 64 * i;
         if (d >= dh) continue;
-        if (p.out_bf16) reinterpret_cast<__bf16*>(p.O)[off + d] = (__bf16)(acc[i] * inv);
-        else p.O[off + d] = acc[i] * inv;
+        store_out(p, off + d, acc[i] * inv);
     }
 }
 

@@ -12,6 +12,7 @@ int mmdm_check_launch(const char* what);
 int mmdm_kernels_init(void);
 int mmdm_gemm_init(void);
 int mmdm_gemm_bf16_init(void);
+int mmdm_gemm_split_init(void);
 
 constexpr int MMDM_NF = 262;      // pose features per person (src/models/in2in.py:426, INPUT_DIM)
 constexpr int MMDM_NJ = 22;       // joints

@@ -38,6 +38,7 @@ int mmdm_kernels_init(void) {
     if (state == 0) return MMDM_OK;
     int rc = mmdm_gemm_init();
     if (!rc) rc = mmdm_gemm_bf16_init();
+    if (!rc) rc = mmdm_gemm_split_init();
     if (!rc) rc = mmdm_attn_init();
     if (!rc) state = 0;
     return rc;
@@ -220,11 +221,12 @@ int build_stack(mmdm_handle h, StackW& st, const std::string& pfx, int D, int F,
     RC(dalloc(h, &st.ada_w, (size_t)L * st.n_ada * 2 * D * D));
     RC(dalloc(h, &st.ada_b, (size_t)L * st.n_ada * 2 * D));
     st.layers.resize(L);
-    const bool bf = h->cfg.precision == 1;
+    const bool bf = h->cfg.precision >= 1;
+    const size_t planes = h->cfg.precision == 2 ? 3 : 1;   // fp32-split: three bf16 planes per weight (gemm_split.hip)
     if (bf) st.layers_b.resize(L);
-    auto twin = [&](void** p, size_t n) -> int {          // n bf16 elements
+    auto twin = [&](void** p, size_t n) -> int {          // n bf16 elements per plane
         float* q = nullptr;
-        RC(dalloc(h, &q, (n + 1) / 2));
+        RC(dalloc(h, &q, (planes * n + 1) / 2));
         *p = q;
         return MMDM_OK;
     };
@@ -403,6 +405,14 @@ int linear_b(const Ctx& c, const void* A, int lda, const void* W, int ldw, const
     return prof_end(c, 0);
 }
 
+// fp32-split GEMM (precision == 2): A and W as three bf16 planes, fp32 accuracy on the bf16 matrix cores (gemm_split.hip)
+int linear_s(const Ctx& c, const void* A, int lda, size_t a_plane, const void* W, int ldw, size_t w_plane, const float* bias, void* C, int ldc,
+             size_t c_plane, int out_split, int M, int N, int K, int epi, const float* extra, int ld_extra) {
+    RC(prof_begin(c, 0, 2.0 * M * N * K, 6.0 * ((double)M * K + (double)N * K) + (out_split ? 6.0 : 4.0) * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
+    RC(mmdm_linear_split(A, lda, (int64_t)a_plane, W, ldw, (int64_t)w_plane, bias, C, ldc, (int64_t)c_plane, out_split, M, N, K, epi, extra, ld_extra, 0, c.st));
+    return prof_end(c, 0);
+}
+
 int attention_b(const Ctx& c, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O, int ldo, int out_bf16,
                 int nseq, int Tq, int Tk, int H, int dh, int shift) {
     RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh, 4.0 * nseq * H * dh * (2.0 * Tq + 2.0 * Tk)));
@@ -416,12 +426,15 @@ int attention_b(const Ctx& c, const float* Q, int ldq, const float* K, int ldk, 
 int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     const Scratch& S = *c.s;
     const int D = w.D, F = w.F, R = r.nseq * r.T, dh = D / w.H;
-    const bool bf = c.h->cfg.precision == 1;
-    const int ob = bf ? 1 : 0;
+    const int prec = c.h->cfg.precision;
+    const bool bf = prec >= 1;
+    const int ob = prec;                    // output mode of the GEMM-operand producers: 0 fp32, 1 bf16, 2 three bf16 planes
     auto bw = [](const void* base, size_t elems) { return static_cast<const void*>(static_cast<const uint16_t*>(base) + elems); };
-    // one GEMM of the stack: fp32 (A fp32, W fp32) or bf16 (A bf16 from the producer, W twin)
-    auto gemm = [&](const float* A, int lda, const float* Wf, const void* Wb, size_t woff, const float* bias, float* C, int ldc, int out_b, int N, int K,
-                    int epi, const float* extra, int ld_extra) -> int {
+    // one GEMM of the stack: fp32 (A fp32, W fp32), bf16 (A bf16 from the producer, W twin) or fp32-split (three planes each).
+    // wtot = elements of the whole weight matrix the twin was made from (its plane stride); the A plane stride is R*K.
+    auto gemm = [&](const float* A, int lda, const float* Wf, const void* Wb, size_t woff, size_t wtot, const float* bias, float* C, int ldc, int out_b,
+                    int N, int K, int epi, const float* extra, int ld_extra) -> int {
+        if (prec == 2) return linear_s(c, A, lda, (size_t)R * K, bw(Wb, woff), K, wtot, bias, C, ldc, (size_t)R * N, out_b == 2, R, N, K, epi, extra, ld_extra);
         if (bf) return linear_b(c, A, lda, bw(Wb, woff), K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra);
         return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra);
     };
@@ -431,27 +444,27 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         auto ss_at = [&](int slot, int row0) { return r.ss + (size_t)row0 * r.ss_ld + ((size_t)l * w.n_ada + slot) * 2 * D; };
         // --- self attention (layers.py:36-45)
         RC(mmdm_adaln_ex(hbuf, ss_at(0, r.sa_row0), r.ss_ld, r.sa_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-        RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+        RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0));
         RC(attention_b(c, S.qkv, 3 * D, S.qkv + D, 3 * D, S.qkv + 2 * D, 3 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, 0));
         if (r.ca_mode) {
             // keys/values of the cross attention come from the layer INPUT of the other stream (or a fixed source):
             // project them before the residual below overwrites h.
             const float* src = r.ca_mode == 1 ? hbuf : r.kv_src;
             RC(mmdm_adaln_ex(src, ss_at(2, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0));
         }
-        RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+        RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         // --- cross attention (layers.py:77-88)
         if (r.ca_mode) {
             RC(mmdm_adaln_ex(hbuf, ss_at(1, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0));
+            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0));
             RC(attention_b(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
-            RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+            RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, (size_t)D * D, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         }
         // --- FFN (layers.py:99-106)
         RC(mmdm_adaln_ex(hbuf, ss_at(w.has_ca ? 3 : 1, r.ffn_row0), r.ss_ld, r.ffn_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-        RC(gemm(S.xn, D, lw.f1_w, lb.f1_w, 0, lw.f1_b, S.f1, F, ob, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
-        RC(gemm(S.f1, F, lw.f2_w, lb.f2_w, 0, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
+        RC(gemm(S.xn, D, lw.f1_w, lb.f1_w, 0, (size_t)F * D, lw.f1_b, S.f1, F, ob, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
+        RC(gemm(S.f1, F, lw.f2_w, lb.f2_w, 0, (size_t)D * F, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
     }
     return MMDM_OK;
 }
@@ -718,10 +731,11 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     if (has_mx && (cfg->mixing_mode < 1 || cfg->mixing_mode > 4)) return mmdm_set_error(MMDM_ERR_ARG, "Mode not recognized");
     if (cfg->max_batch <= 0 || cfg->max_frames <= 0 || cfg->text_dim <= 0 || cfg->text_dim % 4)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: bad max_batch / max_frames / text_dim");
-    if (cfg->precision < 0 || cfg->precision > 1) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: precision must be 0 (fp32) or 1 (bf16 GEMM operands)");
-    if (cfg->precision == 1 && ((D % 32) || (F % 32) || (D1 % 32) || (F1 % 32) || (has_mx && ((cfg->m_latent % 32) || (cfg->m_ff % 32)))))
+    if (cfg->precision < 0 || cfg->precision > 2)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: precision must be 0 (fp32 MFMA), 1 (bf16 GEMM operands) or 2 (fp32 by exact bf16 operand splitting)");
+    if (cfg->precision >= 1 && ((D % 32) || (F % 32) || (D1 % 32) || (F1 % 32) || (has_mx && ((cfg->m_latent % 32) || (cfg->m_ff % 32)))))
         return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: the bf16 path needs latent and ff sizes that are multiples of 32");
-    if (cfg->precision == 1 && mdm) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: the bf16 path does not cover MDMDenoiser");
+    if (cfg->precision >= 1 && mdm) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: the bf16 / fp32-split paths do not cover MDMDenoiser");
     RC(mmdm_kernels_init());
     mmdm_handle h = new mmdm_handle_s();
     h->cfg = *cfg;
@@ -746,8 +760,10 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     for (Scratch* sc : {&h->sa, &h->sb}) {
         if (sc == &h->sb && !two_models) break;
         const size_t d = sc == &h->sa ? Dx : (size_t)D, f = sc == &h->sa ? Fx : (size_t)F;
-        if ((rc = dalloc(h, &sc->h, R * d)) || (rc = dalloc(h, &sc->xn, R * d)) || (rc = dalloc(h, &sc->att, R * d)) ||
-            (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f)))
+        // GEMM-operand buffers (xn, att, f1) hold three bf16 planes in fp32-split mode: 6 bytes per element
+        const size_t opx = c.precision == 2 ? 3 : 2;       // in half-floats
+        if ((rc = dalloc(h, &sc->h, R * d)) || (rc = dalloc(h, &sc->xn, R * d * opx / 2)) || (rc = dalloc(h, &sc->att, R * d * opx / 2)) ||
+            (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f * opx / 2)))
             return fail(rc);
     }
     if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -839,19 +855,21 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
         }
     if (nmiss) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "Missing key(s) in state_dict (%d): %s%s", nmiss, missing.c_str(), nmiss > 4 ? ", ..." : ""));
     if (h->cfg.single_only == 0 && !h->stats_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_prepare: normaliser stats not set"));
-    if (h->cfg.precision == 1) {
+    if (h->cfg.precision >= 1) {
+        const bool split = h->cfg.precision == 2;
+        auto conv = [&](const float* src, void* dst, int64_t n) { return split ? mmdm_f32_split3(src, dst, n, n, nullptr) : mmdm_f32_to_bf16(src, dst, n, nullptr); };
         for (ModuleW* m : {&h->d1, &h->d2, &h->mx}) {
             StackW& st = m->st;
             for (size_t i = 0; i < st.layers_b.size(); ++i) {
                 const LayerW& lw = st.layers[i];
                 LayerWB& lb = st.layers_b[i];
                 const int64_t D = st.D, F = st.F;
-                int rc = mmdm_f32_to_bf16(lw.sa_in_w, lb.sa_in_w, 3 * D * D, nullptr);
-                if (!rc) rc = mmdm_f32_to_bf16(lw.sa_out_w, lb.sa_out_w, D * D, nullptr);
-                if (!rc) rc = mmdm_f32_to_bf16(lw.f1_w, lb.f1_w, F * D, nullptr);
-                if (!rc) rc = mmdm_f32_to_bf16(lw.f2_w, lb.f2_w, D * F, nullptr);
-                if (!rc && st.has_ca) rc = mmdm_f32_to_bf16(lw.ca_in_w, lb.ca_in_w, 3 * D * D, nullptr);
-                if (!rc && st.has_ca) rc = mmdm_f32_to_bf16(lw.ca_out_w, lb.ca_out_w, D * D, nullptr);
+                int rc = conv(lw.sa_in_w, lb.sa_in_w, 3 * D * D);
+                if (!rc) rc = conv(lw.sa_out_w, lb.sa_out_w, D * D);
+                if (!rc) rc = conv(lw.f1_w, lb.f1_w, F * D);
+                if (!rc) rc = conv(lw.f2_w, lb.f2_w, D * F);
+                if (!rc && st.has_ca) rc = conv(lw.ca_in_w, lb.ca_in_w, 3 * D * D);
+                if (!rc && st.has_ca) rc = conv(lw.ca_out_w, lb.ca_out_w, D * D);
                 if (rc) return herr(h, rc);
             }
         }

@@ -18,7 +18,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Reference: AdaLN.forward src/models/utils/layers.py:15-25 (LayerNorm eps 1e-6, biased variance, no affine).
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int MAXV, bool OBF>
+template <int MAXV, int OMODE>      // OMODE: 0 fp32, 1 bf16, 2 three bf16 planes (exact split, plane stride rows*D)
 __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h, const float* __restrict__ ss, int ss_ld, int ss_rows,
                                                      void* __restrict__ outv, int rows, int T, int D) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -54,7 +54,21 @@ __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h,
             const f32x4 sc = *reinterpret_cast<const f32x4*>(sp + 4 * c);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(sp + D + 4 * c);
             const f32x4 y = (v[i] - mean) * rstd * (1.0f + sc) + sh;
-            if (OBF) {
+            if (OMODE == 2) {
+                bf16x4 o1, o2, o3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o1[e] = (__bf16)y[e];
+                    const float r1 = y[e] - (float)o1[e];
+                    o2[e] = (__bf16)r1;
+                    o3[e] = (__bf16)(r1 - (float)o2[e]);
+                }
+                __bf16* op = static_cast<__bf16*>(outv) + (size_t)row * D + 4 * c;
+                const size_t plane = (size_t)rows * D;
+                *reinterpret_cast<bf16x4*>(op) = o1;
+                *reinterpret_cast<bf16x4*>(op + plane) = o2;
+                *reinterpret_cast<bf16x4*>(op + 2 * plane) = o3;
+            } else if (OMODE == 1) {
                 const bf16x4 o = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
                 *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(outv) + (size_t)row * D + 4 * c) = o;
             } else {
@@ -224,8 +238,9 @@ extern "C" int mmdm_adaln_ex(const float* h, const float* ss, int ss_ld, int ss_
     dim3 grid((rows + 3) / 4), block(256);
 #define ADALN_LAUNCH(V)                                                                                                   \
     do {                                                                                                                  \
-        if (out_bf16) hipLaunchKernelGGL((adaln_kernel<V, true>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);  \
-        else hipLaunchKernelGGL((adaln_kernel<V, false>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);          \
+        if (out_bf16 == 2) hipLaunchKernelGGL((adaln_kernel<V, 2>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);       \
+        else if (out_bf16) hipLaunchKernelGGL((adaln_kernel<V, 1>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);       \
+        else hipLaunchKernelGGL((adaln_kernel<V, 0>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);                     \
     } while (0)
     if (D <= 256) ADALN_LAUNCH(1);
     else if (D <= 512) ADALN_LAUNCH(2);

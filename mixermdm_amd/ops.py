@@ -231,3 +231,28 @@ def linear_bf16(x, weight, bias=None, epilogue="bias", extra=None, period=0, out
                                           C.c_void_p(out.data_ptr()), out.stride(0), int(out_dtype == torch.bfloat16), M, N, K, EPI[epilogue],
                                           _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
     return out.reshape(*x.shape[:-1], N)
+
+
+def split3(x):
+    """Exact 3-way bf16 split of an fp32 tensor: returns [3, *x.shape] torch.bfloat16 with x == out[0] + out[1] + out[2] (in real arithmetic)."""
+    _chk(x)
+    x = x.contiguous()
+    out = torch.empty(3, *x.shape, device=x.device, dtype=torch.bfloat16)
+    n = x.numel()
+    check(load_library().mmdm_f32_split3(_p(x), C.c_void_p(out.data_ptr()), n, n, _stream()))
+    return out
+
+
+def linear_split(xs, ws, bias=None, epilogue="bias", extra=None, period=0, split_out=False):
+    """fp32 y = x @ w.T + bias computed on the bf16 matrix cores from exactly split operands xs [3, M, K], ws [3, N, K] (split3).
+    Returns fp32 [M, N], or its split [3, M, N] when split_out."""
+    for t in (xs, ws):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or t.shape[0] != 3 or not t.is_contiguous():
+            raise TypeError("linear_split expects contiguous CUDA bfloat16 [3, rows, K] operands (ops.split3)")
+    _chk(bias, extra)
+    _, M, K = xs.shape
+    N = ws.shape[1]
+    out = torch.empty((3, M, N) if split_out else (M, N), device=xs.device, dtype=torch.bfloat16 if split_out else torch.float32)
+    check(load_library().mmdm_linear_split(C.c_void_p(xs.data_ptr()), K, M * K, C.c_void_p(ws.data_ptr()), K, N * K, _p(bias), C.c_void_p(out.data_ptr()), N,
+                                           M * N, int(split_out), M, N, K, EPI[epilogue], _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
+    return out

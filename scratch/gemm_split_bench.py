@@ -1,0 +1,47 @@
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, math, statistics, ctypes as C
+from mixermdm_amd import ops, load_library
+lib = load_library()
+lib.mmdmx_set_split_cfg.argtypes = [C.c_int]
+lib.mmdmx_set_split_ablate(int(os.environ.get('ABL','0')))
+d = torch.device("cuda:0")
+vp = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def split(x):
+    n = x.numel()
+    out = torch.empty(3, *x.shape, device=d, dtype=torch.bfloat16)
+    assert lib.mmdm_f32_split3(vp(x), vp(out), n, n, st()) == 0
+    return out
+def lin_split(xs, ws, b, epi, extra, out, M, N, K):
+    rc = lib.mmdm_linear_split(vp(xs), K, M * K, vp(ws), K, N * K, vp(b), vp(out), N, 0, 0, M, N, K, ops.EPI[epi], vp(extra), N if extra is not None else 0, 0, st())
+    assert rc == 0, lib.mmdm_last_error()
+shapes = [(19200,3072,1024,"qkv","bias"),(19200,1024,1024,"out","resid"),(19200,2048,1024,"ffn1","gelu"),(19200,1024,2048,"ffn2","resid"),
+          (19200,1536,512,"m.qkv","bias"),(19200,512,512,"m.out","resid"),(19200,512,1024,"m.ffn2","resid"),(4096,4096,4096,"sq4k","bias")]
+# accuracy vs float64
+M,N,K = 512, 384, 1024
+x = torch.randn(M,K,device=d); w = torch.randn(N,K,device=d)/math.sqrt(K); b = torch.randn(N,device=d)
+ref = (x.double() @ w.double().T + b.double())
+out = torch.empty(M,N,device=d)
+xs, ws = split(x), split(w)
+assert torch.equal((xs[0].float()+xs[1].float()+xs[2].float()), x), "split not exact"
+lin_split(xs, ws, b, "bias", None, out, M, N, K)
+nat = ops.linear(x, w, b)
+sc = ref.abs().mean()
+print(f"err/mean|ref|: split mean {(out.double()-ref).abs().mean()/sc:.3e} max {(out.double()-ref).abs().max()/sc:.3e} | native fp32 MFMA mean {(nat.double()-ref).abs().mean()/sc:.3e} max {(nat.double()-ref).abs().max()/sc:.3e}")
+cfgs = [int(c) for c in os.environ.get("CFGS","0,1,2,4").split(",")]
+for M,N,K,name,epi in shapes:
+    x = torch.randn(M,K,device=d); w = torch.randn(N,K,device=d)/math.sqrt(K); b = torch.randn(N,device=d)
+    out = torch.empty(M,N,device=d); extra = out if epi=="resid" else None
+    xs, ws = split(x), split(w)
+    line = f"{name:7s} {M}x{N}x{K} {epi:5s}"
+    for c in cfgs:
+        lib.mmdmx_set_split_cfg(c)
+        ts = []
+        for r in range(5):
+            lin_split(xs, ws, b, epi, extra, out, M, N, K)
+            e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4): lin_split(xs, ws, b, epi, extra, out, M, N, K)
+            e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1)/4)
+        ms = statistics.median(ts); line += f" | cfg{c}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:6.1f}TF"
+    print(line, flush=True)

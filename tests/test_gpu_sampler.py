@@ -374,3 +374,58 @@ def test_bf16_linear_matches_rounded_operand_reference():
     assert_close(g.float(), F.gelu(ref).float(), atol=1e-2, rtol=1e-2)
     with pytest.raises(MMDMError, match="K %% 32|K % 32"):
         ops.linear_bf16(xb[:, :48].contiguous(), wb[:, :48].contiguous())
+
+
+def test_split_linear_is_as_accurate_as_the_fp32_mfma():
+    """fp32-split GEMM (six bf16 MFMAs on exactly split operands) against a float64 product: error within 1.5x of the native fp32 MFMA
+    kernel's, orders of magnitude below bf16's; the split itself is exact; epilogues and split output included."""
+    from mixermdm_amd import ops, MMDMError
+    import torch.nn.functional as F
+    M, N, K = 500, 384, 1024
+    x, w, b, r = rnd(190, M, K), rnd(191, N, K, scale=0.03), rnd(192, N), rnd(193, M, N)
+    xs, ws = ops.split3(x.to(dev())), ops.split3(w.to(dev()))
+    assert torch.equal(xs[0].float() + xs[1].float() + xs[2].float(), x.to(dev()))     # fp32 sum of the planes restores x exactly
+    assert torch.equal(xs[0].cpu(), x.bfloat16())
+    ref = F.linear(x.double(), w.double(), b.double())
+    got = ops.linear_split(xs, ws, b.to(dev()))
+    nat = ops.linear(x.to(dev()), w.to(dev()), b.to(dev()))
+    e_split, e_nat = (got.cpu().double() - ref).abs(), (nat.cpu().double() - ref).abs()
+    assert e_split.mean() <= 1.5 * e_nat.mean() and e_split.max() <= 2.0 * e_nat.max(), (e_split.mean(), e_nat.mean(), e_split.max(), e_nat.max())
+    bf = ops.linear_bf16(ops.to_bf16(x.to(dev())), ops.to_bf16(w.to(dev())), b.to(dev()))
+    assert e_split.mean() * 200 < (bf.cpu().double() - ref).abs().mean()
+    assert_close(ops.linear_split(xs, ws, b.to(dev()), "resid", r.to(dev())), (ref + r.double()).float(), atol=1e-5, rtol=1e-5)
+    g = ops.linear_split(xs, ws, b.to(dev()), "gelu", split_out=True)
+    gs = g[0].float() + g[1].float() + g[2].float()
+    assert_close(gs, F.gelu(ref).float(), atol=1e-5, rtol=1e-5)
+    assert torch.equal(gs, ops.linear_split(xs, ws, b.to(dev()), "gelu"))              # the split output is the exact split of the fp32 one
+    with pytest.raises(MMDMError, match="K %% 32|K % 32"):
+        ops.linear_split(ops.split3(x[:, :40].contiguous().to(dev())), ops.split3(w[:, :40].contiguous().to(dev())))
+
+
+@pytest.mark.parametrize("B,T", [(2, 17), (1, 299), (3, 64)])
+def test_fp32_split_path_matches_oracle_like_the_fp32_path(full_small, B, T):
+    """precision="fp32_split" against the CPU oracle at real head sizes, SAME tolerance as the native fp32 path (STEP_TOL), and at
+    least as close to the oracle as 2x the native path's own distance."""
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd.synthetic import synthetic_inputs
+    s32, W, ostats = full_small
+    dims = dict(d_latent=512, d_ff=1024, d_layers=2, m_latent=256, m_ff=512, m_layers=2)
+    cond, xT = synthetic_inputs(B, T, seed_cond=21, seed_x=22)
+    spec = MX.MixerSpec(d_heads=4, m_heads=4)
+    osch = OS.make_schedule("cosine", 1000, "ddim20")
+    rx, rx2, p1, p2 = MX.mixer_ddim_step(W, spec, ostats, osch, 3.5, 19, xT, xT, cond)
+    s = Sampler(d_heads=4, m_heads=4, max_batch=B, max_frames=T, precision="fp32_split", **dims)
+    s.load_state_dict({k: v for k, v in W.items() if not k.endswith("sequence_pos_encoder.pe")})
+    s.set_norm_stats(*[t.numpy() for t in ostats])
+    s.prepare()
+    outs = {}
+    for nm, smp in (("split", s), ("native", s32)):
+        smp.set_schedule("ddim20")
+        smp.begin(cond, xT)
+        smp.run(1, use_graph=(nm == "split"))
+        outs[nm] = {k: v.clone() for k, v in smp.state().items() if v is not None}
+    for nm, ref in [("x", rx), ("x2", rx2), ("pred_xstart2", p2)]:
+        assert_close(outs["split"][nm], ref, what=f"fp32_split B={B} T={T} {nm}", **STEP_TOL)
+    med = lambda a, b: (a.cpu() - b).abs().median().item()
+    assert med(outs["split"]["x2"], rx2) <= 2 * med(outs["native"]["x2"], rx2) + 1e-7
+    s.close()
