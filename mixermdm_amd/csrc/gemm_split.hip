@@ -225,6 +225,238 @@ int set_attr() {
     return MMDM_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Deep-pipelined variant: K step 16 (32-byte LDS rows), NS-stage ring, counted vmcnt.
+//
+// Why: at the bf16 MFMA rate a 256x128 tile consumes 72 KB of operand planes per 0.64 us, and ~17 % of those lines miss the
+// 4 MiB XCD L2 (panels of K = 1024 are MBs) and come from the Infinity Cache 1-2 us later: with one stage of prefetch the K step
+// lasts as long as the slowest miss (measured 6.4 TB/s of L2->LDS traffic, 37 % of the split roof).  This kernel keeps NS-1
+// stages in flight (`s_waitcnt vmcnt(loads of the newer stages)`, never 0 inside the loop) and moves fewer bytes per flop
+// (256x256 tile: 48 KB per stage of 16 K-elements).  32-byte rows make the LDS image of a 32-row fragment 1 KiB contiguous: the
+// DMA piece and the ds_read_b128 fragment read are conflict-free without a swizzle.
+template <int TM_, int TN_, int NS_>
+struct PCfg {
+    static constexpr int WGM = TM_ / 10, WGN = TN_ / 10, TM = TM_ % 10, TN = TN_ % 10, NS = NS_;
+    static constexpr int NWAVES = WGM * WGN, THREADS = 64 * NWAVES;
+    static constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 16;
+    static constexpr int A_PLANE = BM * 8, B_PLANE = BN * 8;                      // 4-byte units (32 B per row)
+    static constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+    static constexpr int SMEM_BYTES = NS * STAGE * 4;
+    static constexpr int NAP = BM / 32, NBP = BN / 32;                            // 1-KiB pieces (32 rows x 32 B) per plane
+    static constexpr int NA = 3 * NAP, NB = 3 * NBP;
+    // DMA instructions per wave per stage; when the pieces do not divide evenly the surplus slots re-load the first pieces
+    // (same source, same destination: harmless) so that every wave counts the same number of loads per stage
+    static constexpr int NI = (NA + NB + NWAVES - 1) / NWAVES;
+    static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
+};
+
+// LDS-DMA issued from inline asm: hipcc (ROCm 7.2) otherwise treats every pending LDS-DMA as a possible writer of whatever a later
+// ds_read reads and drains the whole queue (s_waitcnt vmcnt(0)) before the first fragment is used -- which is exactly the overlap a
+// multi-stage ring exists for.  The queue is counted by hand instead (wait_vmcnt below).  LDS address = m0 + lane * 16.
+__device__ __forceinline__ void glds16(const void* gsrc, const float* lds_dst) {
+    const unsigned lds = (unsigned)(size_t)(lptr_t)lds_dst;
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds));      // no "memory" clobber: see above
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <class C_>
+__device__ __forceinline__ void pipe_step(float* __restrict__ wr, const float* __restrict__ rd, bool do_stage, const char* (&src)[C_::NI], const int (&dst)[C_::NI],
+                                          f32x16 (&acc)[C_::TM][C_::TN], int a_row, int b_row, bool do_read, bf16x8 (&af)[3][C_::TM], bf16x8 (&bf)[3][C_::TN]) {
+    constexpr int TM = C_::TM, TN = C_::TN;
+    if (do_stage) {
+#pragma unroll
+        for (int u = 0; u < C_::NI; ++u) {
+            glds16(src[u], wr + dst[u]);
+            src[u] += 2 * C_::BK;
+        }
+    }
+    if (do_read) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(rd + b_row + pl * C_::B_PLANE + j * 32 * 8));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(rd + a_row + pl * C_::A_PLANE + i * 32 * 8));
+        }
+    }
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);
+}
+
+template <int TM_, int TN_, int NS_>
+__global__ __launch_bounds__((PCfg<TM_, TN_, NS_>::THREADS)) void gemm_split_pipe_kernel(SArgs p) {
+    using C_ = PCfg<TM_, TN_, NS_>;
+    constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN, NS = C_::NS, NI = C_::NI;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][A planes 3*BM*8 | B planes 3*BN*8]
+
+    const int nwg = p.mt * p.nt;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // tiles that run together on an XCD form GM x nt groups walked n-fastest: a W panel is shared by GM concurrent tiles
+    constexpr int GM = 4;
+    const int grp = swz / (GM * p.nt), in = swz % (GM * p.nt);
+    const int gm = min(GM, p.mt - grp * GM);
+    const int m0 = (grp * GM + in % gm) * BM;
+    const int n0 = (in / gm) * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C_::WGN, wn = wave % C_::WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const char* src[NI];
+    int dst[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        int pq = wave + C_::NWAVES * u;
+        if (pq >= C_::NA + C_::NB) pq -= C_::NA + C_::NB;
+        const int prow = lane >> 1, pc = lane & 1;
+        const bool isa = pq < C_::NA;
+        const int pl = isa ? pq / C_::NAP : (pq - C_::NA) / C_::NBP;
+        const int pp = isa ? pq % C_::NAP : (pq - C_::NA) % C_::NBP;
+        const int trow = 32 * pp + prow;
+        if (isa) {
+            int grow = m0 + trow;
+            grow = grow < p.M ? grow : p.M - 1;
+            src[u] = reinterpret_cast<const char*>(p.A + (size_t)pl * p.pa + (size_t)grow * p.lda) + 16 * pc;
+            dst[u] = pl * C_::A_PLANE + 32 * pp * 8;
+        } else {
+            int grow = n0 + trow;
+            grow = grow < p.N ? grow : p.N - 1;
+            src[u] = reinterpret_cast<const char*>(p.W + (size_t)pl * p.pw + (size_t)grow * p.ldw) + 16 * pc;
+            dst[u] = 3 * C_::A_PLANE + pl * C_::B_PLANE + 32 * pp * 8;
+        }
+    }
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            glds16(src[u], smem + buf * C_::STAGE + dst[u]);
+            src[u] += 2 * BK;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * (32 * TM) + i * 32 + l31;
+        const bool rok = row < p.M;
+        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+        const bool ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && rok;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (col < p.N) {
+                    if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + col);
+                    if (ext) v += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = v[c];
+            }
+    }
+
+    const int nkt = p.K / BK;
+    // The bias / residual loads that initialise the accumulators must be retired HERE: left pending, the compiler waits for them at
+    // their first use -- the first MFMA of the loop body -- with an s_waitcnt vmcnt(0) that also drains the DMA ring every iteration.
+    // An opaque asm that touches each accumulator makes that wait land before the loop.
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // prologue: NS-1 stages in flight
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nkt) stage(s);
+
+    const int a_row = (wm * (32 * TM) + l31) * 8 + 4 * lh;
+    const int b_row = 3 * C_::A_PLANE + (wn * (32 * TN) + l31) * 8 + 4 * lh;
+
+    bf16x8 af[3][TM], bf[3][TN];
+    int buf = 0, nbuf = NS - 1;
+    for (int kt = 0; kt < nkt; ++kt) {
+        // stage kt has landed when at most the loads of the (NS-2) newer stages are still in flight
+        if (kt + NS - 1 <= nkt) wait_vmcnt<(NS - 2) * NI>();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tail: fewer stages behind it
+        __builtin_amdgcn_s_barrier();
+        // DMA destination and fragment source are different ring slots: passed as __restrict__ arguments of one inlined function so
+        // that the compiler's LDS-DMA tracking (alias scopes) does not drain the DMA queue (vmcnt(0)) before the fragment reads are used
+        pipe_step<C_>(smem + nbuf * C_::STAGE, smem + buf * C_::STAGE, kt + NS - 1 < nkt && !(p.ablate & 1), src, dst, acc, a_row, b_row,
+                      !(p.ablate & 2) || kt == 0, af, bf);
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * (32 * TM) + i * 32 + l31;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
+                if (col >= p.N) continue;
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float t = acc[i][j][4 * qd + c];
+                    if (p.epilogue == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
+                    else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
+                    v[c] = t;
+                }
+                if (p.out_split) {
+                    bf16x4 o1, o2, o3;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        o1[c] = (__bf16)v[c];
+                        const float r1 = v[c] - (float)o1[c];
+                        o2[c] = (__bf16)r1;
+                        o3[c] = (__bf16)(r1 - (float)o2[c]);
+                    }
+                    __bf16* cp = static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col;
+                    *reinterpret_cast<bf16x4*>(cp) = o1;
+                    *reinterpret_cast<bf16x4*>(cp + p.pc) = o2;
+                    *reinterpret_cast<bf16x4*>(cp + 2 * p.pc) = o3;
+                } else {
+                    *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
+                }
+            }
+    }
+}
+
+template <int TM_, int TN_, int NS_>
+int launch_pipe(SArgs a, hipStream_t st) {
+    using C_ = PCfg<TM_, TN_, NS_>;
+    a.mt = (a.M + C_::BM - 1) / C_::BM;
+    a.nt = (a.N + C_::BN - 1) / C_::BN;
+    hipLaunchKernelGGL((gemm_split_pipe_kernel<TM_, TN_, NS_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+    return mmdm_check_launch("gemm_split_pipe");
+}
+
+template <int TM_, int TN_, int NS_>
+int set_attr_pipe() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_pipe_kernel<TM_, TN_, NS_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PCfg<TM_, TN_, NS_>::SMEM_BYTES);
+    if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_split_pipe): %s", hipGetErrorString(e));
+    return MMDM_OK;
+}
+
 // x -> three bf16 planes out[0], out[plane], out[2*plane]; exact: x == out0 + out1 + out2 in real arithmetic
 __global__ void split3_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n, size_t plane) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -249,6 +481,10 @@ int mmdm_gemm_split_init(void) {
     if ((rc = set_attr<42, 22>())) return rc;
     if ((rc = set_attr<22, 21>())) return rc;
     if ((rc = set_attr<24, 22>())) return rc;
+    if ((rc = set_attr_pipe<24, 42, 3>())) return rc;     // 256 x 256, 8 waves (2 x 4), 128 x 64 per wave
+    if ((rc = set_attr_pipe<24, 22, 4>())) return rc;     // 256 x 128, 4 waves (2 x 2), 128 x 64 per wave
+    if ((rc = set_attr_pipe<22, 22, 6>())) return rc;     // 128 x 128, 4 waves
+    if ((rc = set_attr_pipe<42, 22, 4>())) return rc;     // 256 x 128, 8 waves (4 x 2), 64 x 64 per wave
     const char* e = getenv("MMDM_SPLIT_CFG");
     g_split_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
@@ -291,6 +527,13 @@ extern "C" int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const 
         case 1: return launch<42, 22>(a, st);
         case 2: return launch<22, 21>(a, st);
         case 4: return launch<24, 22>(a, st);
-        default: return launch<42, 22>(a, st);
+        case 10: return launch_pipe<24, 42, 3>(a, st);
+        case 11: return launch_pipe<24, 22, 4>(a, st);
+        case 12: return launch_pipe<22, 22, 6>(a, st);
+        case 13: return launch_pipe<42, 22, 4>(a, st);
+        default: break;
     }
+    // measured on M = 19 200 (scratch/gemm_split_bench.py): 128x64 tiles for the N = 512 mixer GEMMs (more tiles than CUs), 256x128 otherwise
+    if (N <= 512) return launch<22, 21>(a, st);
+    return launch<42, 22>(a, st);
 }

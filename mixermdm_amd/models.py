@@ -168,6 +168,7 @@ class MixerMDM(nn.Module):
         self.sampling_strategy = sampling_strategy
         self.betas = get_named_beta_schedule(self.beta_scheduler, self.diffusion_steps)
         self.history_every = 1
+        self.precision = "fp32"             # "fp32" (native fp32 MFMA, the parity path) | "fp32_split" (same accuracy, bf16 matrix cores) | "bf16"
         self.text_encoder = None            # optional callable(batch) -> cond [B, 8*768] overriding the built-in text stage
         self._text_sd, self._text_enc = None, None
         self.mixing = Mixer(self, self.mixing_mode, store_influence, cfg.FORCE_INFLUENCE_VAL, align=align)
@@ -251,7 +252,7 @@ class MixerMDM(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("MixerMDM runs on an MI355X only: call .to('cuda:N') first (no CPU path)")
         m = self.mixing
-        key = (str(dev), m.mixing_mode, bool(m.align), m.force_influence_val, self.cfg_model2.NAME, self.cfg_model1.NAME)
+        key = (str(dev), m.mixing_mode, bool(m.align), m.force_influence_val, self.cfg_model2.NAME, self.cfg_model1.NAME, self.precision)
         s = self._sampler
         if s is None or s._key != key or B > s.cfg.max_batch or T > s.cfg.max_frames:
             if s is not None:
@@ -260,7 +261,7 @@ class MixerMDM(nn.Module):
                         mixing_mode=m.mixing_mode, align=m.align, xstart_align=True,
                         model2_kind=1 if self.cfg_model2.NAME == "InterGen" else 0, force_influence_val=m.force_influence_val,
                         cfg_scale=self.cfg_mixing_weight, max_batch=max(B, s.cfg.max_batch if s else 1),
-                        max_frames=max(T, self.num_frames), device=dev, **self.dims)
+                        max_frames=max(T, self.num_frames), device=dev, precision=self.precision, **self.dims)
             s._key = key
             self._sampler, self._dirty = s, True
         if self._dirty:
