@@ -31,6 +31,7 @@ struct SArgs {
     int lda, ldw, ldc, ld_extra;
     int M, N, K, epilogue, period, out_split;
     int mt, nt, ablate;
+    int row0;                             // global index of row 0 (PE epilogue of a row-sliced launch)
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -109,7 +110,7 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
     for (int i = 0; i < TM; ++i) {
         const int row = m0 + wm * (32 * TM) + i * 32 + l31;
         const bool rok = row < p.M;
-        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (row + p.row0) % p.period : row;
         const bool ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && rok;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -349,7 +350,7 @@ __global__ __launch_bounds__((PCfg<TM_, TN_, NS_>::THREADS)) void gemm_split_pip
     for (int i = 0; i < TM; ++i) {
         const int row = m0 + wm * (32 * TM) + i * 32 + l31;
         const bool rok = row < p.M;
-        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (row + p.row0) % p.period : row;
         const bool ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && rok;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -520,7 +521,7 @@ extern "C" int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const 
     a.pa = (size_t)a_plane; a.pw = (size_t)w_plane; a.pc = (size_t)c_plane;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
     a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_split = out_split;
-    a.mt = a.nt = 0; a.ablate = g_split_ablate;
+    a.mt = a.nt = 0; a.ablate = g_split_ablate; a.row0 = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (g_split_cfg) {
         case 0: return launch<22, 22>(a, st);
@@ -535,5 +536,29 @@ extern "C" int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const 
     }
     // measured on M = 19 200 (scratch/gemm_split_bench.py): 128x64 tiles for the N = 512 mixer GEMMs (more tiles than CUs), 256x128 otherwise
     if (N <= 512) return launch<22, 21>(a, st);
-    return launch<42, 22>(a, st);
+    // 256x128 tiles run one workgroup per CU (144 KB of LDS), so a launch takes ceil(tiles / 256) rounds of equal-length tiles and a
+    // partly filled last round is pure loss (N = 1024, M = 19 200: 600 tiles = 2.34 -> 3 rounds).  Hybrid tiling: the leading M-tiles
+    // that fill whole rounds go to the 256x128 kernel, the remaining rows to the 128x64 kernel (2 workgroups per CU, 4x finer tiles).
+    int ncu = 256;
+    const int mt = (M + 255) / 256, nt = (N + 127) / 128;
+    int m_main = mt;
+    // measured (scratch/gemm_split_bench.py, M = 19 200): +5 % at N = 1024 (K = 1024 and 2048); at N >= 1536 the single launch is faster
+    // (tiles are not equally long there: L2 reuse differs along N), so the split is applied to N <= 1024 only
+    if ((long)mt * nt > ncu && N <= 1024 && !(g_split_ablate & 4)) {
+        for (int m = mt; m >= 1; --m) {
+            const long tiles = (long)m * nt, rounds = (tiles + ncu - 1) / ncu;
+            if ((double)tiles / (double)(rounds * ncu) >= 0.97) { m_main = m; break; }
+        }
+    }
+    if (m_main >= mt || (long)m_main * 256 >= M) return launch<42, 22>(a, st);
+    SArgs b = a;
+    const int M1 = m_main * 256;
+    a.M = M1;
+    if (int rc = launch<42, 22>(a, st)) return rc;
+    b.M = M - M1;
+    b.row0 = M1;
+    b.A = a.A + (size_t)M1 * lda;
+    b.C = out_split ? static_cast<void*>(static_cast<__bf16*>(C) + (size_t)M1 * ldc) : static_cast<void*>(static_cast<float*>(C) + (size_t)M1 * ldc);
+    if (ext && epilogue == MMDM_EPI_BIAS_RESID) b.extra = extra + (size_t)M1 * ld_extra;
+    return launch<22, 21>(b, st);
 }

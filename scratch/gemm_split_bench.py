@@ -28,7 +28,7 @@ lin_split(xs, ws, b, "bias", None, out, M, N, K)
 nat = ops.linear(x, w, b)
 sc = ref.abs().mean()
 print(f"err/mean|ref|: split mean {(out.double()-ref).abs().mean()/sc:.3e} max {(out.double()-ref).abs().max()/sc:.3e} | native fp32 MFMA mean {(nat.double()-ref).abs().mean()/sc:.3e} max {(nat.double()-ref).abs().max()/sc:.3e}")
-cfgs = [int(c) for c in os.environ.get("CFGS","0,1,2,4").split(",")]
+cfgs = [int(c) for c in os.environ.get("CFGS","-1,1").split(",")]
 for M,N,K,name,epi in shapes:
     x = torch.randn(M,K,device=d); w = torch.randn(N,K,device=d)/math.sqrt(K); b = torch.randn(N,device=d)
     out = torch.empty(M,N,device=d); extra = out if epi=="resid" else None
