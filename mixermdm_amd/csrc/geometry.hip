@@ -376,6 +376,20 @@ __global__ void hist_copy_kernel(const float* __restrict__ src, float* __restric
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) d[i] = src[i];
 }
 
+// Pose rows -> 16-byte-aligned, zero-padded GEMM operands: dst[p][r][0:ldp] = (src[r][p*262 : p*262+262], 0 ...).  The 262-float person
+// slices of a [rows, 524] motion tensor start at byte 1048 (not 16-byte aligned) and 262 is not a multiple of the GEMM's K step, so
+// the embedding GEMMs would otherwise run on the register-staged fallback kernel.
+__global__ void repack_pose_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int npers, int rows, int ldp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)rows * ldp;
+    if (i >= per * npers) return;
+    const int p = (int)(i / per);
+    const size_t rem = i - (size_t)p * per;
+    const size_t r = rem / ldp;
+    const int c = (int)(rem - r * ldp);
+    dst[i] = c < MMDM_NF ? src[r * ld_src + (size_t)p * MMDM_NF + c] : 0.f;
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int n, int D) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n * D) return;
@@ -482,6 +496,13 @@ extern "C" int mmdm_dual_ddim_f32(const float* m_ind, const float* m_int, const 
     hipLaunchKernelGGL(dual_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        m_ind, m_int, coef, S, step_idx, w_table, s_ind, s_int, x, pred_xstart, total);
     return mmdm_check_launch("dual_ddim");
+}
+
+int mmdm_repack_pose(const float* src, int ld_src, float* dst, int npers, int rows, int ldp, hipStream_t st) {
+    const size_t total = (size_t)npers * rows * ldp;
+    if (total == 0) return MMDM_OK;
+    hipLaunchKernelGGL(repack_pose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, ld_src, dst, npers, rows, ldp);
+    return mmdm_check_launch("repack_pose");
 }
 
 extern "C" int mmdm_gather_rows_f32(const float* src, const int* idx, float* dst, int n, int D, void* stream) {

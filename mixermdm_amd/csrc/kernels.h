@@ -30,3 +30,4 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
 int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
                   int nseq, int T, int D, hipStream_t st);
 int mmdm_mdm_unpack(const float* src, float* dst, int nseq, int T, int D, hipStream_t st);
+int mmdm_repack_pose(const float* src, int ld_src, float* dst, int npers, int rows, int ldp, hipStream_t st);

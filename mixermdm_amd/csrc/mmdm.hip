@@ -61,7 +61,8 @@ extern "C" const char* mmdm_version(void) { return "gfx950;mmdm-hip r1"; }
 namespace {
 
 constexpr int NF = MMDM_NF, NF2 = 2 * MMDM_NF;
-constexpr int NFP = 264;  // motion_embed weight rows padded to a multiple of 4 floats (16-byte loads)
+constexpr int NFP = 272;  // pose width padded to the GEMM's K step (16 floats): motion_embed weights are stored [D, 272] with zero columns and
+                          // the embedding GEMMs read repacked, zero-padded pose rows (mmdm_repack_pose), so they run on the LDS-DMA kernel
 
 // ------------------------------------------------------------------------------------------------------
 // weights
@@ -109,6 +110,7 @@ struct ModuleW {         // denoiser or mixer front/back ends
 
 struct Scratch {          // transformer-stack work buffers (one set per concurrently running stack)
     float *h = nullptr, *xn = nullptr, *qkv = nullptr, *kv = nullptr, *att = nullptr, *f1 = nullptr;
+    float *xp = nullptr;      // [2][rows][NFP] repacked pose operands of the embedding GEMMs
 };
 
 struct Prof {
@@ -478,8 +480,9 @@ int cond_vectors(const Ctx& c, const ModuleW& m, const float* txt, float* se, fl
 }
 
 // motion_embed + positional encoding of one person slice (in2in.py:426-431): x [nb*T rows, ld 524 or 262] -> h rows
-int embed(const Ctx& c, const ModuleW& m, const float* xsrc, int ldx, float* hdst, int nb, int T) {
-    return linear(c, xsrc, ldx, m.me_w, NFP, m.me_b, hdst, m.st.D, nb * T, m.st.D, NF, MMDM_EPI_BIAS_PE, m.pe, m.st.D, T, NFP);
+// xpad: one person's repacked rows [nb*T, NFP] (mmdm_repack_pose); pe_row0 = 1 for MDMDenoiser (token 0 is the conditioning token)
+int embed(const Ctx& c, const ModuleW& m, const float* xpad, float* hdst, int nb, int T, int pe_row0 = 0) {
+    return linear(c, xpad, NFP, m.me_w, NFP, m.me_b, hdst, m.st.D, nb * T, m.st.D, NFP, MMDM_EPI_BIAS_PE, m.pe + (size_t)pe_row0 * m.st.D, m.st.D, T, NFP);
 }
 
 // denoiser1 on the CFG-doubled batch n; xa [B or n rows...]: source rows are taken from `x` with `xrows` samples, repeated to n.
@@ -489,9 +492,10 @@ int run_denoiser(const Ctx& c, const ModuleW& m, bool interaction, const float* 
     mmdm_handle H = c.h;
     const int D = m.st.D;
     // embed: `x` holds xb samples (xb == n, or xb == n/2 when cond/uncond halves share the same x: cfg_sampler.py:41-42)
+    RC(mmdm_repack_pose(x, ldx, c.s->xp, npers, xb * T, NFP, c.st));
     for (int p = 0; p < npers; ++p)
         for (int rep = 0; rep < n / xb; ++rep)
-            RC(embed(c, m, x + (size_t)p * NF, ldx, c.s->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
+            RC(embed(c, m, c.s->xp + (size_t)p * xb * T * NFP, c.s->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
     StackRun r;
     r.nseq = npers * n; r.T = T; r.ss = ss; r.ss_ld = ss_ld;
     r.sa_row0 = 0; r.sa_rows = npers * n;
@@ -537,10 +541,10 @@ int run_denoiser_mdm(const Ctx& c, const ModuleW& m, const float* x, int xb, int
     const Scratch& S = *c.s;
     const int D = m.st.D, nseq = npers * n;
     // pose embeddings + pe[1 + t] (token 0 is the conditioning token) into S.att, then assemble [nseq, T+1, D] in S.h
+    RC(mmdm_repack_pose(x, ldx, S.xp, npers, xb * T, NFP, c.st));
     for (int p = 0; p < npers; ++p)
         for (int rep = 0; rep < n / xb; ++rep)
-            RC(linear(c, x + (size_t)p * NF, ldx, m.me_w, NFP, m.me_b, S.att + ((size_t)p * n + (size_t)rep * xb) * T * D, D, xb * T, D, NF,
-                      MMDM_EPI_BIAS_PE, m.pe + D, D, T, NFP));
+            RC(embed(c, m, S.xp + (size_t)p * xb * T * NFP, S.att + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T, 1));
     for (int p = 0; p < npers; ++p)
         RC(mmdm_mdm_pack(S.att + (size_t)p * n * T * D, cond + (size_t)p * D, ldc, m.time_tab, c.h->d_step, m.pe,
                          S.h + (size_t)p * n * (T + 1) * D, n, T, D, c.st));
@@ -562,9 +566,10 @@ int text_rows(const Ctx& c, const ModuleW& m, const float* cond, int ldc, int co
 // blocks in the reference, so its output is the LAST block applied once to the embedded input.
 int run_dual_individual(const Ctx& c, const ModuleW& m, const float* x, int xb, int n, int T, const float* ss, int ss_ld, float* out) {
     const int D = m.st.D;
+    RC(mmdm_repack_pose(x, NF2, c.s->xp, 2, xb * T, NFP, c.st));
     for (int p = 0; p < 2; ++p)
         for (int rep = 0; rep < n / xb; ++rep)
-            RC(embed(c, m, x + (size_t)p * NF, NF2, c.s->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
+            RC(embed(c, m, c.s->xp + (size_t)p * xb * T * NFP, c.s->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
     StackRun r;
     r.nseq = n; r.T = T; r.ss = ss; r.ss_ld = ss_ld;
     r.ca_row0 = 0; r.ca_rows = n; r.ca_mode = 0; r.kv_src = nullptr;
@@ -584,9 +589,11 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     const mmdm_config& cf = H->cfg;
     RC(mmdm_mixer_pre_f32(H->o1, H->o2, H->d_stats, H->out1, H->out2, n, T, cf.align, c.st));
     // motion_embed + PE of the four streams (mixermdm.py:722-732); seq = p*n + b
+    RC(mmdm_repack_pose(H->out1, NF2, H->sa.xp, 2, n * T, NFP, c.st));
+    RC(mmdm_repack_pose(H->out2, NF2, H->sb.xp, 2, n * T, NFP, c.st));
     for (int p = 0; p < 2; ++p) {
-        RC(embed(c, H->mx, H->out1 + (size_t)p * NF, NF2, c.s->h + (size_t)p * n * T * Dm, n, T));
-        RC(embed(c, H->mx, H->out2 + (size_t)p * NF, NF2, H->mI + (size_t)p * n * T * Dm, n, T));
+        RC(embed(c, H->mx, H->sa.xp + (size_t)p * n * T * NFP, c.s->h + (size_t)p * n * T * Dm, n, T));
+        RC(embed(c, H->mx, H->sb.xp + (size_t)p * n * T * NFP, H->mI + (size_t)p * n * T * Dm, n, T));
     }
     StackRun r;
     r.nseq = 2 * n; r.T = T; r.ss = H->ss_mx; r.ss_ld = H->mx.st.L * H->mx.st.n_ada * 2 * Dm;
@@ -763,7 +770,8 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
         // GEMM-operand buffers (xn, att, f1) hold three bf16 planes in fp32-split mode: 6 bytes per element
         const size_t opx = c.precision == 2 ? 3 : 2;       // in half-floats
         if ((rc = dalloc(h, &sc->h, R * d)) || (rc = dalloc(h, &sc->xn, R * d * opx / 2)) || (rc = dalloc(h, &sc->att, R * d * opx / 2)) ||
-            (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f * opx / 2)))
+            (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f * opx / 2)) ||
+            (rc = dalloc(h, &sc->xp, (size_t)2 * n * T * NFP)))
             return fail(rc);
     }
     if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
