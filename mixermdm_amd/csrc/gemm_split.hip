@@ -265,14 +265,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 template <class C_>
 __device__ __forceinline__ void pipe_step(float* __restrict__ wr, const float* __restrict__ rd, bool do_stage, const char* (&src)[C_::NI], const int (&dst)[C_::NI],
                                           f32x16 (&acc)[C_::TM][C_::TN], int a_row, int b_row, bool do_read, bf16x8 (&af)[3][C_::TM], bf16x8 (&bf)[3][C_::TN]) {
-    constexpr int TM = C_::TM, TN = C_::TN;
-    if (do_stage) {
-#pragma unroll
-        for (int u = 0; u < C_::NI; ++u) {
-            glds16(src[u], wr + dst[u]);
-            src[u] += 2 * C_::BK;
-        }
-    }
+    constexpr int TM = C_::TM, TN = C_::TN, NI = C_::NI;
     if (do_read) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
@@ -282,13 +275,26 @@ __device__ __forceinline__ void pipe_step(float* __restrict__ wr, const float* _
             for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(rd + a_row + pl * C_::A_PLANE + i * 32 * 8));
         }
     }
+    // The stage's DMA instructions are issued ONE PER GROUP OF MFMAs, not in a burst behind the barrier: an LDS-DMA issue holds the wave's
+    // instruction stream for ~20 cycles (per-lane addresses), and with both waves of a SIMD at the same program point a burst of NI of
+    // them leaves the MFMA pipe empty; between MFMAs the issue hides under the 32-cycle MFMA in flight.  sched_barrier pins the order.
     constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int PER = (NI + 5) / 6;
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < 6; ++t) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);
+        if (do_stage) {
+#pragma unroll
+            for (int u = t * PER; u < (t + 1) * PER && u < NI; ++u) {
+                glds16(src[u], wr + dst[u]);
+                src[u] += 2 * C_::BK;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int TM_, int TN_, int NS_>
