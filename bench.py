@@ -160,7 +160,7 @@ def main():
         alt_smp.close()
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:       # reported at N=1 only (the other ranks of an N>1 run would idle behind it)
         cpu = cpu_baseline(sd_cpu, stats, T, args.cpu_steps, single)
 
     if rank == 0:

@@ -101,6 +101,13 @@ enum { MMDM_ATTN_NO_ZERO_KEY = 1, MMDM_ATTN_CAUSAL = 2 };
 int mmdm_attention_opts(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O, int ldo, int out_bf16,
                         int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
 
+/* Attention with Q K^T on the bf16 matrix cores: Q and K are given as `nplanes` bf16 planes [plane][rows][ld] (plane strides in elements).
+ * nplanes = 3: exact 3-way splits of the fp32 projections -> fp32-accurate scores from six v_mfma_f32_16x16x32_bf16 per block (the
+ * fp32-split precision mode); nplanes = 1: bf16 Q and K (the bf16 path).  V is fp32; softmax, P.V and the output are those of
+ * mmdm_attention_opts (out_mode: 0 fp32, 1 bf16, 2 three bf16 planes; flags as there; zero key by default).  dh = 64 or 128. */
+int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
+                          void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
+
 /* out[r,:] = silu(time_row[:] + txt[r,:]) for r < rows; time_row = time_tab + (*step_idx) * D.
  * Replaces `embed_timestep(t) + text_embed(c)` followed by AdaLN's SiLU  in2in.py:415-422, layers.py:9-10. */
 int mmdm_cond_silu_f32(const float* time_tab, const int* step_idx, const float* txt, float* out, int rows, int D, void* stream);

@@ -42,6 +42,10 @@ struct AttnArgs {
     float scale, scale2;
     int out_bf16;      // 1: O written as bf16 (feeds the bf16 out-projection GEMM); 2: as three bf16 planes (exact split, plane stride nseq*Tq*ldo)
     int flags;         // MMDM_ATTN_NO_ZERO_KEY: plain softmax (nn.MultiheadAttention default); MMDM_ATTN_CAUSAL: key <= query only
+    // bf16-plane operands of Q K^T (attn_qkp_kernel): NP planes each, [plane][rows][ld] bf16
+    const __bf16* Qp; const __bf16* Kp;
+    size_t q_plane, k_plane;
+    int ldqp, ldkp;
 };
 
 // LDS image of one stage (KC keys): K rows and V rows are DH floats, unpadded (LDS-DMA writes 1 KiB contiguous pieces);
@@ -253,6 +257,227 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     }
 }
 
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Q K^T on the bf16 matrix cores, everything else as attn_mfma_kernel.
+// NP = 3: Q and K arrive as exact 3-way bf16 splits of the fp32 projections (written by the QKV GEMM's epilogue) and every score is the
+// six-term sum q1k1 + q1k2 + q2k1 + q1k3 + q3k1 + q2k2 accumulated in fp32 -- fp32-accurate scores (gemm_split.hip has the argument) from
+// 24 v_mfma_f32_16x16x32_bf16 (16 cycles each) instead of 32 v_mfma_f32_16x16x4_f32 (32 cycles each) per 16 keys x 16 queries x dh = 128.
+// NP = 1: plain bf16 Q and K (the bf16 path).  The 16x16 C/D register map is the same for every 16x16 MFMA (col = lane & 15 = query,
+// row = 4 * (lane >> 4) + reg = key), so the softmax and the fp32 P.V half of the kernel are untouched; V stays fp32.
+// K planes in LDS: [plane][16 keys][DH bf16], 16-byte chunk c of key row r stored at c ^ (r & (chunks_per_row - 1)).
+template <int DH, int NP>
+__global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
+    constexpr int NJ = DH / 16;                 // 16-wide output column tiles (PV)
+    constexpr int NS = DH / 32;                 // 32-deep reduction steps of Q K^T
+    constexpr int CPRK = DH / 8;                // 16-byte chunks per K row (bf16)
+    constexpr int RPPK = 64 / CPRK;             // K rows per 1-KiB DMA piece
+    constexpr int NPK = KC / RPPK;              // pieces per K plane
+    constexpr int CPR = DH / 4;                 // 16-byte chunks per V row (fp32)
+    constexpr int RPP = 64 / CPR;
+    constexpr int NPV = KC / RPP;
+    constexpr int NPIECE = NP * NPK + NPV;
+    constexpr int NI = (NPIECE + 3) / 4;
+    constexpr int KPLANE = KC * DH / 2;         // floats per K plane
+    constexpr int STAGE = NP * KPLANE + KC * DH;
+    constexpr int NT = NP == 3 ? 6 : 1;
+    constexpr int TK[6] = {1, 2, 0, 1, 0, 0}, TQ[6] = {1, 0, 2, 0, 1, 0};      // (K plane, Q plane) per term, small terms first
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 stages][K planes | V]
+
+    const int bid = blockIdx.x;
+    const int local = bid >> 3, xcd = bid & 7;
+    const int qt = local % p.qtiles;
+    const int sh = xcd * p.pairs_per_xcd + local / p.qtiles;
+    if (sh >= p.nseq * p.H) return;
+    const int head = sh % p.H;
+    const int seq = sh / p.H;
+    const int kvseq = (seq + p.shift) % p.nseq;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 15, g = lane >> 4;
+    const int q0 = qt * QB + wave * QW;
+
+    // Q fragments (B operand): lane (q = lq, g) holds Q[q][32 s + 8 g .. + 7] of every plane
+    bf16x8 qf[NP][NS];
+    {
+        int qrow = q0 + lq;
+        if (qrow >= p.Tq) qrow = p.Tq - 1;
+        const __bf16* qp = p.Qp + ((size_t)seq * p.Tq + qrow) * p.ldqp + head * DH + 8 * g;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) qf[pl][s] = *reinterpret_cast<const bf16x8*>(qp + (size_t)pl * p.q_plane + 32 * s);
+    }
+
+    f32x4 o[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool nozero = (p.flags & MMDM_ATTN_NO_ZERO_KEY) != 0, causal = (p.flags & MMDM_ATTN_CAUSAL) != 0;
+    float m_run = nozero ? -INFINITY : 0.f, l_run = nozero ? 0.f : 1.f;
+
+    const __bf16* Kg = p.Kp + (size_t)kvseq * p.Tk * p.ldkp + head * DH;
+    const float* Vg = p.V + (size_t)kvseq * p.Tk * p.ldv + head * DH;
+
+    auto stage = [&](int c0, int buf) {
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int pq = wave + 4 * u;
+            if (pq >= NPIECE) break;                                   // wave-uniform
+            float* base = smem + buf * STAGE;
+            if (pq < NP * NPK) {
+                const int pl = pq / NPK, pp = pq % NPK;
+                const int trow = RPPK * pp + lane / CPRK;
+                const int pos = lane % CPRK;
+                const int src_chunk = pos ^ (trow & (CPRK - 1));
+                int krow = c0 + trow;
+                krow = krow < p.Tk ? krow : p.Tk - 1;
+                const __bf16* src = Kg + (size_t)pl * p.k_plane + (size_t)krow * p.ldkp + 8 * src_chunk;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + pl * KPLANE + RPPK * pp * (DH / 2)), 16, 0, 0);
+            } else {
+                const int pp = pq - NP * NPK;
+                const int trow = RPP * pp + lane / CPR;
+                const int pos = lane % CPR;
+                const int src_chunk = pos ^ (4 * ((trow >> 2) & 1));
+                int krow = c0 + trow;
+                krow = krow < p.Tk ? krow : p.Tk - 1;
+                const float* src = Vg + (size_t)krow * p.ldv + 4 * src_chunk;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + NP * KPLANE + RPP * pp * DH), 16, 0, 0);
+            }
+        }
+    };
+
+    int nchunks = (p.Tk + KC - 1) / KC;
+    if (causal) {
+        const int last_q = min(qt * QB + QB - 1, p.Tq - 1);
+        nchunks = min(nchunks, last_q / KC + 1);
+    }
+    stage(0, 0);
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int c0 = ci * KC, cur = ci & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ci + 1 < nchunks) stage(c0 + KC, cur ^ 1);
+        const float* Ks = smem + cur * STAGE;
+        const float* Vs = Ks + NP * KPLANE;
+
+        // S^T tile (16 keys x 16 queries): one accumulator per 32-deep reduction step so that consecutive MFMAs are independent
+        f32x4 sa[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sa[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 kf[NP][NS];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                kf[pl][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Ks[pl * KPLANE + lq * (DH / 2) + 4 * ((4 * s + g) ^ (lq & (CPRK - 1)))]));
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                sa[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[NP == 3 ? TK[t] : 0][s], qf[NP == 3 ? TQ[t] : 0][s], sa[s], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) MFMA_SETTLE(sa[s]);
+        f32x4 st[1];
+        st[0] = sa[0];
+#pragma unroll
+        for (int s = 1; s < NS; ++s) st[0] += sa[s];
+        st[0] *= p.scale2;
+
+        if (c0 + KC > p.Tk || (causal && c0 + KC - 1 > q0)) {
+            const int kmax = causal ? min(p.Tk - 1, q0 + lq) : p.Tk - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c0 + 4 * g + r > kmax) st[0][r] = -INFINITY;
+        }
+        float cmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float m_new = fmaxf(m_run, cmax);
+        const float alpha = EXP2(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st[0][r] = EXP2(st[0][r] - m_new);
+            lsum += st[0][r];
+        }
+        lsum += __shfl_xor(lsum, 16);
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+
+        float ar[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];
+
+        const int vsw = 16 * (g & 1);
+        float vb[2][NJ];
+        {
+            const float* vrow = &Vs[(4 * g) * DH + lq];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) vb[0][j] = vrow[(16 * j) ^ vsw];
+        }
+#pragma unroll
+        for (int idx = 0; idx < 4; ++idx) {
+            const int r = idx & 3, cb = idx & 1;
+            if (idx + 1 < 4) {
+                const float* vrow = &Vs[(4 * g + idx + 1) * DH + lq];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) vb[cb ^ 1][j] = vrow[(16 * j) ^ vsw];
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[0][r], vb[cb][j], o[j], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
+    float lr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run, 4 * g + r);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * g + r;
+        if (qrow >= p.Tq) continue;
+        const float inv = 1.0f / lr[r];
+        const size_t off = ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH + lq;
+        const size_t plane = (size_t)p.nseq * p.Tq * p.ldo;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float y = o[j][r] * inv;
+            if (p.out_bf16 == 2) {
+                __bf16* op = reinterpret_cast<__bf16*>(p.O) + off + 16 * j;
+                const __bf16 b1 = (__bf16)y;
+                const float r1 = y - (float)b1;
+                const __bf16 b2 = (__bf16)r1;
+                op[0] = b1;
+                op[plane] = b2;
+                op[2 * plane] = (__bf16)(r1 - (float)b2);
+            } else if (p.out_bf16) {
+                reinterpret_cast<__bf16*>(p.O)[off + 16 * j] = (__bf16)y;
+            } else {
+                p.O[off + 16 * j] = y;
+            }
+        }
+    }
+}
+
+template <int DH, int NP>
+constexpr int qkp_smem() { return 2 * (NP * KC * DH / 2 + KC * DH) * 4; }
+
+template <int DH, int NP>
+int launch_qkp(const AttnArgs& a, hipStream_t st) {
+    constexpr int smem_bytes = qkp_smem<DH, NP>();
+    hipLaunchKernelGGL((attn_qkp_kernel<DH, NP>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), smem_bytes, st, a);
+    return mmdm_check_launch("attn_qkp");
+}
+
 __device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y) {
     if (p.out_bf16 == 2) {
         __bf16* op = reinterpret_cast<__bf16*>(p.O) + idx;
@@ -383,6 +608,10 @@ int mmdm_attn_init(void) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<64>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem<64>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<128, 3>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<64, 3>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<128, 1>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<64, 1>());
     if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(attn): %s", hipGetErrorString(e));
     return MMDM_OK;
 }
@@ -412,6 +641,7 @@ extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int 
     AttnArgs a;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
     a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags;
+    a.Qp = a.Kp = nullptr; a.q_plane = a.k_plane = 0; a.ldqp = a.ldkp = 0;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
     a.pairs_per_xcd = (nseq * H + 7) / 8;
@@ -435,4 +665,32 @@ extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int 
     const int total = nseq * H * Tq;
     hipLaunchKernelGGL(attn_wave_kernel, dim3((total + 3) / 4), dim3(256), 0, st, a, dh);
     return mmdm_check_launch("attn_wave");
+}
+
+extern "C" int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
+                                     void* Ov, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
+    if (nseq == 0 || Tq == 0) return MMDM_OK;
+    if (int rc = mmdm_kernels_init()) return rc;
+    if (!Qp || !Kp || !V || !Ov || nseq < 0 || Tq < 0 || Tk <= 0 || H <= 0 || (nplanes != 1 && nplanes != 3))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: bad arguments nseq=%d Tq=%d Tk=%d H=%d planes=%d", nseq, Tq, Tk, H, nplanes);
+    if (dh != 64 && dh != 128) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_attention_planes: head dim %d not supported (64, 128)", dh);
+    if (flags & ~(MMDM_ATTN_NO_ZERO_KEY | MMDM_ATTN_CAUSAL)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: unknown flags 0x%x", flags);
+    if ((flags & MMDM_ATTN_CAUSAL) && (Tq != Tk || !(flags & MMDM_ATTN_NO_ZERO_KEY)))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: the causal mask needs Tq == Tk and no zero key");
+    if (ldq < H * dh || ldk < H * dh || ldv < H * dh || ldo < H * dh) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: row strides must cover H*dh=%d", H * dh);
+    const bool al = ((reinterpret_cast<uintptr_t>(Qp) | reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(V)) & 15) == 0 && ((ldq | ldk) & 7) == 0 &&
+                    (ldv & 3) == 0 && (q_plane & 7) == 0 && (k_plane & 7) == 0;
+    if (!al) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: Q/K planes and V must be 16-byte aligned (bf16 strides %% 8, fp32 strides %% 4)");
+    AttnArgs a;
+    a.Q = nullptr; a.K = nullptr; a.V = V; a.O = static_cast<float*>(Ov); a.ldq = 0; a.ldk = 0; a.ldv = ldv; a.ldo = ldo;
+    a.Qp = static_cast<const __bf16*>(Qp); a.Kp = static_cast<const __bf16*>(Kp); a.q_plane = (size_t)q_plane; a.k_plane = (size_t)k_plane; a.ldqp = ldq; a.ldkp = ldk;
+    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags;
+    a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
+    a.qtiles = (Tq + QB - 1) / QB;
+    a.pairs_per_xcd = (nseq * H + 7) / 8;
+    a.scale = 1.0f / sqrtf((float)dh);
+    a.scale2 = a.scale * 1.4426950408889634f;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (nplanes == 3) return dh == 128 ? launch_qkp<128, 3>(a, st) : launch_qkp<64, 3>(a, st);
+    return dh == 128 ? launch_qkp<128, 1>(a, st) : launch_qkp<64, 1>(a, st);
 }

@@ -24,6 +24,7 @@ struct BArgs {
     int lda, ldw, ldc, ld_extra;          // element strides
     int M, N, K, epilogue, period, out_bf16;
     int mt, nt;
+    __bf16* P2; int p2_cols, ld2;         // optional second output: columns [0, p2_cols) also as bf16 (attention Q/K operands)
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -170,12 +171,13 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BA
                     else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
                     v[c] = t;
                 }
-                if (p.out_bf16) {
-                    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col) = o;
-                } else {
-                    *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
+                const bool second = p.P2 && col < p.p2_cols;
+                if (p.out_bf16 || second) {
+                    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    if (p.out_bf16) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col) = o;
+                    if (second) *reinterpret_cast<bf16x4*>(p.P2 + (size_t)row * p.ld2 + col) = o;
                 }
+                if (!p.out_bf16) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
             }
     }
 }
@@ -227,6 +229,11 @@ extern "C" int mmdm_f32_to_bf16(const float* in, void* out, int64_t n, void* str
 
 extern "C" int mmdm_linear_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16,
                                 int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
+    return mmdm_linear_bf16_ex(A, lda, W, ldw, bias, C, ldc, out_bf16, M, N, K, epilogue, extra, ld_extra, period, nullptr, 0, 0, stream);
+}
+
+int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16,
+                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* bf16_copy, int ld2, int copy_cols, void* stream) {
     if (M == 0 || N == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < K || ldc < N)
@@ -245,6 +252,8 @@ extern "C" int mmdm_linear_bf16(const void* A, int lda, const void* W, int ldw, 
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
     a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_bf16 = out_bf16;
     a.mt = a.nt = 0;
+    a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
+    if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (g_bf16_cfg) {
         case 0: return launch<22, 22>(a, st);

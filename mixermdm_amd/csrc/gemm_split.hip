@@ -32,6 +32,7 @@ struct SArgs {
     int M, N, K, epilogue, period, out_split;
     int mt, nt, ablate;
     int row0;                             // global index of row 0 (PE epilogue of a row-sliced launch)
+    __bf16* P2; size_t p2_plane; int p2_cols, ld2;   // optional second output: columns [0, p2_cols) also as three bf16 planes (attention Q/K operands)
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -189,7 +190,8 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
                     else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
                     v[c] = t;
                 }
-                if (p.out_split) {
+                const bool second = p.P2 && col < p.p2_cols;
+                if (p.out_split || second) {
                     bf16x4 o1, o2, o3;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -198,13 +200,20 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
                         o2[c] = (__bf16)r1;
                         o3[c] = (__bf16)(r1 - (float)o2[c]);
                     }
-                    __bf16* cp = static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col;
-                    *reinterpret_cast<bf16x4*>(cp) = o1;
-                    *reinterpret_cast<bf16x4*>(cp + p.pc) = o2;
-                    *reinterpret_cast<bf16x4*>(cp + 2 * p.pc) = o3;
-                } else {
-                    *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
+                    if (p.out_split) {
+                        __bf16* cp = static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col;
+                        *reinterpret_cast<bf16x4*>(cp) = o1;
+                        *reinterpret_cast<bf16x4*>(cp + p.pc) = o2;
+                        *reinterpret_cast<bf16x4*>(cp + 2 * p.pc) = o3;
+                    }
+                    if (second) {
+                        __bf16* cp = p.P2 + (size_t)(row + p.row0) * p.ld2 + col;
+                        *reinterpret_cast<bf16x4*>(cp) = o1;
+                        *reinterpret_cast<bf16x4*>(cp + p.p2_plane) = o2;
+                        *reinterpret_cast<bf16x4*>(cp + 2 * p.p2_plane) = o3;
+                    }
                 }
+                if (!p.out_split) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
             }
     }
 }
@@ -427,7 +436,8 @@ __global__ __launch_bounds__((PCfg<TM_, TN_, NS_>::THREADS)) void gemm_split_pip
                     else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
                     v[c] = t;
                 }
-                if (p.out_split) {
+                const bool second = p.P2 && col < p.p2_cols;
+                if (p.out_split || second) {
                     bf16x4 o1, o2, o3;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -436,13 +446,20 @@ __global__ __launch_bounds__((PCfg<TM_, TN_, NS_>::THREADS)) void gemm_split_pip
                         o2[c] = (__bf16)r1;
                         o3[c] = (__bf16)(r1 - (float)o2[c]);
                     }
-                    __bf16* cp = static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col;
-                    *reinterpret_cast<bf16x4*>(cp) = o1;
-                    *reinterpret_cast<bf16x4*>(cp + p.pc) = o2;
-                    *reinterpret_cast<bf16x4*>(cp + 2 * p.pc) = o3;
-                } else {
-                    *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
+                    if (p.out_split) {
+                        __bf16* cp = static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col;
+                        *reinterpret_cast<bf16x4*>(cp) = o1;
+                        *reinterpret_cast<bf16x4*>(cp + p.pc) = o2;
+                        *reinterpret_cast<bf16x4*>(cp + 2 * p.pc) = o3;
+                    }
+                    if (second) {
+                        __bf16* cp = p.P2 + (size_t)(row + p.row0) * p.ld2 + col;
+                        *reinterpret_cast<bf16x4*>(cp) = o1;
+                        *reinterpret_cast<bf16x4*>(cp + p.p2_plane) = o2;
+                        *reinterpret_cast<bf16x4*>(cp + 2 * p.p2_plane) = o3;
+                    }
                 }
+                if (!p.out_split) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
             }
     }
 }
@@ -509,6 +526,12 @@ extern "C" int mmdm_f32_split3(const float* in, void* out, int64_t n, int64_t pl
 
 extern "C" int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const void* W, int ldw, int64_t w_plane, const float* bias, void* C, int ldc,
                                  int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
+    return mmdm_linear_split_ex(A, lda, a_plane, W, ldw, w_plane, bias, C, ldc, c_plane, out_split, M, N, K, epilogue, extra, ld_extra, period, nullptr, 0, 0, 0, stream);
+}
+
+int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W, int ldw, int64_t w_plane, const float* bias, void* C, int ldc,
+                         int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period,
+                         void* planes2, int ld2, int64_t plane2_stride, int planes2_cols, void* stream) {
     if (M == 0 || N == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < K || ldc < N || a_plane <= 0 || w_plane <= 0 || (out_split && c_plane <= 0))
@@ -528,6 +551,9 @@ extern "C" int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const 
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
     a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_split = out_split;
     a.mt = a.nt = 0; a.ablate = g_split_ablate; a.row0 = 0;
+    a.P2 = static_cast<__bf16*>(planes2); a.p2_plane = (size_t)plane2_stride; a.p2_cols = planes2_cols; a.ld2 = ld2;
+    if (planes2 && ((ld2 & 3) || (plane2_stride & 3) || (planes2_cols & 3) || !al16(planes2)))
+        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split: second output needs 8-byte aligned bf16 rows / planes");
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (g_split_cfg) {
         case 0: return launch<22, 22>(a, st);

@@ -31,3 +31,8 @@ int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* tim
                   int nseq, int T, int D, hipStream_t st);
 int mmdm_mdm_unpack(const float* src, float* dst, int nseq, int T, int D, hipStream_t st);
 int mmdm_repack_pose(const float* src, int ld_src, float* dst, int npers, int rows, int ldp, hipStream_t st);
+int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W, int ldw, int64_t w_plane, const float* bias, void* C, int ldc,
+                         int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period,
+                         void* planes2, int ld2, int64_t plane2_stride, int planes2_cols, void* stream);
+int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16,
+                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* bf16_copy, int ld2, int copy_cols, void* stream);

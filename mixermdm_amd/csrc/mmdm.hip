@@ -111,6 +111,7 @@ struct ModuleW {         // denoiser or mixer front/back ends
 struct Scratch {          // transformer-stack work buffers (one set per concurrently running stack)
     float *h = nullptr, *xn = nullptr, *qkv = nullptr, *kv = nullptr, *att = nullptr, *f1 = nullptr;
     float *xp = nullptr;      // [2][rows][NFP] repacked pose operands of the embedding GEMMs
+    void *qk = nullptr, *kvp = nullptr;   // precision >= 1: bf16 plane copies of the attention's Q|K ([planes][R][2D]) and cross-attention K ([planes][R][D])
 };
 
 struct Prof {
@@ -400,19 +401,34 @@ struct StackRun {
 
 // h [nseq*T, D] is updated in place through the L blocks (TransformerBlockDoubleCond / TransformerBlock / InfluenceBlockCross).
 // bf16-operand GEMM with the same accounting as linear()
+struct Second {           // optional second GEMM output: leading columns also as bf16 plane(s) for the attention kernel
+    void* p = nullptr;
+    int ld = 0, cols = 0;
+    size_t plane = 0;
+};
+
 int linear_b(const Ctx& c, const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16, int M, int N, int K,
-             int epi = MMDM_EPI_BIAS, const float* extra = nullptr, int ld_extra = 0) {
+             int epi = MMDM_EPI_BIAS, const float* extra = nullptr, int ld_extra = 0, Second s2 = Second()) {
     RC(prof_begin(c, 0, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + (out_bf16 ? 2.0 : 4.0) * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
-    RC(mmdm_linear_bf16(A, lda, W, ldw, bias, C, ldc, out_bf16, M, N, K, epi, extra, ld_extra, 0, c.st));
+    RC(mmdm_linear_bf16_ex(A, lda, W, ldw, bias, C, ldc, out_bf16, M, N, K, epi, extra, ld_extra, 0, s2.p, s2.ld, s2.cols, c.st));
     return prof_end(c, 0);
 }
 
 // fp32-split GEMM (precision == 2): A and W as three bf16 planes, fp32 accuracy on the bf16 matrix cores (gemm_split.hip)
 int linear_s(const Ctx& c, const void* A, int lda, size_t a_plane, const void* W, int ldw, size_t w_plane, const float* bias, void* C, int ldc,
-             size_t c_plane, int out_split, int M, int N, int K, int epi, const float* extra, int ld_extra) {
+             size_t c_plane, int out_split, int M, int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) {
     RC(prof_begin(c, 0, 2.0 * M * N * K, 6.0 * ((double)M * K + (double)N * K) + (out_split ? 6.0 : 4.0) * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
-    RC(mmdm_linear_split(A, lda, (int64_t)a_plane, W, ldw, (int64_t)w_plane, bias, C, ldc, (int64_t)c_plane, out_split, M, N, K, epi, extra, ld_extra, 0, c.st));
+    RC(mmdm_linear_split_ex(A, lda, (int64_t)a_plane, W, ldw, (int64_t)w_plane, bias, C, ldc, (int64_t)c_plane, out_split, M, N, K, epi, extra, ld_extra, 0,
+                            s2.p, s2.ld, (int64_t)s2.plane, s2.cols, c.st));
     return prof_end(c, 0);
+}
+
+// attention whose Q K^T runs on the bf16 matrix cores from the plane copies written by the projection GEMMs
+int attention_p(const Ctx& c, const void* Qp, int ldq, size_t q_plane, const void* Kp, int ldk, size_t k_plane, int np, const float* V, int ldv, void* O, int ldo,
+                int out_mode, int nseq, int Tq, int Tk, int H, int dh, int shift) {
+    RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh, 4.0 * nseq * H * dh * (2.0 * Tq + 2.0 * Tk)));
+    RC(mmdm_attention_planes(Qp, ldq, (int64_t)q_plane, Kp, ldk, (int64_t)k_plane, np, V, ldv, O, ldo, out_mode, 0, nseq, Tq, Tk, H, dh, shift, c.st));
+    return prof_end(c, 1);
 }
 
 int attention_b(const Ctx& c, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O, int ldo, int out_bf16,
@@ -435,32 +451,43 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     // one GEMM of the stack: fp32 (A fp32, W fp32), bf16 (A bf16 from the producer, W twin) or fp32-split (three planes each).
     // wtot = elements of the whole weight matrix the twin was made from (its plane stride); the A plane stride is R*K.
     auto gemm = [&](const float* A, int lda, const float* Wf, const void* Wb, size_t woff, size_t wtot, const float* bias, float* C, int ldc, int out_b,
-                    int N, int K, int epi, const float* extra, int ld_extra) -> int {
-        if (prec == 2) return linear_s(c, A, lda, (size_t)R * K, bw(Wb, woff), K, wtot, bias, C, ldc, (size_t)R * N, out_b == 2, R, N, K, epi, extra, ld_extra);
-        if (bf) return linear_b(c, A, lda, bw(Wb, woff), K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra);
+                    int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) -> int {
+        if (prec == 2) return linear_s(c, A, lda, (size_t)R * K, bw(Wb, woff), K, wtot, bias, C, ldc, (size_t)R * N, out_b == 2, R, N, K, epi, extra, ld_extra, s2);
+        if (bf) return linear_b(c, A, lda, bw(Wb, woff), K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra, s2);
         return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra);
     };
+    // bf16 path with a head size the plane kernel covers: the projection GEMMs also emit a bf16 copy of Q and K and the scores come from
+    // the bf16 matrix cores (attn_qkp_kernel): 20.1 -> 18.7 ms/step.  In fp32-split mode the three-plane copies cost more than the faster
+    // Q K^T gains (51.6 vs 49.8 ms/step: P.V and the softmax are 60 % of the kernel), so that mode keeps the fp32 attention (MMDM_QKP=1 forces it).
+    static const bool force_qkp = getenv("MMDM_QKP") != nullptr, no_qkp = getenv("MMDM_NO_QKP") != nullptr;
+    const bool qkp = bf && (prec == 1 || force_qkp) && (dh == 64 || dh == 128) && S.qk && !no_qkp;
+    const int np = prec == 2 ? 3 : 1;
+    auto second = [&](void* buf, int ld, int cols) { Second s2; if (qkp) { s2.p = buf; s2.ld = ld; s2.cols = cols; s2.plane = (size_t)R * ld; } return s2; };
     for (int l = r.l0; l < w.L; ++l) {
         const LayerW& lw = w.layers[l];
         const LayerWB lb = bf ? w.layers_b[l] : LayerWB();
         auto ss_at = [&](int slot, int row0) { return r.ss + (size_t)row0 * r.ss_ld + ((size_t)l * w.n_ada + slot) * 2 * D; };
         // --- self attention (layers.py:36-45)
         RC(mmdm_adaln_ex(hbuf, ss_at(0, r.sa_row0), r.ss_ld, r.sa_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-        RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0));
-        RC(attention_b(c, S.qkv, 3 * D, S.qkv + D, 3 * D, S.qkv + 2 * D, 3 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, 0));
+        RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, 2 * D, 2 * D)));
+        if (qkp) RC(attention_p(c, S.qk, 2 * D, (size_t)R * 2 * D, static_cast<const uint16_t*>(S.qk) + D, 2 * D, (size_t)R * 2 * D, np, S.qkv + 2 * D, 3 * D, S.att, D, ob,
+                                r.nseq, r.T, r.T, w.H, dh, 0));
+        else RC(attention_b(c, S.qkv, 3 * D, S.qkv + D, 3 * D, S.qkv + 2 * D, 3 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, 0));
         if (r.ca_mode) {
             // keys/values of the cross attention come from the layer INPUT of the other stream (or a fixed source):
             // project them before the residual below overwrites h.
             const float* src = r.ca_mode == 1 ? hbuf : r.kv_src;
             RC(mmdm_adaln_ex(src, ss_at(2, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, D, D)));
         }
         RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         // --- cross attention (layers.py:77-88)
         if (r.ca_mode) {
             RC(mmdm_adaln_ex(hbuf, ss_at(1, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0));
-            RC(attention_b(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
+            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
+            if (qkp) RC(attention_p(c, S.qk, D, (size_t)R * D, S.kvp, D, (size_t)R * D, np, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
+                                    r.ca_mode == 1 ? r.nseq / 2 : 0));
+            else RC(attention_b(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
             RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, (size_t)D * D, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         }
         // --- FFN (layers.py:99-106)
@@ -773,6 +800,12 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
             (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f * opx / 2)) ||
             (rc = dalloc(h, &sc->xp, (size_t)2 * n * T * NFP)))
             return fail(rc);
+        if (c.precision >= 1) {
+            const size_t npl = c.precision == 2 ? 3 : 1;
+            float *q1 = nullptr, *q2 = nullptr;
+            if ((rc = dalloc(h, &q1, npl * R * d)) || (rc = dalloc(h, &q2, npl * R * d / 2 + 1))) return fail(rc);     // bf16 [npl][R][2d], [npl][R][d]
+            sc->qk = q1; sc->kvp = q2;
+        }
     }
     if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)

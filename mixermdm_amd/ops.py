@@ -256,3 +256,18 @@ def linear_split(xs, ws, bias=None, epilogue="bias", extra=None, period=0, split
     check(load_library().mmdm_linear_split(C.c_void_p(xs.data_ptr()), K, M * K, C.c_void_p(ws.data_ptr()), K, N * K, _p(bias), C.c_void_p(out.data_ptr()), N,
                                            M * N, int(split_out), M, N, K, EPI[epilogue], _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
     return out
+
+
+def attention_planes(qp, kp, v, num_heads, kv_seq_shift=0, zero_key=True, causal=False):
+    """Attention with Q K^T on the bf16 matrix cores.  qp [NP, nseq, Tq, H*dh], kp [NP, nseq, Tk, H*dh] torch.bfloat16 (NP = 3: exact splits
+    from split3 -> fp32-accurate scores; NP = 1: bf16), v [nseq, Tk, H*dh] fp32 (may be a column slice).  Returns fp32 [nseq, Tq, H*dh]."""
+    _chk(v)
+    NP, nseq, Tq, HD = qp.shape
+    Tk = kp.shape[2]
+    assert qp.dtype == torch.bfloat16 and kp.dtype == torch.bfloat16 and qp.is_cuda and kp.is_cuda and kp.shape[0] == NP
+    assert qp.stride(3) == 1 and kp.stride(3) == 1 and v.stride(2) == 1
+    out = torch.empty(nseq, Tq, HD, device=v.device, dtype=torch.float32)
+    flags = (0 if zero_key else ATTN_NO_ZERO_KEY) | (ATTN_CAUSAL if causal else 0)
+    check(load_library().mmdm_attention_planes(C.c_void_p(qp.data_ptr()), qp.stride(2), qp.stride(0), C.c_void_p(kp.data_ptr()), kp.stride(2), kp.stride(0), NP,
+                                               _p(v), v.stride(1), _p(out), HD, 0, flags, nseq, Tq, Tk, num_heads, HD // num_heads, kv_seq_shift, _stream()))
+    return out

@@ -405,3 +405,36 @@ def test_cfg_ddim_single_chain():
     p = ops.cfg_ddim(m.to(dev()), coef, torch.tensor([17], dtype=torch.int32, device=dev()), 3.5, xd)
     assert_close(p, x0, atol=2e-6, rtol=1e-5)
     assert_close(xd, ref, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dh,H,T,zero_key,causal", [(128, 2, 300, True, False), (64, 3, 77, True, False), (128, 1, 45, False, False), (64, 2, 130, False, True)])
+def test_attention_with_bf16_plane_scores(dh, H, T, zero_key, causal):
+    """Q K^T from exactly split bf16 planes (six MFMAs per block) must reproduce the fp32 attention to fp32 accuracy; with one plane
+    (bf16 Q, K) it must match a reference that rounds Q and K to bf16."""
+    from mixermdm_amd import ops
+    import math
+    n = 3
+    qkv = rnd(17, n, T, 3 * H * dh)
+    d = qkv.to(dev())
+    q, k, v = d[..., :H * dh], d[..., H * dh:2 * H * dh], d[..., 2 * H * dh:]
+
+    def ref(qr, kr, vr):
+        sp = lambda t: t.reshape(n, -1, H, dh).transpose(1, 2).double()
+        qs, ks, vs = sp(qr), sp(kr), sp(vr)
+        if zero_key:
+            z = torch.zeros(n, H, 1, dh, dtype=torch.float64)
+            ks, vs = torch.cat([ks, z], 2), torch.cat([vs, z], 2)
+        sc = (qs @ ks.transpose(-1, -2)) / math.sqrt(dh)
+        if causal:
+            sc = sc + torch.full((T, T), float("-inf"), dtype=torch.float64).triu_(1)
+        return (torch.softmax(sc, -1) @ vs).transpose(1, 2).reshape(n, T, H * dh).float()
+
+    qc, kc, vc = q.cpu(), k.cpu(), v.cpu()
+    got3 = ops.attention_planes(ops.split3(q.contiguous()), ops.split3(k.contiguous()), v, H, zero_key=zero_key, causal=causal)
+    native = ops.attention(q, k, v, H, zero_key=zero_key, causal=causal)
+    want = ref(qc, kc, vc)
+    assert_close(got3, want, atol=2e-5, rtol=1e-4, what="attention, split planes")
+    e3, en = (got3.cpu() - want).abs().mean().item(), (native.cpu() - want).abs().mean().item()
+    assert e3 <= 2 * en + 1e-8, (e3, en)
+    got1 = ops.attention_planes(q.contiguous().bfloat16()[None], k.contiguous().bfloat16()[None], v, H, zero_key=zero_key, causal=causal)
+    assert_close(got1, ref(qc.bfloat16().float(), kc.bfloat16().float(), vc), atol=2e-5, rtol=1e-4, what="attention, bf16 Q/K")
