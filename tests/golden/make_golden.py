@@ -480,7 +480,39 @@ def g_text():
     save("text", **out)
 
 
+# ---- G16 mixer at dimensions the bf16-matrix-core GEMM modes accept (K % 32 == 0) ---------------------------------------
+def g_mixer32():
+    """Same objects as g_mixer with latent 32 / ff 64: the smallest sizes the fp32-split (and bf16) GEMM kernels take, so that those modes
+    are pinned against the reference itself and not only against the oracle."""
+    den = dict(latent_dim=32, ff_size=64, num_layers=2, num_heads=2, dropout=0.1)
+    d1 = in2INDenoiser(262, mode="individual", **den)
+    d2 = in2INDenoiser(262, mode="interaction", **den)
+    mix = reinit(Mixer(d1, d2, nfeats=262, latent_dim=32, ff_size=64, text_dim=768, n_blocks=2, n_heads=2, mixing_mode=4, store_influence=True,
+                       force_influence_val=None, mode="eval", align=True), 200)
+    B, T = 2, 8
+    out = {k: v for k, v in STATS.items()}
+    out.update(sd(mix, "mix."))
+    B2 = 2 * B
+    x1, x2, cond = rnd(280, B2, T, 524), rnd(281, B2, T, 524), rnd(282, B2, 8 * 768)
+    cond[B:] = 0
+    t = torch.full((B2,), 640, dtype=torch.long)
+    out.update(x1=x1, x2=x2, cond=cond, t=t)
+    reset_hist(mix)
+    out["fwd"] = mix(x1, t, cond=cond, mask=None, x2=x2)
+    cfg = ClassifierFreeSampleModelX2(mix, 3.5)
+    xT, cb = rnd(286, B, T, 524), rnd(285, B, 8 * 768)
+    out.update(x_T=xT, cfg_cond=cb)
+    reset_hist(mix)
+    r = make_diffusion("ddim20").ddim_sample(cfg, xT, xT.clone(), torch.tensor([12] * B), clip_denoised=False, model_kwargs={"mask": None, "cond": cb})
+    for k in ["sample", "sample2", "pred_xstart", "pred_xstart2"]:
+        out[f"ddim:i12:{k}"] = r[k]
+    reset_hist(mix)
+    out["loop:ddim20:output"] = make_diffusion("ddim20").ddim_sample_loop(cfg, (B, T, 524), noise=xT.clone(), clip_denoised=False, progress=False,
+                                                                         model_kwargs={"mask": None, "cond": cb})
+    save("mixer32", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "pe", "layers", "denoisers", "influence", "geometry", "mixer", "single", "interaction", "dual", "mdm", "text"]
+    which = sys.argv[1:] or ["schedule", "pe", "layers", "denoisers", "influence", "geometry", "mixer", "single", "interaction", "dual", "mdm", "text", "mixer32"]
     for w in which:
         globals()["g_" + w]()

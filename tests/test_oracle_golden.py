@@ -307,3 +307,17 @@ def test_text_heads(golden):
     for enc, ln, key in [("clipTransEncoder.", "clip_ln", "mixer:cond"), ("clipTransEncoder_individual.", "clip_ln_individual", "in2in:individual:cond"),
                          ("clipTransEncoder_interaction.", "clip_ln_interaction", "in2in:interaction:cond"), ("clipTransEncoder.", "clip_ln", "intergen:cond")]:
         close(EN.text_head(W, enc, ln, clip_out, tok, H), g[key], atol=1e-5, rtol=1e-4)
+
+
+# ---- G16 ----------------------------------------------------------------------------------------
+def test_mixer32_fixture(golden):
+    """The latent-32 fixture (pins the bf16-matrix-core GEMM modes on the GPU side): oracle == reference."""
+    g, w, t = golden("mixer32")
+    W = w("mix.", [("sequence_pos_encoder.pe", 32), ("denoiser1.sequence_pos_encoder.pe", 32), ("denoiser2.sequence_pos_encoder.pe", 32)])
+    stats = tuple(torch.from_numpy(g[k]) for k in ["mean_hml", "std_hml", "mean_ih", "std_ih"])
+    spec = MX.MixerSpec(d_heads=2, m_heads=2)
+    close_frac(MX.mixer_forward(W, spec, stats, t("x1"), t("t").long(), t("cond"), t("x2")), g["fwd"], **MIX_TOL)
+    sched = S.make_schedule("cosine", 1000, "ddim20")
+    r = MX.mixer_ddim_step(W, spec, stats, sched, 3.5, 12, t("x_T"), t("x_T"), t("cfg_cond"))
+    for k, v in zip(["sample", "sample2", "pred_xstart", "pred_xstart2"], r):
+        close_frac(v, g[f"ddim:i12:{k}"], atol=2e-4, rtol=2e-4)
