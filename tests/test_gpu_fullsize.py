@@ -85,3 +85,37 @@ def test_full_size_history_contract_and_reference_quirks(big):
     p = out["pred_xstart"][..., :262] * std + mean
     assert p[:, 0, 0].abs().max() < 1e-3 and p[:, 0, 2].abs().max() < 1e-3
     assert (p[:, :, 1:66:3].amin(dim=(1, 2))).abs().max() < 1e-3                                            # feet on the floor: min Y == 0
+
+
+def test_full_size_fp32_split_mode_is_deterministic_batch_independent_and_tracks_fp32(big):
+    """precision="fp32_split" at full size: bitwise deterministic, graph == eager, motion k independent of the batch it is sampled in (the
+    hybrid 256x128 / 128x64 tiling sends a row to different kernels depending on M: both accumulate in the same order), and within fp32
+    rounding noise of the native path after STEPS steps."""
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_stats, FULL_DIMS
+    s32, cond, xT, st = big
+    s32.set_schedule("ddim1000")
+    ref, _ = run(s32, cond, xT, STEPS)
+    sd = synthetic_state_dict(seed=0, std=0.02, bias_std=0.02, **FULL_DIMS)
+    s = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, precision="fp32_split", **FULL_DIMS)
+    s.load_state_dict(sd)
+    s.set_norm_stats(st["mean_hml"], st["std_hml"], st["mean_ih"], st["std_ih"])
+    s.prepare()
+    s.set_schedule("ddim1000")
+    a, _ = run(s, cond, xT, STEPS, graph=True)
+    b, _ = run(s, cond, xT, STEPS, graph=False)
+    # yardstick: how far the NATIVE path moves when x_T is perturbed at the fp32 rounding level (1 ulp ~ 6e-8 relative) -- the network
+    # (26 blocks, softmax, LayerNorm, atan2 geometry) amplifies rounding noise by 2-3 orders of magnitude, whichever kernel produced it
+    g = torch.Generator().manual_seed(99)
+    noisy, _ = run(s32, cond, xT * (1 + 1.2e-7 * torch.randn(xT.shape, generator=g)), STEPS)
+    relf = lambda u, v: ((u - v).pow(2).mean().sqrt() / v.pow(2).mean().sqrt()).item()
+    for k in ("x", "x2", "pred_xstart2"):
+        assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k
+        rel, yard = relf(a[k], ref[k]), relf(noisy[k], ref[k])
+        print(f"{k}: fp32_split vs fp32 {rel:.3e}; fp32 with 1-ulp input noise vs fp32 {yard:.3e}")
+        assert rel < 4 * yard + 1e-7, (k, rel, yard)
+    assert not torch.equal(a["x"], ref["x"])                # the split kernels really ran
+    for k in (3, 15):
+        one, _ = run(s, cond[k:k + 1], xT[k:k + 1], STEPS)
+        assert torch.equal(one["x"][0], a["x"][k]) and torch.equal(one["x2"][0], a["x2"][k]), k
+    s.close()
