@@ -244,7 +244,6 @@ def test_attention_unsupported_head_dim():
     with pytest.raises(MMDMError, match="head dim"):
         ops.attention(x, x, x, 1)
     x = torch.randn(2, 9, 2 * 24, device=dev())    # dh = 24 runs on the fallback, with the zero key
-    q, k, v = x.cpu().view(2, 9, 2, 24).transpose(1, 2).unbind(0)[0], None, None
     ref = torch.nn.functional.scaled_dot_product_attention
     xs = x.cpu().view(2, 9, 2, 24).transpose(1, 2)
     z = torch.zeros(2, 2, 1, 24)
