@@ -106,30 +106,59 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
         }
     };
 
+    // Accumulators start as bias (+ residual / + PE row).  All loads are issued back to back behind WAVE-UNIFORM branches and waited for
+    // once: with per-element runtime conditions hipcc branches around every load and waits vmcnt(0) after each one -- 16-32 serialized
+    // L2 round trips per tile, fully exposed at one workgroup per CU.  Rows / columns past the edge read a clamped (valid) address: their
+    // accumulators are never stored.
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = m0 + wm * (32 * TM) + i * 32 + l31;
-        const bool rok = row < p.M;
-        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (row + p.row0) % p.period : row;
-        const bool ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && rok;
+    {
+        const bool has_bias = p.bias != nullptr;
+        const bool has_ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
+        f32x4 bv[TN][4], ev[TM][TN][4];
+        int colc[TN][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (col < p.N) {
-                    if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + col);
-                    if (ext) v += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = v[c];
+                colc[j][qd] = min(n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh, p.N - 4);
+                bv[j][qd] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        if (has_bias) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) bv[j][qd] = *reinterpret_cast<const f32x4*>(p.bias + colc[j][qd]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) ev[i][j][qd] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_ext) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rowc = min(m0 + wm * (32 * TM) + i * 32 + l31, p.M - 1);
+                const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (rowc + p.row0) % p.period : rowc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) ev[i][j][qd] = *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + colc[j][qd]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x4 v = bv[j][qd] + ev[i][j][qd];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = v[c];
+                }
     }
 
     const int nkt = p.K / BK;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stage(0);
 
     const int sw = (l31 >> 2) & 3;
@@ -360,26 +389,56 @@ __global__ __launch_bounds__((PCfg<TM_, TN_, NS_>::THREADS)) void gemm_split_pip
         }
     };
 
+    // Accumulators start as bias (+ residual / + PE row).  All loads are issued back to back behind WAVE-UNIFORM branches and waited for
+    // once: with per-element runtime conditions hipcc branches around every load and waits vmcnt(0) after each one -- 16-32 serialized
+    // L2 round trips per tile, fully exposed at one workgroup per CU.  Rows / columns past the edge read a clamped (valid) address: their
+    // accumulators are never stored.
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = m0 + wm * (32 * TM) + i * 32 + l31;
-        const bool rok = row < p.M;
-        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (row + p.row0) % p.period : row;
-        const bool ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && rok;
+    {
+        const bool has_bias = p.bias != nullptr;
+        const bool has_ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
+        f32x4 bv[TN][4], ev[TM][TN][4];
+        int colc[TN][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (col < p.N) {
-                    if (p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + col);
-                    if (ext) v += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = v[c];
+                colc[j][qd] = min(n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh, p.N - 4);
+                bv[j][qd] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        if (has_bias) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) bv[j][qd] = *reinterpret_cast<const f32x4*>(p.bias + colc[j][qd]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) ev[i][j][qd] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_ext) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rowc = min(m0 + wm * (32 * TM) + i * 32 + l31, p.M - 1);
+                const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (rowc + p.row0) % p.period : rowc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) ev[i][j][qd] = *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + colc[j][qd]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x4 v = bv[j][qd] + ev[i][j][qd];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = v[c];
+                }
     }
 
     const int nkt = p.K / BK;
