@@ -454,3 +454,28 @@ def test_every_precision_mode_vs_reference_golden_at_latent_32(golden, prec):
     else:
         assert d.mean() <= 2e-3 and np.percentile(d, 99) <= 3e-2, (prec, d.mean(), np.percentile(d, 99), d.max())
     s.close()
+
+
+def test_long_sequence_beyond_the_reference_default(full_small):
+    """T = 700 frames (the reference's default is 300; its pe table allows 5000): one step against the oracle, own handle sized for it."""
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd.synthetic import synthetic_inputs
+    _, W, ostats = full_small
+    dims = dict(d_latent=512, d_ff=1024, d_layers=2, m_latent=256, m_ff=512, m_layers=2)
+    B, T = 1, 700
+    s = Sampler(d_heads=4, m_heads=4, max_batch=B, max_frames=T, **dims)
+    s.load_state_dict({k: v for k, v in W.items() if not k.endswith("sequence_pos_encoder.pe")})
+    s.set_norm_stats(*[t.numpy() for t in ostats])
+    s.prepare()
+    s.set_schedule("ddim20")
+    cond, xT = synthetic_inputs(B, T, seed_cond=31, seed_x=32)
+    s.begin(cond, xT)
+    s.run(1, use_graph=True)
+    st = s.state()
+    rx, rx2, p1, p2 = MX.mixer_ddim_step(W, MX.MixerSpec(d_heads=4, m_heads=4), ostats, OS.make_schedule("cosine", 1000, "ddim20"), 3.5, 19, xT, xT, cond)
+    for nm, ref in [("x", rx), ("x2", rx2), ("pred_xstart2", p2)]:
+        assert_close(st[nm], ref, what=f"T=700 {nm}", **STEP_TOL)
+    from mixermdm_amd._lib import MMDMError
+    with pytest.raises(MMDMError, match="exceed"):
+        s.begin(*synthetic_inputs(1, 701))
+    s.close()
