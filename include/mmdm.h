@@ -46,7 +46,8 @@ enum {
     MMDM_EPI_BIAS_RESID = 2, /* C = A W^T + b + R   (R may alias C)             "+ x" residuals         src/models/utils/blocks.py:50-63 */
     MMDM_EPI_BIAS_PE = 3,    /* C = A W^T + b + pe[m % period]                  motion_embed + PositionalEncoding  src/models/in2in.py:426-431 */
     MMDM_EPI_BIAS_SILU = 4,  /* C = silu(A W^T + b)                             TimestepEmbedder time_embed.0+SiLU src/models/utils/utils.py:47-51 */
-    MMDM_EPI_BIAS_QUICKGELU = 5 /* C = z*sigmoid(1.702 z), z = A W^T + b            CLIP text tower MLP (clip==1.0 model.py QuickGELU; src/models/mixermdm.py:213) */
+    MMDM_EPI_BIAS_QUICKGELU = 5, /* C = z*sigmoid(1.702 z), z = A W^T + b           CLIP text tower MLP (clip==1.0 model.py QuickGELU; src/models/mixermdm.py:213) */
+    MMDM_EPI_BIAS_SIGMOID = 6   /* C = sigmoid(A W^T + b)                           Influence.out + sigmoid  src/models/utils/influence.py:124-125 */
 };
 
 /* y = x W^T + b with a fused epilogue; exact fp32 (v_mfma_f32_32x32x2_f32).

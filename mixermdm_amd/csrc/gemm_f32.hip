@@ -48,6 +48,7 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ base, int ld, i
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x * (1.0f / (1.0f + expf(-1.702f * x))); }   // CLIP QuickGELU: x * sigmoid(1.702 x)
 
 // Tile configuration: the workgroup is WGM x WGN waves (encoded as TM = 10*WGM + tiles, TN likewise: TM=22 -> 2 waves x 2 tiles),
@@ -189,6 +190,7 @@ __global__ __launch_bounds__((Cfg<TM_, TN_, BK_>::THREADS)) void gemm_f32_kernel
                 if (p.epilogue == MMDM_EPI_BIAS_GELU) v = gelu_erf(v);
                 else if (p.epilogue == MMDM_EPI_BIAS_SILU) v = silu(v);
                 else if (p.epilogue == MMDM_EPI_BIAS_QUICKGELU) v = quick_gelu(v);
+                else if (p.epilogue == MMDM_EPI_BIAS_SIGMOID) v = sigmoidf(v);
                 p.C[(size_t)row * p.ldc + col] = v;
             }
         }
@@ -401,6 +403,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
                         if (p.epilogue == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
                         else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
                         else if (p.epilogue == MMDM_EPI_BIAS_QUICKGELU) t = quick_gelu(t);
+                        else if (p.epilogue == MMDM_EPI_BIAS_SIGMOID) t = sigmoidf(t);
                         v[c] = t;
                     }
                     *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
@@ -422,6 +425,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
                 if (p.epilogue == MMDM_EPI_BIAS_GELU) v = gelu_erf(v);
                 else if (p.epilogue == MMDM_EPI_BIAS_SILU) v = silu(v);
                 else if (p.epilogue == MMDM_EPI_BIAS_QUICKGELU) v = quick_gelu(v);
+                else if (p.epilogue == MMDM_EPI_BIAS_SIGMOID) v = sigmoidf(v);
                 p.C[(size_t)row * p.ldc + col] = v;
             }
         }
@@ -547,7 +551,7 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     if (int rc = mmdm_kernels_init()) return rc;
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < Kw || Kw < K || ldc < N)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32: bad shape M=%d N=%d K=%d lda=%d ldw=%d ldc=%d", M, N, K, lda, ldw, ldc);
-    if (epilogue < MMDM_EPI_BIAS || epilogue > MMDM_EPI_BIAS_QUICKGELU)
+    if (epilogue < MMDM_EPI_BIAS || epilogue > MMDM_EPI_BIAS_SIGMOID)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32: unknown epilogue %d", epilogue);
     if ((epilogue == MMDM_EPI_BIAS_RESID || epilogue == MMDM_EPI_BIAS_PE) && (!extra || ld_extra < N))
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32: epilogue %d needs `extra` with ld >= N", epilogue);

@@ -630,11 +630,13 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     r.ca_mode = 2; r.kv_src = H->mI;
     RC(run_stack(c, H->mx.st, c.s->h, r));
     const int mode = cf.mixing_mode;
+    // Influence.out + sigmoid (influence.py:124-125) as a GEMM with a sigmoid epilogue: N = 1 or 23 columns of a 64-wide MFMA tile --
+    // wasteful per flop and still 8x faster than a wave-per-row dot-product kernel at 19 200 rows
     if (mode == 1 || mode == 3) {
         RC(mmdm_mean_time_f32(c.s->h, H->hpool, 2 * n, T, Dm, c.st));
-        RC(mmdm_influence_head_f32(H->hpool, H->mx.out_w, H->mx.out_b, H->w23, 2 * n, Dm, H->nw, c.st));
+        RC(linear(c, H->hpool, Dm, H->mx.out_w, Dm, H->mx.out_b, H->w23, H->nw, 2 * n, H->nw, Dm, MMDM_EPI_BIAS_SIGMOID));
     } else {
-        RC(mmdm_influence_head_f32(c.s->h, H->mx.out_w, H->mx.out_b, H->w23, 2 * n * T, Dm, H->nw, c.st));
+        RC(linear(c, c.s->h, Dm, H->mx.out_w, Dm, H->mx.out_b, H->w23, H->nw, 2 * n * T, H->nw, Dm, MMDM_EPI_BIAS_SIGMOID));
     }
     const int* lp = dyn_hist ? H->d_step + 1 : nullptr;
     RC(mmdm_blend_cfg_dyn(H->out1, H->out2, H->w23, mode, cf.use_force, cf.force_val, cf.cfg_scale, H->model_out,

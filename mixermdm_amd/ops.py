@@ -8,7 +8,7 @@ import torch
 
 from ._lib import load_library, check, EncoderLayerWeights
 
-EPI = {"bias": 0, "gelu": 1, "resid": 2, "pe": 3, "silu": 4, "quickgelu": 5}
+EPI = {"bias": 0, "gelu": 1, "resid": 2, "pe": 3, "silu": 4, "quickgelu": 5, "sigmoid": 6}
 ATTN_NO_ZERO_KEY, ATTN_CAUSAL = 1, 2
 
 

@@ -108,12 +108,18 @@ def test_full_size_fp32_split_mode_is_deterministic_batch_independent_and_tracks
     # (26 blocks, softmax, LayerNorm, atan2 geometry) amplifies rounding noise by 2-3 orders of magnitude, whichever kernel produced it
     g = torch.Generator().manual_seed(99)
     noisy, _ = run(s32, cond, xT * (1 + 1.2e-7 * torch.randn(xT.shape, generator=g)), STEPS)
-    relf = lambda u, v: ((u - v).pow(2).mean().sqrt() / v.pow(2).mean().sqrt()).item()
+    # robust distance: the 99th percentile of |difference| relative to the RMS of the reference (a handful of near-degenerate joints can
+    # cross an atan2 / quaternion branch in one run and not in the other, whichever kernels produced the rounding; an RMS would be theirs)
+    def dist(u, v):
+        d = (u - v).abs().flatten().float()
+        return (torch.quantile(d[torch.randperm(d.numel(), generator=torch.Generator().manual_seed(0))[:2_000_000]], 0.99) / v.pow(2).mean().sqrt()).item()
     for k in ("x", "x2", "pred_xstart2"):
         assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), k
-        rel, yard = relf(a[k], ref[k]), relf(noisy[k], ref[k])
-        print(f"{k}: fp32_split vs fp32 {rel:.3e}; fp32 with 1-ulp input noise vs fp32 {yard:.3e}")
+        rel, yard = dist(a[k].cpu(), ref[k].cpu()), dist(noisy[k].cpu(), ref[k].cpu())
+        print(f"{k}: fp32_split vs fp32 p99 {rel:.3e}; fp32 with 1-ulp input noise vs fp32 p99 {yard:.3e}")
         assert rel < 4 * yard + 1e-7, (k, rel, yard)
+        bad = ((a[k] - ref[k]).abs() > 2e-4 + 2e-4 * ref[k].abs()).float().mean().item()
+        assert bad <= 2e-3, (k, bad)                                 # and the step tolerance of the parity tests, mode against mode
     assert not torch.equal(a["x"], ref["x"])                # the split kernels really ran
     for k in (3, 15):
         one, _ = run(s, cond[k:k + 1], xT[k:k + 1], STEPS)
