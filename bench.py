@@ -60,7 +60,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # MMDM_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1 exercises the RCCL code path (init, broadcast, barrier, all_reduce) on one GPU
+    force_dist = world == 1 and os.environ.get("MMDM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
@@ -91,7 +93,7 @@ def main():
         raise SystemExit("warmup + steps must be <= 1000")
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -103,7 +105,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
@@ -130,7 +132,7 @@ def main():
                 "gflop_per_launch": round(g_fl / g_n / 1e9, 3), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
                 "attention": {"achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a_ms / args.profile_steps, 3),
                               "launches_per_step": a_n // args.profile_steps}}
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
 
     # Same workload, same inputs, in the fp32-split mode (fp32-accurate GEMMs on the bf16 matrix cores: DESIGN.md 6c).  Reported beside the
@@ -182,7 +184,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     smp.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
