@@ -14,6 +14,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Safety net: if the in-tree library did not travel with the checkout, build it (hipcc cross-compiles gfx950 without a GPU)."""
+    from mixermdm_amd import build as B
+    if not os.path.exists(B.LIB):
+        B.build(verbose=False)
+
+
 def load_golden(name):
     """Return (arrays, weights-by-prefix-getter) for tests/golden/<name>.npz."""
     import torch
