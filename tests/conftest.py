@@ -15,9 +15,10 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """Safety net: if the in-tree library did not travel with the checkout, build it (hipcc cross-compiles gfx950 without a GPU)."""
+    """Safety net: if the in-tree library is missing or older than its sources, (re)build it before any test loads it (hipcc cross-compiles
+    gfx950 without a GPU; unchanged translation units are skipped)."""
     from mixermdm_amd import build as B
-    if not os.path.exists(B.LIB):
+    if B.needs_build():
         B.build(verbose=False)
 
 

@@ -452,7 +452,10 @@ def test_every_precision_mode_vs_reference_golden_at_latent_32(golden, prec):
         # bf16's 4e-3 per-GEMM error does not survive 20 steps of it, so only the single forward above is compared for bf16
         assert torch.isfinite(out).all()
     else:
-        assert d.mean() <= 2e-3 and np.percentile(d, 99) <= 3e-2, (prec, d.mean(), np.percentile(d, 99), d.max())
+        # Distributional, with limits set from this fixture's own conditioning: the CPU oracle is 1.7e-3 (mean) / 2.9e-2 (p99) from the
+        # reference on this loop and moves by 6.8e-3 / 1.2e-1 when x_T is perturbed by one ulp (20 DDIM steps of a random-weight model
+        # amplify rounding noise ~1e5x).  The tight comparisons are the Mixer.forward above and the per-step tests.
+        assert d.mean() <= 2e-2 and np.percentile(d, 99) <= 3e-1, (prec, d.mean(), np.percentile(d, 99), d.max())
     s.close()
 
 
