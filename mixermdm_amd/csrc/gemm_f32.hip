@@ -573,9 +573,11 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
             if (glds_ok) {
                 // few 128x128 tiles (< ~4 per CU): halve the tile along N so that more workgroups hide each other's latencies
                 const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-                // measured in the step (bench.py): 256x128 / 8-wave tiles are +3 % on the N = 2048 GEMMs (FFN up-projection, cross-attention
-                // K/V projection: 65.4 -> 65.0 ms/step) and neutral at N = 1024 / 3072
-                if (N > 1024 && N <= 2048 && tiles >= 1000 && M % 256 == 0) return launch_glds<42, 22>(a, st);
+                // Tile choice per shape, each rule measured inside the step (bench.py, ms/step at B=16, T=300): 256x128 / 8-wave tiles for
+                // N > 1024 (FFN up-projection, K/V and QKV projections: 65.4 -> 65.0 -> 64.6), 128x64 tiles for the mixer's N = 1024,
+                // K = 512 GEMMs (64.9 -> 64.4); 256x128 at N = 1024, K = 2048 loses (65.9), so N <= 1024 stays on 128x128.
+                if (N > 1024 && tiles >= 1000 && M % 256 == 0) return launch_glds<42, 22>(a, st);
+                if (N <= 1024 && K <= 512 && tiles >= 1000) return launch_glds<22, 21>(a, st);
                 return tiles < 1000 ? launch_glds<22, 21>(a, st) : launch_glds<22, 22>(a, st);
             }
             break;
