@@ -695,19 +695,23 @@ int run_step(const Ctx& c) {
         return run_denoiser(cc, H->d1, false, H->x, B, 2, NF2, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF2);
     };
     const float* xin2 = dual ? H->x : H->x2;       // DualMDM feeds the same x to both models (cfg_sampler.py:141-142)
-    if (H->d1.kind == 0) RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n));
-    RC(cond_vectors(c, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n));
-    if (!dual) RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n));
     if (H->overlap && !H->prof.on) {
-        // fork: denoiser2 on the auxiliary stream with its own scratch, denoiser1 on the caller's stream; join before the mixer
+        // fork: denoiser2 (with its AdaLN-projection GEMM) on the auxiliary stream with its own scratch; denoiser1 and the mixer's
+        // projections on the caller's stream (denoiser1 is the shorter model); join before the mixer
         Ctx c2{H, H->st2, &H->sb};
         HIPCHK(hipEventRecord(H->ev_fork, c.st));
         HIPCHK(hipStreamWaitEvent(H->st2, H->ev_fork, 0));
+        RC(cond_vectors(c2, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n));
         RC(run_denoiser(c2, H->d2, true, xin2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
+        if (H->d1.kind == 0) RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n));
         RC(model1(c));
+        if (!dual) RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n));
         HIPCHK(hipEventRecord(H->ev_join, H->st2));
         HIPCHK(hipStreamWaitEvent(c.st, H->ev_join, 0));
     } else {
+        if (H->d1.kind == 0) RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n));
+        RC(cond_vectors(c, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n));
+        if (!dual) RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n));
         RC(model1(c));
         RC(run_denoiser(c, H->d2, true, xin2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
     }
