@@ -17,6 +17,7 @@
 #ifndef MMDM_H
 #define MMDM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

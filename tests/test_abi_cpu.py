@@ -79,3 +79,16 @@ def test_synthetic_state_dict_keys_cover_reference_names(golden):
     assert set(ref) == set(mine), set(ref) ^ set(mine)
     for k in ref:
         assert tuple(ref[k]) == tuple(mine[k]), k
+
+
+def test_public_header_is_self_contained_c_and_cpp(tmp_path):
+    """include/mmdm.h is the boundary a non-Python caller binds: it must compile on its own as C99 and as C++17."""
+    import shutil
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "mmdm.h"\nint main(void) { mmdm_config c; (void)c; return (int)MMDM_EPI_BIAS; }\n')
+    inc = os.path.join(ROOT, "include")
+    if shutil.which("gcc"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "c.o")])
+    if shutil.which("g++"):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-I", inc, "-c", str(src), "-o", str(tmp_path / "cpp.o")])
