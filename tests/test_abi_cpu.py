@@ -92,3 +92,30 @@ def test_public_header_is_self_contained_c_and_cpp(tmp_path):
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "c.o")])
     if shutil.which("g++"):
         subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-I", inc, "-c", str(src), "-o", str(tmp_path / "cpp.o")])
+
+
+def test_plain_c_client_links_and_calls_the_library(tmp_path):
+    """A C99 program (no Python, no torch) links libmmdm_hip.so through include/mmdm.h, reads the version and gets a status code + message
+    back from an argument check that runs before any HIP call."""
+    import shutil
+    import subprocess
+    from mixermdm_amd._lib import lib_path
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "client.c"
+    src.write_text("""#include <stdio.h>
+#include "mmdm.h"
+int main(void) {
+    mmdm_config cfg = {0};
+    mmdm_handle h = 0;
+    int rc = mmdm_create(&cfg, &h);
+    printf("%s|%d|%s\n", mmdm_version(), rc, mmdm_last_error());
+    return 0;
+}
+""")
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(lib_path())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir, "-lmmdm_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)], text=True).strip().split("|")
+    assert out[0].startswith("gfx950;") and int(out[1]) != 0 and "nfeats must be 262" in out[2]
