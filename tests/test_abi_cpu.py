@@ -109,7 +109,7 @@ int main(void) {
     mmdm_config cfg = {0};
     mmdm_handle h = 0;
     int rc = mmdm_create(&cfg, &h);
-    printf("%s|%d|%s\n", mmdm_version(), rc, mmdm_last_error());
+    printf("%s|%d|%s\\n", mmdm_version(), rc, mmdm_last_error());
     return 0;
 }
 """)
