@@ -16,6 +16,10 @@ the builder container (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``
 its own, so those captured vectors are the pin.
 
 Third-party arithmetic: ``torch`` CPU kernels (matmul, softmax, erf, atan2, ...),
-the same library the reference executes on; OpenAI CLIP (text tower) is upstream
-of this path and not restated -- text features are an input here.
+the same library the reference executes on.  One function is PARITY UNPINNED:
+``oracle.encoder.clip_text_tower`` (and ``clip_encode_text``) restates the published
+architecture of OpenAI CLIP's text transformer (package ``clip==1.0``, environment.yaml:49;
+call sites src/models/mixermdm.py:212-217, 297-303), which is not under /root/reference
+and cannot be imported here; everything around the tower in the text stage is pinned
+(tests/golden/text.npz).
 """
