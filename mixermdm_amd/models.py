@@ -189,6 +189,7 @@ class MixerMDM(nn.Module):
         self._dirty = True
         self._stats = None
         self._try_load_norm_stats()
+        self._try_load_submodel_checkpoints()
 
     # ---- weights / stats -----------------------------------------------------------------------------
     def _try_load_norm_stats(self):
@@ -196,6 +197,34 @@ class MixerMDM(nn.Module):
         paths = ["./data/HumanML3D/mean_ih_new.npy", "./data/HumanML3D/std_ih_new.npy", "./data/global_mean.npy", "./data/global_std.npy"]
         if all(os.path.exists(p) for p in paths):
             self.set_norm_stats(*[np.load(p) for p in paths])
+
+    def _try_load_submodel_checkpoints(self):
+        """The reference's constructor loads the two frozen sub-models from MODEL1/MODEL2.CHECKPOINT (mixermdm.py:43-59): raw state dicts
+        for in2IN (keys ``decoder.net_{individual,interaction}.*``), ``{"state_dict": ...}`` with a Lightning ``model.`` prefix for MDM
+        (denoiser under ``model.*``) and InterGen (``decoder.net.*``).  Here they are optional: when a file exists its denoiser weights
+        initialise ``mixing.denoiser{1,2}.*`` (a MixerMDM checkpoint loaded afterwards carries the same tensors and overrides them)."""
+        own = dict(self.named_parameters())
+        for which, cfgm in (("1", self.cfg_model1), ("2", self.cfg_model2)):
+            path = cfgm.CHECKPOINT if "CHECKPOINT" in cfgm else None
+            if not path or not os.path.exists(path):
+                continue
+            ck = torch.load(path, map_location="cpu")
+            if cfgm.NAME == "MDM":
+                sd = {k[6:]: v for k, v in ck["state_dict"].items()}
+                pfx = "model."
+            elif cfgm.NAME == "InterGen":
+                sd = {k.replace("model.", "") if "model" in k else k: v for k, v in ck["state_dict"].items()}
+                pfx = "decoder.net."
+            else:
+                sd = ck
+                pfx = "decoder.net_individual." if which == "1" else "decoder.net_interaction."
+            with torch.no_grad():
+                for k, v in sd.items():
+                    if k.startswith(pfx):
+                        tgt = "mixing.denoiser%s.%s" % (which, k[len(pfx):])
+                        if tgt in own and tuple(own[tgt].shape) == tuple(v.shape):
+                            own[tgt].copy_(v)
+            self._dirty = True
 
     def set_norm_stats(self, mean_hml, std_hml, mean_ih, std_ih):
         self._stats = [np.asarray(a, dtype=np.float32).reshape(262) for a in (mean_hml, std_hml, mean_ih, std_ih)]

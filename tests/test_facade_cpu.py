@@ -83,3 +83,29 @@ def test_sampler_args_the_reference_rejects():
         d.ddim_sample_loop(None, (1, 4, 524), dump_steps=[1])
     with pytest.raises(NotImplementedError):
         d.ddim_sample_loop(None, (1, 4, 524), const_noise=True)
+
+
+def test_constructor_picks_up_submodel_checkpoints_when_present(tmp_path):
+    """MODEL1/MODEL2.CHECKPOINT files (mixermdm.py:43-59 formats: raw in2IN state dict; Lightning-wrapped InterGen) initialise the denoisers."""
+    import torch
+    import yaml
+    from mixermdm_amd.configs import CfgNode
+    from mixermdm_amd.models import MixerMDM
+    from mixermdm_amd.synthetic import denoiser_shapes
+    sub = dict(NUM_LAYERS=1, NUM_HEADS=2, DROPOUT=0.1, INPUT_DIM=262, LATENT_DIM=16, FF_SIZE=32)
+    g = torch.Generator().manual_seed(0)
+    sd1 = {k: torch.randn(s, generator=g) for k, s in denoiser_shapes("decoder.net_individual.", 16, 32, 1).items()}
+    sd1["clip_ln_individual.weight"] = torch.ones(768)                      # other keys of the sub-model's checkpoint are ignored
+    sd2 = {"model." + k: torch.randn(s, generator=g) for k, s in denoiser_shapes("decoder.net.", 16, 32, 1).items()}
+    torch.save(sd1, tmp_path / "ind.ckpt")
+    torch.save({"state_dict": sd2}, tmp_path / "ig.ckpt")
+    yaml.safe_dump(dict(NAME="in2INind", CHECKPOINT=str(tmp_path / "ind.ckpt"), **sub), open(tmp_path / "individual.yaml", "w"))
+    yaml.safe_dump(dict(NAME="InterGen", CHECKPOINT=str(tmp_path / "ig.ckpt"), **sub), open(tmp_path / "intergen.yaml", "w"))
+    cfg = CfgNode(dict(NAME="MixerMDM", GENERATOR=dict(sub), DISCRIMINATOR=dict(sub), ACTIVATION="gelu", DIFFUSION_STEPS=1000, BETA_SCHEDULER="cosine",
+                       SAMPLER="uniform", MOTION_REP="global", CFG_WEIGHT=3.5, MIXING_MODE=4, FORCE_INFLUENCE_VAL="None",
+                       MODEL1="individual.yaml", MODEL2="intergen.yaml"))
+    m = MixerMDM(cfg, num_frames=16, config_root=str(tmp_path))
+    p = dict(m.named_parameters())
+    assert torch.equal(p["mixing.denoiser1.blocks.0.ffn.linear1.weight"], sd1["decoder.net_individual.blocks.0.ffn.linear1.weight"])
+    assert torch.equal(p["mixing.denoiser2.out.linear.weight"], sd2["model.decoder.net.out.linear.weight"])
+    assert float(p["mixing.influence.out.weight"].abs().sum()) == 0.0           # the mixer's own weights stay untouched
