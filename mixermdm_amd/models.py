@@ -465,22 +465,55 @@ class in2INDiffusion(nn.Module):
 
 
 class in2IN(nn.Module):
-    """in2IN(cfg, mode) facade (src/models/in2in.py:14-135) around the stand-alone sampler; text encoding is upstream (pass the
-    encoded ``cond_*`` entries in the batch or register ``text_encoder(batch) -> batch``)."""
+    """in2IN(cfg, mode) facade (src/models/in2in.py:14-135) around the stand-alone sampler.  Text conditioning: when the loaded checkpoint
+    carries the CLIP tower and the clipTransEncoder_{individual,interaction} heads (in2in.py:24-69), ``text_process`` runs them on the GPU
+    (mixermdm_amd.text); otherwise pass the encoded ``cond_*`` entries in the batch or register ``text_encoder(batch, mode, text_name, out_name)``."""
 
     def __init__(self, cfg, mode):
         super().__init__()
         self.cfg, self.mode = cfg, mode
         self.decoder = in2INDiffusion(cfg, mode, sampling_strategy=cfg.STRATEGY)
         self.text_encoder = None
+        self.text_num_heads = 8               # nhead of the clipTransEncoder layers (hard-coded in the reference: in2in.py:27, 43)
+        self._text_sd, self._text = None, None
+
+    def load_state_dict(self, state_dict, strict=True):
+        """in2IN checkpoint (raw state dict, in2in.py keys): ``decoder.*`` -> the sampler; tower + text heads -> the GPU text stage."""
+        dec = {k[len("decoder."):]: v for k, v in state_dict.items() if k.startswith("decoder.")}
+        res = self.decoder.load_state_dict(dec, strict=strict)
+        pre = ("token_embedding.", "positional_embedding", "clip_transformer.", "ln_final.", "clipTransEncoder_", "clip_ln_")
+        txt = {k: v for k, v in state_dict.items() if k.startswith(pre)}
+        if "token_embedding.weight" in txt:
+            self._text_sd, self._text = txt, None
+        return res
+
+    def _text_stage(self, mode):
+        from .text import ClipTextTower, TextHead
+        dev = next(self.decoder.parameters()).device
+        if self._text is None or self._text["tower"].table.device != dev:
+            sd = self._text_sd
+            heads = sd["clip_transformer.resblocks.0.attn.in_proj_weight"].shape[1] // 64 if "clip_transformer.resblocks.0.attn.in_proj_weight" in sd else 12
+            self._text = {"tower": ClipTextTower(sd, "", heads, dev)}
+            for m in ("individual", "interaction"):
+                if f"clip_ln_{m}.weight" in sd:
+                    self._text[m] = TextHead(sd, f"clipTransEncoder_{m}.", f"clip_ln_{m}", self.text_num_heads, dev)
+        if mode not in self._text:
+            raise ValueError("Mode not recognized")
+        return self._text["tower"], self._text[mode]
 
     def text_process(self, batch, mode=None, text_name="text", out_name="cond"):
         if out_name in batch:
             return batch
-        if self.text_encoder is None:
+        if self.text_encoder is not None:
+            return self.text_encoder(batch, mode, text_name, out_name)
+        if self._text_sd is None:
             raise NotImplementedError("text encoding (CLIP tower + clipTransEncoder, in2in.py:109-135) is upstream of the HIP path: "
-                                      f"put the encoded '{out_name}' in the batch or set model.text_encoder")
-        return self.text_encoder(batch, mode, text_name, out_name)
+                                      f"put the encoded '{out_name}' in the batch, load a checkpoint that carries the text modules, or set model.text_encoder")
+        from .text import tokenize
+        tower, head = self._text_stage(mode)
+        tok = torch.as_tensor(batch["tokens_" + text_name]) if "tokens_" + text_name in batch else tokenize(batch[text_name])
+        batch[out_name] = head(tower(tok), tok)
+        return batch
 
     def decode_motion(self, batch):
         batch.update(self.decoder(batch))

