@@ -7,10 +7,13 @@ update) over one batch of B motions per GPU (BASELINE.json configs[2]: B=16, T=3
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+    python bench.py --gpus 8            (no launcher: starts the N ranks itself as fresh child processes, before any GPU call)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,7 +51,21 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-alt", action="store_true", help="skip the extra fp32_split measurement reported next to the fp32 headline (N=1 only)")
+    ap.add_argument("--no-full-loop", action="store_true", help="skip the real 1000-step sample() from x_T to x_0 reported as `full_loop`")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks meet on gloo, time a barrier, rank 0 prints a line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Bare `python bench.py --gpus N`: start the N ranks as FRESH child processes (one per GPU) through torch.distributed.run and
+        # relay their output.  This parent has made no GPU call (torch is not even imported yet) and never replaces itself: it waits
+        # for the launcher and exits with its status.
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -56,8 +73,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); run `python bench.py --gpus N` or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank_seen": int(t.item())}), flush=True)
+        return
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     # MMDM_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1 exercises the RCCL code path (init, broadcast, barrier, all_reduce) on one GPU
@@ -71,7 +99,8 @@ def main():
     from mixermdm_amd.distributed import broadcast_state_dict
 
     single = args.workload == "single"
-    B = args.batch or (32 if single else 16)
+    # motions per GPU: configs[2] = 16 on one GPU (the headline); configs[3] = 256 over 8 GPUs = 32 per GPU; configs[1] (single) = 32
+    B = args.batch or (32 if single else (32 if world == 8 else 16))
     T = args.frames or (196 if single else 300)
     S = 1000
     # weights: rank 0 draws them on the host, ONE RCCL broadcast of the packed 1.46 GB vector over xGMI (no other collective on the path)
@@ -105,10 +134,15 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    per_rank = [dt]
     if dist.is_initialized():
+        every = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(every, tmax)
+        per_rank = [float(v.item()) for v in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
+    rank_ms = {"min": round(min(per_rank) / args.steps * 1e3, 3), "max": round(max(per_rank) / args.steps * 1e3, 3)}
     finite = bool(torch.isfinite(smp.state()["x"]).all().item())
 
     # dominant kernel: the fp32 MFMA GEMM -- live HIP-event timing of every launch, eager, on the handle's stream
@@ -161,6 +195,21 @@ def main():
                "achieved_tflops_algorithmic": round(algorithmic_flops_per_motion_step(T, single=single) * B / (a_ms * 1e-3) / 1e12, 2)}
         alt_smp.close()
 
+    # The metric itself, not an extrapolation: one whole sample() from x_T to x_0 (S graph replays + the begin() set-up), every rank
+    # on its own shard, wall time = max over ranks.
+    full = None
+    if not args.no_full_loop:
+        barrier()
+        t1 = time.perf_counter()
+        out = smp.sample(cond, xT, use_graph=use_graph)
+        barrier()
+        fl = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+        if dist.is_initialized():
+            dist.all_reduce(fl, op=dist.ReduceOp.MAX)
+        wall = float(fl.item())
+        full = {"steps": S, "wall_s": round(wall, 3), "motions_per_s": round(world * B / wall, 5), "outputs_finite": bool(torch.isfinite(out).all().item())}
+        del out
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:       # reported at N=1 only (the other ranks of an N>1 run would idle behind it)
         cpu = cpu_baseline(sd_cpu, stats, T, args.cpu_steps, single)
@@ -169,18 +218,19 @@ def main():
         flops = algorithmic_flops_per_motion_step(T, single=single)
         value = world * B / (ms_per_step * 1e-3 * S)
         wl = ("BASELINE configs[1]: single-person in2IN (individual denoiser, CFG 3.5), T=%d, ddim1000 (eta=0), batch %d per GPU, %s, random-init weights" % (T, B, args.precision)) if single else \
-             ("BASELINE configs[2]: 2-person MixerMDM (in2IN individual + in2IN interaction + Mixer mode 4, align, CFG 3.5), "
-              "T=%d, ddim1000 (eta=0), batch %d per GPU, %s, random-init weights" % (T, B, {"fp32": "fp32", "fp32_split": "fp32 via exact 3-way bf16 operand split (six bf16 MFMAs per product)", "bf16": "bf16 GEMM operands / fp32 accumulate (configs[4]-style)"}[args.precision]))
+             ("BASELINE %s: 2-person MixerMDM (in2IN individual + in2IN interaction + Mixer mode 4, align, CFG 3.5), "
+              "T=%d, ddim1000 (eta=0), batch %d per GPU, %s, random-init weights" % ("configs[3] (batch 256 over 8 GPUs = 32 per GPU)" if world == 8 and B == 32 else "configs[2]", T, B, {"fp32": "fp32", "fp32_split": "fp32 via exact 3-way bf16 operand split (six bf16 MFMAs per product)", "bf16": "bf16 GEMM operands / fp32 accumulate (configs[4]-style)"}[args.precision]))
         line = {
-            "metric": "generated motions/sec (1000-step DDPM, T=%d, %s)" % (T, "single-person" if single else "2-person"), "value": round(value, 5), "unit": "motions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "metric": "generated motions/sec (1000-step DDPM schedule sampled with DDIM eta=0, T=%d, %s)" % (T, "single-person" if single else "2-person"),
+            "value": round(value, 5), "unit": "motions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "ms_per_step_ranks": rank_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32_split": "f32 (3xbf16 exact operand split, fp32 accumulate)", "bf16": "bf16"}[args.precision], "data": "synthetic",
             "config": {"workload": wl,
                        "batch_per_gpu": B, "frames": T, "sampler_steps": S, "hipgraph": use_graph, "parallelism": "batch-sharded x%d, no in-loop collective" % world},
             "achieved_tflops_algorithmic": round(flops * B * world / (ms_per_step * 1e-3) / 1e12, 2),
             "frac_of_f32_mfma_peak": round(flops * B / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if args.precision != "bf16" else None,
             "outputs_finite": finite,
-            "roofline": roof, "cpu_baseline": cpu, "fp32_split": alt,
+            "full_loop": full, "roofline": roof, "cpu_baseline": cpu, "fp32_split": alt,
         }
         print(json.dumps(line), flush=True)
     smp.close()
@@ -189,14 +239,20 @@ def main():
 
 
 def measured_traffic(single):
-    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this workload (profiles/r01_gemm_traffic.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane
-    streams on gfx950).  bench.py cannot collect PMC counters itself; null when the artefact is absent or for another workload."""
-    path = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this workload (profiles/gemm_traffic.json, written by
+    tools/pmc_summary.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    16-byte-per-lane streams on gfx950).  bench.py cannot collect PMC counters itself.  The artefact records the hash of the kernel
+    sources it was measured on: null when it is absent, for another workload, or was taken on different kernel sources than the
+    ones this run executes."""
+    from mixermdm_amd.build import sources_sha
+    path = os.path.join(ROOT, "profiles", "gemm_traffic.json")
     if single or not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f)["traffic_bytes_per_launch"]
+        rec = json.load(f)
+    if rec.get("kernel_sources_sha") != sources_sha():
+        return None
+    return rec["traffic_bytes_per_launch"]
 
 
 def cpu_baseline(sd_cpu, stats, T, nsteps, single=False):
@@ -220,12 +276,13 @@ def cpu_baseline(sd_cpu, stats, T, nsteps, single=False):
     with torch.no_grad():
         # thread-count calibration (one untimed step each): B=1 GEMMs are small, all cores is not always the fastest
         ncpu = os.cpu_count() or 1
-        best = (None, 1e30)
+        best, calib = (None, 1e30), {}
         for nt in sorted({min(ncpu, c) for c in (16, 32, 64, ncpu)}):
             torch.set_num_threads(nt)
             t0 = time.perf_counter()
             MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 999, x, x2, cond)
             dt1 = time.perf_counter() - t0
+            calib[nt] = dt1
             if dt1 < best[1]:
                 best = (nt, dt1)
         torch.set_num_threads(best[0])
@@ -234,9 +291,10 @@ def cpu_baseline(sd_cpu, stats, T, nsteps, single=False):
         for k in range(nsteps):
             x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 998 - k, x, x2, cond)
         dt = (time.perf_counter() - t0) / nsteps
-    return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "host_threads": ncpu, "kind": "port",
             "sample": "%d consecutive DDIM steps (i=998..) of the same workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), "
-                      "%.3f s/step, extrapolated x1000 steps" % (nsteps, T, torch.__version__, dt),
+                      "%.3f s/step, extrapolated x1000 steps; thread count calibrated over {16, 32, 64, all %d}: %d fastest (one step: %s)"
+                      % (nsteps, T, torch.__version__, dt, ncpu, best[0], ", ".join("%d thr %.2f s" % kv for kv in sorted(calib.items()))),
             "s_per_step_b1": round(dt, 4)}
 
 
@@ -256,7 +314,7 @@ def cpu_baseline_single(sd_cpu, T, nsteps):
         for k in range(nsteps):
             x = step(998 - k, x)
         dt = (time.perf_counter() - t0) / nsteps
-    return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "host_threads": os.cpu_count(), "kind": "port",
             "sample": "%d consecutive DDIM steps of the single-person workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), %.3f s/step, extrapolated x1000 steps" % (nsteps, T, torch.__version__, dt),
             "s_per_step_b1": round(dt, 4)}
 

@@ -35,6 +35,11 @@ typedef enum {
 const char* mmdm_last_error(void);
 /* "gfx950;<build id>" -- lets the host check that the right library was loaded. */
 const char* mmdm_version(void);
+/* Debug getter: the GEMM instantiation(s) the calling thread's last mmdm_linear_f32 / _bf16 / _split / _fp8 call launched, e.g.
+ * "gemm_glds<22,22,16,2,vepi>" (tile code: 10*waves + 32x32-tiles-per-wave along M, N; K step; LDS buffers; epilogue form) or
+ * "gemm_split<42,22>+gemm_split<22,21>" when a call splits its rows over two kernels.  Lets parity tests assert that a shape
+ * really runs on the production tiles. */
+const char* mmdm_last_gemm_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------
  * 1. Stateless kernels (used by the handle below and exposed for per-kernel parity tests).
@@ -271,13 +276,21 @@ int mmdm_prepare(mmdm_handle h);
 int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, int B, int T, void* stream);
 
 /* Optional history side outputs (src/models/mixermdm.py:794-796, 805-808), CFG-doubled batch 2B.  Each pointer may be NULL.
- * Slot k of a buffer receives the step whose position in the loop is k*every (k = 0 .. ceil(S/every)-1). */
+ * Slot k of a buffer receives the step whose position in the loop is k*every (k = 0 .. ceil(S/every)-1).
+ * influence_i1/i2: [slots, 2B, T, 262] for mixing modes 3-4 and [slots, 2B, T, 1] for modes 1-2 (the reference appends the tensor as
+ * it stands before the blend: expanded per channel in modes 3-4, one value per frame in modes 1-2, mixermdm.py:739-745);
+ * out1/out2/out_influenced: [slots, 2B, T, 524].  Call after mmdm_begin (which resets the call to "no history"); the destinations are
+ * written to a device-side descriptor on mmdm_begin's stream, so captured step graphs do not depend on them. */
 int mmdm_set_history(mmdm_handle h, float* influence_i1, float* influence_i2, float* out1, float* out2, float* out_influenced, int every);
 
 /* Run `nsteps` consecutive DDIM steps starting at the handle's current position (S-1 after mmdm_begin, counting down).
- * use_graph != 0: one step is captured into a hipGraph on first use (per (B,T)) and replayed.
+ * use_graph != 0: one step is captured into a hipGraph on first use and replayed; captured graphs are kept in a least-recently-used
+ * cache keyed by (B, T, S) (8 entries; MMDM_GRAPH_CACHE=n overrides), so a caller that alternates shapes -- the evaluation loops of
+ * src/evaluation/datasets.py:101-122, 438 call the sampler per item with per-sample T -- re-captures nothing.
  * = MixerDiffusion.ddim_sample_loop_progressive body  gaussian_diffusion.py:1871-1899. */
 int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream);
+/* Counters of the graph cache: steps captured so far, steps replayed, entries currently cached (each pointer may be NULL). */
+int mmdm_graph_stats(mmdm_handle h, int64_t* captures, int64_t* replays, int* cached);
 
 /* Device pointers owned by the handle, valid until destroy: current chains and the last pred_xstart(2). */
 int mmdm_get_state(mmdm_handle h, float** x, float** x2, float** pred_xstart, float** pred_xstart2, float** model_out);
@@ -287,8 +300,11 @@ int mmdm_get_state(mmdm_handle h, float** x, float** x2, float** pred_xstart, fl
  *          1 = denoiser2 (interaction; x [n,T,524], cond [n,3*text_dim]) -> out [n,T,524]
  *          2 = Mixer.forward (x = x1 [n,T,524], x2 [n,T,524], cond [n,8*text_dim]) -> out [n,T,524] (out_influenced)
  *          3 = denoiser1 in "dual_individual" mode (dual handle; x [n,T,524], cond [n,5*text_dim]) -> out [n,T,524]
+ *          4 = ClassifierFreeSampleModelX2.forward (src/models/utils/cfg_sampler.py:38-56): n = B UN-doubled rows of x, x2 [B,T,524] and
+ *              cond [B,8*text_dim] -> out [B,T,524] = s*Mixer(cond rows) + (1-s)*Mixer(zero-cond rows), s = cfg_scale
  *          (which = 0 with model1_kind = 1: MDMDenoiser.forward, cond [n, d1_latent])
- * t = original (remapped) timestep shared by all rows.  Replaces in2INDenoiser.forward / Mixer.forward. */
+ * t = original (remapped) timestep shared by all rows.  Replaces in2INDenoiser.forward / Mixer.forward / the CFG wrapper's forward.
+ * A schedule set with mmdm_set_schedule survives the call; a sampling call in progress does not (call mmdm_begin again). */
 int mmdm_module_forward(mmdm_handle h, int which, const float* x, const float* x2, const float* cond, int t,
                         float* out, int n, int T, void* stream);
 

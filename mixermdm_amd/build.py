@@ -9,6 +9,19 @@ LIB = os.path.join(HERE, "libmmdm_hip.so")
 SOURCES = ["mmdm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "attn_f32.hip", "rowops.hip", "geometry.hip"]
 
 
+def sources_sha():
+    """sha256 over the kernel sources (csrc/*.hip, csrc/kernels.h, include/mmdm.h): profile artefacts under profiles/ record it so
+    that bench.py can tell whether a committed PMC measurement belongs to the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "mmdm.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

@@ -215,6 +215,7 @@ int launch(BArgs a, hipStream_t st) {
     using C_ = BCfg<TM_, TN_>;
     a.mt = (a.M + C_::BM - 1) / C_::BM;
     a.nt = (a.N + C_::BN - 1) / C_::BN;
+    mmdm_note_gemm("gemm_bf16<%d,%d>", TM_, TN_);
     hipLaunchKernelGGL((gemm_bf16_kernel<TM_, TN_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_bf16");
 }
@@ -262,6 +263,7 @@ extern "C" int mmdm_linear_bf16(const void* A, int lda, const void* W, int ldw, 
 
 int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16,
                         int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* bf16_copy, int ld2, int copy_cols, void* stream) {
+    mmdm_note_gemm_reset();
     if (M == 0 || N == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < K || ldc < N)

@@ -25,7 +25,7 @@ struct GemmArgs {
     int lda, ldw, ldc, ld_extra;
     int M, N, K, Kw, epilogue, period;   // Kw >= K: readable columns of W (zero beyond K)
     int mt, nt;
-    int ablate;                          // timing experiments only (scratch/gemm_bench.py); 0 in production
+    int ablate;                          // timing experiments only (tools/gemm_bench.py); 0 in production
 };
 
 template <int VEC, bool FULL>
@@ -444,9 +444,10 @@ int launch_glds(GemmArgs a, hipStream_t st) {
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
     a.mt = (a.M + C_::BM - 1) / C_::BM;
     a.nt = (a.N + C_::BN - 1) / C_::BN;
-    // measured (scratch/gemm_bench.py): the 16-byte epilogue pays where the accumulators are initialised from memory (+10 % on
+    // measured (tools/gemm_bench.py): the 16-byte epilogue pays where the accumulators are initialised from memory (+10 % on
     // the K = 1024 residual GEMMs) and is neutral-to-slightly-negative for bias/GELU-only epilogues
     const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
+    mmdm_note_gemm("gemm_glds<%d,%d,%d,%d,%s>", TM_, TN_, BK_, NBUF_, (ext && vepi_ok(a) && !(a.ablate & 16)) ? "vepi" : "scalar");
     if (ext && vepi_ok(a) && !(a.ablate & 16))
         hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
     else
@@ -478,6 +479,7 @@ int launch(GemmArgs a, hipStream_t st) {
     using C_ = Cfg<TM, TN, BK>;
     a.mt = (a.M + C_::BM - 1) / C_::BM;
     a.nt = (a.N + C_::BN - 1) / C_::BN;
+    mmdm_note_gemm("gemm_f32<%d,%d,%d>", TM, TN, BK);
     hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, BK, AVEC, WVEC, FULL>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_f32");
 }
@@ -534,7 +536,7 @@ int mmdm_gemm_init(void) {
     return MMDM_OK;
 }
 
-// tuning hook for scratch/gemm_bench.py (not part of the public ABI): force a tile configuration, -1 = automatic
+// tuning hook for tools/gemm_bench.py (not part of the public ABI): force a tile configuration, -1 = automatic
 extern "C" void mmdmx_set_gemm_cfg(int cfg) { g_gemm_cfg = cfg; }
 extern "C" void mmdmx_set_gemm_ablate(int a) { g_gemm_ablate = a; }
 
@@ -547,6 +549,7 @@ extern "C" int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw,
 // handle stores zero-padded to 264 columns be fetched with 16-byte loads.
 int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
+    mmdm_note_gemm_reset();
     if (M == 0 || N == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < Kw || Kw < K || ldc < N)

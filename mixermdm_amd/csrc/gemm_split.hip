@@ -252,6 +252,7 @@ int launch(SArgs a, hipStream_t st) {
     using C_ = SCfg<TM_, TN_>;
     a.mt = (a.M + C_::BM - 1) / C_::BM;
     a.nt = (a.N + C_::BN - 1) / C_::BN;
+    mmdm_note_gemm("gemm_split<%d,%d>", TM_, TN_);
     hipLaunchKernelGGL((gemm_split_kernel<TM_, TN_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_split");
 }
@@ -528,6 +529,7 @@ int launch_pipe(SArgs a, hipStream_t st) {
     using C_ = PCfg<TM_, TN_, NS_>;
     a.mt = (a.M + C_::BM - 1) / C_::BM;
     a.nt = (a.N + C_::BN - 1) / C_::BN;
+    mmdm_note_gemm("gemm_split_pipe<%d,%d,%d>", TM_, TN_, NS_);
     hipLaunchKernelGGL((gemm_split_pipe_kernel<TM_, TN_, NS_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_split_pipe");
 }
@@ -591,6 +593,7 @@ extern "C" int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const 
 int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W, int ldw, int64_t w_plane, const float* bias, void* C, int ldc,
                          int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period,
                          void* planes2, int ld2, int64_t plane2_stride, int planes2_cols, void* stream) {
+    mmdm_note_gemm_reset();
     if (M == 0 || N == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < K || ldc < N || a_plane <= 0 || w_plane <= 0 || (out_split && c_plane <= 0))
@@ -625,7 +628,7 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
         case 13: return launch_pipe<42, 22, 4>(a, st);
         default: break;
     }
-    // measured on M = 19 200 (scratch/gemm_split_bench.py): 128x64 tiles for the N = 512 mixer GEMMs (more tiles than CUs), 256x128 otherwise
+    // measured on M = 19 200 (tools/gemm_split_bench.py): 128x64 tiles for the N = 512 mixer GEMMs (more tiles than CUs), 256x128 otherwise
     if (N <= 512) return launch<22, 21>(a, st);
     // 256x128 tiles run one workgroup per CU (144 KB of LDS), so a launch takes ceil(tiles / 256) rounds of equal-length tiles and a
     // partly filled last round is pure loss (N = 1024, M = 19 200: 600 tiles = 2.34 -> 3 rounds).  Hybrid tiling: the leading M-tiles
@@ -633,7 +636,7 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
     int ncu = 256;
     const int mt = (M + 255) / 256, nt = (N + 127) / 128;
     int m_main = mt;
-    // measured (scratch/gemm_split_bench.py, M = 19 200): +5 % at N = 1024 (K = 1024 and 2048); at N >= 1536 the single launch is faster
+    // measured (tools/gemm_split_bench.py, M = 19 200): +5 % at N = 1024 (K = 1024 and 2048); at N >= 1536 the single launch is faster
     // (tiles are not equally long there: L2 reuse differs along N), so the split is applied to N <= 1024 only
     if ((long)mt * nt > ncu && N <= 1024 && !(g_split_ablate & 4)) {
         for (int m = mt; m >= 1; --m) {

@@ -173,25 +173,34 @@ __device__ __forceinline__ int influence_index(int c) {   // 262 channels -> 23 
     return c < 66 ? c / 3 : (c < 132 ? (c - 66) / 3 : (c < FEET0 ? (c - ROT0) / 6 : 22));
 }
 
-// History slot selection under graph replay: slot = *loop_pos / every when *loop_pos % every == 0, else none.
+// History side outputs under graph replay.  The destination pointers and the stride live in a DEVICE-side descriptor (mmdm_hist_desc,
+// kernels.h) that the kernels read at run time, so a captured step graph does not depend on them: the same graph serves calls with
+// different (or no) history buffers, and a stale buffer can never be baked into a replayed node.
+// slot = *loop_pos / every when *loop_pos % every == 0, else none.
 __device__ __forceinline__ long hist_slot(const int* loop_pos, int every) {
     if (!loop_pos) return 0;
     const int lp = *loop_pos;
     return (lp % every == 0) ? (long)(lp / every) : -1;
 }
 
+// hd != nullptr: history pointers / stride come from the descriptor (the explicit pointer arguments are ignored).
+// nwh: channels of an influence history row: 262 (modes 3, 4: the expanded tensor) or 1 (modes 1, 2: the reference appends the
+// un-expanded [2B, T, 1] tensor, mixermdm.py:739-745, 794-796).
 __global__ __launch_bounds__(256) void blend_cfg_kernel(const float* __restrict__ out1, const float* __restrict__ out2, const float* __restrict__ w,
                                                          int Tw, int nw, int use_force, float force, float s,
                                                          float* __restrict__ model_out, float* __restrict__ hist_i1, float* __restrict__ hist_i2,
-                                                         float* __restrict__ hist_mix, const int* __restrict__ loop_pos, int every, int B, int T) {
+                                                         float* __restrict__ hist_mix, const mmdm_hist_desc* __restrict__ hd,
+                                                         const int* __restrict__ loop_pos, int nwh, int B, int T) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)B * T * NF2;
     if (idx >= total) return;
+    int every = 1;
+    if (hd) { hist_i1 = hd->i1; hist_i2 = hd->i2; hist_mix = hd->mix; every = hd->every; }
     const long slot = hist_slot(loop_pos, every);
     if (slot < 0) { hist_i1 = nullptr; hist_i2 = nullptr; hist_mix = nullptr; }
     else {
-        if (hist_i1) hist_i1 += (size_t)slot * 2 * B * T * NF;
-        if (hist_i2) hist_i2 += (size_t)slot * 2 * B * T * NF;
+        if (hist_i1) hist_i1 += (size_t)slot * 2 * B * T * nwh;
+        if (hist_i2) hist_i2 += (size_t)slot * 2 * B * T * nwh;
         if (hist_mix) hist_mix += (size_t)slot * 2 * B * T * NF2;
     }
     const int ch = (int)(idx % NF2);
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(256) void blend_cfg_kernel(const float* __restrict_
         mix[u] = v2 + wv * (v1 - v2);
         if (hist_mix) hist_mix[e] = mix[u];
         float* hi = p ? hist_i2 : hist_i1;
-        if (hi) hi[((size_t)row * T + t) * NF + c] = wv;
+        if (hi && c < nwh) hi[((size_t)row * T + t) * nwh + c] = wv;
     }
     model_out[idx] = s * mix[0] + (1.0f - s) * mix[1];
 }
@@ -369,8 +378,11 @@ __global__ __launch_bounds__(256) void dual_ddim_kernel(const float* __restrict_
 __global__ void step_dec_kernel(int* step_idx, int* loop_pos) { *step_idx -= 1; *loop_pos += 1; }
 __global__ void set_step_kernel(int* step_idx, int* loop_pos, int s, int l) { *step_idx = s; *loop_pos = l; }
 
-__global__ void hist_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t count, const int* __restrict__ loop_pos, int every) {
-    const long slot = hist_slot(loop_pos, every);
+// which: 0 -> hd->o1, 1 -> hd->o2; a null destination (history not requested for this call) makes the launch a no-op
+__global__ void hist_copy_kernel(const float* __restrict__ src, const mmdm_hist_desc* __restrict__ hd, int which, size_t count, const int* __restrict__ loop_pos) {
+    float* dst = which ? hd->o2 : hd->o1;
+    if (!dst) return;
+    const long slot = hist_slot(loop_pos, hd->every);
     if (slot < 0) return;
     float* d = dst + (size_t)slot * count;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) d[i] = src[i];
@@ -417,26 +429,35 @@ extern "C" int mmdm_blend_cfg_f32(const float* out1, const float* out2, const fl
     const int nw = (mode >= 3) ? 23 : 1;
     const size_t total = (size_t)B * T * NF2;
     hipLaunchKernelGGL(blend_cfg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       out1, out2, w, Tw, nw, use_force, force, cfg_scale, model_out, hist_i1, hist_i2, hist_mix, (const int*)nullptr, 1, B, T);
+                       out1, out2, w, Tw, nw, use_force, force, cfg_scale, model_out, hist_i1, hist_i2, hist_mix,
+                       (const mmdm_hist_desc*)nullptr, (const int*)nullptr, MMDM_NF, B, T);
     return mmdm_check_launch("blend_cfg");
 }
 
-// Same as mmdm_blend_cfg_f32 with the history slot chosen on the device (graph replay): see hist_slot().
+// Same as mmdm_blend_cfg_f32 with the history destinations read from the device-side descriptor and the slot chosen on the device
+// (graph replay): see hist_slot().  Influence history rows are [.., 262] for modes 3-4 and [.., 1] for modes 1-2 (the reference's shapes).
 int mmdm_blend_cfg_dyn(const float* out1, const float* out2, const float* w, int mode, int use_force, float force, float cfg_scale,
-                       float* model_out, float* hist_i1, float* hist_i2, float* hist_mix, const int* loop_pos, int every,
-                       int B, int T, hipStream_t st) {
+                       float* model_out, const mmdm_hist_desc* hd, const int* loop_pos, int B, int T, hipStream_t st) {
     if (mode < 1 || mode > 4) return mmdm_set_error(MMDM_ERR_ARG, "Mixing mode not recognized");
     const int Tw = (mode == 2 || mode == 4) ? T : 1;
     const int nw = (mode >= 3) ? 23 : 1;
     const size_t total = (size_t)B * T * NF2;
     hipLaunchKernelGGL(blend_cfg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       out1, out2, w, Tw, nw, use_force, force, cfg_scale, model_out, hist_i1, hist_i2, hist_mix, loop_pos, every, B, T);
+                       out1, out2, w, Tw, nw, use_force, force, cfg_scale, model_out, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       hd, loop_pos, mode >= 3 ? MMDM_NF : 1, B, T);
     return mmdm_check_launch("blend_cfg");
 }
 
-int mmdm_hist_copy(const float* src, float* dst, size_t count, const int* loop_pos, int every, hipStream_t st) {
-    hipLaunchKernelGGL(hist_copy_kernel, dim3(1024), dim3(256), 0, st, src, dst, count, loop_pos, every);
+int mmdm_hist_copy(const float* src, const mmdm_hist_desc* hd, int which, size_t count, const int* loop_pos, hipStream_t st) {
+    hipLaunchKernelGGL(hist_copy_kernel, dim3(1024), dim3(256), 0, st, src, hd, which, count, loop_pos);
     return mmdm_check_launch("hist_copy");
+}
+
+__global__ void set_hist_kernel(mmdm_hist_desc* d, mmdm_hist_desc v) { *d = v; }
+
+int mmdm_set_hist_desc(mmdm_hist_desc* d, const mmdm_hist_desc& v, hipStream_t st) {
+    hipLaunchKernelGGL(set_hist_kernel, dim3(1), dim3(1), 0, st, d, v);
+    return mmdm_check_launch("set_hist");
 }
 
 int mmdm_set_step(int* step_idx, int* loop_pos, int s, int l, hipStream_t st) {

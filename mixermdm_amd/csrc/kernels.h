@@ -10,6 +10,11 @@ int mmdm_set_error(int code, const char* fmt, ...) __attribute__((format(printf,
 int mmdm_check_launch(const char* what);
 // One-time per-process kernel attribute setup (dynamic LDS sizes); safe to call repeatedly, never during capture.
 int mmdm_kernels_init(void);
+// Records which GEMM instantiation the last mmdm_linear_* call of this thread launched (mmdm_last_gemm_kernel(), a debug getter the
+// parity tests use to assert that a shape really lands on the production tiles).  A call that splits its rows over two kernels
+// records both, "+"-joined.
+void mmdm_note_gemm(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+void mmdm_note_gemm_reset(void);
 int mmdm_gemm_init(void);
 int mmdm_gemm_bf16_init(void);
 int mmdm_gemm_split_init(void);
@@ -21,10 +26,17 @@ int mmdm_attn_init(void);
 int mmdm_step_dec(int* step_idx, int* loop_pos, hipStream_t st);
 int mmdm_set_step(int* step_idx, int* loop_pos, int s, int l, hipStream_t st);
 int mmdm_gather_rows(const float* src, const int* idx, float* dst, int n, int D, hipStream_t st);
-int mmdm_hist_copy(const float* src, float* dst, size_t count, const int* loop_pos, int every, hipStream_t st);
+// History destinations of the current sampling call, kept in DEVICE memory and read by the step's kernels at run time, so that a
+// captured step graph is independent of them (mmdm_set_history rewrites the descriptor, never the graph).
+struct mmdm_hist_desc {
+    float *i1, *i2, *o1, *o2, *mix;   // influence_i1/i2 [slots, 2B, T, 262 or 1], out1/out2/out_influenced [slots, 2B, T, 524]; null = not kept
+    int every;                        // slot k receives the step at loop position k*every
+    int pad;
+};
+int mmdm_set_hist_desc(mmdm_hist_desc* d, const mmdm_hist_desc& v, hipStream_t st);
+int mmdm_hist_copy(const float* src, const mmdm_hist_desc* hd, int which, size_t count, const int* loop_pos, hipStream_t st);
 int mmdm_blend_cfg_dyn(const float* out1, const float* out2, const float* w, int mode, int use_force, float force, float cfg_scale,
-                       float* model_out, float* hist_i1, float* hist_i2, float* hist_mix, const int* loop_pos, int every,
-                       int B, int T, hipStream_t st);
+                       float* model_out, const mmdm_hist_desc* hd, const int* loop_pos, int B, int T, hipStream_t st);
 int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
 int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,

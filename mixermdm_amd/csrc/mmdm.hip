@@ -44,8 +44,20 @@ int mmdm_kernels_init(void) {
     return rc;
 }
 
+static thread_local char g_gemm_note[160] = "";
+void mmdm_note_gemm_reset(void) { g_gemm_note[0] = 0; }
+void mmdm_note_gemm(const char* fmt, ...) {
+    size_t n = strlen(g_gemm_note);
+    if (n && n + 1 < sizeof(g_gemm_note)) g_gemm_note[n++] = '+';
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_gemm_note + n, sizeof(g_gemm_note) - n, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mmdm_last_gemm_kernel(void) { return g_gemm_note; }
+
 extern "C" const char* mmdm_last_error(void) { return g_err; }
-extern "C" const char* mmdm_version(void) { return "gfx950;mmdm-hip r1"; }
+extern "C" const char* mmdm_version(void) { return "gfx950;mmdm-hip r2"; }
 
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
@@ -143,6 +155,7 @@ struct mmdm_handle_s {
     bool stats_set = false;
     int* d_step = nullptr;       // [2]: step_idx, loop_pos
     int host_step = -1;          // mirror of step_idx
+    int h_tmap0 = 0;             // host copy of timestep_map[0] (mmdm_module_forward borrows slot 0 of the tables and puts it back)
     int Smax = 1000;
 
     // call state
@@ -160,16 +173,25 @@ struct mmdm_handle_s {
     float *se_d1 = nullptr, *se_d2 = nullptr, *se_mx = nullptr;         // silu(time + text)
     float *ss_d1 = nullptr, *ss_d2 = nullptr, *ss_mx = nullptr;         // AdaLN (scale|shift) for every layer/norm
     float *tt_tmp = nullptr, *tt_tmp2 = nullptr;           // [Smax, maxD] schedule scratch
+    float *tt_stash = nullptr;                             // [3, maxD] row 0 of the three time tables while mmdm_module_forward borrows it
     float *dual_w = nullptr;                               // [Smax] DualMDM composition weight per respaced step (single_only == 3)
     bool dual_w_set = false;
     int td1 = 0, cond_w = 0;                               // denoiser1's cond width (text_dim, or the latent size for MDM) and the cond row width
 
-    // history
-    float *hist_i1 = nullptr, *hist_i2 = nullptr, *hist_o1 = nullptr, *hist_o2 = nullptr, *hist_mix = nullptr;
-    int hist_every = 1;
+    // history: host mirror + the device-side descriptor the step's kernels read (kernels.h: mmdm_hist_desc)
+    mmdm_hist_desc hist = {nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0};
+    mmdm_hist_desc* d_hist = nullptr;
+    hipStream_t call_stream = nullptr;      // stream of the last mmdm_begin: mmdm_set_history orders its descriptor update on it
 
-    // graph
-    hipGraphExec_t gexec = nullptr;
+    // Captured step graphs, least-recently-used cache keyed by everything a captured node bakes in: (B, T, S).  History
+    // destinations, schedule tables, conditioning and the step index are device-side data, not node arguments, so the eval
+    // caller's alternating (B, T) requests (src/evaluation/datasets.py:101-122, 438) replay cached graphs instead of re-capturing.
+    struct GraphEntry { int B, T, S; hipGraphExec_t exec; uint64_t used; };
+    std::vector<GraphEntry> graphs;
+    size_t graph_cap = 8;
+    uint64_t graph_clock = 0;
+    int64_t n_captures = 0, n_replays = 0;
+    int device = 0;
 
     // denoiser1 || denoiser2 on two streams: the two stacks are independent until the mixer (mixermdm.py:685-687), so the
     // tail of one model's kernels overlaps the other's and the HBM-bound kernels hide under MFMA-bound ones.
@@ -654,12 +676,13 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     } else {
         RC(linear(c, c.s->h, Dm, H->mx.out_w, Dm, H->mx.out_b, H->w23, H->nw, 2 * n * T, H->nw, Dm, MMDM_EPI_BIAS_SIGMOID));
     }
-    const int* lp = dyn_hist ? H->d_step + 1 : nullptr;
-    RC(mmdm_blend_cfg_dyn(H->out1, H->out2, H->w23, mode, cf.use_force, cf.force_val, cf.cfg_scale, H->model_out,
-                          dyn_hist ? H->hist_i1 : nullptr, dyn_hist ? H->hist_i2 : nullptr, dyn_hist ? H->hist_mix : nullptr,
-                          lp, H->hist_every, B, T, c.st));
-    if (dyn_hist && H->hist_o1) RC(mmdm_hist_copy(H->out1, H->hist_o1, (size_t)n * T * NF2, lp, H->hist_every, c.st));
-    if (dyn_hist && H->hist_o2) RC(mmdm_hist_copy(H->out2, H->hist_o2, (size_t)n * T * NF2, lp, H->hist_every, c.st));
+    // history destinations come from the device-side descriptor: the launches below are identical whether or not (and where) a call
+    // keeps history, so one captured graph serves all of them; the two copy kernels return at once on a null destination
+    const int* lp = H->d_step + 1;
+    RC(mmdm_blend_cfg_dyn(H->out1, H->out2, H->w23, mode, cf.use_force, cf.force_val, cf.cfg_scale, H->model_out, H->d_hist, lp, B, T, c.st));
+    RC(mmdm_hist_copy(H->out1, H->d_hist, 0, (size_t)n * T * NF2, lp, c.st));
+    RC(mmdm_hist_copy(H->out2, H->d_hist, 1, (size_t)n * T * NF2, lp, c.st));
+    (void)dyn_hist;
     return MMDM_OK;
 }
 
@@ -759,6 +782,21 @@ int build_time_tab(const Ctx& c, ModuleW& m) {
 
 size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
+void drop_graphs(mmdm_handle h) {
+    for (auto& g : h->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
+// profiling is switched off around set-up launches (they are not part of a step) and restored on every exit path
+struct ProfPause {
+    Prof& p; bool was;
+    explicit ProfPause(Prof& pr) : p(pr), was(pr.on) { p.on = false; }
+    ~ProfPause() { p.on = was; }
+};
+
+int push_hist(mmdm_handle h, hipStream_t st) { return mmdm_set_hist_desc(h->d_hist, h->hist, st); }
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------
@@ -795,6 +833,7 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     RC(mmdm_kernels_init());
     mmdm_handle h = new mmdm_handle_s();
     h->cfg = *cfg;
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return mmdm_set_error(MMDM_ERR_HIP, "mmdm_create: hipGetDevice failed"); }
     const mmdm_config& c = h->cfg;
     h->nw = (c.mixing_mode >= 3) ? 23 : 1;
     int rc = MMDM_OK;
@@ -858,21 +897,30 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
             return fail(rc);
     }
     if ((rc = dalloc(h, &h->cond_cat, (size_t)n * h->cond_w))) return fail(rc);
-    if ((rc = dalloc(h, &h->tt_tmp, (size_t)h->Smax * Dx)) || (rc = dalloc(h, &h->tt_tmp2, (size_t)h->Smax * Dx))) return fail(rc);
+    if ((rc = dalloc(h, &h->tt_tmp, (size_t)h->Smax * Dx)) || (rc = dalloc(h, &h->tt_tmp2, (size_t)h->Smax * Dx)) || (rc = dalloc(h, &h->tt_stash, 3 * Dx))) return fail(rc);
     if ((rc = dalloc(h, &h->d_coef, (size_t)4 * h->Smax)) || (rc = dalloc(h, &h->d_stats, 4 * NF)) || (rc = dalloc(h, &h->dual_w, h->Smax))) return fail(rc);
     float* tmp = nullptr;
     if ((rc = dalloc(h, &tmp, h->Smax))) return fail(rc);
     h->d_tmap = reinterpret_cast<int*>(tmp);
     if ((rc = dalloc(h, &tmp, 4))) return fail(rc);
     h->d_step = reinterpret_cast<int*>(tmp);
+    if ((rc = dalloc(h, &tmp, (sizeof(mmdm_hist_desc) + 3) / 4))) return fail(rc);
+    h->d_hist = reinterpret_cast<mmdm_hist_desc*>(tmp);
+    if (hipMemcpy(h->d_hist, &h->hist, sizeof(mmdm_hist_desc), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(mmdm_set_error(MMDM_ERR_HIP, "mmdm_create: history descriptor upload failed"));
+    if (const char* e = getenv("MMDM_GRAPH_CACHE")) { long v = atol(e); if (v >= 1 && v <= 64) h->graph_cap = (size_t)v; }
     *out = h;
     return MMDM_OK;
 }
 
 extern "C" void mmdm_destroy(mmdm_handle h) {
     if (!h) return;
+    // the handle's streams, events and buffers live on the device it was created on, which need not be the caller's current one
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != h->device) (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    drop_graphs(h);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
@@ -881,6 +929,7 @@ extern "C" void mmdm_destroy(mmdm_handle h) {
     for (int k = 0; k < 2; ++k)
         for (hipEvent_t e : h->prof.ev[k]) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (cur >= 0 && cur != h->device) (void)hipSetDevice(cur);
     delete h;
 }
 
@@ -957,15 +1006,14 @@ extern "C" int mmdm_set_schedule(mmdm_handle h, const int* timestep_map, const f
         HIPCHK(hipMemcpyAsync(h->d_coef + (size_t)k * S, coef + (size_t)k * S, S * sizeof(float), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));   // host buffers may be transient
     h->S = S;
+    h->h_tmap0 = timestep_map[0];
     h->dual_w_set = false;
-    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // S is a kernel argument baked into the graph
+    // cached step graphs stay valid: S is part of their key, the tables are device data at fixed addresses
     Ctx c{h, st, &h->sa};
-    const bool pon = h->prof.on;
-    h->prof.on = false;
+    ProfPause pause(h->prof);
     int rc = h->cfg.single_only != 2 ? build_time_tab(c, h->d1) : MMDM_OK;
     if (!rc && h->cfg.single_only != 1) rc = build_time_tab(c, h->d2);
     if (!rc && h->cfg.single_only == 0) rc = build_time_tab(c, h->mx);
-    h->prof.on = pon;
     h->begun = false;
     return herr(h, rc);
 }
@@ -987,8 +1035,8 @@ extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     Ctx c{h, st, &h->sa};
     const int n = 2 * B, td = h->cfg.text_dim;
-    const bool pon = h->prof.on;
-    h->prof.on = false;
+    if (h->cfg.single_only == 3 && !h->dual_w_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_begin: call mmdm_set_dual_weights after mmdm_set_schedule"));
+    ProfPause pause(h->prof);
     int rc = MMDM_OK;
     if (h->cfg.single_only == 2) {
         // 4 CFG copies of cond [B, 3*td]: full | interaction only (first td columns) | individuals only (columns td..) | zeros
@@ -1012,7 +1060,6 @@ extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, in
     } else {
         // mixer: cond [B, 6*td + 2*td1] (mixermdm.py:342-354); dual: cond [B, 5*td] (in2in.py:299-305) -- same column order for the
         // first five slices, so text_all serves both
-        if (h->cfg.single_only == 3 && !h->dual_w_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_begin: call mmdm_set_dual_weights after mmdm_set_schedule"));
         const int cw = h->cond_w;
         HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n * cw * sizeof(float), st));
         HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * cw * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1020,27 +1067,25 @@ extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, in
         HIPCHK(hipMemcpyAsync(h->x, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));
         if (h->x2) HIPCHK(hipMemcpyAsync(h->x2, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));   // img2 = img.clone()
     }
-    h->prof.on = pon;
     if (rc) return herr(h, rc);
     RC(mmdm_set_step(h->d_step, h->d_step + 1, h->S - 1, 0, st));
     h->host_step = h->S - 1;
-    if (h->B != B || h->T != T) {
-        if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
-    }
     h->B = B; h->T = T; h->begun = true;
-    h->hist_i1 = h->hist_i2 = h->hist_o1 = h->hist_o2 = h->hist_mix = nullptr;
-    h->hist_every = 1;
-    return MMDM_OK;
+    h->call_stream = st;
+    // a new call keeps no history until mmdm_set_history says so: the descriptor is rewritten ON THE STREAM, behind any step of the
+    // previous call still in flight, so an earlier call's buffers can never be written again (graphs do not bake them in)
+    h->hist = mmdm_hist_desc{nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0};
+    return herr(h, push_hist(h, st));
 }
 
 extern "C" int mmdm_set_history(mmdm_handle h, float* influence_i1, float* influence_i2, float* out1, float* out2, float* out_influenced, int every) {
     if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_history: null handle");
     if (!h->begun) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_set_history: call after mmdm_begin"));
     if (every <= 0) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_history: every must be >= 1"));
-    h->hist_i1 = influence_i1; h->hist_i2 = influence_i2; h->hist_o1 = out1; h->hist_o2 = out2; h->hist_mix = out_influenced;
-    h->hist_every = every;
-    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }   // pointers are baked into the graph
-    return MMDM_OK;
+    if (h->cfg.single_only != 0 && (influence_i1 || influence_i2 || out1 || out2 || out_influenced))
+        return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_set_history: only the two-chain MixerMDM sampler has history side outputs"));
+    h->hist = mmdm_hist_desc{influence_i1, influence_i2, out1, out2, out_influenced, every, 0};
+    return herr(h, push_hist(h, h->call_stream));     // device-side descriptor: cached graphs are unaffected
 }
 
 extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) {
@@ -1052,18 +1097,33 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
     Ctx c{h, st, &h->sa};
     if (use_graph && !h->prof.on) {
         if (!st) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: graph capture needs a non-default stream"));
-        if (!h->gexec) {
+        if (nsteps == 0) return MMDM_OK;
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : h->graphs)
+            if (g.B == h->B && g.T == h->T && g.S == h->S) { exec = g.exec; g.used = ++h->graph_clock; break; }
+        if (!exec) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
             int rc = run_step(c);
             hipError_t e = hipStreamEndCapture(st, &g);
             if (rc) { if (g) (void)hipGraphDestroy(g); return herr(h, rc); }
             if (e != hipSuccess) return herr(h, mmdm_set_error(MMDM_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e)));
-            e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+            e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
-            if (e != hipSuccess) { h->gexec = nullptr; return herr(h, mmdm_set_error(MMDM_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e))); }
+            if (e != hipSuccess) return herr(h, mmdm_set_error(MMDM_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)));
+            if (h->graphs.size() >= h->graph_cap) {               // evict the least recently used entry (its replays may still be queued)
+                size_t lru = 0;
+                for (size_t i = 1; i < h->graphs.size(); ++i)
+                    if (h->graphs[i].used < h->graphs[lru].used) lru = i;
+                HIPCHK(hipStreamSynchronize(st));
+                (void)hipGraphExecDestroy(h->graphs[lru].exec);
+                h->graphs.erase(h->graphs.begin() + lru);
+            }
+            h->graphs.push_back({h->B, h->T, h->S, exec, ++h->graph_clock});
+            ++h->n_captures;
         }
-        for (int k = 0; k < nsteps; ++k) HIPCHK(hipGraphLaunch(h->gexec, st));
+        for (int k = 0; k < nsteps; ++k) HIPCHK(hipGraphLaunch(exec, st));
+        h->n_replays += nsteps;
     } else {
         for (int k = 0; k < nsteps; ++k) {
             int rc = run_step(c);
@@ -1088,24 +1148,46 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
                                    float* out, int n, int T, void* stream) {
     if (!h || !x || !cond || !out) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: null argument");
     if (!h->prepared) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_module_forward: call mmdm_prepare first"));
-    if (n <= 0 || (n & 1) || n / 2 > h->cfg.max_batch * (h->cfg.single_only == 2 ? 2 : 1) || T <= 0 || T > h->cfg.max_frames)
+    const int so_ = h->cfg.single_only;
+    const bool cfgx2 = which == 4;               // ClassifierFreeSampleModelX2.forward: n = B rows in, B rows out
+    if (cfgx2) {
+        if (so_ != 0) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: module 4 (CFG x2) needs the two-chain handle"));
+        if (n <= 0 || n > h->cfg.max_batch || T <= 0 || T > h->cfg.max_frames)
+            return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: B=%d (<= max_batch) T=%d out of range", n, T));
+    } else if (n <= 0 || (n & 1) || n / 2 > h->cfg.max_batch * (so_ == 2 ? 2 : 1) || T <= 0 || T > h->cfg.max_frames)
         return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: n=%d (even, <= 2*max_batch) T=%d out of range", n, T));
     if (t < 0 || t >= 5000) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: timestep %d out of range", t));
-    const int so_ = h->cfg.single_only;
-    if (which < 0 || which > 3 || (so_ == 1 && which != 0) || (so_ == 2 && which != 1) || (so_ == 3 && (which == 2 || which == 0)) || (so_ != 3 && which == 3)) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: bad module %d", which));
+    if (which < 0 || which > 4 || (so_ == 1 && which != 0) || (so_ == 2 && which != 1) || (so_ == 3 && (which == 2 || which == 0)) || (so_ != 3 && which == 3)) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: bad module %d", which));
     hipStream_t st = static_cast<hipStream_t>(stream);
     Ctx c{h, st, &h->sa};
     const int td = h->cfg.text_dim;
-    // a one-entry schedule at slot 0 of the tables: time_tab[0] = time_embed(pe[t]); restored by the next set_schedule
+    ProfPause pause(h->prof);
+    // The forward borrows slot 0 of the schedule tables (timestep_map[0] and row 0 of every time_tab) for a one-entry schedule
+    // time_tab[0] = time_embed(pe[t]) and puts the caller's entries back afterwards, so a schedule set before survives the call
+    // (a sampling call in progress does not: text embeddings, scratch and the step index are overwritten -- mmdm_begin again).
     const int S_keep = h->S;
+    ModuleW* mods[3] = {so_ != 2 ? &h->d1 : nullptr, so_ != 1 ? &h->d2 : nullptr, so_ == 0 ? &h->mx : nullptr};
+    const size_t Dst = max2(max2(h->d1.st.D, h->d2.st.D), h->mx.st.D);
+    if (S_keep > 0)
+        for (int k = 0; k < 3; ++k)
+            if (mods[k]) HIPCHK(hipMemcpyAsync(h->tt_stash + k * Dst, mods[k]->time_tab, mods[k]->st.D * sizeof(float), hipMemcpyDeviceToDevice, st));
     h->S = 1;
     h->begun = false;
-    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     int rc = MMDM_OK;
     HIPCHK(hipMemcpyAsync(h->d_tmap, &t, sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     RC(mmdm_set_step(h->d_step, h->d_step + 1, 0, 0, st));
-    auto done = [&](int code) { h->S = 0; (void)S_keep; return herr(h, code); };   // schedule must be set again
+    auto done = [&](int code) {
+        h->S = S_keep;
+        if (S_keep > 0) {
+            hipError_t e = hipMemcpyAsync(h->d_tmap, &h->h_tmap0, sizeof(int), hipMemcpyHostToDevice, st);
+            for (int k = 0; k < 3 && e == hipSuccess; ++k)
+                if (mods[k]) e = hipMemcpyAsync(mods[k]->time_tab, h->tt_stash + k * Dst, mods[k]->st.D * sizeof(float), hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess && !code) code = mmdm_set_error(MMDM_ERR_HIP, "mmdm_module_forward: restoring the schedule tables failed: %s", hipGetErrorString(e));
+        }
+        return herr(h, code);
+    };
     if (which == 3) {                         // in2INDenoiser "dual_individual": x [n,T,524], cond [n, 5*td]
         if ((rc = build_time_tab(c, h->d1))) return done(rc);
         if ((rc = text_rows(c, h->d1, cond, 5 * td, 3 * td, h->txt_d1, 0, n))) return done(rc);
@@ -1139,21 +1221,46 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
     }
     if (!x2) return done(mmdm_set_error(MMDM_ERR_ARG, "mmdm_module_forward: Mixer.forward needs x2"));
     if ((rc = build_time_tab(c, h->d1)) || (rc = build_time_tab(c, h->d2)) || (rc = build_time_tab(c, h->mx))) return done(rc);
-    if ((rc = text_all(c, cond, n))) return done(rc);
-    if (h->d1.kind == 0 && (rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, 2 * n))) return done(rc);
-    if ((rc = cond_vectors(c, h->d2, h->txt_d2, h->se_d2, h->ss_d2, 3 * n))) return done(rc);
-    if ((rc = cond_vectors(c, h->mx, h->txt_mx, h->se_mx, h->ss_mx, 3 * n))) return done(rc);
-    rc = h->d1.kind == 1 ? run_denoiser_mdm(c, h->d1, x, n, 2, NF2, n, T, cond + 3 * td, h->cond_w, h->o1, NF2)
-                         : run_denoiser(c, h->d1, false, x, n, 2, NF2, n, T, h->ss_d1, ss_ld_of(h->d1), h->o1, NF2);
+    // which == 2: Mixer.forward on a batch the caller has already CFG-doubled (n rows of x / x2 / cond).
+    // which == 4: ClassifierFreeSampleModelX2.forward (cfg_sampler.py:38-56): B = n rows in; the doubling (x repeated, cond followed by
+    //             zero rows) is this library's row layout, the s*cond + (1-s)*uncond combine is fused in the blend kernel.
+    const int nn = cfgx2 ? 2 * n : n, xb = n;
+    const float* cnd = cond;
+    if (cfgx2) {
+        const int cw = h->cond_w;
+        hipError_t e = hipMemsetAsync(h->cond_cat, 0, (size_t)nn * cw * sizeof(float), st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->cond_cat, cond, (size_t)n * cw * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return done(mmdm_set_error(MMDM_ERR_HIP, "mmdm_module_forward: %s", hipGetErrorString(e)));
+        cnd = h->cond_cat;
+    }
+    if ((rc = text_all(c, cnd, nn))) return done(rc);
+    if (h->d1.kind == 0 && (rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, 2 * nn))) return done(rc);
+    if ((rc = cond_vectors(c, h->d2, h->txt_d2, h->se_d2, h->ss_d2, 3 * nn))) return done(rc);
+    if ((rc = cond_vectors(c, h->mx, h->txt_mx, h->se_mx, h->ss_mx, 3 * nn))) return done(rc);
+    rc = h->d1.kind == 1 ? run_denoiser_mdm(c, h->d1, x, xb, 2, NF2, nn, T, cnd + 3 * td, h->cond_w, h->o1, NF2)
+                         : run_denoiser(c, h->d1, false, x, xb, 2, NF2, nn, T, h->ss_d1, ss_ld_of(h->d1), h->o1, NF2);
     if (rc) return done(rc);
-    if ((rc = run_denoiser(c, h->d2, true, x2, n, 2, NF2, n, T, h->ss_d2, ss_ld_of(h->d2), h->o2, NF2))) return done(rc);
-    // Mixer.forward returns out_influenced for the whole CFG-doubled batch: reuse the blend kernel's history output.
-    h->hist_i1 = h->hist_i2 = h->hist_o1 = h->hist_o2 = nullptr;
-    h->hist_mix = out;
-    h->hist_every = 1;
-    rc = mixer_core(c, n / 2, T, true);
-    h->hist_mix = nullptr;
+    if ((rc = run_denoiser(c, h->d2, true, x2, xb, 2, NF2, nn, T, h->ss_d2, ss_ld_of(h->d2), h->o2, NF2))) return done(rc);
+    // Mixer.forward returns out_influenced for the whole CFG-doubled batch: it is the blend kernel's out_influenced history output
+    // (slot 0 of a one-step history); the CFG wrapper returns the combined rows the same kernel leaves in model_out.
+    h->hist = mmdm_hist_desc{nullptr, nullptr, nullptr, nullptr, cfgx2 ? nullptr : out, 1, 0};
+    if ((rc = push_hist(h, st))) return done(rc);
+    rc = mixer_core(c, nn / 2, T, true);
+    h->hist.mix = nullptr;
+    if (!rc) rc = push_hist(h, st);
+    if (!rc && cfgx2) {
+        hipError_t e = hipMemcpyAsync(out, h->model_out, (size_t)n * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) rc = mmdm_set_error(MMDM_ERR_HIP, "mmdm_module_forward: %s", hipGetErrorString(e));
+    }
     return done(rc);
+}
+
+extern "C" int mmdm_graph_stats(mmdm_handle h, int64_t* captures, int64_t* replays, int* cached) {
+    if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_graph_stats: null handle");
+    if (captures) *captures = h->n_captures;
+    if (replays) *replays = h->n_replays;
+    if (cached) *cached = (int)h->graphs.size();
+    return MMDM_OK;
 }
 
 extern "C" size_t mmdm_encoder_layer_workspace(int nseq, int T, int D, int F) {

@@ -100,12 +100,26 @@ class Mixer(_Callable):
 
 
 class ClassifierFreeSampleModelX2(nn.Module):
-    """cfg_sampler.py:31-56: the doubling and the s*cond + (1-s)*uncond combine happen inside the HIP step."""
+    """cfg_sampler.py:31-56.  Inside the sampling loop the doubling and the s*cond + (1-s)*uncond combine are part of the captured HIP
+    step; called on its own (the reference's inner-callable protocol ``f(x, x2, timesteps, cond, mask)``, cfg_sampler.py:38) it runs the
+    same kernels through ``mmdm_module_forward(which=4)``: B un-doubled rows in, B combined rows out."""
 
     def __init__(self, model, cfg_scale):
         super().__init__()
         self.model = model
         self.s = cfg_scale
+
+    def forward(self, x, x2, timesteps, cond=None, mask=None):
+        if mask is not None:
+            raise NotImplementedError("mask must be None on the inference path")
+        if cond is None:
+            raise NotImplementedError("the HIP mixer is text-conditioned: cond [B, 8*768] is required (mixermdm.py:342-354)")
+        mixer = self.model
+        if mixer.mixing_mode not in (1, 2, 3, 4):
+            raise ValueError("Mixing mode not recognized")
+        owner = mixer._owner
+        smp = owner._sampler_for(x.shape[0], x.shape[1], cfg_scale=self.s)
+        return smp.module_forward(4, x, cond, _Callable._uniform_t(timesteps), x2=x2)
 
 
 class MixerDiffusion:
@@ -276,12 +290,15 @@ class MixerMDM(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
-    def _sampler_for(self, B, T):
+    def _sampler_for(self, B, T, cfg_scale=None):
+        if cfg_scale is not None and float(cfg_scale) != float(self.cfg_mixing_weight):
+            self.cfg_mixing_weight = cfg_scale         # the guidance scale is a handle constant (fused into the blend kernel)
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("MixerMDM runs on an MI355X only: call .to('cuda:N') first (no CPU path)")
         m = self.mixing
-        key = (str(dev), m.mixing_mode, bool(m.align), m.force_influence_val, self.cfg_model2.NAME, self.cfg_model1.NAME, self.precision)
+        key = (str(dev), m.mixing_mode, bool(m.align), m.force_influence_val, self.cfg_model2.NAME, self.cfg_model1.NAME, self.precision,
+               float(self.cfg_mixing_weight))
         s = self._sampler
         if s is None or s._key != key or B > s.cfg.max_batch or T > s.cfg.max_frames:
             if s is not None:
@@ -323,21 +340,19 @@ class MixerMDM(nn.Module):
     # ---- sampling -----------------------------------------------------------------------------------
     def _run_loop(self, diffusion, cond, x_T, cfg_scale=None):
         B, T = x_T.shape[:2]
-        smp = self._sampler_for(B, T)
-        if cfg_scale is not None and float(cfg_scale) != float(smp.cfg.cfg_scale):
-            self.cfg_mixing_weight = cfg_scale
-            smp.close()
-            self._sampler = None
-            smp = self._sampler_for(B, T)
+        smp = self._sampler_for(B, T, cfg_scale=cfg_scale)
         sch = diffusion.schedule
-        if getattr(smp, "_strategy", None) is not sch:
+        # the facade builds a new MixerDiffusion per call (as the reference does, mixermdm.py:515-522): compare schedules by CONTENT so
+        # that the tables are uploaded, the time-embedding tables rebuilt and (through the (B, T, S) graph cache) nothing re-captured
+        # only when the strategy really changed
+        if getattr(smp, "_strategy", None) != sch.key():
             import ctypes as C
             from ._lib import check
             tmap = np.ascontiguousarray(np.array(sch.timestep_map, dtype=np.int32))
             coef = np.ascontiguousarray(sch.device_coefficients())
             with torch.cuda.device(smp.device):
                 check(smp.lib.mmdm_set_schedule(smp.h, tmap.ctypes.data_as(C.c_void_p), coef.ctypes.data_as(C.c_void_p), sch.num_timesteps, smp._s()), smp.h)
-            smp.schedule, smp._strategy = sch, sch
+            smp.schedule, smp._strategy = sch, sch.key()
         m = self.mixing
         names = []
         if m.store_influence:
@@ -345,7 +360,8 @@ class MixerMDM(nn.Module):
         if m.mode == "eval":
             names += ["out1", "out2", "out_influenced"]
         slots = (sch.num_timesteps + self.history_every - 1) // self.history_every
-        need = slots * 2 * B * T * 4 * sum(262 if n.startswith("influence") else 524 for n in names)
+        wi = 262 if m.mixing_mode >= 3 else 1          # modes 1-2 keep the un-expanded [2B, T, 1] influence (mixermdm.py:739-745)
+        need = slots * 2 * B * T * 4 * sum(wi if n.startswith("influence") else 524 for n in names)
         if need > HISTORY_BUDGET_BYTES:
             raise MemoryError(f"history side outputs need {need / 2**30:.1f} GiB for {sch.num_timesteps} steps (the reference keeps every step: "
                               "mixermdm.py:794-808); set model.history_every = k to keep every k-th step, or store_influence=False / forward_test")

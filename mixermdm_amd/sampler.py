@@ -52,9 +52,12 @@ class Sampler:
             # graph capture is not allowed on the legacy default stream: the handle works on its own stream
             self.stream = torch.cuda.Stream(device=self.device)
         self.schedule = None
+        self._strategy = None
         self._hist = None
 
     def close(self):
+        """Frees the handle (mmdm_destroy selects the handle's own device before synchronising and freeing).  Tensors returned by
+        state() are views of handle memory and are invalid afterwards."""
         if getattr(self, "h", None) and self.h.value:
             self.lib.mmdm_destroy(self.h)
             self.h = C.c_void_p()
@@ -115,6 +118,7 @@ class Sampler:
         with torch.cuda.device(self.device):
             check(self.lib.mmdm_set_schedule(self.h, tmap.ctypes.data_as(C.c_void_p), coef.ctypes.data_as(C.c_void_p), sch.num_timesteps, self._s()), self.h)
         self.schedule = sch
+        self._strategy = sch.key()
         return sch
 
     def set_dual_weights(self, func, value):
@@ -150,14 +154,15 @@ class Sampler:
         return self
 
     def set_history(self, names=("influence_i1", "influence_i2", "out1", "out2", "out_influenced"), every=1):
-        """Allocate history buffers [slots, 2B, T, C] for the requested side outputs (mixermdm.py:794-796, 805-808)."""
+        """Allocate history buffers [slots, 2B, T, C] for the requested side outputs (mixermdm.py:794-796, 805-808).  C = 524 for
+        out1 / out2 / out_influenced; for the influences 262 in mixing modes 3-4 and 1 in modes 1-2 (the reference's shapes)."""
         S = self.schedule.num_timesteps
         slots = (S + every - 1) // every
         n = 2 * self.B
         bufs = {}
         for nm in ("influence_i1", "influence_i2", "out1", "out2", "out_influenced"):
             if nm in names:
-                Cc = 262 if nm.startswith("influence") else 524
+                Cc = (262 if self.cfg.mixing_mode >= 3 else 1) if nm.startswith("influence") else 524
                 bufs[nm] = torch.empty(slots, n, self.T, Cc, device=self.device, dtype=torch.float32)
         ptr = lambda nm: C.c_void_p(bufs[nm].data_ptr() if nm in bufs else 0)
         with torch.cuda.device(self.device):
@@ -199,8 +204,8 @@ class Sampler:
 
     # ---- teacher-forced module forwards (tests / swappable inner protocol) ----------------------------
     def module_forward(self, which, x, cond, t, x2=None):
-        """which: 0 denoiser1, 1 denoiser2, 2 Mixer.forward, 3 denoiser1 in "dual_individual" mode; inputs are the CFG-doubled batch.
-        Invalidates the schedule."""
+        """which: 0 denoiser1, 1 denoiser2, 2 Mixer.forward, 3 denoiser1 in "dual_individual" mode (inputs are the CFG-doubled batch);
+        4 ClassifierFreeSampleModelX2.forward (B un-doubled rows in, B combined rows out).  The schedule survives; a begun call does not."""
         x = x.to(self.device, torch.float32).contiguous()
         cond = cond.to(self.device, torch.float32).contiguous()
         x2c = x2.to(self.device, torch.float32).contiguous() if x2 is not None else None
@@ -211,8 +216,13 @@ class Sampler:
             check(self.lib.mmdm_module_forward(self.h, which, C.c_void_p(x.data_ptr()), C.c_void_p(x2c.data_ptr() if x2c is not None else 0),
                                                C.c_void_p(cond.data_ptr()), int(t), C.c_void_p(out.data_ptr()), n, T, self._s()), self.h)
         self.stream.synchronize()
-        self.schedule = None
         return out
+
+    def graph_stats(self):
+        """(steps captured, steps replayed, graphs cached) of the handle's (B, T, S)-keyed hipGraph cache."""
+        cap, rep, n = C.c_int64(), C.c_int64(), C.c_int()
+        check(self.lib.mmdm_graph_stats(self.h, C.byref(cap), C.byref(rep), C.byref(n)), self.h)
+        return cap.value, rep.value, n.value
 
     # ---- profiling ----------------------------------------------------------------------------------
     def profile(self, on=True):
