@@ -292,6 +292,11 @@ int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream);
 /* Counters of the graph cache: steps captured so far, steps replayed, entries currently cached (each pointer may be NULL). */
 int mmdm_graph_stats(mmdm_handle h, int64_t* captures, int64_t* replays, int* cached);
 
+/* Move a begun call to respaced step `step_index` (S-1 = first step of the loop, 0 = last): the next mmdm_run continues from there
+ * with the chains as they stand (history slots follow the loop position S-1-step_index).  Lets a caller resume a loop, or drive
+ * teacher-forced steps -- overwrite x / x2 through mmdm_get_state, seek, run one step (the parity tests' ddim1000 first/last-20). */
+int mmdm_seek(mmdm_handle h, int step_index, void* stream);
+
 /* Device pointers owned by the handle, valid until destroy: current chains and the last pred_xstart(2). */
 int mmdm_get_state(mmdm_handle h, float** x, float** x2, float** pred_xstart, float** pred_xstart2, float** model_out);
 

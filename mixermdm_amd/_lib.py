@@ -72,6 +72,7 @@ SYMBOLS = {
     "mmdm_begin": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
     "mmdm_set_history": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I]),
     "mmdm_run": (_I, [_VP, _I, _I, _VP]),
+    "mmdm_seek": (_I, [_VP, _I, _VP]),
     "mmdm_graph_stats": (_I, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_I)]),
     "mmdm_last_gemm_kernel": (C.c_char_p, []),
     "mmdm_get_state": (_I, [_VP] + [C.POINTER(_VP)] * 5),

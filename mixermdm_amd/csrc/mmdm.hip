@@ -1134,6 +1134,15 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
     return MMDM_OK;
 }
 
+extern "C" int mmdm_seek(mmdm_handle h, int step_index, void* stream) {
+    if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_seek: null handle");
+    if (!h->begun) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_seek: call mmdm_begin first"));
+    if (step_index < 0 || step_index >= h->S) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_seek: step index %d outside [0, %d)", step_index, h->S));
+    RC(mmdm_set_step(h->d_step, h->d_step + 1, step_index, h->S - 1 - step_index, static_cast<hipStream_t>(stream)));
+    h->host_step = step_index;
+    return MMDM_OK;
+}
+
 extern "C" int mmdm_get_state(mmdm_handle h, float** x, float** x2, float** pred_xstart, float** pred_xstart2, float** model_out) {
     if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_get_state: null handle");
     if (x) *x = h->x;

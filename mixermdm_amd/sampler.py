@@ -177,6 +177,12 @@ class Sampler:
             check(self.lib.mmdm_run(self.h, nsteps, int(use_graph), self._s()), self.h)
         return self
 
+    def seek(self, step_index):
+        """Continue the begun call from respaced step `step_index` (S-1 = first, 0 = last) with the chains as they stand."""
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_seek(self.h, int(step_index), self._s()), self.h)
+        return self
+
     def synchronize(self):
         self.stream.synchronize()
 

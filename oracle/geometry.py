@@ -118,8 +118,11 @@ def smpl_to_ih(motion):
     return torch.cat([motion[:, :, :132], poses, motion[:, :, -4:]], dim=2)
 
 
-def align_motions(motion1, motion2):
-    """alignment.py:112-158 + align_trajectories :69-109, mask=None.  Returns the moved motion2 (201-d)."""
+def align_motions(motion1, motion2, diag=None):
+    """alignment.py:112-158 + align_trajectories :69-109, mask=None.  Returns the moved motion2 (201-d).
+    diag (tests only): a list that receives this call's conditioning figures per sample -- the XZ root displacement lengths of the two
+    trajectories (the rotation is the angle between their DIRECTIONS: a near-stationary root makes it rounding noise), the real part of
+    the un-normalised qbetween quaternion (-> 0 for anti-parallel directions) and the largest |position| the rotation is applied to."""
     B = motion1.shape[0]
     p1 = motion1[..., :66].reshape(B, -1, 22, 3)
     p2 = motion2[..., :66].reshape(B, -1, 22, 3)
@@ -131,6 +134,10 @@ def align_motions(motion1, motion2):
     d2 = (t2[:, -1] - t2[:, 0]).clone()
     d1[:, 1] = 0
     d2[:, 1] = 0
+    if diag is not None:
+        n1, n2 = d1.norm(dim=1), d2.norm(dim=1)
+        u1, u2 = d1 / torch.sqrt((d1 ** 2).sum(dim=1, keepdim=True) + 1e-8), d2 / torch.sqrt((d2 ** 2).sum(dim=1, keepdim=True) + 1e-8)
+        diag.append(dict(disp_target=n1, disp_moved=n2, w=1 + (u1 * u2).sum(dim=1), reach=(p2 - p2[:, :1, :1]).abs().amax(dim=(1, 2, 3))))
     d1 = d1 / torch.sqrt((d1 ** 2).sum(dim=1, keepdim=True) + 1e-8)
     d2 = d2 / torch.sqrt((d2 ** 2).sum(dim=1, keepdim=True) + 1e-8)
     q = qbetween(d2, d1)[:, None, None, :].expand(-1, p2.shape[1], 22, -1)
@@ -140,8 +147,10 @@ def align_motions(motion1, motion2):
     return torch.cat([p2.reshape(B, -1, 66), v2.reshape(B, -1, 66), r2], dim=-1)
 
 
-def center_motion(motion):
-    """alignment.py:161-222 (201-d output).  torch.cross there has no dim (quirk 9): B != 3 assumed."""
+def center_motion(motion, diag=None):
+    """alignment.py:161-222 (201-d output).  torch.cross there has no dim (quirk 9): B != 3 assumed.
+    diag (tests only): receives per sample the first-frame hip distance |across|, the length of Y x across before normalisation
+    (-> 0 when the hips are stacked vertically) and the real part of the un-normalised facing quaternion (-> 0 when facing -Z)."""
     B = motion.shape[0]
     pos = motion[:, :, :66].reshape(B, -1, 22, 3).clone()
     vel = motion[:, :, 66:132].reshape(B, -1, 22, 3)
@@ -153,9 +162,13 @@ def center_motion(motion):
     pos2 = pos - xz[:, None, None, :]
     r_hip, l_hip = FACE_JOINT_INDX[:2]
     across = root_init[:, r_hip] - root_init[:, l_hip]
-    across = across / torch.sqrt((across ** 2).sum(dim=-1)).unsqueeze(-1)
+    across_len = torch.sqrt((across ** 2).sum(dim=-1))
+    across = across / across_len.unsqueeze(-1)
     fwd = torch.cross(torch.tensor([0.0, 1.0, 0.0]).expand(B, -1), across, dim=-1)
-    fwd = fwd / torch.sqrt((fwd ** 2).sum(dim=-1)).unsqueeze(-1)
+    fwd_len = torch.sqrt((fwd ** 2).sum(dim=-1))
+    fwd = fwd / fwd_len.unsqueeze(-1)
+    if diag is not None:
+        diag.append(dict(across=across_len, fwd=fwd_len, w=1 + fwd[:, 2], reach=pos2.abs().amax(dim=(1, 2, 3))))
     target = torch.tensor([0.0, 0.0, 1.0]).expand(B, -1)
     q = qbetween(fwd, target)[:, None, None, :].expand(-1, pos2.shape[1], 22, -1)
     pos2 = qrot(q, pos2)

@@ -80,8 +80,9 @@ def mixer_forward(W, spec, stats, x1, timesteps, cond, x2, hist=None):
     o21, o22 = o2[..., :nf], o2[..., nf:]
     if spec.align:
         s11, s12, s21, s22 = G.ih_to_smpl(o11), G.ih_to_smpl(o12), G.ih_to_smpl(o21), G.ih_to_smpl(o22)
-        s11 = G.align_motions(s21, s11)
-        s12 = G.align_motions(s22, s12)
+        dg = hist.setdefault("align_diag", []) if hist is not None else None      # conditioning of the two alignments (person 1, person 2)
+        s11 = G.align_motions(s21, s11, dg)
+        s12 = G.align_motions(s22, s12, dg)
         o11, o12, o21, o22 = G.smpl_to_ih(s11), G.smpl_to_ih(s12), G.smpl_to_ih(s21), G.smpl_to_ih(s22)
     out1 = torch.cat([o11, o12], dim=-1)
     out2 = torch.cat([o21, o22], dim=-1)
@@ -112,7 +113,7 @@ def cfg_x2(W, spec, stats, s, x, x2, timesteps, cond, hist=None):
     return s * out[:B] + (1 - s) * out[B:]
 
 
-def process_xstart(x, stats, t0_positive, align=True):
+def process_xstart(x, stats, t0_positive, align=True, diag=None):
     """MixerDiffusion.p_mean_variance.process_xstart -- gaussian_diffusion.py:2031-2062 (clip_denoised=False).
 
     When t[0]==0 BOTH returns are the raw x: x1 is only rebuilt inside the ``if t[0] > 0`` branch (:2052-2056).
@@ -123,8 +124,8 @@ def process_xstart(x, stats, t0_positive, align=True):
         return x.clone(), x.clone()
     x11, x12 = x[..., :262], x[..., 262:]
     if align:
-        x11 = G.smpl_to_ih(G.center_motion(G.ih_to_smpl(x11)))
-        x12 = G.smpl_to_ih(G.center_motion(G.ih_to_smpl(x12)))
+        x11 = G.smpl_to_ih(G.center_motion(G.ih_to_smpl(x11), diag))
+        x12 = G.smpl_to_ih(G.center_motion(G.ih_to_smpl(x12), diag))
     x1 = torch.cat([(x11 - mean_h) / std_h, (x12 - mean_h) / std_h], dim=-1)
     x2 = ((x.reshape(B, T, 2, -1) - mean_i) / std_i).reshape(B, T, -1)
     return x1, x2
@@ -146,7 +147,7 @@ def mixer_ddim_step(W, spec, stats, sched, s, i, x, x2, cond, hist=None, xstart_
     B = x.shape[0]
     ts = torch.full((B,), sched.timestep_map[i], dtype=torch.long)
     out = cfg_x2(W, spec, stats, s, x, x2, ts, cond, hist)
-    p1, p2 = process_xstart(out, stats, i > 0, xstart_align)
+    p1, p2 = process_xstart(out, stats, i > 0, xstart_align, hist.setdefault("center_diag", []) if hist is not None else None)
     return ddim_update(sched, i, x, p1), ddim_update(sched, i, x2, p2), p1, p2
 
 

@@ -45,3 +45,32 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def fulldims_case():
+    """tests/golden/fulldims.npz: the reference at the real model sizes.  The fixture carries seeds, statistics and reference outputs only;
+    weights and inputs are re-drawn here from the same seeded CPU generators make_golden.py used.  Returns (g, W, stats, inputs)."""
+    import torch
+    from oracle.layers import pe_table
+    from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_inputs, FULL_DIMS
+    d = np.load(os.path.join(GOLDEN, "fulldims.npz"))
+    g = {k: d[k] for k in d.files}
+    sd = synthetic_state_dict(seed=int(g["weights_seed"]), std=float(g["weights_std"]), bias_std=float(g["weights_bias_std"]), **FULL_DIMS)
+    W = dict(sd)
+    W["sequence_pos_encoder.pe"] = pe_table(512)
+    W["denoiser1.sequence_pos_encoder.pe"] = pe_table(1024)
+    W["denoiser2.sequence_pos_encoder.pe"] = pe_table(1024)
+    stats = tuple(torch.from_numpy(g[k]) for k in ["mean_hml", "std_hml", "mean_ih", "std_ih"])
+    rnd = lambda seed, *shape: torch.randn(*shape, generator=torch.Generator().manual_seed(int(seed)))
+    n, T = [int(v) for v in g["fwd_shape"]]
+    s1, s2, s3 = [int(v) for v in g["fwd_seeds"]]
+    cond = rnd(s3, n, 8 * 768)
+    cond[n // 2:] = 0
+    B, Ts = int(g["step_B"]), int(g["step_T"])
+    cb, xT = synthetic_inputs(B, Ts)
+    c300, x300 = synthetic_inputs(1, 300)
+    la, lb = [int(v) for v in g["late_seeds"]]
+    inputs = dict(fwd=(rnd(s1, n, T, 524), rnd(s2, n, T, 524), cond, int(g["fwd_t"])),
+                  step=(cb, xT, rnd(int(g["step_x2_seed"]), B, Ts, 524)),
+                  t300=(c300, x300), late=(rnd(la, 1, 300, 524), rnd(lb, 1, 300, 524)))
+    return g, sd, W, stats, inputs

@@ -512,7 +512,67 @@ def g_mixer32():
     save("mixer32", **out)
 
 
+# ---- full model dimensions (configs/models/*.yaml), weights from the repo's seeded generator ------------------------------
+def g_fulldims():
+    """The REFERENCE at the real model sizes (D=1024, F=2048, L=8, H=8; mixer 512/1024/4/8), with the weights of
+    mixermdm_amd.synthetic.synthetic_state_dict(seed=0, std=0.02, bias_std=0.02) loaded into the reference modules by name.  The fixture
+    holds NO weights and no inputs -- only the seeds they are drawn from (same deterministic CPU generators on every box), the
+    normaliser statistics and the reference's outputs: Mixer.forward and MixerDiffusion.ddim_sample at B=2, T=32 and one ddim1000
+    step at the headline length T=300 (B=1)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_inputs, FULL_DIMS
+    den = dict(latent_dim=1024, ff_size=2048, num_layers=8, num_heads=8, dropout=0.1)
+    d1 = in2INDenoiser(262, mode="individual", **den)
+    d2 = in2INDenoiser(262, mode="interaction", **den)
+    mix = Mixer(d1, d2, nfeats=262, latent_dim=512, ff_size=1024, text_dim=768, n_blocks=4, n_heads=8, mixing_mode=4, store_influence=True,
+                force_influence_val=None, mode="eval", align=True)
+    wsd = synthetic_state_dict(seed=0, std=0.02, bias_std=0.02, **FULL_DIMS)
+    res = mix.load_state_dict(wsd, strict=False)
+    assert not res.unexpected_keys and all(k.endswith("sequence_pos_encoder.pe") for k in res.missing_keys), res
+    mix.eval()
+    out = {k: v for k, v in STATS.items()}
+    out.update(weights_seed=0, weights_std=0.02, weights_bias_std=0.02, cfg_scale=3.5, d_heads=8, m_heads=8)
+    # Mixer.forward on a CFG-doubled batch, inputs rnd(seed, ...) as in the other fixtures
+    B, T = 2, 32
+    B2 = 2 * B
+    seeds = dict(x1=380, x2=381, cond=382)
+    x1, x2, cond = rnd(seeds["x1"], B2, T, 524), rnd(seeds["x2"], B2, T, 524), rnd(seeds["cond"], B2, 8 * 768)
+    cond[B:] = 0
+    tt = 640
+    out.update(fwd_seeds=np.array([seeds["x1"], seeds["x2"], seeds["cond"]]), fwd_shape=np.array([B2, T]), fwd_t=tt)
+    reset_hist(mix)
+    out["fwd"] = mix(x1, torch.full((B2,), tt, dtype=torch.long), cond=cond, mask=None, x2=x2)
+    out["fwd:influence_i1"] = mix.history_influence_i1[0][..., [0, 3, 66, 132, 258]]      # one channel of five of the 23 groups
+    cfg = ClassifierFreeSampleModelX2(mix, 3.5)
+    # ddim_sample (ddim50, i = 32 and the un-normalised i = 0 branch) from synthetic_inputs(B, T) = the bench's input generator
+    cb, xT = synthetic_inputs(B, T)
+    xb2 = rnd(383, B, T, 524)
+    out.update(step_B=B, step_T=T, step_x2_seed=383)
+    diff = make_diffusion("ddim50")
+    for i in [32, 0]:
+        reset_hist(mix)
+        r = diff.ddim_sample(cfg, xT, xb2, torch.tensor([i] * B), clip_denoised=False, model_kwargs={"mask": None, "cond": cb})
+        for k in ["sample", "sample2", "pred_xstart2"]:
+            out[f"ddim50:i{i}:{k}"] = r[k]
+    # the headline length: one ddim1000 step at T = 300, B = 1, both chains at x_T (the first step of the benchmarked loop) ...
+    cb, xT = synthetic_inputs(1, 300)
+    diff = make_diffusion("ddim1000")
+    reset_hist(mix)
+    r = diff.ddim_sample(cfg, xT, xT.clone(), torch.tensor([999]), clip_denoised=False, model_kwargs={"mask": None, "cond": cb})
+    for k in ["sample", "sample2"]:
+        out[f"ddim1000:T300:i999:{k}"] = r[k]
+    # ... and a late one (i = 3: alpha_bar ~ 1) from chains that differ
+    xa, xb_ = rnd(384, 1, 300, 524), rnd(385, 1, 300, 524)
+    out.update(late_seeds=np.array([384, 385]))
+    reset_hist(mix)
+    r = diff.ddim_sample(cfg, xa, xb_, torch.tensor([3]), clip_denoised=False, model_kwargs={"mask": None, "cond": cb})
+    for k in ["sample", "sample2"]:
+        out[f"ddim1000:T300:i3:{k}"] = r[k]
+    save("fulldims", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedule", "pe", "layers", "denoisers", "influence", "geometry", "mixer", "single", "interaction", "dual", "mdm", "text", "mixer32"]
+    which = sys.argv[1:] or ["schedule", "pe", "layers", "denoisers", "influence", "geometry", "mixer", "single", "interaction", "dual", "mdm", "text", "mixer32",
+                             "fulldims"]
     for w in which:
         globals()["g_" + w]()

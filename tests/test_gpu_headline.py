@@ -1,0 +1,365 @@
+"""GPU: the headline configuration VALUE-checked -- full model dimensions (D=1024/F=2048/L=8/H=8, mixer 512/1024/4/8), T=300, the
+ddim1000 schedule -- in the native fp32 mode and in fp32_split, against (1) the CPU oracle and (2) outputs captured from the REFERENCE
+itself at these sizes (tests/golden/fulldims.npz), plus float64 checks of the GEMM instantiations the B=16 step actually launches
+(M = 19 200 rows), with the launched kernel asserted through the mmdm_last_gemm_kernel() debug getter.
+
+Tolerance of a step (tests/test_gpu_sampler.py::STEP_TOL): all but 0.2 % of the elements within atol 2e-4 + rtol 2e-4, none beyond 5e-2
+(a handful of near-degenerate joints amplify rounding through the rot6d -> quaternion round trip); the tolerance of a person's position /
+velocity channels is scaled by the conditioning factor of the global rotations that produced them (see KAPPA_MASK below).
+"""
+import math
+import os
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mixer as MX            # noqa: E402  (checker only)
+from oracle import schedule as OS         # noqa: E402
+from test_gpu_kernels import assert_close, rnd, dev   # noqa: E402
+from test_gpu_sampler import STEP_TOL      # noqa: E402
+from conftest import fulldims_case         # noqa: E402
+
+MODES = ["fp32", "fp32_split"]
+ORACLE_THREADS = 16          # B=1..2 GEMMs on the GPU box's 128-thread host run fastest on 16 threads (bench.py calibrates the same way)
+
+
+class _Threads:
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(min(ORACLE_THREADS, os.cpu_count() or 1))
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.n)
+
+
+@pytest.fixture(scope="module")
+def case():
+    """(golden arrays, state dict, oracle weights incl. pe tables, stats tuple, seeded inputs) of fulldims.npz."""
+    return fulldims_case()
+
+
+@pytest.fixture(scope="module")
+def samplers(case):
+    """One handle per precision mode at the real sizes, B <= 2, T <= 300, with the fixture's statistics."""
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd.synthetic import FULL_DIMS
+    g, sd, W, stats, _ = case
+    made = {}
+    for mode in MODES:
+        s = Sampler(d_heads=8, m_heads=8, max_batch=2, max_frames=300, precision=mode, **FULL_DIMS)
+        s.load_state_dict(sd)
+        s.set_norm_stats(*[t.numpy() for t in stats])
+        s.prepare()
+        made[mode] = s
+    yield made
+    for s in made.values():
+        s.close()
+
+
+# Conditioning of the reference's two global rotations (geometry near its branch points needs a discriminant-aware comparison).
+# Both are qbetween(u, v) of two directions and both are applied to whole position / velocity sequences:
+#   * align_motions turns the individual model's motion by the angle between two root-displacement DIRECTIONS (alignment.py:84-101).  A
+#     pre-geometry difference e in the root positions (HIP vs CPU rounding through 8-16 blocks: ~2e-5) turns the sequence by e / |disp| and
+#     moves a position at distance `reach` from the pivot by reach * e / |disp|: that stays inside the 2e-4 tolerance only while
+#     |disp| >= 0.1 reach.  The random-weight individual model barely moves its root (|disp| / reach = 0.04-0.07), so the factor
+#     kappa = 0.1 reach / |disp| (>= 1) scales the tolerance of that person's position / velocity channels.
+#   * qbetween is singular for anti-parallel directions: w = 1 + u.v -> 0 and |u x v| -> 0, and an fp32 rounding of w (1e-7) turns the
+#     sequence by 2e-7 / sqrt(2 w): beyond the tolerance at 8 m reach once w < 3e-5.  center_motion (alignment.py:188-206) rotates every
+#     person to face +Z, so person 2 of a pair facing each other -- where these trajectories sit for many late steps -- is exactly that
+#     half turn.  kappa = sqrt(3e-4 / w) (10x margin on the figure above).
+# Persons with kappa > KAPPA_MASK are on the branch point: their position / velocity channels are compared for sanity only (finite,
+# |err| <= 1).  Rotation-6D and foot-contact channels are never affected and always meet the plain tolerance.
+KAPPA_MASK = 25.0
+
+
+def _kappa(hist, B):
+    """Oracle diagnostics of one step -> (kappa_chain1 [B, 2 persons], kappa_chain2 [B, 2]) tolerance factors >= 1."""
+    k_align = torch.ones(B, 2, dtype=torch.float64)
+    for p, d in enumerate(hist["align_diag"][-2:]):            # rows: B cond + B uncond of the CFG-doubled batch
+        k = torch.maximum(0.1 * d["reach"] / torch.minimum(d["disp_target"], d["disp_moved"]).clamp_min(1e-12), torch.sqrt(3e-4 / d["w"].clamp_min(1e-12))).double()
+        k_align[:, p] = torch.maximum(k[:B], k[B:]).clamp_min(1.0)
+    k_center = torch.ones(B, 2, dtype=torch.float64)
+    for p, d in enumerate(hist.get("center_diag", [])[-2:]):
+        k = torch.maximum(torch.sqrt(3e-4 / d["w"].clamp_min(1e-12)), 0.01 * d["reach"] / (d["across"] * d["fwd"]).clamp_min(1e-12)).double()
+        k_center[:, p] = k.clamp_min(1.0)
+    return torch.maximum(k_align, k_center), k_align
+
+
+def _step(s, x, x2, i, names=("x", "x2", "pred_xstart", "pred_xstart2")):
+    """One teacher-forced step of the begun call from chains (x, x2) at respaced index i -> cloned outputs."""
+    _force(s, x, x2, i)
+    s.run(1, use_graph=True)
+    st = s.state()
+    return {k: st[k].clone() for k in names}
+
+
+def _check_step(s, x, x2, i, refs, what, hist):
+    """refs: {state name: reference tensor}; hist: the oracle's diagnostics of this very step (conditioning factors)."""
+    out = _step(s, x, x2, i)
+    B, T = x.shape[:2]
+    k1, k2 = _kappa(hist, B)
+    worst, masked = 0.0, False
+    for nm, ref in refs.items():
+        got, ref = out[nm].detach().cpu().double(), torch.as_tensor(ref).detach().cpu().double()
+        assert torch.isfinite(got).all(), f"{what} {nm}: non-finite"
+        kap = k1 if nm in ("x", "pred_xstart") else k2
+        scale = torch.ones(B, T, 524, dtype=torch.float64)
+        for p in range(2):
+            scale[:, :, p * 262:p * 262 + 132] = kap[:, p, None, None]
+        keep = scale <= KAPPA_MASK
+        masked |= not bool(keep.all())
+        d = (got - ref).abs()
+        bad = (d > scale * (STEP_TOL["atol"] + STEP_TOL["rtol"] * ref.abs())) & keep
+        frac = bad.double().sum().item() / max(1, int(keep.sum()))
+        note = f"(conditioning factors per [sample, person]: {[[round(v, 1) for v in r] for r in kap.tolist()]})"
+        assert frac <= STEP_TOL["frac"], f"{what} {nm}: {frac:.2e} of the elements outside tolerance, max err {d[keep].max().item():.2e} {note}"
+        assert (d[keep] / scale[keep]).max().item() <= STEP_TOL["hard"], f"{what} {nm}: max err {d[keep].max().item():.2e} {note}"
+        assert d.max().item() <= 1.0, f"{what} {nm}: an element on a branch point is off by {d.max().item():.2e}"
+        worst = max(worst, frac)
+    return out, worst, masked
+
+
+def _force(s, x, x2, i):
+    """Teacher forcing: overwrite both chains of the begun call and continue from respaced step i."""
+    st = s.state()
+    st["x"].copy_(x.to(st["x"].device))
+    st["x2"].copy_(x2.to(st["x2"].device))
+    torch.cuda.synchronize()
+    s.seek(i)
+
+
+# ---------------------------------------------------------------------------------------------------
+# (d) the reference itself at the real sizes
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_diag(case):
+    """The oracle's conditioning diagnostics for the fixture's steps (the expected VALUES stay the reference's own outputs)."""
+    g, _, W, stats, inp = case
+    spec = MX.MixerSpec(d_heads=8, m_heads=8)
+    out = {}
+    with _Threads(), torch.no_grad():
+        cb, xT, xb2 = inp["step"]
+        for i in (32, 0):
+            out[f"ddim50:{i}"] = h = {}
+            MX.mixer_ddim_step(W, spec, stats, OS.make_schedule("cosine", 1000, "ddim50"), 3.5, i, xT, xb2, cb, h)
+        c300, x300 = inp["t300"]
+        xa, xb = inp["late"]
+        sch = OS.make_schedule("cosine", 1000, "ddim1000")
+        out["t300:999"] = h = {}
+        MX.mixer_ddim_step(W, spec, stats, sch, 3.5, 999, x300, x300, c300, h)
+        out["t300:3"] = h = {}
+        MX.mixer_ddim_step(W, spec, stats, sch, 3.5, 3, xa, xb, c300, h)
+    return out
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_reference_golden_at_full_dims(case, samplers, golden_diag, mode):
+    """Mixer.forward, ddim_sample at i=32 / i=0 (B=2, T=32) and two ddim1000 steps at T=300 (B=1): HIP == reference outputs captured at
+    D=1024/512 with the seeded weights (tests/golden/make_golden.py::g_fulldims)."""
+    g, _, _, _, inp = case
+    s = samplers[mode]
+    x1, x2, cond, tt = inp["fwd"]
+    out = s.module_forward(2, x1, cond, tt, x2=x2)
+    assert_close(out, torch.from_numpy(g["fwd"]), what=f"Mixer.forward [{mode}]", **STEP_TOL)
+    cb, xT, xb2 = inp["step"]
+    s.set_schedule("ddim50")
+    s.begin(cb, xT)
+    diag = golden_diag
+    for i in (32, 0):
+        refs = {nm: torch.from_numpy(g[f"ddim50:i{i}:{key}"]) for nm, key in (("x", "sample"), ("x2", "sample2"), ("pred_xstart2", "pred_xstart2"))}
+        _check_step(s, xT, xb2, i, refs, f"ddim50 i={i} [{mode}]", diag[f"ddim50:{i}"])
+    c300, x300 = inp["t300"]
+    s.set_schedule("ddim1000")
+    s.begin(c300, x300)
+    _check_step(s, x300, x300, 999, {"x": torch.from_numpy(g["ddim1000:T300:i999:sample"]), "x2": torch.from_numpy(g["ddim1000:T300:i999:sample2"])},
+                f"T=300 i=999 [{mode}]", diag["t300:999"])
+    xa, xb = inp["late"]
+    _check_step(s, xa, xb, 3, {"x": torch.from_numpy(g["ddim1000:T300:i3:sample"]), "x2": torch.from_numpy(g["ddim1000:T300:i3:sample2"])},
+                f"T=300 i=3 [{mode}]", diag["t300:3"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# (a) one full-dims DDIM step at T = 300, B = 2 against the oracle
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def oracle_t300_b2(case):
+    from mixermdm_amd.synthetic import synthetic_inputs
+    _, _, W, stats, _ = case
+    cond, xT = synthetic_inputs(2, 300, seed_cond=41, seed_x=42)
+    x2 = rnd(43, 2, 300, 524)
+    sch = OS.make_schedule("cosine", 1000, "ddim1000")
+    h1, h2 = {}, {}
+    with _Threads(), torch.no_grad():
+        first = MX.mixer_ddim_step(W, MX.MixerSpec(d_heads=8, m_heads=8), stats, sch, 3.5, 999, xT, xT, cond, h1)
+        mid = MX.mixer_ddim_step(W, MX.MixerSpec(d_heads=8, m_heads=8), stats, sch, 3.5, 500, xT, x2, cond, h2)
+    return cond, xT, x2, (first, h1), (mid, h2)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_full_dims_T300_B2_step_vs_oracle(samplers, oracle_t300_b2, mode):
+    cond, xT, x2, (first, h1), (mid, h2) = oracle_t300_b2
+    s = samplers[mode]
+    s.set_schedule("ddim1000")
+    s.begin(cond, xT)
+    names = ("x", "x2", "pred_xstart", "pred_xstart2")
+    _check_step(s, xT, xT, 999, dict(zip(names, first)), f"T=300 B=2 i=999 [{mode}]", h1)
+    _check_step(s, xT, x2, 500, dict(zip(names, mid)), f"T=300 B=2 i=500 [{mode}]", h2)      # chains that differ, mid-schedule coefficients
+
+
+# ---------------------------------------------------------------------------------------------------
+# (b) ddim1000: first 20 and last 20 steps, teacher-forced, B = 1, T = 300
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def oracle_chains(case, samplers):
+    """Oracle trajectories: 20 free-running steps from x_T (i = 999..980), and 20 from the state the HIP fp32 sampler reaches at
+    i = 19 after 980 steps of its own loop (i = 19..0, incl. the un-normalised i == 0 branch).  states[k] -> states[k+1] is one oracle
+    step; every HIP mode is forced to states[k] before its step k, so one oracle pass serves both modes."""
+    _, _, W, stats, inp = case
+    cond, xT = inp["t300"]
+    sch = OS.make_schedule("cosine", 1000, "ddim1000")
+    spec = MX.MixerSpec(d_heads=8, m_heads=8)
+    s = samplers["fp32"]
+    s.set_schedule("ddim1000")
+    s.begin(cond, xT)
+    s.run(980, use_graph=True)
+    st = s.state()
+    late0 = (st["x"].cpu().clone(), st["x2"].cpu().clone())
+    assert torch.isfinite(late0[0]).all() and torch.isfinite(late0[1]).all()
+    chains = {}
+    with _Threads(), torch.no_grad():
+        for name, i0, (x, x2) in (("first", 999, (xT, xT)), ("last", 19, late0)):
+            states = [(x, x2, None, None, None)]
+            for k in range(20):
+                h = {}
+                nx, nx2, p1, p2 = MX.mixer_ddim_step(W, spec, stats, sch, 3.5, i0 - k, states[-1][0], states[-1][1], cond, h)
+                states.append((nx, nx2, p1, p2, {"align_diag": h["align_diag"], "center_diag": h.get("center_diag", [])}))
+            chains[name] = (i0, states)
+    return cond, xT, chains
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("which", ["first", "last"])
+def test_ddim1000_teacher_forced_20_steps(samplers, oracle_chains, mode, which):
+    cond, xT, chains = oracle_chains
+    i0, states = chains[which]
+    s = samplers[mode]
+    s.set_schedule("ddim1000")
+    s.begin(cond, xT)
+    worst, masked = 0.0, 0
+    for k in range(20):
+        x, x2 = states[k][:2]
+        rx, rx2, rp1, rp2, h = states[k + 1]
+        out, w, m = _check_step(s, x, x2, i0 - k, {"x": rx, "x2": rx2, "pred_xstart": rp1, "pred_xstart2": rp2}, f"ddim1000 {which} i={i0 - k} [{mode}]", h)
+        worst = max(worst, w)
+        masked += int(m)
+    if which == "last":                       # quirk 6: the final step returns the raw (un-normalised) blend in both pred_xstart
+        assert torch.equal(out["pred_xstart"], out["pred_xstart2"])
+    print(f"{mode} {which}: worst out-of-tolerance fraction over 20 steps {worst:.2e}; steps with a masked (branch-point) person: {masked}")
+    assert masked <= 16                    # the comparison must not be vacuous: a rotation on a branch point is the exception
+
+
+# ---------------------------------------------------------------------------------------------------
+# (c) the GEMM instantiations of the B = 16 step (M = 19 200 rows), each against a float64 product
+# ---------------------------------------------------------------------------------------------------
+M_FULL = 19200        # 2 persons x 2B x T = 4 x 16 x 300 rows of a denoiser stack at BASELINE configs[2]
+SHAPES = [(1024, 1024, "resid"), (1024, 2048, "resid"), (3072, 1024, "bias"), (2048, 1024, "gelu"), (2048, 1024, "bias"),
+          (1024, 512, "gelu"), (512, 1024, "resid"), (512, 512, "resid"), (1536, 512, "bias")]
+
+
+def _f64_ref(x, w, b, epi, r):
+    y = F.linear(x.double(), w.double(), b.double())
+    if epi == "gelu":
+        y = F.gelu(y)
+    elif epi == "resid":
+        y = y + r.double()
+    return y
+
+
+@pytest.fixture(scope="module")
+def gemm_operands():
+    cache = {}
+
+    def get(N, K, epi):
+        if (N, K, epi) not in cache:
+            x, w, b = rnd(301, M_FULL, K), rnd(302, N, K, scale=1 / math.sqrt(K)), rnd(303, N)
+            r = rnd(304, M_FULL, N) if epi == "resid" else None
+            with _Threads():
+                ref = _f64_ref(x, w, b, epi, r)
+            cache.clear()                     # one 19200 x 3072 float64 reference at a time is enough host memory
+            cache[(N, K, epi)] = (x, w, b, r, ref)
+        return cache[(N, K, epi)]
+    return get
+
+
+@pytest.mark.parametrize("N,K,epi", SHAPES)
+def test_production_gemm_tiles_vs_float64(gemm_operands, N, K, epi):
+    """mmdm_linear_f32 at M = 19 200 on the tiles the step uses; the launched instantiation is asserted, so a later change of the
+    dispatch rules cannot silently move the production shapes onto an untested kernel."""
+    from mixermdm_amd import ops
+    from mixermdm_amd._lib import load_library
+    x, w, b, r, ref = gemm_operands(N, K, epi)
+    d = dev()
+    rd = r.to(d) if r is not None else None
+    got = ops.linear(x.to(d), w.to(d), b.to(d), epi, rd)
+    kern = load_library().mmdm_last_gemm_kernel().decode()
+    assert kern in PRODUCTION_F32, (N, K, epi, kern)
+    assert_close(got, ref.float(), atol=2e-5 * math.sqrt(K / 1024), rtol=1e-5, what=f"linear 19200x{N}x{K} {epi} on {kern}")
+    if epi == "resid":                        # in place, as the residual stream is updated
+        ops.linear(x.to(d), w.to(d), b.to(d), epi, rd, out=rd)
+        assert torch.equal(rd, got)
+
+
+@pytest.mark.parametrize("N,K,epi", SHAPES)
+def test_production_split_gemm_tiles_vs_float64(gemm_operands, N, K, epi):
+    from mixermdm_amd import ops
+    from mixermdm_amd._lib import load_library
+    x, w, b, r, ref = gemm_operands(N, K, epi)
+    d = dev()
+    xs, ws = ops.split3(x.to(d)), ops.split3(w.to(d))
+    got = ops.linear_split(xs, ws, b.to(d), epi, r.to(d) if r is not None else None)
+    kern = load_library().mmdm_last_gemm_kernel().decode()
+    assert all(k in PRODUCTION_SPLIT for k in kern.split("+")), (N, K, epi, kern)
+    assert_close(got, ref.float(), atol=2e-5 * math.sqrt(K / 1024), rtol=1e-5, what=f"linear_split 19200x{N}x{K} {epi} on {kern}")
+    if epi == "gelu":                         # three-plane output = exact split of the fp32 output
+        g3 = ops.linear_split(xs, ws, b.to(d), epi, split_out=True)
+        assert torch.equal(g3[0].float() + g3[1].float() + g3[2].float(), got)
+
+
+@pytest.mark.parametrize("N,K,epi", SHAPES[:4])
+def test_production_bf16_gemm_tiles_vs_float64_of_rounded_operands(N, K, epi):
+    from mixermdm_amd import ops
+    from mixermdm_amd._lib import load_library
+    d = dev()
+    x, w, b = rnd(301, M_FULL, K), rnd(302, N, K, scale=1 / math.sqrt(K)), rnd(303, N)
+    r = rnd(304, M_FULL, N) if epi == "resid" else None
+    xb, wb = ops.to_bf16(x.to(d)), ops.to_bf16(w.to(d))
+    with _Threads():
+        ref = _f64_ref(xb.float().cpu(), wb.float().cpu(), b, epi, r)
+    got = ops.linear_bf16(xb, wb, b.to(d), epi, r.to(d) if r is not None else None)
+    kern = load_library().mmdm_last_gemm_kernel().decode()
+    assert kern in PRODUCTION_BF16, kern
+    assert_close(got, ref.float(), atol=2e-5 * math.sqrt(K / 1024), rtol=1e-5, what=f"linear_bf16 19200x{N}x{K} {epi} on {kern}")
+
+
+# instantiations the dispatch rules pick at M = 19 200 (update together with the rules in gemm_f32.hip / gemm_split.hip / gemm_bf16.hip)
+PRODUCTION_F32 = {"gemm_glds<22,22,16,2,vepi>", "gemm_glds<22,22,16,2,scalar>", "gemm_glds<42,22,16,2,scalar>", "gemm_glds<42,22,16,2,vepi>",
+                  "gemm_glds<22,21,16,2,vepi>", "gemm_glds<22,21,16,2,scalar>"}
+PRODUCTION_SPLIT = {"gemm_split<42,22>", "gemm_split<22,21>"}
+PRODUCTION_BF16 = {"gemm_bf16<42,22>"}
+
+
+def test_dispatch_puts_the_layer_gemms_on_the_large_tiles():
+    """The four GEMMs that are 90 % of a step's FLOPs must not run on the small-shape fallbacks."""
+    from mixermdm_amd import ops
+    from mixermdm_amd._lib import load_library
+    d = dev()
+    lib = load_library()
+    for N, K, epi, want in [(1024, 1024, "resid", "gemm_glds<22,22"), (1024, 2048, "resid", "gemm_glds<22,22"),
+                            (3072, 1024, "bias", "gemm_glds<42,22"), (2048, 1024, "gelu", "gemm_glds<42,22")]:
+        x, w = torch.zeros(M_FULL, K, device=d), torch.zeros(N, K, device=d)
+        r = torch.zeros(M_FULL, N, device=d) if epi == "resid" else None
+        ops.linear(x, w, None, epi, r)
+        assert lib.mmdm_last_gemm_kernel().decode().startswith(want), (N, K, lib.mmdm_last_gemm_kernel())

@@ -321,3 +321,33 @@ def test_mixer32_fixture(golden):
     r = MX.mixer_ddim_step(W, spec, stats, sched, 3.5, 12, t("x_T"), t("x_T"), t("cfg_cond"))
     for k, v in zip(["sample", "sample2", "pred_xstart", "pred_xstart2"], r):
         close_frac(v, g[f"ddim:i12:{k}"], atol=2e-4, rtol=2e-4)
+
+
+# ---- full model dimensions -----------------------------------------------------------------------
+def test_fulldims_fixture_pins_the_oracle_at_the_real_model_sizes():
+    """tests/golden/fulldims.npz: oracle == REFERENCE at D=1024/F=2048/L=8/H=8 (dh=128) + mixer 512/1024/4/8 (dh=64): Mixer.forward and
+    ddim_sample (i=32, i=0) at B=2, T=32, and ddim1000 steps at the headline length T=300 (B=1; i=999 from x_T and a late step i=3)."""
+    from conftest import fulldims_case
+    g, _, W, stats, inp = fulldims_case()
+    spec = MX.MixerSpec(d_heads=8, m_heads=8)
+    x1, x2, cond, tt = inp["fwd"]
+    hist = {}
+    out = MX.mixer_forward(W, spec, stats, x1, torch.full((x1.shape[0],), tt, dtype=torch.long), cond, x2, hist)
+    close_frac(out, g["fwd"], **MIX_TOL)
+    close_frac(hist["influence_i1"][0][..., [0, 3, 66, 132, 258]], g["fwd:influence_i1"], atol=2e-5, rtol=1e-4)
+    cb, xT, xb2 = inp["step"]
+    sched = S.make_schedule("cosine", 1000, "ddim50")
+    for i in [32, 0]:
+        r = MX.mixer_ddim_step(W, spec, stats, sched, 3.5, i, xT, xb2, cb)
+        for k, v in zip(["sample", "sample2", "pred_xstart", "pred_xstart2"], r):
+            if k != "pred_xstart":
+                close_frac(v, g[f"ddim50:i{i}:{k}"], atol=2e-4, rtol=2e-4)
+    c300, x300 = inp["t300"]
+    sched = S.make_schedule("cosine", 1000, "ddim1000")
+    r = MX.mixer_ddim_step(W, spec, stats, sched, 3.5, 999, x300, x300, c300)
+    close_frac(r[0], g["ddim1000:T300:i999:sample"], atol=2e-4, rtol=2e-4)
+    close_frac(r[1], g["ddim1000:T300:i999:sample2"], atol=2e-4, rtol=2e-4)
+    xa, xb = inp["late"]
+    r = MX.mixer_ddim_step(W, spec, stats, sched, 3.5, 3, xa, xb, c300)
+    close_frac(r[0], g["ddim1000:T300:i3:sample"], atol=2e-4, rtol=2e-4)
+    close_frac(r[1], g["ddim1000:T300:i3:sample2"], atol=2e-4, rtol=2e-4)
