@@ -277,7 +277,9 @@ def cpu_baseline(sd_cpu, stats, T, nsteps, single=False):
         # thread-count calibration (one untimed step each): B=1 GEMMs are small, all cores is not always the fastest
         ncpu = os.cpu_count() or 1
         best, calib = (None, 1e30), {}
-        for nt in sorted({min(ncpu, c) for c in (16, 32, 64, ncpu)}):
+        # (all hardware threads is never the fastest for B=1 and can be pathological -- 265 s per step on a 256-thread host -- so the
+        # calibration stops at 64; `host_threads` reports what the box has)
+        for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
             torch.set_num_threads(nt)
             t0 = time.perf_counter()
             MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 999, x, x2, cond)
@@ -293,7 +295,7 @@ def cpu_baseline(sd_cpu, stats, T, nsteps, single=False):
         dt = (time.perf_counter() - t0) / nsteps
     return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "host_threads": ncpu, "kind": "port",
             "sample": "%d consecutive DDIM steps (i=998..) of the same workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), "
-                      "%.3f s/step, extrapolated x1000 steps; thread count calibrated over {16, 32, 64, all %d}: %d fastest (one step: %s)"
+                      "%.3f s/step, extrapolated x1000 steps; thread count calibrated over {8, 16, 32, 64} of the host's %d hardware threads: %d fastest (one step: %s)"
                       % (nsteps, T, torch.__version__, dt, ncpu, best[0], ", ".join("%d thr %.2f s" % kv for kv in sorted(calib.items()))),
             "s_per_step_b1": round(dt, 4)}
 

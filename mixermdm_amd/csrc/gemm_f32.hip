@@ -26,6 +26,8 @@ struct GemmArgs {
     int M, N, K, Kw, epilogue, period;   // Kw >= K: readable columns of W (zero beyond K)
     int mt, nt;
     int ablate;                          // timing experiments only (tools/gemm_bench.py); 0 in production
+    unsigned long long* stamps;          // diagnostic builds of a launch only (tools/gemm_timeline.py): per-workgroup {start, loop start, end, placement}
+                                         // in 100 MHz s_memrealtime ticks; nullptr in production (one never-taken scalar branch per workgroup)
 };
 
 template <int VEC, bool FULL>
@@ -250,6 +252,11 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C_::WGN, wn = wave % C_::WGN;
     const int l31 = lane & 31, lh = lane >> 5;
+    if (p.stamps && tid == 0) {
+        p.stamps[4 * (size_t)bid + 0] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[4 * (size_t)bid + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                                        ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
+    }
 
     // staging pieces of this wave: piece id pq = wave + NWAVES*u; pq < NA -> A rows RPP*pq.., else W rows RPP*(pq-NA)..
     const float* src[C_::NI];
@@ -332,6 +339,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
     const int nkt = p.K / BK;
     // the accumulator-init loads above must not be counted by the pipeline's vmcnt arithmetic
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.stamps && tid == 0) p.stamps[4 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime();
     stage(0);
     if (NBUF == 3 && nkt > 1) stage(1);
 
@@ -383,6 +391,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
+    if (p.stamps && tid == 0) p.stamps[4 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
 
     if (VEPI) {
         // D^T map: lane&31 = output row inside the 32-row tile, register 4*qd + c = output column 8*qd + 4*(lane>>5) + c
@@ -514,6 +523,7 @@ inline bool vec_ok(const float* p, int ld, int K) {
 
 int g_gemm_cfg = -1;
 int g_gemm_ablate = 0;
+unsigned long long* g_gemm_stamps = nullptr;
 
 int mmdm_gemm_init(void) {
     int rc;
@@ -539,6 +549,7 @@ int mmdm_gemm_init(void) {
 // tuning hook for tools/gemm_bench.py (not part of the public ABI): force a tile configuration, -1 = automatic
 extern "C" void mmdmx_set_gemm_cfg(int cfg) { g_gemm_cfg = cfg; }
 extern "C" void mmdmx_set_gemm_ablate(int a) { g_gemm_ablate = a; }
+extern "C" void mmdmx_set_gemm_stamps(void* p) { g_gemm_stamps = static_cast<unsigned long long*>(p); }
 
 extern "C" int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                                int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
@@ -566,6 +577,7 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     a.M = M; a.N = N; a.K = K; a.Kw = Kw; a.epilogue = epilogue; a.period = period > 0 ? period : 1;
     a.mt = a.nt = 0;
     a.ablate = g_gemm_ablate;
+    a.stamps = g_gemm_stamps;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool av = vec_ok(A, lda, K), wv = vec_ok(W, ldw, Kw);
     const bool glds_ok = av && wv && (K % 16 == 0) && Kw == K;
