@@ -13,6 +13,7 @@
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles that share A rows.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace {
@@ -232,8 +233,26 @@ template <int CPR> __device__ __forceinline__ int swz_of(int r) { return CPR == 
 // VEPI: the MFMA operands are swapped (D^T = W A^T), which puts the output ROW on the lane and four consecutive output
 // COLUMNS in consecutive accumulator registers -- bias / residual / PE loads and the result stores are then 16-byte
 // accesses (4x fewer memory instructions than the one-float-per-lane map).  Needs N % 4 == 0 and 16-byte aligned C / extra rows.
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI>
-__global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_glds_kernel(GemmArgs p) {
+// MINW_: minimum waves per SIMD the register allocation must allow (second __launch_bounds__ argument; 1 = no constraint).  The 64
+// accumulator registers of a 64x64 wave tile plus operands, addresses and the accumulator-initialisation transients come to ~144
+// registers when unconstrained (3 waves per SIMD = THREE 4-wave workgroups per CU); MINW_ = 5 makes the compiler fit 96.
+//
+// PIPE_ = 1: software-pipelined K loop for NBUF_ >= 3 stages (the production loop).  The 2-stage loop above it makes every K step pay
+// its own latencies in sequence -- vmcnt(0) on a tile issued only one step (2048 MFMA cycles) earlier, the barrier, the LDS-DMA issue
+// of the next tile, then the fragment reads -- before its first MFMA can issue: a workgroup alone on a CU reaches ~70 % of the MFMA rate
+// and the kernel depends on co-resident workgroups to fill the holes (three fit: 144 registers; tools/gemm_timeline.py).  Here
+//   * tile kt+NBUF-1 is issued during step kt (NBUF-2 whole steps of latency budget), its DMA instructions interleaved one by one
+//     behind MFMAs (an LDS-DMA issue costs ~60-100 cycles of the wave's issue stream: it hides in the 64-cycle shadow of an MFMA);
+//   * the fragments of k-group 1 are read at the top of the step and those of the NEXT tile's k-group 0 in the middle of it, so every
+//     ds_read has 16 MFMAs (1024 cycles) to land and no MFMA ever waits on LDS;
+//   * the one wait + barrier per step sits between the two MFMA groups, where the matrix pipe still holds queued work.
+// Hazards: a buffer is restaged only after a barrier that every wave reached with lgkmcnt(0) behind its last read of that buffer; a
+// staged tile is read only after each wave's counted vmcnt has retired its own pieces of it AND the barrier (guide: "read a staged
+// buffer after the wait that retires it and a barrier the reader has passed").
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0>
+__global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void gemm_glds_kernel(GemmArgs p) {
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN, CPR = C_::CPR, RPP = C_::RPP, NBUF = C_::NBUF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -290,7 +309,14 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
         }
     };
 
-    // accumulators start as bias (+ residual / + PE row)
+    const int nkt = p.K / BK;
+    // Pipelined kernel, 16-byte epilogue form (residual / PE GEMMs): the accumulators start as the bias only and the residual tile is
+    // fetched while the LAST operand tiles are consumed and added after the loop, y = (b + sum_k a_k w_k) + r -- the order of the
+    // reference's `x + linear(...)` -- so a workgroup's first MFMA waits for one 16 KB operand tile instead of 64 KB of residual plus
+    // NBUF-1 tiles (13-19 us of every workgroup's life, and of every kernel's start, in the round-1 kernel).  Every pipelined
+    // instantiation uses this order, so a row's result does not depend on the tile shape that produced it.
+    constexpr bool LATE_R = PIPE_ != 0 && VEPI;
+    // accumulators start as bias (+ residual / + PE row unless LATE_R)
     f32x16 acc[TM][TN];
     if (VEPI) {
 #pragma unroll
@@ -298,7 +324,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
             const int row = m0 + wm * (32 * TM) + i * 32 + l31;
             const bool rok = row < p.M;
             const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
-            const bool ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && rok;
+            const bool ext = !LATE_R && (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && rok;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -336,18 +362,133 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
         }
     }
 
-    const int nkt = p.K / BK;
-    // the accumulator-init loads above must not be counted by the pipeline's vmcnt arithmetic
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (PIPE_ != 0) {
+        // The first NBUF-1 operand tiles are requested behind the accumulator-initialisation loads; vmcnt retires in order, so
+        // "at most the NBUF-2 newest tiles outstanding" means the initialisation values and tile 0 have landed: the loop starts on
+        // tile 0 while the others are still on their way (the host side guarantees nkt >= NBUF).
+#pragma unroll
+        for (int t = 0; t < NBUF - 1; ++t) stage(t);
+        wait_vm<(NBUF - 2) * C_::NI>();
+    } else {
+        // the accumulator-init loads above must not be counted by the pipeline's vmcnt arithmetic
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (p.stamps && tid == 0) p.stamps[4 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime();
-    stage(0);
-    if (NBUF == 3 && nkt > 1) stage(1);
-
     // fragment read offsets (floats): row*BK + 4*((2g + lh) ^ sw)
     const int sw = swz_of<CPR>(l31);
     const int a_row = (wm * (32 * TM) + l31) * BK;
     const int b_row = (wn * (32 * TN) + l31) * BK;
 
+    f32x4 rv[LATE_R ? TM : 1][LATE_R ? TN : 1][4];               // the late residual tile (LATE_R only)
+    if constexpr (PIPE_ != 0) {
+        static_assert((C_::G == 2 || C_::G == 4) && NBUF >= 3 && NBUF <= 6, "pipelined loop: K step 16 or 32 (two / four k-groups), 3 to 6 stages");
+        static_assert(C_::NI <= 2 * (4 * TM * TN - 1), "LDS-DMA pieces of a tile must fit behind the MFMAs of two k-groups");
+        constexpr int NI = C_::NI;
+        f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+        auto rd = [&](int buf, int g, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+            const int cg = 4 * ((2 * g + lh) ^ sw);
+            const float* Ac = As + buf * C_::A_FLOATS + a_row + cg;
+            const float* Bc = Bs + buf * C_::B_FLOATS + b_row + cg;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * BK);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * BK);
+        };
+        auto mm = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = VEPI ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        };
+        // `left` = tiles that may stay in flight behind the one being waited for (+ the NR residual loads issued at the start of the drain)
+        constexpr int NR = LATE_R ? TM * TN * 4 : 0;
+        auto wait_left = [&](int left) {
+            if (left >= 4) wait_vm<4 * NI + NR>();
+            else if (left == 3) wait_vm<3 * NI + NR>();
+            else if (left == 2) wait_vm<2 * NI + NR>();
+            else if (left == 1) wait_vm<NI + NR>();
+            else wait_vm<NR>();
+        };
+        __builtin_amdgcn_s_barrier();                        // tile 0 has landed for every wave
+        rd(0, 0, a0, b0);
+        int cur = 0, nxt = 1, stg = NBUF - 1;
+        const int n_main = nkt - (NBUF - 1);                 // steps that still issue a new tile
+        constexpr int G = C_::G, NMM = 4 * TM * TN;          // k-groups per step (even), MFMAs per group
+        // One group: its MFMAs from register set `cs`; behind the FIRST of them the fragment reads of the following group into the other
+        // set (the wave's wait for `cs` comes before those reads are issued, so it never waits on them, and they have NMM-1 MFMAs to
+        // land); in group 0 of a staging step one LDS-DMA piece behind each of the next MFMAs (at most NMM-2 per group, the rest spill
+        // into group 1).  The step's single wait + barrier precedes the LAST group, whose reads are the next tile's group 0.
+        auto group = [&](auto gi, auto do_stage, int left, bool more) {
+            constexpr int g = decltype(gi)::value;
+            constexpr bool STG = decltype(do_stage)::value;
+            constexpr int dma_here = (!STG || PIPE_ == 2) ? 0 : (g == 0 ? (NI < NMM - 1 ? NI : NMM - 1) : (g == 1 && NI > NMM - 1 ? NI - (NMM - 1) : 0));
+            if constexpr (g == G - 1) {
+                if (more) {
+                    if constexpr (STG) wait_vm<(NBUF - 2) * NI>();      // tile kt+1 landed; tiles kt+2 .. kt+NBUF-1 may be in flight
+                    else wait_left(left);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if constexpr (PIPE_ != 3) __builtin_amdgcn_s_barrier();      // PIPE_ 2 / 3: timing ablations (tools/gemm_bench.py), wrong results
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if constexpr (g % 2 == 0) {
+                if constexpr (g < G - 1) rd(cur, g + 1, a1, b1);
+                else if (more) rd(nxt, 0, a1, b1);
+                if constexpr (STG && g == 0 && PIPE_ != 2) stage(stg);
+                mm(a0, b0);
+            } else {
+                if constexpr (g < G - 1) rd(cur, g + 1, a0, b0);
+                else if (more) rd(nxt, 0, a0, b0);
+                mm(a1, b1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, g);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, g);
+#pragma unroll
+            for (int u = 0; u < dma_here; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, g);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, g);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMM - 1 - dma_here, g);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto step = [&](auto do_stage, int left, bool more) {
+            group(std::integral_constant<int, 0>{}, do_stage, left, more);
+            group(std::integral_constant<int, 1>{}, do_stage, left, more);
+            if constexpr (G >= 4) {
+                group(std::integral_constant<int, 2>{}, do_stage, left, more);
+                group(std::integral_constant<int, 3>{}, do_stage, left, more);
+            }
+            cur = nxt; nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+        };
+        for (int kt = 0; kt < n_main; ++kt) {
+            step(std::true_type{}, 0, true);
+            stg = stg + 1 == NBUF ? 0 : stg + 1;
+        }
+        if constexpr (LATE_R) {                                          // residual / PE tile: NR 16-byte loads per lane, in flight through the drain
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = m0 + wm * (32 * TM) + i * 32 + l31;
+                const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
+                        // rows / columns past the edge read a valid address (row 0 / column 0 of the tile's clamp) and are never stored
+                        const int rr = row < p.M ? er : 0, cc = col < p.N ? col : 0;
+                        rv[i][j][qd] = *reinterpret_cast<const f32x4*>(p.extra + (size_t)rr * p.ld_extra + cc);
+                    }
+            }
+        }
+        for (int kt = n_main < 0 ? 0 : n_main; kt < nkt; ++kt)           // drain: no new tile
+            step(std::false_type{}, nkt - kt - 2, kt + 1 < nkt);
+    } else {
+    stage(0);
+    if (NBUF == 3 && nkt > 1) stage(1);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = NBUF == 3 ? kt % 3 : (kt & 1);
         if (NBUF == 3) {
@@ -385,6 +526,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
             if (p.ablate & 8) __builtin_amdgcn_s_setprio(0);
         }
     }
+    }
     if ((p.ablate & 7) >= 3) return;
     // MFMA -> VALU hazard across the loop-exit branch: see MFMA_SETTLE in attn_f32.hip
 #pragma unroll
@@ -409,6 +551,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS)) void gemm_gl
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         float t = acc[i][j][4 * qd + c];
+                        if constexpr (LATE_R) t += rv[i][j][qd][c];
                         if (p.epilogue == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
                         else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
                         else if (p.epilogue == MMDM_EPI_BIAS_QUICKGELU) t = quick_gelu(t);
@@ -448,7 +591,7 @@ inline bool vepi_ok(const GemmArgs& a) {
            (!ext || ((a.ld_extra & 3) == 0 && (reinterpret_cast<uintptr_t>(a.extra) & 15) == 0));
 }
 
-template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2>
+template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2, int MINW_ = 1, int PIPE_ = 0>
 int launch_glds(GemmArgs a, hipStream_t st) {
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
     a.mt = (a.M + C_::BM - 1) / C_::BM;
@@ -456,20 +599,20 @@ int launch_glds(GemmArgs a, hipStream_t st) {
     // measured (tools/gemm_bench.py): the 16-byte epilogue pays where the accumulators are initialised from memory (+10 % on
     // the K = 1024 residual GEMMs) and is neutral-to-slightly-negative for bias/GELU-only epilogues
     const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
-    mmdm_note_gemm("gemm_glds<%d,%d,%d,%d,%s>", TM_, TN_, BK_, NBUF_, (ext && vepi_ok(a) && !(a.ablate & 16)) ? "vepi" : "scalar");
+    mmdm_note_gemm("%s<%d,%d,%d,%d,%s>", PIPE_ ? "gemm_pipe" : "gemm_glds", TM_, TN_, BK_, NBUF_, (ext && vepi_ok(a) && !(a.ablate & 16)) ? "vepi" : "scalar");
     if (ext && vepi_ok(a) && !(a.ablate & 16))
-        hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+        hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
     else
-        hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+        hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_glds");
 }
 
-template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2>
+template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2, int MINW_ = 1, int PIPE_ = 0>
 int set_attr_glds() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<TM_, TN_, BK_, NBUF_>::SMEM_BYTES);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<TM_, TN_, BK_, NBUF_>::SMEM_BYTES);
     if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_glds): %s", hipGetErrorString(e));
     return MMDM_OK;
@@ -541,6 +684,30 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_glds<22, 12>())) return rc;
     if ((rc = set_attr_glds<12, 22>())) return rc;
     if ((rc = set_attr_glds<22, 21>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 16, 2, 5>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 16, 2, 4>())) return rc;
+    if ((rc = set_attr_glds<42, 22, 16, 2, 4>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 16, 3, 4>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 16, 3, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 16, 4, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<42, 22, 16, 3, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 21, 16, 3, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 16, 5, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<42, 22, 16, 4, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 21, 16, 4, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 42, 16, 4, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 21, 16, 5, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<21, 22, 16, 4, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<21, 21, 16, 4, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 12, 16, 4, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 21, 16, 6, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 21, 32, 3, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 32, 3, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 21, 32, 4, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<21, 21, 32, 4, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 32, 4, 1, 1>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 16, 5, 1, 2>())) return rc;
+    if ((rc = set_attr_glds<22, 22, 16, 5, 1, 3>())) return rc;
     const char* e = getenv("MMDM_GEMM_CFG");
     g_gemm_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
@@ -585,14 +752,20 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     switch (g_gemm_cfg) {
         case 10: if (glds_ok) return launch_glds<42, 22>(a, st); break;
         case -1:
+            if (glds_ok && K >= 96) {
+                // Production: the software-pipelined loop (gemm_pipe).  Tile / stage choice per shape, measured at M = 19 200 with
+                // tools/gemm_bench.py (TFLOP/s; the 2-stage kernels of round 1 reached 100-121 on the same shapes):
+                //   N = 3072, K = 1024 (QKV):        128x128, 5 stages 128      N = 2048, K = 1024 (FFN up, K|V): 128x64, 4 stages 119-122
+                //   N = 1024, K = 1024 / 2048:       128x128, 5 stages 124 / 128   mixer (N or K <= 512):          128x64, 4 stages 107-121
+                // Few tiles (small batches): 64x64 tiles so that every CU has work.  All instantiations accumulate each output element in
+                // the same order (bias + residual first, then k ascending), so a row's result does not depend on the tile that produced it.
+                const long t64 = (long)((M + 127) / 128) * ((N + 63) / 64);
+                if (t64 < 512) return launch_glds<21, 21, 16, 4, 1, 1>(a, st);
+                if (N <= 512 || K <= 512 || N == 2048) return launch_glds<22, 21, 16, 4, 1, 1>(a, st);
+                return launch_glds<22, 22, 16, 5, 1, 1>(a, st);
+            }
             if (glds_ok) {
-                // few 128x128 tiles (< ~4 per CU): halve the tile along N so that more workgroups hide each other's latencies
                 const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-                // Tile choice per shape, each rule measured inside the step (bench.py, ms/step at B=16, T=300): 256x128 / 8-wave tiles for
-                // N > 1024 (FFN up-projection, K/V and QKV projections: 65.4 -> 65.0 -> 64.6), 128x64 tiles for the mixer's N = 1024,
-                // K = 512 GEMMs (64.9 -> 64.4); 256x128 at N = 1024, K = 2048 loses (65.9), so N <= 1024 stays on 128x128.
-                if (N > 1024 && tiles >= 1000 && M % 256 == 0) return launch_glds<42, 22>(a, st);
-                if (N <= 1024 && K <= 512 && tiles >= 1000) return launch_glds<22, 21>(a, st);
                 return tiles < 1000 ? launch_glds<22, 21>(a, st) : launch_glds<22, 22>(a, st);
             }
             break;
@@ -603,6 +776,30 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
         case 15: if (glds_ok) return launch_glds<22, 12>(a, st); break;     // 128 x 64 tile, 2 waves
         case 16: if (glds_ok) return launch_glds<12, 22>(a, st); break;     // 64 x 128 tile, 2 waves
         case 17: if (glds_ok) return launch_glds<22, 21>(a, st); break;     // 128 x 64 tile, 4 waves (64 x 32 per wave)
+        case 21: if (glds_ok) return launch_glds<22, 22, 16, 2, 5>(a, st); break;   // 128 x 128, registers capped for 5 workgroups per CU
+        case 22: if (glds_ok) return launch_glds<22, 22, 16, 2, 4>(a, st); break;   // ... 4 per CU
+        case 23: if (glds_ok) return launch_glds<42, 22, 16, 2, 4>(a, st); break;   // 256 x 128 / 8 waves, 2 per CU
+        case 24: if (glds_ok) return launch_glds<22, 22, 16, 3, 4>(a, st); break;   // 128 x 128, 3 LDS stages (48 KB: 3 per CU by LDS)
+        case 30: if (glds_ok && K >= 64) return launch_glds<22, 22, 16, 3, 1, 1>(a, st); break;   // pipelined loop, 128 x 128, 3 stages
+        case 31: if (glds_ok && K >= 64) return launch_glds<22, 22, 16, 4, 1, 1>(a, st); break;   // ... 4 stages (64 KB: 2 per CU)
+        case 32: if (glds_ok && K >= 64) return launch_glds<42, 22, 16, 3, 1, 1>(a, st); break;   // ... 256 x 128 / 8 waves, 3 stages (72 KB: 2 per CU)
+        case 33: if (glds_ok && K >= 64) return launch_glds<22, 21, 16, 3, 1, 1>(a, st); break;   // ... 128 x 64 / 4 waves
+        case 34: if (glds_ok && K >= 80) return launch_glds<22, 22, 16, 5, 1, 1>(a, st); break;   // ... 128 x 128, 5 stages (80 KB: 2 per CU)
+        case 35: if (glds_ok && K >= 64) return launch_glds<42, 22, 16, 4, 1, 1>(a, st); break;   // ... 256 x 128 / 8 waves, 4 stages (96 KB: 1 per CU)
+        case 36: if (glds_ok && K >= 64) return launch_glds<22, 21, 16, 4, 1, 1>(a, st); break;   // ... 128 x 64, 4 stages (48 KB: 3 per CU)
+        case 37: if (glds_ok && K >= 64) return launch_glds<22, 42, 16, 4, 1, 1>(a, st); break;   // ... 128 x 256 / 8 waves, 4 stages
+        case 38: if (glds_ok && K >= 80) return launch_glds<22, 21, 16, 5, 1, 1>(a, st); break;   // ... 128 x 64, 5 stages (60 KB: 2 per CU)
+        case 40: if (glds_ok && K >= 64) return launch_glds<21, 22, 16, 4, 1, 1>(a, st); break;   // ... 64 x 128, 4 stages
+        case 41: if (glds_ok && K >= 64) return launch_glds<21, 21, 16, 4, 1, 1>(a, st); break;   // ... 64 x 64 / 4 waves of 32 x 32
+        case 42: if (glds_ok && K >= 64) return launch_glds<22, 12, 16, 4, 1, 1>(a, st); break;   // ... 128 x 64 / 2 waves of 64 x 64
+        case 43: if (glds_ok && K >= 96) return launch_glds<22, 21, 16, 6, 1, 1>(a, st); break;   // ... 128 x 64, 6 stages (72 KB: 2 per CU)
+        case 50: if (glds_ok && K % 32 == 0 && K >= 128) return launch_glds<22, 21, 32, 3, 1, 1>(a, st); break;   // K step 32: 128 x 64, 3 stages (72 KB: 2 per CU)
+        case 51: if (glds_ok && K % 32 == 0 && K >= 128) return launch_glds<22, 22, 32, 3, 1, 1>(a, st); break;   // 128 x 128, 3 stages (96 KB: 1 per CU)
+        case 52: if (glds_ok && K % 32 == 0 && K >= 128) return launch_glds<22, 21, 32, 4, 1, 1>(a, st); break;   // 128 x 64, 4 stages (96 KB: 1 per CU)
+        case 53: if (glds_ok && K % 32 == 0 && K >= 128) return launch_glds<21, 21, 32, 4, 1, 1>(a, st); break;   // 64 x 64, 4 stages (64 KB: 2 per CU)
+        case 60: if (glds_ok && K >= 96) return launch_glds<22, 22, 16, 5, 1, 2>(a, st); break;   // ablation: no LDS-DMA in the main loop
+        case 61: if (glds_ok && K >= 96) return launch_glds<22, 22, 16, 5, 1, 3>(a, st); break;   // ablation: no barrier
+        case 54: if (glds_ok && K % 32 == 0 && K >= 128) return launch_glds<22, 22, 32, 4, 1, 1>(a, st); break;   // 128 x 128, 4 stages (128 KB: 1 per CU)
         default: break;
     }
     switch (g_gemm_cfg) {

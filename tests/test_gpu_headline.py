@@ -345,8 +345,7 @@ def test_production_bf16_gemm_tiles_vs_float64_of_rounded_operands(N, K, epi):
 
 
 # instantiations the dispatch rules pick at M = 19 200 (update together with the rules in gemm_f32.hip / gemm_split.hip / gemm_bf16.hip)
-PRODUCTION_F32 = {"gemm_glds<22,22,16,2,vepi>", "gemm_glds<22,22,16,2,scalar>", "gemm_glds<42,22,16,2,scalar>", "gemm_glds<42,22,16,2,vepi>",
-                  "gemm_glds<22,21,16,2,vepi>", "gemm_glds<22,21,16,2,scalar>"}
+PRODUCTION_F32 = {"gemm_pipe<22,22,16,5,vepi>", "gemm_pipe<22,22,16,5,scalar>", "gemm_pipe<22,21,16,4,vepi>", "gemm_pipe<22,21,16,4,scalar>"}
 PRODUCTION_SPLIT = {"gemm_split<42,22>", "gemm_split<22,21>"}
 PRODUCTION_BF16 = {"gemm_bf16<42,22>"}
 
@@ -357,8 +356,8 @@ def test_dispatch_puts_the_layer_gemms_on_the_large_tiles():
     from mixermdm_amd._lib import load_library
     d = dev()
     lib = load_library()
-    for N, K, epi, want in [(1024, 1024, "resid", "gemm_glds<22,22"), (1024, 2048, "resid", "gemm_glds<22,22"),
-                            (3072, 1024, "bias", "gemm_glds<42,22"), (2048, 1024, "gelu", "gemm_glds<42,22")]:
+    for N, K, epi, want in [(1024, 1024, "resid", "gemm_pipe<22,22,16,5"), (1024, 2048, "resid", "gemm_pipe<22,22,16,5"),
+                            (3072, 1024, "bias", "gemm_pipe<22,22,16,5"), (2048, 1024, "gelu", "gemm_pipe<22,21,16,4")]:
         x, w = torch.zeros(M_FULL, K, device=d), torch.zeros(N, K, device=d)
         r = torch.zeros(M_FULL, N, device=d) if epi == "resid" else None
         ops.linear(x, w, None, epi, r)

@@ -7,6 +7,8 @@ from mixermdm_amd import ops, load_library
 lib = load_library()
 d = torch.device("cuda:0")
 shapes = {"out": (19200, 1024, 1024, "resid"), "ffn2": (19200, 1024, 2048, "resid"), "qkv": (19200, 3072, 1024, "bias"), "ffn1": (19200, 2048, 1024, "gelu")}
+ops.linear(torch.zeros(8, 64, device=d), torch.zeros(8, 64, device=d))     # lazy init first (it resets the forced configuration)
+lib.mmdmx_set_gemm_cfg(int(os.environ.get("CFG", "-1")))
 for name in (sys.argv[1:] or ["out", "qkv"]):
     M, N, K, epi = shapes[name]
     x = torch.randn(M, K, device=d); w = torch.randn(N, K, device=d) / math.sqrt(K); b = torch.randn(N, device=d)
