@@ -63,6 +63,10 @@ struct AttnArgs {
     float scale, scale2;
     int out_bf16;      // 1: O written as bf16 (feeds the bf16 out-projection GEMM); 2: as three bf16 planes (exact split, plane stride nseq*Tq*ldo)
     int flags;         // MMDM_ATTN_NO_ZERO_KEY: plain softmax (nn.MultiheadAttention default); MMDM_ATTN_CAUSAL: key <= query only
+    int dh;            // real head width (<= the kernel's DH, multiple of 4): heads narrower than the template (the 96-wide heads of the
+                       // 768 / 8 clipTransEncoder text heads on the DH = 128 kernel) are zero-padded in registers -- Q columns >= dh are
+                       // loaded as 0, K/V chunks past dh are fetched from a valid address and never influence a stored value, O columns
+                       // >= dh are not stored
     // bf16-plane operands of Q K^T (attn_qkp_kernel): NP planes each, [plane][rows][ld] bf16
     const __bf16* Qp; const __bf16* Kp;
     size_t q_plane, k_plane;
@@ -79,6 +83,7 @@ __device__ __forceinline__ void store_o_row(const P& p, const f32x4 (&o)[DH / 16
 #pragma unroll
     for (int h = 0; h < NJ / 4; ++h) {
         const int col = NJ * lq + (DH == 128 ? ((lq >= 8 ? 4 : 0) ^ (4 * h)) : 0);
+        if (col >= p.dh) continue;
         const f32x4 y = f32x4{o[4 * h][r], o[4 * h + 1][r], o[4 * h + 2][r], o[4 * h + 3][r]} * inv;
         const size_t off = row_off + col;
         if (p.out_bf16 == 2) {
@@ -141,11 +146,12 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     {
         int qrow = q0 + lq;
         if (qrow >= p.Tq) qrow = p.Tq - 1;
-        const float* qp = p.Q + ((size_t)seq * p.Tq + qrow) * p.ldq + head * DH + 4 * g;
+        const float* qp = p.Q + ((size_t)seq * p.Tq + qrow) * p.ldq + head * p.dh + 4 * g;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(qp + 16 * j);
-            qf[j] = v * p.scale2;
+            const bool in = 16 * j + 4 * g < p.dh;                       // dh % 4 == 0: a 16-byte group is wholly inside or outside
+            f32x4 v = *reinterpret_cast<const f32x4*>(qp + (in ? 16 * j : 0));
+            qf[j] = in ? v * p.scale2 : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 
@@ -157,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     const bool nozero = (p.flags & MMDM_ATTN_NO_ZERO_KEY) != 0, causal = (p.flags & MMDM_ATTN_CAUSAL) != 0;
     float m_run = nozero ? -INFINITY : 0.f, l_run = nozero ? 0.f : 1.f;
 
-    const float* Kg = p.K + (size_t)kvseq * p.Tk * p.ldk + head * DH;
-    const float* Vg = p.V + (size_t)kvseq * p.Tk * p.ldv + head * DH;
+    const float* Kg = p.K + (size_t)kvseq * p.Tk * p.ldk + head * p.dh;
+    const float* Vg = p.V + (size_t)kvseq * p.Tk * p.ldv + head * p.dh;
 
     // DMA pieces of this wave: piece pq = wave + 4u; pq < NPIECE/2 -> K rows RPP*pq.., else V rows.  Rows past Tk are clamped
     // (their scores are masked to -inf below, so the values never matter).
@@ -169,7 +175,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
             const bool isk = pq < NPIECE / 2;
             const int trow = RPP * (isk ? pq : pq - NPIECE / 2) + lane / CPR;
             const int pos = lane % CPR;
-            const int src_chunk = isk ? (pos ^ (trow & 15)) : pos;                 // V rows are stored unswizzled (load_v_row)
+            int src_chunk = isk ? (pos ^ (trow & 15)) : pos;                       // V rows are stored unswizzled (load_v_row)
+            if (4 * src_chunk >= p.dh) src_chunk = 0;                              // padded head: any valid address (Q is 0 there / column not stored)
             int krow = c0 + trow;
             krow = krow < p.Tk ? krow : p.Tk - 1;
             const float* src = (isk ? Kg + (size_t)krow * p.ldk : Vg + (size_t)krow * p.ldv) + 4 * src_chunk;
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     for (int r = 0; r < 4; ++r) {
         const int qrow = q0 + 4 * g + r;
         if (qrow >= p.Tq) continue;
-        store_o_row<DH>(p, o, r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH, lq);
+        store_o_row<DH>(p, o, r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * p.dh, lq);
     }
 }
 
@@ -639,7 +646,7 @@ extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int 
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_f32: row strides must cover H*dh=%d", H * dh);
     AttnArgs a;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
-    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags;
+    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags; a.dh = dh;
     a.Qp = a.Kp = nullptr; a.q_plane = a.k_plane = 0; a.ldqp = a.ldkp = 0;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
@@ -647,12 +654,13 @@ extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int 
     a.scale = 1.0f / sqrtf((float)dh);
     a.scale2 = a.scale * 1.4426950408889634f;     // scores kept in the log2 domain: softmax via v_exp_f32 (2^x)
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dh == 128 || dh == 64) {
+    // MFMA kernel: head widths 64 and 128 natively; any other multiple of 4 in (32, 128] zero-padded to the next of the two (AttnArgs::dh)
+    if (dh == 128 || dh == 64 || (dh > 32 && dh < 128 && (dh & 3) == 0)) {
         const bool al = ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) | reinterpret_cast<uintptr_t>(V)) & 15) == 0 &&
                         ((ldq | ldk | ldv) & 3) == 0;
         if (!al) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_f32: Q/K/V must be 16-byte aligned with row strides %% 4 == 0");
         if ((reinterpret_cast<uintptr_t>(O) & 15) || (ldo & 3)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_f32: O must be 16-byte aligned with a row stride %% 4 == 0");
-        return dh == 128 ? launch_mfma<128>(a, st) : launch_mfma<64>(a, st);
+        return dh > 64 ? launch_mfma<128>(a, st) : launch_mfma<64>(a, st);
     }
     switch (dh) {
         case 4: return launch_small<4>(a, st);
@@ -685,7 +693,7 @@ extern "C" int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, c
     AttnArgs a;
     a.Q = nullptr; a.K = nullptr; a.V = V; a.O = static_cast<float*>(Ov); a.ldq = 0; a.ldk = 0; a.ldv = ldv; a.ldo = ldo;
     a.Qp = static_cast<const __bf16*>(Qp); a.Kp = static_cast<const __bf16*>(Kp); a.q_plane = (size_t)q_plane; a.k_plane = (size_t)k_plane; a.ldqp = ldq; a.ldkp = ldk;
-    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags;
+    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags; a.dh = dh;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
     a.pairs_per_xcd = (nseq * H + 7) / 8;

@@ -276,3 +276,64 @@ def test_dual_sampler_vs_reference_golden_and_oracle(golden):
             d = np.abs(out.cpu().numpy() - g[f"loop:{func}:ddim20:output"])
             assert out.shape == (2, 12, 524) and d.mean() <= 1e-4 and d.max() <= 1e-2, (func, d.mean(), d.max())
     s.close()
+
+
+# ---- the text stage at the REAL sizes of CLIP ViT-L/14's text tower and the clipTransEncoder heads -----------------------------
+def test_text_stage_at_vit_l14_dimensions_vs_oracle():
+    """Width 768, 12 blocks x 12 heads (dh = 64), context 77, vocabulary 49 408 (clip.load("ViT-L/14@336px"), src/models/mixermdm.py:212-217)
+    and the 2-layer 768 / 8-head (dh = 96: zero-padded onto the DH = 128 MFMA kernel) / ff 2048 heads (mixermdm.py:246-259): tower and
+    generate_cond against the oracle's restatement, and a wall-clock figure for the whole 8-slice conditioning of a B = 16 batch.
+    PARITY UNPINNED for the tower (the clip package and its weights are not under /root/reference); the heads are pinned by text.npz."""
+    import time
+    from mixermdm_amd import ops
+    from mixermdm_amd._lib import load_library
+    from mixermdm_amd.text import ClipTextTower, MixerTextEncoder
+    V, ctx, D, L, H, HH = 49408, 77, 768, 12, 12, 8
+    W = clip_weights(900, V, ctx, D, L, 4 * D)
+    # residual towers of 12 random blocks grow activations: keep the block outputs small so that 12 of them stay O(1) like a trained tower
+    for k in list(W):
+        if k.endswith("out_proj.weight") or k.endswith("c_proj.weight"):
+            W[k] = W[k] * 0.25
+    for j, (pfx, ln) in enumerate([("clipTransEncoder.", "clip_ln"), ("model1.clipTransEncoder_individual.", "model1.clip_ln_individual"),
+                                   ("model2.clipTransEncoder_interaction.", "model2.clip_ln_interaction")]):
+        for i in range(2):
+            for k, v in enc_weights(950 + 50 * j + 10 * i, D, 2048, std=0.03).items():
+                W[f"{pfx}layers.{i}.{k}"] = v
+        W[ln + ".weight"], W[ln + ".bias"] = 1 + rnd(980 + j, D) * 0.1, rnd(990 + j, D) * 0.1
+    g = torch.Generator().manual_seed(19)
+
+    def prompts(B, lens):
+        rows = []
+        for b in range(B):
+            e = lens[b % len(lens)]
+            rows.append(torch.cat([torch.tensor([V - 2]), torch.randint(1, V - 2, (e,), generator=g), torch.tensor([V - 1]), torch.zeros(ctx - e - 2, dtype=torch.long)]))
+        return torch.stack(rows)
+    tok = prompts(3, [5, 30, 74])
+    tower = ClipTextTower(W, "", num_heads=H)
+    ref = EN.clip_text_tower(W, "", tok, H)
+    assert_close(tower(tok), ref, atol=5e-4, rtol=5e-4, what="ViT-L/14-sized text tower")
+    # the heads run their 96-wide heads on the MFMA kernel (zero-padded), not on the scalar any-size fallback
+    x = dev(rnd(7, 2, ctx, 3 * D))
+    a = ops.attention(x[..., :D], x[..., D:2 * D], x[..., 2 * D:], HH, zero_key=False)
+    qh, kh, vh = [t.reshape(2, ctx, HH, 96).transpose(1, 2).double().cpu() for t in (x[..., :D], x[..., D:2 * D], x[..., 2 * D:])]
+    want = (torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(96), -1) @ vh).transpose(1, 2).reshape(2, ctx, D)
+    assert_close(a, want.float(), atol=2e-5, rtol=1e-4, what="dh = 96 attention on the padded MFMA kernel")
+    enc = MixerTextEncoder(W, clip_heads=H, head_heads=HH)
+    t1, t2, tI = prompts(2, [6, 11]), prompts(2, [9, 20]), prompts(2, [17, 40])
+    cond = enc.generate_cond({"tokens_text_individual1": t1, "tokens_text_individual2": t2, "tokens_text": tI})
+    c = {k: EN.clip_text_tower(W, "", tk, H) for k, tk in [("1", t1), ("2", t2), ("I", tI)]}
+    hd = lambda pfx, ln, key, tk: EN.text_head(W, pfx, ln, c[key], tk, HH)
+    mi, m1, m2 = ("clipTransEncoder.", "clip_ln"), ("model1.clipTransEncoder_individual.", "model1.clip_ln_individual"), ("model2.clipTransEncoder_interaction.", "model2.clip_ln_interaction")
+    want = torch.cat([hd(*m2, "I", tI), hd(*m2, "1", t1), hd(*m2, "2", t2), hd(*m1, "1", t1), hd(*m1, "2", t2),
+                      hd(*mi, "I", tI), hd(*mi, "1", t1), hd(*mi, "2", t2)], dim=1)
+    assert cond.shape == (2, 8 * D)
+    assert_close(cond, want, atol=5e-4, rtol=5e-4, what="generate_cond at ViT-L/14 sizes")
+    # timing: the conditioning of a B = 16 batch (3 tower passes + 8 head passes)
+    big = {"tokens_text_individual1": prompts(16, [6, 11, 30]), "tokens_text_individual2": prompts(16, [9, 20, 44]), "tokens_text": prompts(16, [17, 40, 70])}
+    enc.generate_cond(big)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        enc.generate_cond(big)
+    torch.cuda.synchronize()
+    print(f"text stage at ViT-L/14 sizes, B = 16: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms per generate_cond (3 tower passes + 8 heads)")
