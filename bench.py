@@ -44,8 +44,9 @@ def main():
                     help="mixer = BASELINE configs[2] (2-person MixerMDM, the headline metric); single = configs[1] (single-person in2IN, T=196, B=32)")
     ap.add_argument("--batch", type=int, default=None, help="motions per GPU (weak scaling); default 16 (mixer) / 32 (single)")
     ap.add_argument("--frames", type=int, default=None, help="default 300 (mixer) / 196 (single)")
-    ap.add_argument("--precision", choices=["fp32", "fp32_split", "bf16"], default="fp32",
-                    help="fp32 = the parity path and the headline metric; bf16 = BASELINE configs[4]-style path (bf16 GEMM operands, fp32 accumulate)")
+    ap.add_argument("--precision", choices=["fp32", "fp32_split", "bf16", "bf16_fp8"], default="fp32",
+                    help="fp32 = the parity path and the headline metric; bf16 / bf16_fp8 = BASELINE configs[4] path (bf16 GEMM operands, fp32 accumulate; "
+                         "bf16_fp8: QKV / cross-attention input / FFN GEMMs on fp8 e4m3 operands)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -155,10 +156,14 @@ def main():
         smp.profile(False)
         ach = g_fl / (g_ms * 1e-3) / 1e12
         # fp32_split executes SIX bf16 MFMAs per algorithmic multiply-add block: its roof is the dense bf16 peak / 6
-        peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 6, 1)}[args.precision]
+        # bf16_fp8: the non-scaled fp8 MFMA (v_mfma_f32_32x32x16_fp8_fp8) issues at the bf16 rate on gfx950 (MI355X_MICROARCH.md, Matrix
+        # cores), and a third of the mode's GEMM launches are bf16: both priced against the dense bf16 peak
+        peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 6, 1), "bf16_fp8": PEAK_BF16_MFMA_TFLOPS}[args.precision]
         kname = {"fp32": "gemm_glds_kernel (v_mfma_f32_32x32x2_f32, LDS-DMA staged; 128x128 tiles, 128x64 when N <= 512)",
                  "bf16": "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, LDS-DMA staged, 256x128 tiles)",
-                 "fp32_split": "gemm_split_kernel (fp32 result from 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 operand splits; peak = 2500/6 algorithmic TFLOP/s)"}[args.precision]
+                 "fp32_split": "gemm_split_kernel (fp32 result from 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 operand splits; peak = 2500/6 algorithmic TFLOP/s)",
+                 "bf16_fp8": "gemm_bf16_kernel<ET=1> (v_mfma_f32_32x32x16_fp8_fp8: e4m3 operands, per-row / per-output-channel scales, fp32 accumulate) "
+                             "+ gemm_bf16_kernel for the attention output projections"}[args.precision]
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(single) if args.precision == "fp32" else None,
                 "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1),
@@ -219,16 +224,16 @@ def main():
         value = world * B / (ms_per_step * 1e-3 * S)
         wl = ("BASELINE configs[1]: single-person in2IN (individual denoiser, CFG 3.5), T=%d, ddim1000 (eta=0), batch %d per GPU, %s, random-init weights" % (T, B, args.precision)) if single else \
              ("BASELINE %s: 2-person MixerMDM (in2IN individual + in2IN interaction + Mixer mode 4, align, CFG 3.5), "
-              "T=%d, ddim1000 (eta=0), batch %d per GPU, %s, random-init weights" % ("configs[3] (batch 256 over 8 GPUs = 32 per GPU)" if world == 8 and B == 32 else "configs[2]", T, B, {"fp32": "fp32", "fp32_split": "fp32 via exact 3-way bf16 operand split (six bf16 MFMAs per product)", "bf16": "bf16 GEMM operands / fp32 accumulate (configs[4]-style)"}[args.precision]))
+              "T=%d, ddim1000 (eta=0), batch %d per GPU, %s, random-init weights" % ("configs[3] (batch 256 over 8 GPUs = 32 per GPU)" if world == 8 and B == 32 else "configs[2]", T, B, {"fp32": "fp32", "fp32_split": "fp32 via exact 3-way bf16 operand split (six bf16 MFMAs per product)", "bf16": "bf16 GEMM operands / fp32 accumulate (configs[4]-style)", "bf16_fp8": "configs[4]: bf16 path with fp8 e4m3 QKV / FFN GEMM operands, fp32 accumulate"}[args.precision]))
         line = {
             "metric": "generated motions/sec (1000-step DDPM schedule sampled with DDIM eta=0, T=%d, %s)" % (T, "single-person" if single else "2-person"),
             "value": round(value, 5), "unit": "motions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "ms_per_step_ranks": rank_ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32_split": "f32 (3xbf16 exact operand split, fp32 accumulate)", "bf16": "bf16"}[args.precision], "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32_split": "f32 (3xbf16 exact operand split, fp32 accumulate)", "bf16": "bf16", "bf16_fp8": "bf16 + fp8 e4m3 QKV/FFN operands"}[args.precision], "data": "synthetic",
             "config": {"workload": wl,
                        "batch_per_gpu": B, "frames": T, "sampler_steps": S, "hipgraph": use_graph, "parallelism": "batch-sharded x%d, no in-loop collective" % world},
             "achieved_tflops_algorithmic": round(flops * B * world / (ms_per_step * 1e-3) / 1e12, 2),
-            "frac_of_f32_mfma_peak": round(flops * B / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if args.precision != "bf16" else None,
+            "frac_of_f32_mfma_peak": round(flops * B / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if args.precision in ("fp32", "fp32_split") else None,
             "outputs_finite": finite,
             "full_loop": full, "roofline": roof, "cpu_baseline": cpu, "fp32_split": alt,
         }

@@ -70,6 +70,19 @@ int mmdm_linear_bf16(const void* A, int lda, const void* W, int ldw, const float
 /* Round-to-nearest-even fp32 -> bf16 conversion of n contiguous elements. */
 int mmdm_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 
+/* fp8 operands (OCP e4m3; BASELINE configs[4] "fp8 MFMA QKV/FFN GEMMs", mmdm_config.precision = 3): A [M,K] and W [N,K] are fp8 bytes
+ * (16-byte aligned rows, K % 64 == 0), accumulated in fp32 on v_mfma_f32_32x32x16_fp8_fp8 and de-quantised in the epilogue:
+ *   C[m][n] = acc[m][n] * a_scale[m] * w_scale[n] + bias[n] (+ residual / PE row), then the activation;
+ * a_scale [M] per-row activation scales, w_scale [N] per-output-channel weight scales (either may be NULL = 1).
+ * out_mode: 0 fp32, 1 bf16, 2 fp8 at unit scale (values saturate at +-448).  Epilogues / extra / period as mmdm_linear_f32; N % 4 == 0. */
+int mmdm_linear_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, const float* bias, void* C, int ldc,
+                    int out_mode, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
+/* Row-wise e4m3 quantisation of in [rows, K] (fp32, row stride ld_in): scale[r] = max|in[r,:]| / 448 (1 for a zero row),
+ * out[r,k] = e4m3(in[r,k] / scale[r]), round to nearest even.  Per-output-channel weight quantisation = this on W [N,K]. */
+int mmdm_quantize_rows_fp8(const float* in, int ld_in, void* out, int ld_out, float* scale, int rows, int K, void* stream);
+/* AdaLN apply (mmdm_adaln_f32) writing the fp8 GEMM's A operand directly: out [rows, D] e4m3 bytes + row_scale [rows]. */
+int mmdm_adaln_fp8(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, float* row_scale, int nseq, int T, int D, void* stream);
+
 /* fp32 linear layer on the bf16 matrix cores by exact 3-way operand splitting ("fp32-split" precision, mmdm_config.precision = 2):
  * every fp32 x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (3 x 8 significand bits = fp32's 24);
  * a*w is accumulated in fp32 as a1w1 + a1w2 + a2w1 + a1w3 + a3w1 + a2w2 (six v_mfma_f32_32x32x16_bf16; the three dropped terms are
@@ -240,7 +253,11 @@ typedef struct {
                         *    residual stream, softmax, geometry, DDIM and embeddings (BASELINE configs[4], "bf16 path")
                         * 2: "fp32-split": fp32 results from the bf16 matrix cores -- the transformer-stack GEMM operands are exact 3-way
                         *    bf16 splits (weights split at mmdm_prepare, AdaLN / attention / GELU outputs written as three planes) and each
-                        *    product is accumulated as six bf16 MFMAs (mmdm_linear_split); accuracy = fp32 MFMA, everything else as 0 */
+                        *    product is accumulated as six bf16 MFMAs (mmdm_linear_split); accuracy = fp32 MFMA, everything else as 0
+                        * 3: "bf16_fp8" (BASELINE configs[4]): as 1, with the QKV / cross-attention input projections and both FFN GEMMs on
+                        *    fp8 e4m3 operands -- weights quantised per output channel at mmdm_prepare, AdaLN outputs quantised per row by
+                        *    the AdaLN kernel, GELU outputs at unit scale -- fp32 accumulation and de-quantisation (mmdm_linear_fp8); the
+                        *    attention output projections stay bf16 */
     int model1_kind;   /* 0 = in2IN individual denoiser, 1 = MDMDenoiser (post-norm nn.TransformerEncoder with a conditioning token,
                         *    src/models/mdm.py:234-298; MODEL1.NAME == "MDM", src/models/mixermdm.py:32-40, 264-265).  Its cond slices are
                         *    latent-sized (mdm.py:279), so the mixer's cond rows are [3*text_dim | 2*d1_latent | 3*text_dim] */

@@ -61,6 +61,9 @@ SYMBOLS = {
     "mmdm_gather_rows_f32": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
     "mmdm_encoder_layer_workspace": (C.c_size_t, [_I, _I, _I, _I]),
     "mmdm_encoder_layer_f32": (_I, [_VP, C.POINTER(EncoderLayerWeights), _I, _I, _I, _I, _I, _I, _I, _I, C.c_float, _VP, C.c_size_t, _VP]),
+    "mmdm_linear_fp8": (_I, [_VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
+    "mmdm_quantize_rows_fp8": (_I, [_VP, _I, _VP, _I, _VP, _I, _I, _VP]),
+    "mmdm_adaln_fp8": (_I, [_VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _VP]),
     "mmdm_set_dual_weights": (_I, [_VP, _VP, _I]),
     "mmdm_create": (_I, [C.POINTER(Config), C.POINTER(_VP)]),
     "mmdm_destroy": (None, [_VP]),

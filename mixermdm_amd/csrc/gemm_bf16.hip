@@ -6,6 +6,13 @@
 // one ds_read_b128 per operand now feeds ONE MFMA of K = 16 (lane (r, h) holds k = 8h .. 8h+7 of MFMA k-block kb: chunk 2kb + h).
 // Operands are swapped (D^T = W A^T) so that the output row sits on the lane and four consecutive columns in consecutive
 // accumulator registers: bias / residual loads and result stores are 16-byte (fp32) or 8-byte (bf16) accesses.
+//
+// ET = 1: fp8 operands (OCP e4m3, BASELINE configs[4] "fp8 MFMA QKV/FFN GEMMs") through the SAME loop: a 64-byte LDS row then holds 64
+// fp8 values, every 16-byte fragment read feeds two v_mfma_f32_32x32x16_fp8_fp8 (its two 8-byte halves; the k order inside a row is
+// permuted identically for both operands), and the result is de-quantised in the epilogue,
+//   C[m][n] = acc[m][n] * a_scale[m] * w_scale[n] + bias[n] (+ residual),
+// with a per-row activation scale (written by the quantising producer: AdaLN sees the whole row) and a per-output-channel weight
+// scale (mmdm_prepare).  Half the operand bytes of the bf16 form per multiply-add; the non-scaled fp8 MFMA issues at the bf16 rate.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include "kernels.h"
@@ -22,8 +29,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 struct BArgs {
     const __bf16* A; const __bf16* W; const float* bias; void* C; const float* extra;
     int lda, ldw, ldc, ld_extra;          // element strides
-    int M, N, K, epilogue, period, out_bf16;
+    int M, N, K, epilogue, period, out_bf16;   // out_bf16: 0 fp32, 1 bf16, 2 fp8 e4m3 at unit scale (GELU output feeding the fp8 FFN down-projection)
     int mt, nt;
+    const float* a_scale; const float* w_scale;   // fp8 operands: per-row / per-output-channel de-quantisation scales (nullptr = 1)
+    float a_const, out_scale;                     // fp8: de-quantisation factor of A when a_scale is null; fp8 output is e4m3(value * out_scale)
     __bf16* P2; int p2_cols, ld2;         // optional second output: columns [0, p2_cols) also as bf16 (attention Q/K operands)
 };
 
@@ -42,7 +51,17 @@ struct BCfg {
     static_assert((NA + NB) % NWAVES == 0, "pieces must divide evenly over the waves");
 };
 
-template <int TM_, int TN_>
+__device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
+    // OCP e4m3, round to nearest even, saturating at +-448 (the conversion instruction does not clamp by itself in the default mode)
+    float c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = fminf(fmaxf(v[i], -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
+    return (unsigned)w;
+}
+
+template <int TM_, int TN_, int ET = 0>
 __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BArgs p) {
     using C_ = BCfg<TM_, TN_>;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
@@ -76,12 +95,12 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BA
         if (isa[u]) {
             int grow = m0 + trow;
             grow = grow < p.M ? grow : p.M - 1;
-            src[u] = reinterpret_cast<const char*>(p.A + (size_t)grow * p.lda) + 16 * gch;
+            src[u] = reinterpret_cast<const char*>(p.A) + (size_t)grow * p.lda * (ET == 1 ? 1 : 2) + 16 * gch;
             dst[u] = 16 * pq * 16;
         } else {
             int grow = n0 + trow;
             grow = grow < p.N ? grow : p.N - 1;
-            src[u] = reinterpret_cast<const char*>(p.W + (size_t)grow * p.ldw) + 16 * gch;
+            src[u] = reinterpret_cast<const char*>(p.W) + (size_t)grow * p.ldw * (ET == 1 ? 1 : 2) + 16 * gch;
             dst[u] = 2 * C_::A_FLOATS + 16 * (pq - C_::NA) * 16;
         }
     }
@@ -99,7 +118,14 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BA
     // L2 round trips per tile, fully exposed at one workgroup per CU.  Rows / columns past the edge read a clamped (valid) address: their
     // accumulators are never stored.
     f32x16 acc[TM][TN];
-    {
+    if constexpr (ET == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    } else {
         const bool has_bias = p.bias != nullptr;
         const bool has_ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
         f32x4 bv[TN][4], ev[TM][TN][4];
@@ -146,7 +172,7 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BA
                 }
     }
 
-    const int nkt = p.K / BK;
+    const int nkt = p.K / (ET == 1 ? 2 * BK : BK);          // a 64-byte row step = 32 bf16 or 64 fp8
     stage(0);
 
     const int sw = (l31 >> 2) & 3;
@@ -168,11 +194,22 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BA
             for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ac + i * 32 * 16 + cg));
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bc + j * 32 * 16 + cg));
+            if constexpr (ET == 1) {
+                typedef long l2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(l2, bf[j])[hh], __builtin_bit_cast(l2, af[i])[hh], acc[i][j], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
         }
     }
     // MFMA -> VALU hazard across the loop-exit branch: see MFMA_SETTLE in attn_f32.hip
@@ -185,44 +222,56 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BA
     for (int i = 0; i < TM; ++i) {
         const int row = m0 + wm * (32 * TM) + i * 32 + l31;
         if (row >= p.M) continue;
+        float sa = 1.f;
+        if constexpr (ET == 1) sa = p.a_scale ? p.a_scale[row] : p.a_const;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
                 if (col >= p.N) continue;
-                f32x4 v;
+                f32x4 v, add = {0.f, 0.f, 0.f, 0.f}, sw4 = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (ET == 1) {            // de-quantise, then bias (+ residual / PE row) as the bf16 form's accumulator start does
+                    if (p.w_scale) sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + col);
+                    if (p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + col);
+                    if (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) {
+                        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+                        add += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float t = acc[i][j][4 * qd + c];
+                    if constexpr (ET == 1) t = t * (sa * sw4[c]) + add[c];
                     if (p.epilogue == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
                     else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
                     v[c] = t;
                 }
                 const bool second = p.P2 && col < p.p2_cols;
-                if (p.out_bf16 || second) {
+                if (p.out_bf16 == 1 || second) {
                     const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    if (p.out_bf16) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col) = o;
+                    if (p.out_bf16 == 1) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col) = o;
                     if (second) *reinterpret_cast<bf16x4*>(p.P2 + (size_t)row * p.ld2 + col) = o;
                 }
+                if (p.out_bf16 == 2) *reinterpret_cast<unsigned*>(static_cast<unsigned char*>(p.C) + (size_t)row * p.ldc + col) = pack_fp8x4(v * p.out_scale);
                 if (!p.out_bf16) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
             }
     }
 }
 
-template <int TM_, int TN_>
+template <int TM_, int TN_, int ET = 0>
 int launch(BArgs a, hipStream_t st) {
     using C_ = BCfg<TM_, TN_>;
     a.mt = (a.M + C_::BM - 1) / C_::BM;
     a.nt = (a.N + C_::BN - 1) / C_::BN;
-    mmdm_note_gemm("gemm_bf16<%d,%d>", TM_, TN_);
-    hipLaunchKernelGGL((gemm_bf16_kernel<TM_, TN_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
-    return mmdm_check_launch("gemm_bf16");
+    mmdm_note_gemm("%s<%d,%d>", ET == 1 ? "gemm_fp8" : "gemm_bf16", TM_, TN_);
+    hipLaunchKernelGGL((gemm_bf16_kernel<TM_, TN_, ET>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+    return mmdm_check_launch(ET == 1 ? "gemm_fp8" : "gemm_bf16");
 }
 
-template <int TM_, int TN_>
+template <int TM_, int TN_, int ET = 0>
 int set_attr() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM_, TN_>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM_, TN_, ET>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, BCfg<TM_, TN_>::SMEM_BYTES);
     if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16): %s", hipGetErrorString(e));
     return MMDM_OK;
@@ -230,6 +279,27 @@ int set_attr() {
 
 __global__ void f32_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (__bf16)in[i];
+}
+
+// Row-wise e4m3 quantisation: scale[r] = max|x[r,:]| / 448 (1 for an all-zero row), q[r,k] = e4m3(x[r,k] / scale[r]).  One wave per row.
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const float* __restrict__ in, int ld_in, unsigned char* __restrict__ out, int ld_out,
+                                                              float* __restrict__ scale, int rows, int K) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = in + (size_t)row * ld_in;
+    float m = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + k);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float sc = m > 0.f ? m * (1.0f / 448.0f) : 1.0f, inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + k) * inv;
+        *reinterpret_cast<unsigned*>(out + (size_t)row * ld_out + k) = pack_fp8x4(v);
+    }
 }
 
 int g_bf16_cfg = -1;
@@ -242,6 +312,10 @@ int mmdm_gemm_bf16_init(void) {
     if ((rc = set_attr<42, 22>())) return rc;
     if ((rc = set_attr<42, 42>())) return rc;
     if ((rc = set_attr<22, 21>())) return rc;
+    if ((rc = set_attr<22, 22, 1>())) return rc;
+    if ((rc = set_attr<42, 22, 1>())) return rc;
+    if ((rc = set_attr<42, 42, 1>())) return rc;
+    if ((rc = set_attr<22, 21, 1>())) return rc;
     const char* e = getenv("MMDM_BF16_CFG");
     g_bf16_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
@@ -282,6 +356,7 @@ int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const fl
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
     a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_bf16 = out_bf16;
     a.mt = a.nt = 0;
+    a.a_scale = a.w_scale = nullptr; a.a_const = a.out_scale = 1.f;
     a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -291,5 +366,62 @@ int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const fl
         case 2: return launch<42, 42>(a, st);
         case 3: return launch<22, 21>(a, st);
         default: return launch<42, 22>(a, st);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) operands: BASELINE configs[4] "fp8 MFMA QKV/FFN GEMMs"
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int mmdm_quantize_rows_fp8(const float* in, int ld_in, void* out, int ld_out, float* scale, int rows, int K, void* stream) {
+    if (rows == 0) return MMDM_OK;
+    if (!in || !out || !scale || rows < 0 || K <= 0 || (K & 3) || (ld_in & 3) || (ld_out & 3) || ld_in < K || ld_out < K ||
+        (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 3))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_quantize_rows_fp8: bad arguments (K and the row strides must be multiples of 4, rows 16-byte aligned)");
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), in, ld_in,
+                       static_cast<unsigned char*>(out), ld_out, scale, rows, K);
+    return mmdm_check_launch("quant_rows_fp8");
+}
+
+extern "C" int mmdm_linear_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, const float* bias, void* C, int ldc,
+                               int out_mode, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
+    return mmdm_linear_fp8_ex(A, lda, a_scale, W, ldw, w_scale, bias, C, ldc, out_mode, M, N, K, epilogue, extra, ld_extra, period, nullptr, 0, 0, 1.0f, 1.0f, stream);
+}
+
+// a_const: de-quantisation factor of A when a_scale is null; out_scale: an fp8 output is e4m3(value * out_scale).  The handle uses the pair
+// for the GELU tensor between the two FFN GEMMs, whose producer sees a 64 x 64 piece of a row and cannot take a row maximum: a static power
+// of two (x 16 stored, 1/16 applied by the consumer) moves e4m3's normal range from |v| in [2^-6, 448] to [2^-10, 28].
+int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, const float* bias, void* C, int ldc,
+                       int out_mode, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* bf16_copy, int ld2, int copy_cols,
+                       float a_const, float out_scale, void* stream) {
+    mmdm_note_gemm_reset();
+    if (M == 0 || N == 0) return MMDM_OK;
+    if (int rc = mmdm_kernels_init()) return rc;
+    if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < K || ldc < N)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_fp8: bad shape M=%d N=%d K=%d lda=%d ldw=%d ldc=%d", M, N, K, lda, ldw, ldc);
+    if (out_mode < 0 || out_mode > 2) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_fp8: out_mode must be 0 (fp32), 1 (bf16) or 2 (fp8 at unit scale)");
+    if (epilogue < MMDM_EPI_BIAS || epilogue > MMDM_EPI_BIAS_SILU) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_fp8: unknown epilogue %d", epilogue);
+    const bool ext = epilogue == MMDM_EPI_BIAS_RESID || epilogue == MMDM_EPI_BIAS_PE;
+    if (ext && (!extra || ld_extra < N)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_fp8: epilogue %d needs `extra` with ld >= N", epilogue);
+    if (epilogue == MMDM_EPI_BIAS_PE && period <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_fp8: PE epilogue needs period > 0");
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if ((K & 63) || (lda & 15) || (ldw & 15) || !al16(A) || !al16(W))
+        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8: needs K %% 64 == 0 and 16-byte aligned fp8 rows");
+    if ((N & 3) || (ldc & 3) || !al16(C) || (bias && !al16(bias)) || (w_scale && !al16(w_scale)) || (ext && ((ld_extra & 3) || !al16(extra))))
+        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8: needs N %% 4 == 0 and 16-byte aligned output / bias / scale / residual rows");
+    BArgs a;
+    a.A = static_cast<const __bf16*>(A); a.W = static_cast<const __bf16*>(W); a.bias = bias; a.C = C; a.extra = extra;
+    a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
+    a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_bf16 = out_mode;
+    a.mt = a.nt = 0;
+    a.a_scale = a_scale; a.w_scale = w_scale;
+    a.a_const = a_const; a.out_scale = out_scale;
+    a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
+    if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8: second output needs 8-byte aligned bf16 rows");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (g_bf16_cfg) {
+        case 0: return launch<22, 22, 1>(a, st);
+        case 2: return launch<42, 42, 1>(a, st);
+        case 3: return launch<22, 21, 1>(a, st);
+        default: return launch<42, 22, 1>(a, st);
     }
 }

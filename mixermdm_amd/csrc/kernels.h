@@ -48,3 +48,7 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
                          void* planes2, int ld2, int64_t plane2_stride, int planes2_cols, void* stream);
 int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16,
                         int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* bf16_copy, int ld2, int copy_cols, void* stream);
+int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, const float* bias, void* C, int ldc,
+                       int out_mode, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* bf16_copy, int ld2, int copy_cols,
+                       float a_const, float out_scale, void* stream);
+int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_mode, float* row_scale, int nseq, int T, int D, void* stream);

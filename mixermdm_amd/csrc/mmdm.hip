@@ -92,8 +92,11 @@ struct LayerW {
     float *f1_w, *f1_b, *f2_w, *f2_b;
 };
 
-struct LayerWB {         // bf16 twins of the stack GEMM weights (precision == 1), converted at mmdm_prepare
+struct LayerWB {         // bf16 twins of the stack GEMM weights (precision >= 1), converted at mmdm_prepare
     void *sa_in_w = nullptr, *sa_out_w = nullptr, *ca_in_w = nullptr, *ca_out_w = nullptr, *f1_w = nullptr, *f2_w = nullptr;
+    // precision == 3: the QKV / cross-attention input projections and both FFN matrices as fp8 e4m3 + one scale per output channel
+    void *sa_in_8 = nullptr, *ca_in_8 = nullptr, *f1_8 = nullptr, *f2_8 = nullptr;
+    float *sa_in_s = nullptr, *ca_in_s = nullptr, *f1_s = nullptr, *f2_s = nullptr;
 };
 
 struct StackW {          // a transformer stack: denoiser blocks or Influence blocks
@@ -124,6 +127,7 @@ struct Scratch {          // transformer-stack work buffers (one set per concurr
     float *h = nullptr, *xn = nullptr, *qkv = nullptr, *kv = nullptr, *att = nullptr, *f1 = nullptr;
     float *xp = nullptr;      // [2][rows][NFP] repacked pose operands of the embedding GEMMs
     void *qk = nullptr, *kvp = nullptr;   // precision >= 1: bf16 plane copies of the attention's Q|K ([planes][R][2D]) and cross-attention K ([planes][R][D])
+    float* xs = nullptr;                  // precision == 3: per-row scales of the fp8 AdaLN output in xn
 };
 
 struct Prof {
@@ -255,10 +259,26 @@ int build_stack(mmdm_handle h, StackW& st, const std::string& pfx, int D, int F,
         *p = q;
         return MMDM_OK;
     };
+    auto twin8 = [&](void** p, float** sc, size_t rows, size_t cols) -> int {      // fp8 bytes [rows, cols] + fp32 scale per row
+        float* q = nullptr;
+        RC(dalloc(h, &q, (rows * cols + 3) / 4));
+        *p = q;
+        return dalloc(h, sc, rows);
+    };
     for (int i = 0; i < L; ++i) {
         LayerW& lw = st.layers[i];
         memset(&lw, 0, sizeof(lw));
-        if (bf) {
+        if (h->cfg.precision == 3) {
+            LayerWB& b2 = st.layers_b[i];
+            RC(twin8(&b2.sa_in_8, &b2.sa_in_s, (size_t)3 * D, D));
+            RC(twin(&b2.sa_out_w, (size_t)D * D));
+            RC(twin8(&b2.f1_8, &b2.f1_s, F, D));
+            RC(twin8(&b2.f2_8, &b2.f2_s, D, F));
+            if (has_ca) {
+                RC(twin8(&b2.ca_in_8, &b2.ca_in_s, (size_t)3 * D, D));
+                RC(twin(&b2.ca_out_w, (size_t)D * D));
+            }
+        } else if (bf) {
             LayerWB& b2 = st.layers_b[i];
             RC(twin(&b2.sa_in_w, (size_t)3 * D * D));
             RC(twin(&b2.sa_out_w, (size_t)D * D));
@@ -436,6 +456,14 @@ int linear_b(const Ctx& c, const void* A, int lda, const void* W, int ldw, const
     return prof_end(c, 0);
 }
 
+// fp8-operand GEMM (precision == 3): A fp8 + per-row scales (nullptr = unit), W fp8 + per-output-channel scales (gemm_bf16.hip, ET = 1)
+int linear_8(const Ctx& c, const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, const float* bias, void* C, int ldc,
+             int out_mode, int M, int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second(), float a_const = 1.f, float out_scale = 1.f) {
+    RC(prof_begin(c, 0, 2.0 * M * N * K, 1.0 * ((double)M * K + (double)N * K) + (out_mode == 0 ? 4.0 : out_mode == 1 ? 2.0 : 1.0) * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
+    RC(mmdm_linear_fp8_ex(A, lda, a_scale, W, ldw, w_scale, bias, C, ldc, out_mode, M, N, K, epi, extra, ld_extra, 0, s2.p, s2.ld, s2.cols, a_const, out_scale, c.st));
+    return prof_end(c, 0);
+}
+
 // fp32-split GEMM (precision == 2): A and W as three bf16 planes, fp32 accuracy on the bf16 matrix cores (gemm_split.hip)
 int linear_s(const Ctx& c, const void* A, int lda, size_t a_plane, const void* W, int ldw, size_t w_plane, const float* bias, void* C, int ldc,
              size_t c_plane, int out_split, int M, int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) {
@@ -467,14 +495,15 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     const Scratch& S = *c.s;
     const int D = w.D, F = w.F, R = r.nseq * r.T, dh = D / w.H;
     const int prec = c.h->cfg.precision;
-    const bool bf = prec >= 1;
-    const int ob = prec;                    // output mode of the GEMM-operand producers: 0 fp32, 1 bf16, 2 three bf16 planes
+    const bool bf = prec >= 1, f8 = prec == 3;
+    const int ob = f8 ? 1 : prec;           // output mode of the attention (operand of the out-projection): 0 fp32, 1 bf16, 2 three bf16 planes
     auto bw = [](const void* base, size_t elems) { return static_cast<const void*>(static_cast<const uint16_t*>(base) + elems); };
     // one GEMM of the stack: fp32 (A fp32, W fp32), bf16 (A bf16 from the producer, W twin) or fp32-split (three planes each).
     // wtot = elements of the whole weight matrix the twin was made from (its plane stride); the A plane stride is R*K.
     auto gemm = [&](const float* A, int lda, const float* Wf, const void* Wb, size_t woff, size_t wtot, const float* bias, float* C, int ldc, int out_b,
                     int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) -> int {
         if (prec == 2) return linear_s(c, A, lda, (size_t)R * K, bw(Wb, woff), K, wtot, bias, C, ldc, (size_t)R * N, out_b == 2, R, N, K, epi, extra, ld_extra, s2);
+
         if (bf) return linear_b(c, A, lda, bw(Wb, woff), K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra, s2);
         return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra);
     };
@@ -482,16 +511,30 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     // the bf16 matrix cores (attn_qkp_kernel): 20.1 -> 18.7 ms/step.  In fp32-split mode the three-plane copies cost more than the faster
     // Q K^T gains (51.6 vs 49.8 ms/step: P.V and the softmax are 60 % of the kernel), so that mode keeps the fp32 attention (MMDM_QKP=1 forces it).
     static const bool force_qkp = getenv("MMDM_QKP") != nullptr, no_qkp = getenv("MMDM_NO_QKP") != nullptr;
-    const bool qkp = bf && (prec == 1 || force_qkp) && (dh == 64 || dh == 128) && S.qk && !no_qkp;
+    const bool qkp = bf && (prec == 1 || prec == 3 || force_qkp) && (dh == 64 || dh == 128) && S.qk && !no_qkp;
     const int np = prec == 2 ? 3 : 1;
+    // precision 3: one fp8 GEMM of the stack.  W8 / Ws: fp8 matrix [rows, K] and its per-output-channel scales, row0 = first output
+    // channel used (the K|V slice of the packed cross-attention projection); unit_a: A is the GELU output, stored at the static scale GSCALE
+    constexpr float GSCALE = 1.0f;       // (a static x16 on the GELU tensor was measured: its range up to 28 saturates in these networks and doubles the error)
+    auto gemm8 = [&](const void* A, bool unit_a, const void* W8, const float* Ws, size_t row0, const float* bias, void* C, int ldc, int out_mode, int N, int K,
+                     int epi, const float* extra, int ld_extra, Second s2 = Second()) -> int {
+        return linear_8(c, A, K, unit_a ? nullptr : S.xs, static_cast<const uint8_t*>(W8) + row0 * K, K, Ws + row0, bias, C, ldc, out_mode, R, N, K, epi, extra, ld_extra, s2,
+                        unit_a ? 1.0f / GSCALE : 1.0f, out_mode == 2 ? GSCALE : 1.0f);
+    };
+    // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / three planes, or fp8 + per-row scales
+    auto norm = [&](const float* src, const float* ssp, int rows) -> int {
+        if (f8) return mmdm_adaln_any(src, ssp, r.ss_ld, rows, S.xn, 3, S.xs, r.nseq, r.T, D, c.st);
+        return mmdm_adaln_ex(src, ssp, r.ss_ld, rows, S.xn, ob, r.nseq, r.T, D, c.st);
+    };
     auto second = [&](void* buf, int ld, int cols) { Second s2; if (qkp) { s2.p = buf; s2.ld = ld; s2.cols = cols; s2.plane = (size_t)R * ld; } return s2; };
     for (int l = r.l0; l < w.L; ++l) {
         const LayerW& lw = w.layers[l];
         const LayerWB lb = bf ? w.layers_b[l] : LayerWB();
         auto ss_at = [&](int slot, int row0) { return r.ss + (size_t)row0 * r.ss_ld + ((size_t)l * w.n_ada + slot) * 2 * D; };
         // --- self attention (layers.py:36-45)
-        RC(mmdm_adaln_ex(hbuf, ss_at(0, r.sa_row0), r.ss_ld, r.sa_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-        RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, 2 * D, 2 * D)));
+        RC(norm(hbuf, ss_at(0, r.sa_row0), r.sa_rows));
+        if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, 2 * D, 2 * D)));
+        else RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, 2 * D, 2 * D)));
         if (qkp) RC(attention_p(c, S.qk, 2 * D, (size_t)R * 2 * D, static_cast<const uint16_t*>(S.qk) + D, 2 * D, (size_t)R * 2 * D, np, S.qkv + 2 * D, 3 * D, S.att, D, ob,
                                 r.nseq, r.T, r.T, w.H, dh, 0));
         else RC(attention_b(c, S.qkv, 3 * D, S.qkv + D, 3 * D, S.qkv + 2 * D, 3 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, 0));
@@ -499,23 +542,30 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
             // keys/values of the cross attention come from the layer INPUT of the other stream (or a fixed source):
             // project them before the residual below overwrites h.
             const float* src = r.ca_mode == 1 ? hbuf : r.kv_src;
-            RC(mmdm_adaln_ex(src, ss_at(2, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, D, D)));
+            RC(norm(src, ss_at(2, r.ca_row0), r.ca_rows));
+            if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, D, D)));
+            else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, D, D)));
         }
         RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         // --- cross attention (layers.py:77-88)
         if (r.ca_mode) {
-            RC(mmdm_adaln_ex(hbuf, ss_at(1, r.ca_row0), r.ss_ld, r.ca_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-            RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
+            RC(norm(hbuf, ss_at(1, r.ca_row0), r.ca_rows));
+            if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
+            else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
             if (qkp) RC(attention_p(c, S.qk, D, (size_t)R * D, S.kvp, D, (size_t)R * D, np, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
                                     r.ca_mode == 1 ? r.nseq / 2 : 0));
             else RC(attention_b(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
             RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, (size_t)D * D, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         }
         // --- FFN (layers.py:99-106)
-        RC(mmdm_adaln_ex(hbuf, ss_at(w.has_ca ? 3 : 1, r.ffn_row0), r.ss_ld, r.ffn_rows, S.xn, ob, r.nseq, r.T, D, c.st));
-        RC(gemm(S.xn, D, lw.f1_w, lb.f1_w, 0, (size_t)F * D, lw.f1_b, S.f1, F, ob, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
-        RC(gemm(S.f1, F, lw.f2_w, lb.f2_w, 0, (size_t)D * F, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
+        RC(norm(hbuf, ss_at(w.has_ca ? 3 : 1, r.ffn_row0), r.ffn_rows));
+        if (f8) {               // FFN on fp8 operands: the GELU output is written as e4m3 at unit scale and read back as the down-projection's A
+            RC(gemm8(S.xn, false, lb.f1_8, lb.f1_s, 0, lw.f1_b, S.f1, F, 2, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
+            RC(gemm8(S.f1, true, lb.f2_8, lb.f2_s, 0, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
+        } else {
+            RC(gemm(S.xn, D, lw.f1_w, lb.f1_w, 0, (size_t)F * D, lw.f1_b, S.f1, F, ob, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
+            RC(gemm(S.f1, F, lw.f2_w, lb.f2_w, 0, (size_t)D * F, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
+        }
     }
     return MMDM_OK;
 }
@@ -825,8 +875,10 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     if (has_mx && (cfg->mixing_mode < 1 || cfg->mixing_mode > 4)) return mmdm_set_error(MMDM_ERR_ARG, "Mode not recognized");
     if (cfg->max_batch <= 0 || cfg->max_frames <= 0 || cfg->text_dim <= 0 || cfg->text_dim % 4)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: bad max_batch / max_frames / text_dim");
-    if (cfg->precision < 0 || cfg->precision > 2)
-        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: precision must be 0 (fp32 MFMA), 1 (bf16 GEMM operands) or 2 (fp32 by exact bf16 operand splitting)");
+    if (cfg->precision < 0 || cfg->precision > 3)
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: precision must be 0 (fp32 MFMA), 1 (bf16 GEMM operands), 2 (fp32 by exact bf16 operand splitting) or 3 (bf16 + fp8 QKV/FFN operands)");
+    if (cfg->precision == 3 && ((D % 64) || (F % 64) || (D1 % 64) || (F1 % 64) || (has_mx && ((cfg->m_latent % 64) || (cfg->m_ff % 64)))))
+        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: the fp8 path needs latent and ff sizes that are multiples of 64");
     if (cfg->precision >= 1 && ((D % 32) || (F % 32) || (D1 % 32) || (F1 % 32) || (has_mx && ((cfg->m_latent % 32) || (cfg->m_ff % 32)))))
         return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: the bf16 path needs latent and ff sizes that are multiples of 32");
     if (cfg->precision >= 1 && mdm) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: the bf16 / fp32-split paths do not cover MDMDenoiser");
@@ -866,6 +918,7 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
             float *q1 = nullptr, *q2 = nullptr;
             if ((rc = dalloc(h, &q1, npl * R * d)) || (rc = dalloc(h, &q2, npl * R * d / 2 + 1))) return fail(rc);     // bf16 [npl][R][2d], [npl][R][d]
             sc->qk = q1; sc->kvp = q2;
+            if (c.precision == 3 && (rc = dalloc(h, &sc->xs, R))) return fail(rc);
         }
     }
     if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -979,7 +1032,19 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
                 const LayerW& lw = st.layers[i];
                 LayerWB& lb = st.layers_b[i];
                 const int64_t D = st.D, F = st.F;
-                int rc = conv(lw.sa_in_w, lb.sa_in_w, 3 * D * D);
+                int rc = MMDM_OK;
+                if (h->cfg.precision == 3) {          // per-output-channel e4m3 for QKV / cross-attention inputs / FFN, bf16 for the output projections
+                    auto q8 = [&](const float* src, void* dst, float* sc, int rows, int cols) { return mmdm_quantize_rows_fp8(src, cols, dst, cols, sc, rows, cols, nullptr); };
+                    rc = q8(lw.sa_in_w, lb.sa_in_8, lb.sa_in_s, (int)(3 * D), (int)D);
+                    if (!rc) rc = conv(lw.sa_out_w, lb.sa_out_w, D * D);
+                    if (!rc) rc = q8(lw.f1_w, lb.f1_8, lb.f1_s, (int)F, (int)D);
+                    if (!rc) rc = q8(lw.f2_w, lb.f2_8, lb.f2_s, (int)D, (int)F);
+                    if (!rc && st.has_ca) rc = q8(lw.ca_in_w, lb.ca_in_8, lb.ca_in_s, (int)(3 * D), (int)D);
+                    if (!rc && st.has_ca) rc = conv(lw.ca_out_w, lb.ca_out_w, D * D);
+                    if (rc) return herr(h, rc);
+                    continue;
+                }
+                rc = conv(lw.sa_in_w, lb.sa_in_w, 3 * D * D);
                 if (!rc) rc = conv(lw.sa_out_w, lb.sa_out_w, D * D);
                 if (!rc) rc = conv(lw.f1_w, lb.f1_w, F * D);
                 if (!rc) rc = conv(lw.f2_w, lb.f2_w, D * F);

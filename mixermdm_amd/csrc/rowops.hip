@@ -18,9 +18,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Reference: AdaLN.forward src/models/utils/layers.py:15-25 (LayerNorm eps 1e-6, biased variance, no affine).
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int MAXV, int OMODE>      // OMODE: 0 fp32, 1 bf16, 2 three bf16 planes (exact split, plane stride rows*D)
+__device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {      // OCP e4m3, RNE, saturating at +-448 (as in gemm_bf16.hip)
+    float c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = fminf(fmaxf(v[i], -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
+    return (unsigned)w;
+}
+
+// OMODE: 0 fp32, 1 bf16, 2 three bf16 planes (exact split, plane stride rows*D), 3 fp8 e4m3 with a per-row scale (row_scale[row] =
+// max|y| / 448; the fp8 GEMM multiplies it back in its epilogue)
+template <int MAXV, int OMODE>
 __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h, const float* __restrict__ ss, int ss_ld, int ss_rows,
-                                                     void* __restrict__ outv, int rows, int T, int D) {
+                                                     void* __restrict__ outv, int rows, int T, int D, float* __restrict__ row_scale = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -47,6 +58,29 @@ __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h,
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-6f);
     const float* sp = ss + (size_t)((row / T) % ss_rows) * ss_ld;
+    if constexpr (OMODE == 3) {
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(sp + 4 * c);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(sp + D + 4 * c);
+                v[i] = (v[i] - mean) * rstd * (1.0f + sc) + sh;
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i][0]), fabsf(v[i][1])), fmaxf(fabsf(v[i][2]), fabsf(v[i][3]))));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        const float scl = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f, inv = 1.0f / scl;
+        if (lane == 0) row_scale[row] = scl;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) *reinterpret_cast<unsigned*>(static_cast<unsigned char*>(outv) + (size_t)row * D + 4 * c) = pack_fp8x4(v[i] * inv);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + 64 * i;
@@ -227,6 +261,16 @@ extern "C" int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss
 }
 
 extern "C" int mmdm_adaln_ex(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, int nseq, int T, int D, void* stream) {
+    if (out_bf16 < 0 || out_bf16 > 2) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_adaln_ex: output mode must be 0 (fp32), 1 (bf16) or 2 (three bf16 planes)");
+    return mmdm_adaln_any(h, ss, ss_ld, ss_rows, out, out_bf16, nullptr, nseq, T, D, stream);
+}
+
+extern "C" int mmdm_adaln_fp8(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, float* row_scale, int nseq, int T, int D, void* stream) {
+    if (!row_scale) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_adaln_fp8: null row_scale");
+    return mmdm_adaln_any(h, ss, ss_ld, ss_rows, out, 3, row_scale, nseq, T, D, stream);
+}
+
+int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, float* row_scale, int nseq, int T, int D, void* stream) {
     if (nseq == 0 || T == 0) return MMDM_OK;
     if (!h || !ss || !out || nseq < 0 || T < 0 || D <= 0 || ss_rows <= 0 || ss_ld < 2 * D)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_adaln_f32: bad arguments nseq=%d T=%d D=%d ss_ld=%d ss_rows=%d", nseq, T, D, ss_ld, ss_rows);
@@ -238,9 +282,10 @@ extern "C" int mmdm_adaln_ex(const float* h, const float* ss, int ss_ld, int ss_
     dim3 grid((rows + 3) / 4), block(256);
 #define ADALN_LAUNCH(V)                                                                                                   \
     do {                                                                                                                  \
-        if (out_bf16 == 2) hipLaunchKernelGGL((adaln_kernel<V, 2>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);       \
-        else if (out_bf16) hipLaunchKernelGGL((adaln_kernel<V, 1>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);       \
-        else hipLaunchKernelGGL((adaln_kernel<V, 0>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D);                     \
+        if (out_bf16 == 3) hipLaunchKernelGGL((adaln_kernel<V, 3>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, row_scale);       \
+        else if (out_bf16 == 2) hipLaunchKernelGGL((adaln_kernel<V, 2>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, (float*)nullptr);       \
+        else if (out_bf16) hipLaunchKernelGGL((adaln_kernel<V, 1>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, (float*)nullptr);       \
+        else hipLaunchKernelGGL((adaln_kernel<V, 0>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, (float*)nullptr);                     \
     } while (0)
     if (D <= 256) ADALN_LAUNCH(1);
     else if (D <= 512) ADALN_LAUNCH(2);

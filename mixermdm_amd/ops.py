@@ -271,3 +271,44 @@ def attention_planes(qp, kp, v, num_heads, kv_seq_shift=0, zero_key=True, causal
     check(load_library().mmdm_attention_planes(C.c_void_p(qp.data_ptr()), qp.stride(2), qp.stride(0), C.c_void_p(kp.data_ptr()), kp.stride(2), kp.stride(0), NP,
                                                _p(v), v.stride(1), _p(out), HD, 0, flags, nseq, Tq, Tk, num_heads, HD // num_heads, kv_seq_shift, _stream()))
     return out
+
+
+def quantize_rows_fp8(x):
+    """Row-wise OCP e4m3 quantisation of an fp32 [rows, K] tensor: returns (q uint8-viewed-as torch.float8_e4m3fn [rows, K], scale fp32 [rows])
+    with x ~= q.float() * scale[:, None].  Per-output-channel weight quantisation is this on W [N, K]."""
+    _chk(x)
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    rows, K = x2.shape
+    q = torch.empty(rows, K, device=x.device, dtype=torch.uint8)
+    scale = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(load_library().mmdm_quantize_rows_fp8(_p(x2), x2.stride(0), C.c_void_p(q.data_ptr()), q.stride(0), _p(scale), rows, K, _stream()))
+    return q.view(torch.float8_e4m3fn), scale
+
+
+def linear_fp8(xq, x_scale, wq, w_scale, bias=None, epilogue="bias", extra=None, period=0, out_dtype=torch.float32):
+    """y = (xq * x_scale[:, None]) @ (wq * w_scale[:, None]).T + bias on the fp8 matrix instructions (fp32 accumulation, de-quantised in the
+    epilogue).  xq [M, K], wq [N, K] torch.float8_e4m3fn; x_scale [M] / w_scale [N] fp32 or None; out fp32, bf16 or float8_e4m3fn (unit scale)."""
+    for t in (xq, wq):
+        if not t.is_cuda or t.dtype != torch.float8_e4m3fn:
+            raise TypeError("linear_fp8 expects CUDA torch.float8_e4m3fn operands")
+    _chk(bias, extra, x_scale, w_scale)
+    K, N = xq.shape[-1], wq.shape[0]
+    x2 = xq.reshape(-1, K)
+    M = x2.shape[0]
+    out = torch.empty(M, N, device=xq.device, dtype=out_dtype)
+    mode = {torch.float32: 0, torch.bfloat16: 1, torch.float8_e4m3fn: 2}[out_dtype]
+    check(load_library().mmdm_linear_fp8(C.c_void_p(x2.data_ptr()), x2.stride(0), _p(x_scale), C.c_void_p(wq.data_ptr()), wq.stride(0), _p(w_scale), _p(bias),
+                                         C.c_void_p(out.data_ptr()), out.stride(0), mode, M, N, K, EPI[epilogue],
+                                         _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
+    return out.reshape(*xq.shape[:-1], N)
+
+
+def adaln_fp8(h, ss, ss_rows=None):
+    """AdaLN apply with an fp8 result: (q float8_e4m3fn [nseq, T, D], row_scale fp32 [nseq*T])."""
+    _chk(h, ss)
+    nseq, T, D = h.shape
+    h = h.contiguous()
+    q = torch.empty(nseq, T, D, device=h.device, dtype=torch.uint8)
+    scale = torch.empty(nseq * T, device=h.device, dtype=torch.float32)
+    check(load_library().mmdm_adaln_fp8(_p(h), _p(ss), ss.stride(0), ss_rows or ss.shape[0], C.c_void_p(q.data_ptr()), _p(scale), nseq, T, D, _stream()))
+    return q.view(torch.float8_e4m3fn), scale

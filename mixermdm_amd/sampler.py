@@ -36,7 +36,8 @@ class Sampler:
         3 = in2IN "dual": both denoisers composed by ClassifierFreeSampleDualMDM (call set_dual_weights after set_schedule).
         model1_kind: 0 = in2IN individual, 1 = MDMDenoiser; d1_*: denoiser1's own sizes (0 = same as d_*).
         precision: "fp32" (native fp32 MFMA), "fp32_split" (fp32 results from six bf16 MFMAs per product on exactly split operands:
-        same accuracy, the bf16 matrix rate), "bf16" (bf16 GEMM operands)."""
+        same accuracy, the bf16 matrix rate), "bf16" (bf16 GEMM operands), "bf16_fp8" (BASELINE configs[4]: as "bf16" with the QKV /
+        cross-attention input projections and both FFN GEMMs on fp8 e4m3 operands)."""
         if not torch.cuda.is_available():
             raise RuntimeError("mixermdm_amd.Sampler needs an MI355X (HIP device); there is no CPU path")
         self.lib = load_library()
@@ -44,7 +45,7 @@ class Sampler:
         self.cfg = Config(d_latent, d_ff, d_layers, d_heads, m_latent, m_ff, m_layers, m_heads, 262, text_dim, mixing_mode, int(align),
                           int(xstart_align), model2_kind, int(force_influence_val is not None), float(force_influence_val or 0.0),
                           float(cfg_scale), max_batch, max_frames, int(single_only), float(cfg_scale_interaction), float(cfg_scale_individual),
-                          {"fp32": 0, "bf16": 1, "fp32_split": 2}[precision], int(model1_kind), d1_latent, d1_ff, d1_layers, d1_heads)
+                          {"fp32": 0, "bf16": 1, "fp32_split": 2, "bf16_fp8": 3}[precision], int(model1_kind), d1_latent, d1_ff, d1_layers, d1_heads)
         self.single_only = int(single_only)
         self.h = C.c_void_p()
         with torch.cuda.device(self.device):
