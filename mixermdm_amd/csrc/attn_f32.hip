@@ -52,7 +52,8 @@ __device__ __forceinline__ void load_v_row(const float* __restrict__ vrow_base, 
 }
 
 
-constexpr int KC = 16;   // keys per LDS stage (two stages in flight)
+constexpr int KC = 16;   // keys per LDS stage
+constexpr int NST = 2;   // LDS stages of attn_mfma_kernel: chunk ci + NST - 1 is requested while chunk ci is consumed (counted vmcnt, raw barrier)
 constexpr int QW = 16;   // queries per wave
 constexpr int QB = 64;   // queries per workgroup
 
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     constexpr int NPIECE = 2 * KC / RPP;        // pieces per stage (K then V)
     constexpr int NI = NPIECE / 4;              // pieces per wave
     constexpr int STAGE = 2 * KC * DH;          // floats per stage
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 stages][K: KC*DH | V: KC*DH]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [NST stages][K: KC*DH | V: KC*DH]
 
     // XCD-aware mapping: blocks b and b+8 share an XCD (private L2), so all query tiles of one (sequence, head) are given to
     // blocks of the same residue mod 8 -- its K/V is then fetched into one L2 once instead of into up to `qtiles` L2s.
@@ -190,12 +191,24 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         const int last_q = min(qt * QB + QB - 1, p.Tq - 1);
         nchunks = min(nchunks, last_q / KC + 1);
     }
-    stage(0, 0);
+    // NST-stage ring: chunks 0 .. NST-2 are requested up front; in iteration ci the wave waits until at most the NST-2 newest of its
+    // chunks are still in flight (= chunk ci has landed), the raw barrier makes that true for every wave and proves that chunk ci-1 --
+    // whose buffer is restaged next -- has been read by all of them (their ds_reads were retired by lgkmcnt(0) before the barrier).
+    // __syncthreads() would drain vmcnt(0) here and serialise the ring; the Q-fragment loads above are older than every DMA piece.
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nchunks) stage(t * KC, t);
+    int cur = 0, stg = NST - 1;
     for (int ci = 0; ci < nchunks; ++ci) {
-        const int c0 = ci * KC, cur = ci & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk ci have landed
-        __syncthreads();                                        // ... everyone's; and chunk ci-1 is fully consumed
-        if (ci + 1 < nchunks) stage(c0 + KC, cur ^ 1);         // prefetch into the other stage while computing this one
+        const int c0 = ci * KC;
+        const int left = nchunks - 1 - ci;                     // chunks requested behind this one (capped at NST - 2 by the ring)
+        if (left >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NI) : "memory");
+        else if (left == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ci + NST - 1 < nchunks) stage(c0 + (NST - 1) * KC, stg);
         const float* Ks = smem + cur * STAGE;
         const float* Vs = Ks + KC * DH;
 
@@ -275,6 +288,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
             for (int j = 0; j < NJ; ++j)
                 o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vb[cb][j], o[j], 0, 0, 0);
         }
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        stg = stg + 1 == NST ? 0 : stg + 1;
     }
 
 #pragma unroll
@@ -591,7 +606,7 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(AttnArgs p, int dh) {
 }
 
 template <int DH>
-constexpr int attn_smem() { return 2 * 2 * KC * DH * 4; }
+constexpr int attn_smem() { return NST * 2 * KC * DH * 4; }
 
 template <int DH>
 int launch_mfma(const AttnArgs& a, hipStream_t st) {
