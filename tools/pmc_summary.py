@@ -1,0 +1,87 @@
+"""Summarise the round's rocprofv3 output (tools/profile_round.sh) into the small artefacts committed under profiles/:
+   kernel_stats_{serial,overlap,...}.csv (per-kernel totals from the kernel traces), pmc_summary.json (MFMA busy, clock, HBM-side
+   bytes and L2 hit rate per kernel) and gemm_traffic.json (what bench.py reports as roofline.traffic, with the hash of the GEMM source
+   it was measured on).  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests of 16-byte-per-lane streams at 64 B: MI355X_MICROARCH.md,
+   HBM); counters are per-XCD sums as rocprofv3 reports them."""
+import sys, os, glob, csv, json, re, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mixermdm_amd.build import sources_sha
+src = sys.argv[1]
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(src, "summary")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(k):
+    k = re.sub(r"\(anonymous namespace\)::", "", k)
+    return re.sub(r"^void ", "", k).split("(")[0]
+
+
+def traces(d):
+    rows = []
+    for f in glob.glob(os.path.join(src, d, "**", "*kernel_trace.csv"), recursive=True):
+        rows += [(r["Dispatch_Id"], short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f))]
+    return rows
+
+
+for d in ("serial", "overlap", "split_serial", "fp8_serial"):
+    rows = traces(d)
+    if not rows:
+        continue
+    agg = collections.defaultdict(list)
+    for _, k, s, e in rows:
+        agg[k].append(e - s)
+    tot = sum(sum(v) for v in agg.values())
+    with open(os.path.join(dst, f"kernel_stats_{d}.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k, len(v), sum(v), round(sum(v) / len(v), 1), round(100 * sum(v) / tot, 3), min(v), max(v)])
+
+# PMC passes
+per = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in glob.glob(os.path.join(src, "pmc_*")):
+    if not os.path.isdir(d):
+        continue
+    dur = {i: (k, e - s) for i, k, s, e in traces(os.path.basename(d))}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] in ("GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
+                per[k]["ns:" + r["Counter_Name"]].append(dur.get(r["Dispatch_Id"], ("", 0))[1])
+mean = lambda v: sum(v) / len(v) if v else None
+out = {"kernel_sources_sha": sources_sha(), "note": "per-dispatch means over the profiled bench steps; FETCH_SIZE / WRITE_SIZE in KB as reported, fetch_bytes = 2 x FETCH_SIZE x 1024", "kernels": {}}
+gemm = {"fetch": [], "write": [], "hit": [], "miss": [], "n": 0}
+for k, c in per.items():
+    e = {"dispatches": len(c.get("GRBM_GUI_ACTIVE", c.get("FETCH_SIZE", c.get("WRITE_SIZE", [])))) }
+    if c.get("GRBM_GUI_ACTIVE"):
+        ns = mean(c["ns:GRBM_GUI_ACTIVE"])
+        e["avg_us"] = round(ns / 1e3, 1)
+        e["clock_ghz"] = round(mean(c["GRBM_GUI_ACTIVE"]) / 8 / ns, 3)
+        e["mfma_busy_frac"] = round(mean(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (1024 * mean(c["GRBM_GUI_ACTIVE"]) / 8), 4)
+    if c.get("FETCH_SIZE"):
+        e["fetch_bytes"] = round(2 * 1024 * mean(c["FETCH_SIZE"]))
+    if c.get("WRITE_SIZE"):
+        e["write_bytes"] = round(1024 * mean(c["WRITE_SIZE"]))
+    if c.get("FETCH_SIZE") and c.get("WRITE_SIZE"):
+        e["hbm_side_TBps"] = round((e["fetch_bytes"] + e["write_bytes"]) / mean(c["ns:FETCH_SIZE"]) / 1e3, 3)
+    if c.get("TCC_HIT_sum"):
+        e["l2_hit_rate"] = round(mean(c["TCC_HIT_sum"]) / (mean(c["TCC_HIT_sum"]) + mean(c["TCC_MISS_sum"])), 4)
+    out["kernels"][k] = e
+    if k.startswith("gemm_glds_kernel"):
+        for nm, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("hit", "TCC_HIT_sum"), ("miss", "TCC_MISS_sum")):
+            gemm[nm] += c.get(key, [])
+json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+if gemm["fetch"] and gemm["write"]:
+    fetch, write = 2 * 1024 * mean(gemm["fetch"]), 1024 * mean(gemm["write"])
+    rec = {"kernel": "gemm_glds_kernel (all pipelined fp32 instantiations of a step)", "kernel_sources_sha": sources_sha(),
+           "workload": "bench.py --steps 2 --warmup 1 --no-graph (BASELINE configs[2], B=16, T=300), MMDM_NO_OVERLAP=1",
+           "dispatches_averaged": len(gemm["fetch"]), "FETCH_SIZE_KB_per_launch_raw": round(mean(gemm["fetch"]), 1), "WRITE_SIZE_KB_per_launch": round(mean(gemm["write"]), 1),
+           "fetch_correction": "x2 (gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16-B-per-lane streams; MI355X_MICROARCH.md, HBM)",
+           "traffic_bytes_per_launch": round(fetch + write), "l2_hit_rate": round(mean(gemm["hit"]) / (mean(gemm["hit"]) + mean(gemm["miss"])), 4) if gemm["hit"] else None,
+           "note": "FETCH_SIZE includes Infinity-Cache hits (operand re-reads that miss the 4 MiB XCD L2)"}
+    json.dump(rec, open(os.path.join(dst, "gemm_traffic.json"), "w"), indent=1)
+    print(json.dumps(rec))
+for k, e in sorted(out["kernels"].items(), key=lambda kv: -(kv[1].get("avg_us") or 0))[:12]:
+    print(k[:70], e)
