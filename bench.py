@@ -159,7 +159,7 @@ def main():
         # bf16_fp8: the non-scaled fp8 MFMA (v_mfma_f32_32x32x16_fp8_fp8) issues at the bf16 rate on gfx950 (MI355X_MICROARCH.md, Matrix
         # cores), and a third of the mode's GEMM launches are bf16: both priced against the dense bf16 peak
         peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 6, 1), "bf16_fp8": PEAK_BF16_MFMA_TFLOPS}[args.precision]
-        kname = {"fp32": "gemm_glds_kernel (v_mfma_f32_32x32x2_f32, LDS-DMA staged; 128x128 tiles, 128x64 when N <= 512)",
+        kname = {"fp32": "gemm_glds_kernel<..., PIPE_=1> (v_mfma_f32_32x32x2_f32; software-pipelined LDS-DMA ring: 128x128 tiles x 5 stages, 128x64 x 4 stages when N = 2048 or N, K <= 512; all instantiations of a step averaged)",
                  "bf16": "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, LDS-DMA staged, 256x128 tiles)",
                  "fp32_split": "gemm_split_kernel (fp32 result from 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 operand splits; peak = 2500/6 algorithmic TFLOP/s)",
                  "bf16_fp8": "gemm_bf16_kernel<ET=1> (v_mfma_f32_32x32x16_fp8_fp8: e4m3 operands, per-row / per-output-channel scales, fp32 accumulate) "

@@ -62,3 +62,21 @@ def test_two_rank_broadcast_shard_gather(tmp_path):
         ref = _row_fn(cond, xT)
         for r in range(2):
             assert torch.equal(torch.load(os.path.join(tmp_path, f"B{B}_r{r}.pt")), ref)
+
+
+def test_bench_starts_its_own_ranks_and_rejects_a_wrong_world():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself; `--dry-run` stops after the rendezvous, so the
+    launcher path runs here without a GPU.  A world that differs from --gpus is an error, not a silently different benchmark."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"dry_run": True, "n_gpus": 2, "max_rank_seen": 1}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode != 0 and "gpus" in (r.stderr + r.stdout)
