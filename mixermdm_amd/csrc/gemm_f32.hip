@@ -20,6 +20,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
     const float* A; const float* W; const float* bias; float* C; const float* extra;
@@ -27,7 +28,8 @@ struct GemmArgs {
     int M, N, K, Kw, epilogue, period;   // Kw >= K: readable columns of W (zero beyond K)
     int mt, nt;
     int ablate;                          // timing experiments only (tools/gemm_bench.py); 0 in production
-    unsigned long long* stamps;          // diagnostic builds of a launch only (tools/gemm_timeline.py): per-workgroup {start, loop start, end, placement}
+    int stagger, stagger_slots;          // first-round workgroups of CU slot s = 1 .. stagger_slots wait s * stagger ticks (100 MHz) before they start; 0 = off
+    unsigned long long* stamps;          // diagnostic builds of a launch only (tools/gemm_timeline.py): per-workgroup {start, loop start, loop end, placement, kernel end, kernel entry, -, -}
                                          // in 100 MHz s_memrealtime ticks; nullptr in production (one never-taken scalar branch per workgroup)
 };
 
@@ -251,7 +253,9 @@ template <int CPR> __device__ __forceinline__ int swz_of(int r) { return CPR == 
 // buffer after the wait that retires it and a barrier the reader has passed").
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// One output tile (`swz` = tile index after the XCD remap) from start to finish.
+// One output tile (`swz` = tile index after the XCD remap) from start to finish.  Device pass only: the buffer-resource type of the
+// LDS-DMA builtins does not exist in the host pass, which only needs the kernel's symbol.
+#if defined(__HIP_DEVICE_COMPILE__)
 template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int swz, int bid) {
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
@@ -268,42 +272,50 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
     const int wm = wave / C_::WGN, wn = wave % C_::WGN;
     const int l31 = lane & 31, lh = lane >> 5;
     if (p.stamps && tid == 0) {
-        p.stamps[4 * (size_t)bid + 0] = __builtin_amdgcn_s_memrealtime();
-        p.stamps[4 * (size_t)bid + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+        p.stamps[8 * (size_t)bid + 0] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[8 * (size_t)bid + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
                                         ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
     }
 
-    // staging pieces of this wave: piece id pq = wave + NWAVES*u; pq < NA -> A rows RPP*pq.., else W rows RPP*(pq-NA)..
-    const float* src[C_::NI];
+    // Staging pieces of this wave: piece id pq = wave + NWAVES*u; pq < NA -> A rows RPP*pq.., else W rows RPP*(pq-NA)..  The pieces are
+    // requested with `buffer_load_dwordx4 ... offen lds`: one buffer resource per operand whose base is the tile's first row, a per-lane
+    // 32-bit byte offset that is fixed for the whole tile (row * ld + swizzled chunk) and ONE scalar offset that walks K.  Measured
+    // (tools/loop_bench3.hip): with per-lane 64-bit pointers (`global_load_lds`, two VALU adds per piece and step, 64-bit address
+    // operands) the operand stream costs 12-16 % of the MFMA rate of this loop; in the buffer form 0-2 %.
+    constexpr int UA = C_::NA / C_::NWAVES;             // pieces u < UA are A pieces for every wave, the others W pieces
+    static_assert(C_::NA % C_::NWAVES == 0, "A pieces must divide evenly over the waves (compile-time operand of a piece)");
+    int voff[C_::NI];                                   // byte offset of this lane's 16 bytes inside the operand's row block, at k = 0
     int dst[C_::NI];                                    // LDS float offset of the piece inside buffer 0 (wave-uniform)
-    bool isa[C_::NI];
 #pragma unroll
     for (int u = 0; u < C_::NI; ++u) {
         const int pq = wave + C_::NWAVES * u;
         const int prow = lane / CPR, pc = lane % CPR;
-        isa[u] = pq < C_::NA;
-        const int trow = (isa[u] ? RPP * pq : RPP * (pq - C_::NA)) + prow;      // row inside the operand tile
+        const bool isa = u < UA;
+        const int trow = (isa ? RPP * pq : RPP * (pq - C_::NA)) + prow;         // row inside the operand tile
         const int gch = pc ^ swz_of<CPR>(trow);                                  // source chunk stored at LDS chunk pc of this row
-        if (isa[u]) {
-            int grow = m0 + trow;
-            grow = grow < p.M ? grow : p.M - 1;
-            src[u] = p.A + (size_t)grow * p.lda + 4 * gch;
+        if (isa) {
+            const int rel = min(trow, p.M - 1 - m0);                            // rows past M re-read the last row (never stored)
+            voff[u] = (rel * p.lda + 4 * gch) * 4;
             dst[u] = RPP * pq * BK;
         } else {
-            int grow = n0 + trow;
-            grow = grow < p.N ? grow : p.N - 1;
-            src[u] = p.W + (size_t)grow * p.ldw + 4 * gch;
+            const int rel = min(trow, p.N - 1 - n0);
+            voff[u] = (rel * p.ldw + 4 * gch) * 4;
             dst[u] = NBUF * C_::A_FLOATS + RPP * (pq - C_::NA) * BK;
         }
     }
-    auto stage = [&](int buf) {
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + (size_t)m0 * p.lda), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W + (size_t)n0 * p.ldw), 0, 0xffffffff, 0x00020000);
+    int koff = 0;                                       // byte offset of the K tile being requested (scalar)
+    auto stage_part = [&](int buf, auto u0c, auto u1c) {
+        constexpr int u0 = decltype(u0c)::value, u1 = decltype(u1c)::value;
 #pragma unroll
-        for (int u = 0; u < C_::NI; ++u) {
-            const int boff = isa[u] ? buf * C_::A_FLOATS : buf * C_::B_FLOATS;
-            __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + dst[u] + boff), 16, 0, 0);
-            src[u] += BK;
+        for (int u = u0; u < u1; ++u) {
+            const int boff = u < UA ? buf * C_::A_FLOATS : buf * C_::B_FLOATS;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(u < UA ? rsA : rsW, (lptr_t)(smem + dst[u] + boff), 16, voff[u], koff, 0, 0);
         }
+        if constexpr (u1 == C_::NI) koff += BK * 4;
     };
+    auto stage = [&](int buf) { stage_part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, C_::NI>{}); };
 
     const int nkt = p.K / BK;
     // Pipelined kernel, 16-byte epilogue form (residual / PE GEMMs): the accumulators start as the bias only and the residual tile is
@@ -369,7 +381,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
         // the accumulator-init loads above must not be counted by the pipeline's vmcnt arithmetic
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (p.stamps && tid == 0) p.stamps[4 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps && tid == 0) p.stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime();
     // fragment read offsets (floats): row*BK + 4*((2g + lh) ^ sw)
     const int sw = swz_of<CPR>(l31);
     const int a_row = (wm * (32 * TM) + l31) * BK;
@@ -378,7 +390,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
     f32x4 rv[LATE_R ? TM : 1][LATE_R ? TN : 1][4];               // the late residual tile (LATE_R only)
     if constexpr (PIPE_ != 0) {
         static_assert((C_::G == 2 || C_::G == 4) && NBUF >= 3 && NBUF <= 6, "pipelined loop: K step 16 or 32 (two / four k-groups), 3 to 6 stages");
-        static_assert(C_::NI <= 2 * (4 * TM * TN - 1), "LDS-DMA pieces of a tile must fit behind the MFMAs of two k-groups");
+        static_assert((C_::NI + 1) / 2 <= 4 * TM * TN - 1, "LDS-DMA pieces of a tile must fit behind the MFMAs of two k-groups");
         constexpr int NI = C_::NI;
         f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
         auto rd = [&](int buf, int g, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
@@ -421,10 +433,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
         auto group = [&](auto gi, auto do_stage, int left, bool more) {
             constexpr int g = decltype(gi)::value;
             constexpr bool STG = decltype(do_stage)::value;
-            constexpr int dma_here = (!STG || PIPE_ == 2) ? 0 : (g == 0 ? (NI < NMM - 1 ? NI : NMM - 1) : (g == 1 && NI > NMM - 1 ? NI - (NMM - 1) : 0));
+            // the pieces of the tile being requested are split over k-groups 0 and 1 (tools/loop_bench3.hip: 2 + 2 beats 4 + 0)
+            constexpr int D0 = (NI + 1) / 2, D1 = NI - D0;
+            constexpr int dma_here = (!STG || PIPE_ == 2) ? 0 : (g == 0 ? D0 : (g == 1 ? D1 : 0));
+            constexpr int before_wait = G == 2 ? D0 : NI;      // pieces of the newest tile already issued when the step's wait executes
             if constexpr (g == G - 1) {
                 if (more) {
-                    if constexpr (STG) wait_vm<(NBUF - 2) * NI>();      // tile kt+1 landed; tiles kt+2 .. kt+NBUF-1 may be in flight
+                    if constexpr (STG) wait_vm<(NBUF - 3) * NI + before_wait>();      // tile kt+1 landed; tiles kt+2 .. may be in flight
                     else wait_left(left);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if constexpr (PIPE_ != 3) __builtin_amdgcn_s_barrier();      // PIPE_ 2 / 3: timing ablations (tools/gemm_bench.py), wrong results
@@ -434,11 +449,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
             if constexpr (g % 2 == 0) {
                 if constexpr (g < G - 1) rd(cur, g + 1, a1, b1);
                 else if (more) rd(nxt, 0, a1, b1);
-                if constexpr (STG && g == 0 && PIPE_ != 2) stage(stg);
+                if constexpr (STG && g == 0 && PIPE_ != 2) stage_part(stg, std::integral_constant<int, 0>{}, std::integral_constant<int, D0>{});
                 mm(a0, b0);
             } else {
                 if constexpr (g < G - 1) rd(cur, g + 1, a0, b0);
                 else if (more) rd(nxt, 0, a0, b0);
+                if constexpr (STG && g == 1 && PIPE_ != 2) stage_part(stg, std::integral_constant<int, D0>{}, std::integral_constant<int, NI>{});
                 mm(a1, b1);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 1, g);
@@ -529,65 +545,115 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
-    if (p.stamps && tid == 0) p.stamps[4 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps && tid == 0) p.stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
+    // The epilogue (accumulator reads, activation, stores) runs beside a co-resident workgroup that is inside its K loop and keeps
+    // the SIMD's issue port busy with MFMAs; at equal priority the epilogue wave only gets the leftovers (measured with the launch
+    // staggered: 27-35 us for 16 stores per lane; tools/gemm_timeline.py).  It is ~300 instructions: let it go first.
+    if (p.ablate & 64) __builtin_amdgcn_s_setprio(3);
+    if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) p.stamps[8 * (size_t)bid + 6] = __builtin_amdgcn_s_memrealtime();
+    }
 
-    if (VEPI) {
-        // D^T map: lane&31 = output row inside the 32-row tile, register 4*qd + c = output column 8*qd + 4*(lane>>5) + c
+    // The activation is chosen ONCE, outside the element loops: with the runtime `p.epilogue` tests inside them every element carried all
+    // four activation bodies (11 000 instructions, ~90 KB of code after the loop) and the wave hopped through it branch by branch --
+    // 27-47 us per tile beside a co-resident workgroup in its K loop, 8 us when every workgroup ran it at once (tools/gemm_timeline.py).
+    // Stores go through a buffer resource over this tile's rows of C: rows past M fall outside `num_records` and are dropped by the
+    // hardware, the row step is a scalar offset, the column step an immediate -- no per-store address arithmetic and no per-store
+    // branch (each `if (row < M)` around a store was an exec-mask branch that the wave had to resolve before its next instruction).
+    // Columns past N (only in the last column tile of an N that is not a multiple of the tile) are masked per 32-column block.
+    const int rows_here = min(p.M - m0, BM);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
+    const int ldc4 = p.ldc * 4;
+    auto finish = [&](auto act_c, auto fulln_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool FULLN = decltype(fulln_c)::value;
+        auto act = [](float t) {
+            if constexpr (ACT == MMDM_EPI_BIAS_GELU) return gelu_erf(t);
+            else if constexpr (ACT == MMDM_EPI_BIAS_SILU) return silu(t);
+            else if constexpr (ACT == MMDM_EPI_BIAS_QUICKGELU) return quick_gelu(t);
+            else if constexpr (ACT == MMDM_EPI_BIAS_SIGMOID) return sigmoidf(t);
+            else return t;
+        };
+        if constexpr (VEPI) {
+            // D^T map: lane&31 = output row inside the 32-row tile, register 4*qd + c = output column 8*qd + 4*(lane>>5) + c
+            const int col0 = n0 + wn * (32 * TN) + 4 * lh;
+            const int voff = (wm * (32 * TM) + l31) * ldc4 + col0 * 4;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = m0 + wm * (32 * TM) + i * 32 + l31;
-            if (row >= p.M) continue;
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
-                    if (col >= p.N) continue;
-                    f32x4 v;
+                    for (int qd = 0; qd < 4; ++qd) {
+                        f32x4 v;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float t = acc[i][j][4 * qd + c];
-                        if constexpr (LATE_R) t += rv[i][j][qd][c];
-                        if (p.epilogue == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
-                        else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
-                        else if (p.epilogue == MMDM_EPI_BIAS_QUICKGELU) t = quick_gelu(t);
-                        else if (p.epilogue == MMDM_EPI_BIAS_SIGMOID) t = sigmoidf(t);
-                        v[c] = t;
+                        for (int c = 0; c < 4; ++c) {
+                            float t = acc[i][j][4 * qd + c];
+                            if constexpr (LATE_R) t += rv[i][j][qd][c];
+                            v[c] = act(t);
+                        }
+                        if (FULLN || col0 + j * 32 + 8 * qd < p.N)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff + (j * 32 + 8 * qd) * 4, i * 32 * ldc4, 0);
                     }
-                    *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
+        } else {
+            const int col0 = n0 + wn * (32 * TN) + l31;
+            const int voff = (wm * (32 * TM) + 4 * lh) * ldc4 + col0 * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (!FULLN && col0 + j * 32 >= p.N) continue;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, act(acc[i][j][e])), rsC, voff + j * 128,
+                                                              (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc4, 0);
                 }
         }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (32 * TN) + j * 32 + l31;
-            if (col >= p.N) continue;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (row >= p.M) continue;
-                float v = acc[i][j][e];
-                if (p.epilogue == MMDM_EPI_BIAS_GELU) v = gelu_erf(v);
-                else if (p.epilogue == MMDM_EPI_BIAS_SILU) v = silu(v);
-                else if (p.epilogue == MMDM_EPI_BIAS_QUICKGELU) v = quick_gelu(v);
-                else if (p.epilogue == MMDM_EPI_BIAS_SIGMOID) v = sigmoidf(v);
-                p.C[(size_t)row * p.ldc + col] = v;
-            }
-        }
+    };
+    auto finish_n = [&](auto act_c) {
+        if (n0 + BN <= p.N) finish(act_c, std::true_type{});
+        else finish(act_c, std::false_type{});
+    };
+    switch (p.epilogue) {
+        case MMDM_EPI_BIAS_GELU: finish_n(std::integral_constant<int, MMDM_EPI_BIAS_GELU>{}); break;
+        case MMDM_EPI_BIAS_SILU: finish_n(std::integral_constant<int, MMDM_EPI_BIAS_SILU>{}); break;
+        case MMDM_EPI_BIAS_QUICKGELU: finish_n(std::integral_constant<int, MMDM_EPI_BIAS_QUICKGELU>{}); break;
+        case MMDM_EPI_BIAS_SIGMOID: finish_n(std::integral_constant<int, MMDM_EPI_BIAS_SIGMOID>{}); break;
+        default: finish_n(std::integral_constant<int, MMDM_EPI_BIAS>{}); break;
     }
 }
+#endif
 
 template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0>
 __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void gemm_glds_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nwg = p.mt * p.nt;
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // Stagger.  On an idle chip the dispatcher puts workgroups b, b + 256, b + 512 .. on the same CU at the same instant, and equal
+    // tiles then stay in lock-step for the whole launch: every co-resident workgroup is in its prologue (an HBM burst of the whole
+    // chip), and later in its epilogue, at the same time, with the matrix pipe idle (tools/gemm_timeline.py: two co-resident
+    // 128x128x1024 tiles took 133-139 us against 109 at the MFMA peak, the next pair started 4 us later).  Holding the first-round
+    // workgroup of CU slot s back by s/occupancy of a tile's duration puts the co-resident tiles out of phase for the rest of the
+    // launch: one is always in its K loop.  The held-back slot costs nothing: a lone workgroup has the CU's matrix pipes to itself.
+    const unsigned long long t_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+    if (p.stagger > 0 && bid >= 256) {
+        const int slot = bid >> 8;
+        if (slot <= p.stagger_slots) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)slot * p.stagger;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    if (p.stamps && threadIdx.x == 0) p.stamps[8 * (size_t)bid + 5] = t_entry;
     gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_>(p, smem, swz, bid);
+    if (p.stamps) {
+        if (threadIdx.x == 0) p.stamps[8 * (size_t)bid + 7] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) p.stamps[8 * (size_t)bid + 4] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 inline bool vepi_ok(const GemmArgs& a) {
@@ -605,6 +671,14 @@ int launch_glds(GemmArgs a, hipStream_t st) {
     // measured (tools/gemm_bench.py): the 16-byte epilogue pays where the accumulators are initialised from memory (+10 % on
     // the K = 1024 residual GEMMs) and is neutral-to-slightly-negative for bias/GELU-only epilogues
     const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
+    a.stagger = a.stagger_slots = 0;
+    if ((a.ablate & 32) && PIPE_ == 1) {
+        // co-resident workgroups by LDS footprint (tools/lds_census.hip) and registers (<= 168: 3 waves per SIMD)
+        const int occ = C_::SMEM_BYTES > 48 * 1024 ? 2 : (C_::SMEM_BYTES > 32 * 1024 ? 3 : 4);
+        const double tile_us = 2.0 * C_::BM * C_::BN * a.K / (157.3e12 / 256 * 0.9) * 1e6;      // one tile alone on a CU
+        a.stagger = (int)(tile_us * 100.0 / occ);
+        a.stagger_slots = occ - 1;
+    }
     mmdm_note_gemm("%s<%d,%d,%d,%d,%s>", PIPE_ ? "gemm_pipe" : "gemm_glds", TM_, TN_, BK_, NBUF_, (ext && vepi_ok(a) && !(a.ablate & 16)) ? "vepi" : "scalar");
     if (ext && vepi_ok(a) && !(a.ablate & 16))
         hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);

@@ -3,9 +3,9 @@ ddim1000 schedule -- in the native fp32 mode and in fp32_split, against (1) the 
 itself at these sizes (tests/golden/fulldims.npz), plus float64 checks of the GEMM instantiations the B=16 step actually launches
 (M = 19 200 rows), with the launched kernel asserted through the mmdm_last_gemm_kernel() debug getter.
 
-Tolerance of a step (tests/test_gpu_sampler.py::STEP_TOL): all but 0.2 % of the elements within atol 2e-4 + rtol 2e-4, none beyond 5e-2
+Tolerance of a step (tests/parity_tol.py::STEP_TOL): all but 0.2 % of the elements within atol 2e-4 + rtol 2e-4, none beyond 5e-2
 (a handful of near-degenerate joints amplify rounding through the rot6d -> quaternion round trip); the tolerance of a person's position /
-velocity channels is scaled by the conditioning factor of the global rotations that produced them (see KAPPA_MASK below).
+velocity channels is scaled by the conditioning factor of the global rotations that produced them (tests/parity_tol.py).
 """
 import math
 import os
@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 from oracle import mixer as MX            # noqa: E402  (checker only)
 from oracle import schedule as OS         # noqa: E402
 from test_gpu_kernels import assert_close, rnd, dev   # noqa: E402
-from test_gpu_sampler import STEP_TOL      # noqa: E402
+from parity_tol import STEP_TOL, compare_step, KAPPA_MASK      # noqa: E402,F401
 from conftest import fulldims_case         # noqa: E402
 
 MODES = ["fp32", "fp32_split"]
@@ -59,35 +59,6 @@ def samplers(case):
         s.close()
 
 
-# Conditioning of the reference's two global rotations (geometry near its branch points needs a discriminant-aware comparison).
-# Both are qbetween(u, v) of two directions and both are applied to whole position / velocity sequences:
-#   * align_motions turns the individual model's motion by the angle between two root-displacement DIRECTIONS (alignment.py:84-101).  A
-#     pre-geometry difference e in the root positions (HIP vs CPU rounding through 8-16 blocks: ~2e-5) turns the sequence by e / |disp| and
-#     moves a position at distance `reach` from the pivot by reach * e / |disp|: that stays inside the 2e-4 tolerance only while
-#     |disp| >= 0.1 reach.  The random-weight individual model barely moves its root (|disp| / reach = 0.04-0.07), so the factor
-#     kappa = 0.1 reach / |disp| (>= 1) scales the tolerance of that person's position / velocity channels.
-#   * qbetween is singular for anti-parallel directions: w = 1 + u.v -> 0 and |u x v| -> 0, and an fp32 rounding of w (1e-7) turns the
-#     sequence by 2e-7 / sqrt(2 w): beyond the tolerance at 8 m reach once w < 3e-5.  center_motion (alignment.py:188-206) rotates every
-#     person to face +Z, so person 2 of a pair facing each other -- where these trajectories sit for many late steps -- is exactly that
-#     half turn.  kappa = sqrt(3e-4 / w) (10x margin on the figure above).
-# Persons with kappa > KAPPA_MASK are on the branch point: their position / velocity channels are compared for sanity only (finite,
-# |err| <= 1).  Rotation-6D and foot-contact channels are never affected and always meet the plain tolerance.
-KAPPA_MASK = 25.0
-
-
-def _kappa(hist, B):
-    """Oracle diagnostics of one step -> (kappa_chain1 [B, 2 persons], kappa_chain2 [B, 2]) tolerance factors >= 1."""
-    k_align = torch.ones(B, 2, dtype=torch.float64)
-    for p, d in enumerate(hist["align_diag"][-2:]):            # rows: B cond + B uncond of the CFG-doubled batch
-        k = torch.maximum(0.1 * d["reach"] / torch.minimum(d["disp_target"], d["disp_moved"]).clamp_min(1e-12), torch.sqrt(3e-4 / d["w"].clamp_min(1e-12))).double()
-        k_align[:, p] = torch.maximum(k[:B], k[B:]).clamp_min(1.0)
-    k_center = torch.ones(B, 2, dtype=torch.float64)
-    for p, d in enumerate(hist.get("center_diag", [])[-2:]):
-        k = torch.maximum(torch.sqrt(3e-4 / d["w"].clamp_min(1e-12)), 0.01 * d["reach"] / (d["across"] * d["fwd"]).clamp_min(1e-12)).double()
-        k_center[:, p] = k.clamp_min(1.0)
-    return torch.maximum(k_align, k_center), k_align
-
-
 def _step(s, x, x2, i, names=("x", "x2", "pred_xstart", "pred_xstart2")):
     """One teacher-forced step of the begun call from chains (x, x2) at respaced index i -> cloned outputs."""
     _force(s, x, x2, i)
@@ -99,26 +70,7 @@ def _step(s, x, x2, i, names=("x", "x2", "pred_xstart", "pred_xstart2")):
 def _check_step(s, x, x2, i, refs, what, hist):
     """refs: {state name: reference tensor}; hist: the oracle's diagnostics of this very step (conditioning factors)."""
     out = _step(s, x, x2, i)
-    B, T = x.shape[:2]
-    k1, k2 = _kappa(hist, B)
-    worst, masked = 0.0, False
-    for nm, ref in refs.items():
-        got, ref = out[nm].detach().cpu().double(), torch.as_tensor(ref).detach().cpu().double()
-        assert torch.isfinite(got).all(), f"{what} {nm}: non-finite"
-        kap = k1 if nm in ("x", "pred_xstart") else k2
-        scale = torch.ones(B, T, 524, dtype=torch.float64)
-        for p in range(2):
-            scale[:, :, p * 262:p * 262 + 132] = kap[:, p, None, None]
-        keep = scale <= KAPPA_MASK
-        masked |= not bool(keep.all())
-        d = (got - ref).abs()
-        bad = (d > scale * (STEP_TOL["atol"] + STEP_TOL["rtol"] * ref.abs())) & keep
-        frac = bad.double().sum().item() / max(1, int(keep.sum()))
-        note = f"(conditioning factors per [sample, person]: {[[round(v, 1) for v in r] for r in kap.tolist()]})"
-        assert frac <= STEP_TOL["frac"], f"{what} {nm}: {frac:.2e} of the elements outside tolerance, max err {d[keep].max().item():.2e} {note}"
-        assert (d[keep] / scale[keep]).max().item() <= STEP_TOL["hard"], f"{what} {nm}: max err {d[keep].max().item():.2e} {note}"
-        assert d.max().item() <= 1.0, f"{what} {nm}: an element on a branch point is off by {d.max().item():.2e}"
-        worst = max(worst, frac)
+    worst, masked = compare_step(out, refs, what, hist)
     return out, worst, masked
 
 

@@ -9,6 +9,7 @@ d = torch.device("cuda:0")
 shapes = {"out": (19200, 1024, 1024, "resid"), "ffn2": (19200, 1024, 2048, "resid"), "qkv": (19200, 3072, 1024, "bias"), "ffn1": (19200, 2048, 1024, "gelu")}
 ops.linear(torch.zeros(8, 64, device=d), torch.zeros(8, 64, device=d))     # lazy init first (it resets the forced configuration)
 lib.mmdmx_set_gemm_cfg(int(os.environ.get("CFG", "-1")))
+lib.mmdmx_set_gemm_ablate(int(os.environ.get("ABL", "0")))
 for name in (sys.argv[1:] or ["out", "qkv"]):
     M, N, K, epi = shapes[name]
     x = torch.randn(M, K, device=d); w = torch.randn(N, K, device=d) / math.sqrt(K); b = torch.randn(N, device=d)
@@ -16,17 +17,19 @@ for name in (sys.argv[1:] or ["out", "qkv"]):
     extra = out if epi == "resid" else None
     for _ in range(3):
         ops.linear(x, w, b, epi, extra, out=out)
-    stamps = torch.zeros(8192 * 4, dtype=torch.int64, device=d)
+    stamps = torch.zeros(8192 * 8, dtype=torch.int64, device=d)
     lib.mmdmx_set_gemm_stamps(C.c_void_p(stamps.data_ptr()))
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); ops.linear(x, w, b, epi, extra, out=out); e1.record(); torch.cuda.synchronize()
     lib.mmdmx_set_gemm_stamps(C.c_void_p(0))
     kern = lib.mmdm_last_gemm_kernel().decode()
-    s = stamps.cpu().numpy().reshape(-1, 4)
+    s = stamps.cpu().numpy().reshape(-1, 8)
     n = int((s[:, 0] != 0).sum())
     s = s[:n]
     t0 = s[:, 0].min()
+    t0 = s[:, 5].min()
     st, lp, en = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0, (s[:, 2] - t0) / 100.0      # us
+    ke, ent = (s[:, 4] - t0) / 100.0, (s[:, 5] - t0) / 100.0                                  # kernel end (after the epilogue), kernel entry (before the stagger wait)
     hw = s[:, 3] & 0xFFFFFFFF; xcc = s[:, 3] >> 32
     cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)       # cu_id, sh_id, se_id, xcc
     ucu, per_cu = np.unique(cu, return_counts=True)
@@ -42,4 +45,7 @@ for name in (sys.argv[1:] or ["out", "qkv"]):
     print("   workgroups in their K loop at 0,5,..100 % of the kernel: " + " ".join(str(a) for a in act))
     for c in ucu[:2]:
         idx = np.where(cu == c)[0]
-        print(f"   CU {c}: " + "; ".join(f"wg{idx[k]} {st[idx[k]]:.0f}->{en[idx[k]]:.0f}" for k in np.argsort(st[idx])))
+        print(f"   CU {c} (entry/start->loop end/kernel end): " + "; ".join(f"wg{idx[k]} {ent[idx[k]]:.0f}/{st[idx[k]]:.0f}->{en[idx[k]]:.0f}/{ke[idx[k]]:.0f}" for k in np.argsort(st[idx])))
+    rvw, sti = (s[:, 6] - t0) / 100.0, (s[:, 7] - t0) / 100.0
+    print(f"   loop end -> residual tile landed: mean {np.mean(rvw-en):.2f} us | -> stores issued: mean {np.mean(sti-rvw):.2f} us | -> stores acknowledged: mean {np.mean(ke-sti):.2f} us")
+    print(f"   epilogue (loop end -> kernel end) mean {np.mean(ke-en):.2f} max {np.max(ke-en):.2f} us")
