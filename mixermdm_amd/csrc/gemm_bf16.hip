@@ -36,8 +36,6 @@ struct BArgs {
     __bf16* P2; int p2_cols, ld2;         // optional second output: columns [0, p2_cols) also as bf16 (attention Q/K operands)
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 template <int TM_, int TN_>
 struct BCfg {

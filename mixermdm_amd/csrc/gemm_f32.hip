@@ -51,10 +51,6 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ base, int ld, i
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float quick_gelu(float x) { return x * (1.0f / (1.0f + expf(-1.702f * x))); }   // CLIP QuickGELU: x * sigmoid(1.702 x)
 
 // Tile configuration: the workgroup is WGM x WGN waves (encoded as TM = 10*WGM + tiles, TN likewise: TM=22 -> 2 waves x 2 tiles),
 // each wave owns (TM%10) x (TN%10) MFMA tiles of 32x32; K step BK.
@@ -559,7 +555,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
     // four activation bodies (11 000 instructions, ~90 KB of code after the loop) and the wave hopped through it branch by branch --
     // 27-47 us per tile beside a co-resident workgroup in its K loop, 8 us when every workgroup ran it at once (tools/gemm_timeline.py).
     // Stores go through a buffer resource over this tile's rows of C: rows past M fall outside `num_records` and are dropped by the
-    // hardware, the row step is a scalar offset, the column step an immediate -- no per-store address arithmetic and no per-store
+    // hardware (the range check sees the vector offset + immediate, so the row step is added there: one VALU add per store), the
+    // column step is an immediate -- no 64-bit address arithmetic and no per-store
     // branch (each `if (row < M)` around a store was an exec-mask branch that the wave had to resolve before its next instruction).
     // Columns past N (only in the last column tile of an N that is not a multiple of the tile) are masked per 32-column block.
     const int rows_here = min(p.M - m0, BM);
@@ -592,8 +589,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
                             if constexpr (LATE_R) t += rv[i][j][qd][c];
                             v[c] = act(t);
                         }
+                        // the row step is part of the VECTOR offset: only that (plus the immediate) takes part in the range check
                         if (FULLN || col0 + j * 32 + 8 * qd < p.N)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff + (j * 32 + 8 * qd) * 4, i * 32 * ldc4, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4, 0, 0);
                     }
         } else {
             const int col0 = n0 + wn * (32 * TN) + l31;
@@ -605,8 +603,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
                     if (!FULLN && col0 + j * 32 >= p.N) continue;
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, act(acc[i][j][e])), rsC, voff + j * 128,
-                                                              (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, act(acc[i][j][e])), rsC,
+                                                              voff + (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc4 + j * 128, 0, 0);
                 }
         }
     };

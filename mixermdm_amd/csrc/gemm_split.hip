@@ -14,12 +14,14 @@
 // three planes per operand tile: LDS-DMA staged, XOR-swizzled 64-byte rows, swapped operands (row on the lane), 16-byte epilogue.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -35,8 +37,6 @@ struct SArgs {
     __bf16* P2; size_t p2_plane; int p2_cols, ld2;   // optional second output: columns [0, p2_cols) also as three bf16 planes (attention Q/K operands)
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 template <int TM_, int TN_>
 struct SCfg {
@@ -52,8 +52,87 @@ struct SCfg {
     static_assert((NA + NB) % NWAVES == 0, "pieces must divide evenly over the waves");
 };
 
+// Epilogue shared by the fp32-split kernels: activation, output form (fp32 rows / three bf16 planes) and the optional second plane
+// output are chosen ONCE per tile, outside the element loops (with the runtime tests inside them every element carried every variant:
+// tens of KB of branchy code that a wave crawls through while a co-resident workgroup owns the matrix pipe; see gemm_f32.hip and
+// tools/gemm_timeline.py).  fp32 rows are stored through a buffer resource over the tile's rows: rows past M are dropped by the hardware.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int TM, int TN, int BM>
+__device__ __forceinline__ void split_finish(const SArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int l31, int lh) {
+    const int rows_here = min(p.M - m0, BM);
+    auto finish = [&](auto act_c, auto split_c, auto sec_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool SPLIT = decltype(split_c)::value, SEC = decltype(sec_c)::value;
+        const int col0 = n0 + wn * (32 * TN) + 4 * lh;
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(static_cast<float*>(p.C) + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
+        const int voffC = (wm * (32 * TM) + l31) * p.ldc * 4 + col0 * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * (32 * TM) + i * 32 + l31;
+            const bool rok = row < p.M;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int col = col0 + j * 32 + 8 * qd;
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float t = acc[i][j][4 * qd + c];
+                        if constexpr (ACT == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
+                        else if constexpr (ACT == MMDM_EPI_BIAS_SILU) t = silu(t);
+                        v[c] = t;
+                    }
+                    if constexpr (SPLIT || SEC) {
+                        bf16x4 o1, o2, o3;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            o1[c] = (__bf16)v[c];
+                            const float r1 = v[c] - (float)o1[c];
+                            o2[c] = (__bf16)r1;
+                            o3[c] = (__bf16)(r1 - (float)o2[c]);
+                        }
+                        if (rok && col < p.N) {
+                            if constexpr (SPLIT) {
+                                __bf16* cp = static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col;
+                                *reinterpret_cast<bf16x4*>(cp) = o1;
+                                *reinterpret_cast<bf16x4*>(cp + p.pc) = o2;
+                                *reinterpret_cast<bf16x4*>(cp + 2 * p.pc) = o3;
+                            }
+                            if constexpr (SEC) {
+                                if (col < p.p2_cols) {
+                                    __bf16* cp = p.P2 + (size_t)(row + p.row0) * p.ld2 + col;
+                                    *reinterpret_cast<bf16x4*>(cp) = o1;
+                                    *reinterpret_cast<bf16x4*>(cp + p.p2_plane) = o2;
+                                    *reinterpret_cast<bf16x4*>(cp + 2 * p.p2_plane) = o3;
+                                }
+                            }
+                        }
+                    }
+                    if constexpr (!SPLIT) {
+                        if (col < p.N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voffC + i * 32 * p.ldc * 4 + (j * 32 + 8 * qd) * 4, 0, 0);
+                    }
+                }
+        }
+    };
+    auto finish_out = [&](auto act_c) {
+        if (p.out_split) {
+            if (p.P2) finish(act_c, std::true_type{}, std::true_type{});
+            else finish(act_c, std::true_type{}, std::false_type{});
+        } else {
+            if (p.P2) finish(act_c, std::false_type{}, std::true_type{});
+            else finish(act_c, std::false_type{}, std::false_type{});
+        }
+    };
+    if (p.epilogue == MMDM_EPI_BIAS_GELU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_GELU>{});
+    else if (p.epilogue == MMDM_EPI_BIAS_SILU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_SILU>{});
+    else finish_out(std::integral_constant<int, MMDM_EPI_BIAS>{});
+}
+#endif
+
 template <int TM_, int TN_>
 __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(SArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA / buffer-store builtins exists in the device pass only
     using C_ = SCfg<TM_, TN_>;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -73,178 +152,157 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
     const int wm = wave / C_::WGN, wn = wave % C_::WGN;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const char* src[C_::NI];
-    int dst[C_::NI];
-    bool isa[C_::NI];
+    // LDS-DMA pieces, buffer-addressed (see gemm_f32.hip): one resource per operand based at the tile's first row, a per-lane byte
+    // offset fixed for the tile (plane, row, swizzled chunk) and a scalar offset that walks K.
+    constexpr int UA = C_::NA / C_::NWAVES;            // pieces u < UA are A pieces for every wave
+    static_assert(C_::NA % C_::NWAVES == 0, "A pieces must divide evenly over the waves");
+    int voff[C_::NI], dst[C_::NI];
 #pragma unroll
     for (int u = 0; u < C_::NI; ++u) {
         const int pq = wave + C_::NWAVES * u;
         const int prow = lane >> 2, pc = lane & 3;
-        isa[u] = pq < C_::NA;
-        const int pl = isa[u] ? pq / C_::NAP : (pq - C_::NA) / C_::NBP;          // plane
-        const int pp = isa[u] ? pq % C_::NAP : (pq - C_::NA) % C_::NBP;          // piece inside the plane
+        const bool isa = u < UA;
+        const int pl = isa ? pq / C_::NAP : (pq - C_::NA) / C_::NBP;          // plane
+        const int pp = isa ? pq % C_::NAP : (pq - C_::NA) % C_::NBP;          // piece inside the plane
         const int trow = 16 * pp + prow;
         const int gch = pc ^ ((trow >> 2) & 3);
-        if (isa[u]) {
-            int grow = m0 + trow;
-            grow = grow < p.M ? grow : p.M - 1;
-            src[u] = reinterpret_cast<const char*>(p.A + (size_t)pl * p.pa + (size_t)grow * p.lda) + 16 * gch;
+        if (isa) {
+            const int rel = min(trow, p.M - 1 - m0);
+            voff[u] = (int)(((size_t)pl * p.pa + (size_t)rel * p.lda) * 2) + 16 * gch;
             dst[u] = pl * C_::A_PLANE + 16 * pp * 16;
         } else {
-            int grow = n0 + trow;
-            grow = grow < p.N ? grow : p.N - 1;
-            src[u] = reinterpret_cast<const char*>(p.W + (size_t)pl * p.pw + (size_t)grow * p.ldw) + 16 * gch;
+            const int rel = min(trow, p.N - 1 - n0);
+            voff[u] = (int)(((size_t)pl * p.pw + (size_t)rel * p.ldw) * 2) + 16 * gch;
             dst[u] = 2 * C_::A_FLOATS + pl * C_::B_PLANE + 16 * pp * 16;
         }
     }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.A + (size_t)m0 * p.lda), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.W + (size_t)n0 * p.ldw), 0, 0xffffffff, 0x00020000);
+    int koff = 0;
     auto stage = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < C_::NI; ++u) {
-            const int boff = isa[u] ? buf * C_::A_FLOATS : buf * C_::B_FLOATS;
-            __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + dst[u] + boff), 16, 0, 0);
-            src[u] += 64;
+            const int boff = u < UA ? buf * C_::A_FLOATS : buf * C_::B_FLOATS;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(u < UA ? rsA : rsW, (lptr_t)(smem + dst[u] + boff), 16, voff[u], koff, 0, 0);
         }
+        koff += 64;
     };
 
-    // Accumulators start as bias (+ residual / + PE row).  All loads are issued back to back behind WAVE-UNIFORM branches and waited for
-    // once: with per-element runtime conditions hipcc branches around every load and waits vmcnt(0) after each one -- 16-32 serialized
-    // L2 round trips per tile, fully exposed at one workgroup per CU.  Rows / columns past the edge read a clamped (valid) address: their
-    // accumulators are never stored.
+    // Accumulators start as the bias; the residual / PE tile is added after the loop, (b + sum_k) + r -- the reference's `x + linear(..)`
+    // order and the order of every fp32-split kernel, so a row's bits do not depend on the kernel that produced it.
     f32x16 acc[TM][TN];
     {
-        const bool has_bias = p.bias != nullptr;
-        const bool has_ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
-        f32x4 bv[TN][4], ev[TM][TN][4];
-        int colc[TN][4];
+        f32x4 bv[TN][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                colc[j][qd] = min(n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh, p.N - 4);
-                bv[j][qd] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int colc = min(n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh, p.N - 4);
+                bv[j][qd] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        if (has_bias) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) bv[j][qd] = *reinterpret_cast<const f32x4*>(p.bias + colc[j][qd]);
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) ev[i][j][qd] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (has_ext) {
+                for (int qd = 0; qd < 4; ++qd)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int rowc = min(m0 + wm * (32 * TM) + i * 32 + l31, p.M - 1);
-                const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (rowc + p.row0) % p.period : rowc;
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) ev[i][j][qd] = *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + colc[j][qd]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const f32x4 v = bv[j][qd] + ev[i][j][qd];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = v[c];
-                }
+                    for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = bv[j][qd][c];
     }
 
     const int nkt = p.K / BK;
-    stage(0);
-
     const int sw = (l31 >> 2) & 3;
     const int a_row = (wm * (32 * TM) + l31) * 16;
     const int b_row = (wn * (32 * TN) + l31) * 16;
-
+    // Two LDS stages, software-pipelined inside the step (round 2; the loop used to run barrier -> 9 DMA issues -> fragment reads ->
+    // MFMAs in sequence, with both waves of a SIMD at the same point: ~20 % of every step with an idle matrix pipe):
+    //   * the fragments of k-block 1 are read behind the first MFMA of k-block 0, those of the NEXT stage's k-block 0 behind the 37th
+    //     MFMA of the step (two register sets): no MFMA waits on LDS;
+    //   * the step's wait + barrier sits before the last 12 MFMAs: by then every wave has read the whole current stage, so the stage
+    //     after next is requested right there, its 9 buffer-addressed DMA pieces placed one by one behind those MFMAs.
+    // The order of the MFMAs on an accumulator (k-block by k-block, six terms smallest first) is unchanged.
+    bf16x8 f0a[3][TM], f0b[3][TN], f1a[3][TM], f1b[3][TN];
+    auto rd = [&](int buf, int kb, bf16x8 (&af)[3][TM], bf16x8 (&bf)[3][TN]) {
+        const float* Ac = As + buf * C_::A_FLOATS + a_row;
+        const float* Bc = Bs + buf * C_::B_FLOATS + b_row;
+        const int cg = 4 * ((2 * kb + lh) ^ sw);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ac + pl * C_::A_PLANE + i * 32 * 16 + cg));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bc + pl * C_::B_PLANE + j * 32 * 16 + cg));
+        }
+    };
+    // six product terms, smallest first; each term walks all TM x TN accumulators so dependent MFMAs are TM*TN apart
+    auto mm = [&](auto t0c, auto t1c, const bf16x8 (&af)[3][TM], const bf16x8 (&bf)[3][TN]) {
+        constexpr int t0 = decltype(t0c)::value, t1 = decltype(t1c)::value;
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = t0; t < t1; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I3 = std::integral_constant<int, 3>; using I6 = std::integral_constant<int, 6>;
+    constexpr int NRD = 3 * (TM + TN), NT = TM * TN;          // fragment reads per k-block, MFMAs per term
+    constexpr int NPAIR = C_::NI < 3 * NT - 1 ? C_::NI : 3 * NT - 1;      // DMA pieces that get an MFMA of their own to hide behind
+    stage(0);
+    if (nkt > 1) { stage(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C_::NI) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rd(0, 0, f0a, f0b);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nkt && !(p.ablate & 1)) stage(cur ^ 1);
-        const float* Ac = As + (p.ablate & 1 ? 0 : cur) * C_::A_FLOATS + a_row;
-        const float* Bc = Bs + (p.ablate & 1 ? 0 : cur) * C_::B_FLOATS + b_row;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int cg = 4 * ((2 * kb + lh) ^ sw);
-            bf16x8 af[3][TM], bf[3][TN];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ac + pl * C_::A_PLANE + i * 32 * 16 + cg));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bf[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bc + pl * C_::B_PLANE + j * 32 * 16 + cg));
-            }
-            // six product terms, smallest first; each pass walks all TM x TN accumulators so dependent MFMAs are TM*TN apart
-            constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);
+        rd(cur, 1, f1a, f1b);
+        mm(I0{}, I6{}, f0a, f0b);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT - 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(I0{}, I3{}, f1a, f1b);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nkt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // stage kt+1 landed (stage kt+2 is requested below)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // every wave has read all of stage kt
+            __builtin_amdgcn_sched_barrier(0);
+            rd(cur ^ 1, 0, f0a, f0b);
+            if (kt + 2 < nkt) stage(cur);
         }
+        mm(I3{}, I6{}, f1a, f1b);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 1);
+#pragma unroll
+        for (int u = 0; u < NPAIR; ++u) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1); }
+        __builtin_amdgcn_sched_group_barrier(0x010, C_::NI - NPAIR, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
 
+    if (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = m0 + wm * (32 * TM) + i * 32 + l31;
-        if (row >= p.M) continue;
+        for (int i = 0; i < TM; ++i) {
+            const int rowc = min(m0 + wm * (32 * TM) + i * 32 + l31, p.M - 1);
+            const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (rowc + p.row0) % p.period : rowc;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
-                if (col >= p.N) continue;
-                f32x4 v;
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int colc = min(n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh, p.N - 4);
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + colc);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float t = acc[i][j][4 * qd + c];
-                    if (p.epilogue == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
-                    else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
-                    v[c] = t;
+                    for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] += rv[c];
                 }
-                const bool second = p.P2 && col < p.p2_cols;
-                if (p.out_split || second) {
-                    bf16x4 o1, o2, o3;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        o1[c] = (__bf16)v[c];
-                        const float r1 = v[c] - (float)o1[c];
-                        o2[c] = (__bf16)r1;
-                        o3[c] = (__bf16)(r1 - (float)o2[c]);
-                    }
-                    if (p.out_split) {
-                        __bf16* cp = static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col;
-                        *reinterpret_cast<bf16x4*>(cp) = o1;
-                        *reinterpret_cast<bf16x4*>(cp + p.pc) = o2;
-                        *reinterpret_cast<bf16x4*>(cp + 2 * p.pc) = o3;
-                    }
-                    if (second) {
-                        __bf16* cp = p.P2 + (size_t)(row + p.row0) * p.ld2 + col;
-                        *reinterpret_cast<bf16x4*>(cp) = o1;
-                        *reinterpret_cast<bf16x4*>(cp + p.p2_plane) = o2;
-                        *reinterpret_cast<bf16x4*>(cp + 2 * p.p2_plane) = o3;
-                    }
-                }
-                if (!p.out_split) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
-            }
+        }
     }
+    split_finish<TM, TN, BM>(p, acc, m0, n0, wm, wn, l31, lh);
+#endif
 }
 
 template <int TM_, int TN_>
@@ -265,282 +323,6 @@ int set_attr() {
     return MMDM_OK;
 }
 
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// Deep-pipelined variant: K step 16 (32-byte LDS rows), NS-stage ring, counted vmcnt.
-//
-// Why: at the bf16 MFMA rate a 256x128 tile consumes 72 KB of operand planes per 0.64 us, and ~17 % of those lines miss the
-// 4 MiB XCD L2 (panels of K = 1024 are MBs) and come from the Infinity Cache 1-2 us later: with one stage of prefetch the K step
-// lasts as long as the slowest miss (measured 6.4 TB/s of L2->LDS traffic, 37 % of the split roof).  This kernel keeps NS-1
-// stages in flight (`s_waitcnt vmcnt(loads of the newer stages)`, never 0 inside the loop) and moves fewer bytes per flop
-// (256x256 tile: 48 KB per stage of 16 K-elements).  32-byte rows make the LDS image of a 32-row fragment 1 KiB contiguous: the
-// DMA piece and the ds_read_b128 fragment read are conflict-free without a swizzle.
-template <int TM_, int TN_, int NS_>
-struct PCfg {
-    static constexpr int WGM = TM_ / 10, WGN = TN_ / 10, TM = TM_ % 10, TN = TN_ % 10, NS = NS_;
-    static constexpr int NWAVES = WGM * WGN, THREADS = 64 * NWAVES;
-    static constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 16;
-    static constexpr int A_PLANE = BM * 8, B_PLANE = BN * 8;                      // 4-byte units (32 B per row)
-    static constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
-    static constexpr int SMEM_BYTES = NS * STAGE * 4;
-    static constexpr int NAP = BM / 32, NBP = BN / 32;                            // 1-KiB pieces (32 rows x 32 B) per plane
-    static constexpr int NA = 3 * NAP, NB = 3 * NBP;
-    // DMA instructions per wave per stage; when the pieces do not divide evenly the surplus slots re-load the first pieces
-    // (same source, same destination: harmless) so that every wave counts the same number of loads per stage
-    static constexpr int NI = (NA + NB + NWAVES - 1) / NWAVES;
-    static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
-};
-
-// LDS-DMA issued from inline asm: hipcc (ROCm 7.2) otherwise treats every pending LDS-DMA as a possible writer of whatever a later
-// ds_read reads and drains the whole queue (s_waitcnt vmcnt(0)) before the first fragment is used -- which is exactly the overlap a
-// multi-stage ring exists for.  The queue is counted by hand instead (wait_vmcnt below).  LDS address = m0 + lane * 16.
-__device__ __forceinline__ void glds16(const void* gsrc, const float* lds_dst) {
-    const unsigned lds = (unsigned)(size_t)(lptr_t)lds_dst;
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds));      // no "memory" clobber: see above
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <class C_>
-__device__ __forceinline__ void pipe_step(float* __restrict__ wr, const float* __restrict__ rd, bool do_stage, const char* (&src)[C_::NI], const int (&dst)[C_::NI],
-                                          f32x16 (&acc)[C_::TM][C_::TN], int a_row, int b_row, bool do_read, bf16x8 (&af)[3][C_::TM], bf16x8 (&bf)[3][C_::TN]) {
-    constexpr int TM = C_::TM, TN = C_::TN, NI = C_::NI;
-    if (do_read) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(rd + b_row + pl * C_::B_PLANE + j * 32 * 8));
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(rd + a_row + pl * C_::A_PLANE + i * 32 * 8));
-        }
-    }
-    // The stage's DMA instructions are issued ONE PER GROUP OF MFMAs, not in a burst behind the barrier: an LDS-DMA issue holds the wave's
-    // instruction stream for ~20 cycles (per-lane addresses), and with both waves of a SIMD at the same program point a burst of NI of
-    // them leaves the MFMA pipe empty; between MFMAs the issue hides under the 32-cycle MFMA in flight.  sched_barrier pins the order.
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-    constexpr int PER = (NI + 5) / 6;
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);
-        if (do_stage) {
-#pragma unroll
-            for (int u = t * PER; u < (t + 1) * PER && u < NI; ++u) {
-                glds16(src[u], wr + dst[u]);
-                src[u] += 2 * C_::BK;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int TM_, int TN_, int NS_>
-__global__ __launch_bounds__((PCfg<TM_, TN_, NS_>::THREADS)) void gemm_split_pipe_kernel(SArgs p) {
-    using C_ = PCfg<TM_, TN_, NS_>;
-    constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN, NS = C_::NS, NI = C_::NI;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][A planes 3*BM*8 | B planes 3*BN*8]
-
-    const int nwg = p.mt * p.nt;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    // tiles that run together on an XCD form GM x nt groups walked n-fastest: a W panel is shared by GM concurrent tiles
-    constexpr int GM = 4;
-    const int grp = swz / (GM * p.nt), in = swz % (GM * p.nt);
-    const int gm = min(GM, p.mt - grp * GM);
-    const int m0 = (grp * GM + in % gm) * BM;
-    const int n0 = (in / gm) * BN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / C_::WGN, wn = wave % C_::WGN;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    const char* src[NI];
-    int dst[NI];
-#pragma unroll
-    for (int u = 0; u < NI; ++u) {
-        int pq = wave + C_::NWAVES * u;
-        if (pq >= C_::NA + C_::NB) pq -= C_::NA + C_::NB;
-        const int prow = lane >> 1, pc = lane & 1;
-        const bool isa = pq < C_::NA;
-        const int pl = isa ? pq / C_::NAP : (pq - C_::NA) / C_::NBP;
-        const int pp = isa ? pq % C_::NAP : (pq - C_::NA) % C_::NBP;
-        const int trow = 32 * pp + prow;
-        if (isa) {
-            int grow = m0 + trow;
-            grow = grow < p.M ? grow : p.M - 1;
-            src[u] = reinterpret_cast<const char*>(p.A + (size_t)pl * p.pa + (size_t)grow * p.lda) + 16 * pc;
-            dst[u] = pl * C_::A_PLANE + 32 * pp * 8;
-        } else {
-            int grow = n0 + trow;
-            grow = grow < p.N ? grow : p.N - 1;
-            src[u] = reinterpret_cast<const char*>(p.W + (size_t)pl * p.pw + (size_t)grow * p.ldw) + 16 * pc;
-            dst[u] = 3 * C_::A_PLANE + pl * C_::B_PLANE + 32 * pp * 8;
-        }
-    }
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            glds16(src[u], smem + buf * C_::STAGE + dst[u]);
-            src[u] += 2 * BK;
-        }
-    };
-
-    // Accumulators start as bias (+ residual / + PE row).  All loads are issued back to back behind WAVE-UNIFORM branches and waited for
-    // once: with per-element runtime conditions hipcc branches around every load and waits vmcnt(0) after each one -- 16-32 serialized
-    // L2 round trips per tile, fully exposed at one workgroup per CU.  Rows / columns past the edge read a clamped (valid) address: their
-    // accumulators are never stored.
-    f32x16 acc[TM][TN];
-    {
-        const bool has_bias = p.bias != nullptr;
-        const bool has_ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
-        f32x4 bv[TN][4], ev[TM][TN][4];
-        int colc[TN][4];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                colc[j][qd] = min(n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh, p.N - 4);
-                bv[j][qd] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        if (has_bias) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) bv[j][qd] = *reinterpret_cast<const f32x4*>(p.bias + colc[j][qd]);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) ev[i][j][qd] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (has_ext) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int rowc = min(m0 + wm * (32 * TM) + i * 32 + l31, p.M - 1);
-                const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (rowc + p.row0) % p.period : rowc;
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) ev[i][j][qd] = *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + colc[j][qd]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const f32x4 v = bv[j][qd] + ev[i][j][qd];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = v[c];
-                }
-    }
-
-    const int nkt = p.K / BK;
-    // The bias / residual loads that initialise the accumulators must be retired HERE: left pending, the compiler waits for them at
-    // their first use -- the first MFMA of the loop body -- with an s_waitcnt vmcnt(0) that also drains the DMA ring every iteration.
-    // An opaque asm that touches each accumulator makes that wait land before the loop.
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // prologue: NS-1 stages in flight
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nkt) stage(s);
-
-    const int a_row = (wm * (32 * TM) + l31) * 8 + 4 * lh;
-    const int b_row = 3 * C_::A_PLANE + (wn * (32 * TN) + l31) * 8 + 4 * lh;
-
-    bf16x8 af[3][TM], bf[3][TN];
-    int buf = 0, nbuf = NS - 1;
-    for (int kt = 0; kt < nkt; ++kt) {
-        // stage kt has landed when at most the loads of the (NS-2) newer stages are still in flight
-        if (kt + NS - 1 <= nkt) wait_vmcnt<(NS - 2) * NI>();
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tail: fewer stages behind it
-        __builtin_amdgcn_s_barrier();
-        // DMA destination and fragment source are different ring slots: passed as __restrict__ arguments of one inlined function so
-        // that the compiler's LDS-DMA tracking (alias scopes) does not drain the DMA queue (vmcnt(0)) before the fragment reads are used
-        pipe_step<C_>(smem + nbuf * C_::STAGE, smem + buf * C_::STAGE, kt + NS - 1 < nkt && !(p.ablate & 1), src, dst, acc, a_row, b_row,
-                      !(p.ablate & 2) || kt == 0, af, bf);
-        buf = buf + 1 == NS ? 0 : buf + 1;
-        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
-
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = m0 + wm * (32 * TM) + i * 32 + l31;
-        if (row >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
-                if (col >= p.N) continue;
-                f32x4 v;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float t = acc[i][j][4 * qd + c];
-                    if (p.epilogue == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
-                    else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
-                    v[c] = t;
-                }
-                const bool second = p.P2 && col < p.p2_cols;
-                if (p.out_split || second) {
-                    bf16x4 o1, o2, o3;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        o1[c] = (__bf16)v[c];
-                        const float r1 = v[c] - (float)o1[c];
-                        o2[c] = (__bf16)r1;
-                        o3[c] = (__bf16)(r1 - (float)o2[c]);
-                    }
-                    if (p.out_split) {
-                        __bf16* cp = static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col;
-                        *reinterpret_cast<bf16x4*>(cp) = o1;
-                        *reinterpret_cast<bf16x4*>(cp + p.pc) = o2;
-                        *reinterpret_cast<bf16x4*>(cp + 2 * p.pc) = o3;
-                    }
-                    if (second) {
-                        __bf16* cp = p.P2 + (size_t)(row + p.row0) * p.ld2 + col;
-                        *reinterpret_cast<bf16x4*>(cp) = o1;
-                        *reinterpret_cast<bf16x4*>(cp + p.p2_plane) = o2;
-                        *reinterpret_cast<bf16x4*>(cp + 2 * p.p2_plane) = o3;
-                    }
-                }
-                if (!p.out_split) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
-            }
-    }
-}
-
-template <int TM_, int TN_, int NS_>
-int launch_pipe(SArgs a, hipStream_t st) {
-    using C_ = PCfg<TM_, TN_, NS_>;
-    a.mt = (a.M + C_::BM - 1) / C_::BM;
-    a.nt = (a.N + C_::BN - 1) / C_::BN;
-    mmdm_note_gemm("gemm_split_pipe<%d,%d,%d>", TM_, TN_, NS_);
-    hipLaunchKernelGGL((gemm_split_pipe_kernel<TM_, TN_, NS_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
-    return mmdm_check_launch("gemm_split_pipe");
-}
-
-template <int TM_, int TN_, int NS_>
-int set_attr_pipe() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_pipe_kernel<TM_, TN_, NS_>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, PCfg<TM_, TN_, NS_>::SMEM_BYTES);
-    if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_split_pipe): %s", hipGetErrorString(e));
-    return MMDM_OK;
-}
 
 // x -> three bf16 planes out[0], out[plane], out[2*plane]; exact: x == out0 + out1 + out2 in real arithmetic
 __global__ void split3_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n, size_t plane) {
@@ -566,10 +348,6 @@ int mmdm_gemm_split_init(void) {
     if ((rc = set_attr<42, 22>())) return rc;
     if ((rc = set_attr<22, 21>())) return rc;
     if ((rc = set_attr<24, 22>())) return rc;
-    if ((rc = set_attr_pipe<24, 42, 3>())) return rc;     // 256 x 256, 8 waves (2 x 4), 128 x 64 per wave
-    if ((rc = set_attr_pipe<24, 22, 4>())) return rc;     // 256 x 128, 4 waves (2 x 2), 128 x 64 per wave
-    if ((rc = set_attr_pipe<22, 22, 6>())) return rc;     // 128 x 128, 4 waves
-    if ((rc = set_attr_pipe<42, 22, 4>())) return rc;     // 256 x 128, 8 waves (4 x 2), 64 x 64 per wave
     const char* e = getenv("MMDM_SPLIT_CFG");
     g_split_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
@@ -607,6 +385,8 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
         return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split: needs K %% 32 == 0 and 16-byte aligned bf16 rows / planes");
     if ((N & 3) || (ldc & 3) || (c_plane & 3) || !al16(C) || (bias && !al16(bias)) || (ext && ((ld_extra & 3) || !al16(extra))))
         return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split: needs N %% 4 == 0 and 16-byte aligned output / bias / residual rows");
+    if ((uint64_t)a_plane * 4 + 512ull * (uint64_t)lda >= (1ull << 32) || (uint64_t)w_plane * 4 + 512ull * (uint64_t)ldw >= (1ull << 32))
+        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split: operand planes beyond the 4 GB reach of a tile's buffer offsets");
     SArgs a;
     a.A = static_cast<const __bf16*>(A); a.W = static_cast<const __bf16*>(W); a.bias = bias; a.C = C; a.extra = extra;
     a.pa = (size_t)a_plane; a.pw = (size_t)w_plane; a.pc = (size_t)c_plane;
@@ -622,10 +402,6 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
         case 1: return launch<42, 22>(a, st);
         case 2: return launch<22, 21>(a, st);
         case 4: return launch<24, 22>(a, st);
-        case 10: return launch_pipe<24, 42, 3>(a, st);
-        case 11: return launch_pipe<24, 22, 4>(a, st);
-        case 12: return launch_pipe<22, 22, 6>(a, st);
-        case 13: return launch_pipe<42, 22, 4>(a, st);
         default: break;
     }
     // measured on M = 19 200 (tools/gemm_split_bench.py): 128x64 tiles for the N = 512 mixer GEMMs (more tiles than CUs), 256x128 otherwise

@@ -19,6 +19,17 @@ int mmdm_gemm_init(void);
 int mmdm_gemm_bf16_init(void);
 int mmdm_gemm_split_init(void);
 
+// Activations of the GEMM epilogues, one definition for every kernel.  Each is a FIXED sequence of operations (explicit fma, no
+// expression the compiler may or may not contract), so two instantiations of an epilogue -- fp32 rows vs bf16 planes, one tile shape vs
+// another -- produce the same bits for the same accumulator value.
+__device__ __forceinline__ float gelu_erf(float x) {            // F.gelu (erf form): 0.5 x (1 + erf(x / sqrt 2))   src/models/utils/layers.py:104
+    const float h = 0.5f * x;
+    return __builtin_fmaf(h, erff(x * 0.70710678118654752440f), h);
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x * (1.0f / (1.0f + expf(-1.702f * x))); }   // CLIP QuickGELU: x * sigmoid(1.702 x)
+
 constexpr int MMDM_NF = 262;      // pose features per person (src/models/in2in.py:426, INPUT_DIM)
 constexpr int MMDM_NJ = 22;       // joints
 

