@@ -52,7 +52,8 @@ __device__ __forceinline__ void load_v_row(const float* __restrict__ vrow_base, 
 }
 
 
-constexpr int KC = 16;   // keys per LDS stage
+constexpr int KC = 16;   // keys per LDS stage (attn_qkp_kernel)
+constexpr int KCF = 16;  // keys per LDS stage of attn_mfma_kernel (32 measured: dh = 128 271 us vs 258, dh = 64 129 vs 131 -- 300 keys pad to 320 and occupancy halves)
 constexpr int NST = 2;   // LDS stages of attn_mfma_kernel: chunk ci + NST - 1 is requested while chunk ci is consumed (counted vmcnt, raw barrier)
 constexpr int QW = 16;   // queries per wave
 constexpr int QB = 64;   // queries per workgroup
@@ -117,6 +118,8 @@ __device__ __forceinline__ void store_o_row(const P& p, const f32x4 (&o)[DH / 16
 //   V: 16-byte chunk c of key row r is stored at chunk (c ^ (4 * ((r >> 2) & 1)))  (conflict-free ds_read_b32 operand reads)
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
+    constexpr int KC = KCF;
     constexpr int NJ = DH / 16;                 // d groups of 16 (QK^T) == 16-wide output column tiles (PV)
     constexpr int NKT = KC / 16;                // 16-key tiles per stage
     constexpr int CPR = DH / 4;                 // 16-byte chunks per row
@@ -167,22 +170,31 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     const float* Kg = p.K + (size_t)kvseq * p.Tk * p.ldk + head * p.dh;
     const float* Vg = p.V + (size_t)kvseq * p.Tk * p.ldv + head * p.dh;
 
-    // DMA pieces of this wave: piece pq = wave + 4u; pq < NPIECE/2 -> K rows RPP*pq.., else V rows.  Rows past Tk are clamped
-    // (their scores are masked to -inf below, so the values never matter).
+    // DMA pieces of this wave: piece pq = wave + 4u; pq < NPIECE/2 -> K rows RPP*pq.., else V rows.  Buffer-addressed (gemm_f32.hip has
+    // the measurement): one resource per operand over this (sequence, head)'s rows, a per-lane byte offset that is fixed for the whole
+    // launch (row inside the chunk, swizzled 16-byte column) and ONE scalar offset per chunk -- the 64-bit per-lane address arithmetic
+    // that used to precede every piece is gone from the loop.  Rows past Tk fall outside the resource and arrive as zeros (their
+    // scores are masked to -inf below, so the values never matter).
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Kg), 0, (unsigned)(((size_t)(p.Tk - 1) * p.ldk + p.dh) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vg), 0, (unsigned)(((size_t)(p.Tk - 1) * p.ldv + p.dh) * 4), 0x00020000);
+    int voff[NI], dsto[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int pq = wave + 4 * u;
+        const bool isk = pq < NPIECE / 2;
+        const int trow = RPP * (isk ? pq : pq - NPIECE / 2) + lane / CPR;
+        const int pos = lane % CPR;
+        int src_chunk = isk ? (pos ^ (trow & 15)) : pos;                       // V rows are stored unswizzled (load_v_row)
+        if (4 * src_chunk >= p.dh) src_chunk = 0;                              // padded head: any valid address (Q is 0 there / column not stored)
+        voff[u] = (trow * (isk ? p.ldk : p.ldv) + 4 * src_chunk) * 4;
+        dsto[u] = (isk ? 0 : KC * DH) + RPP * (isk ? pq : pq - NPIECE / 2) * DH;
+    }
+    static_assert(NPIECE / 2 % 4 == 0, "K and V pieces split evenly over the four waves: piece u is a K piece for every wave or for none");
     auto stage = [&](int c0, int buf) {
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
-            const int pq = wave + 4 * u;
-            const bool isk = pq < NPIECE / 2;
-            const int trow = RPP * (isk ? pq : pq - NPIECE / 2) + lane / CPR;
-            const int pos = lane % CPR;
-            int src_chunk = isk ? (pos ^ (trow & 15)) : pos;                       // V rows are stored unswizzled (load_v_row)
-            if (4 * src_chunk >= p.dh) src_chunk = 0;                              // padded head: any valid address (Q is 0 there / column not stored)
-            int krow = c0 + trow;
-            krow = krow < p.Tk ? krow : p.Tk - 1;
-            const float* src = (isk ? Kg + (size_t)krow * p.ldk : Vg + (size_t)krow * p.ldv) + 4 * src_chunk;
-            float* dst = smem + buf * STAGE + (isk ? 0 : KC * DH) + RPP * (isk ? pq : pq - NPIECE / 2) * DH;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            const bool isk = u < NPIECE / 8;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isk ? rsK : rsV, (lptr_t)(smem + buf * STAGE + dsto[u]), 16, voff[u], c0 * (isk ? p.ldk : p.ldv) * 4, 0, 0);
         }
     };
 
@@ -304,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         if (qrow >= p.Tq) continue;
         store_o_row<DH>(p, o, r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * p.dh, lq);
     }
+#endif
 }
 
 
@@ -606,7 +619,7 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(AttnArgs p, int dh) {
 }
 
 template <int DH>
-constexpr int attn_smem() { return NST * 2 * KC * DH * 4; }
+constexpr int attn_smem() { return NST * 2 * KCF * DH * 4; }
 
 template <int DH>
 int launch_mfma(const AttnArgs& a, hipStream_t st) {

@@ -15,6 +15,7 @@
 // scale (mmdm_prepare).  Half the operand bytes of the bf16 form per multiply-add; the non-scaled fp8 MFMA issues at the bf16 rate.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace {
@@ -60,7 +61,9 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
 }
 
 template <int TM_, int TN_, int ET = 0>
-__global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BArgs p) {
+// two 8-wave workgroups per CU = four waves per SIMD (<= 128 registers per wave; the second __launch_bounds__ argument is waves per SIMD): the 256 x 128 tile's 48 KB of LDS allow three, its 64 accumulators two
+__global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS), (BCfg<TM_, TN_>::THREADS == 512 ? 4 : 1)) void gemm_bf16_kernel(BArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
     using C_ = BCfg<TM_, TN_>;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -80,35 +83,37 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BA
     const int wm = wave / C_::WGN, wn = wave % C_::WGN;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const char* src[C_::NI];
-    int dst[C_::NI];
-    bool isa[C_::NI];
+    // LDS-DMA pieces, buffer-addressed (gemm_f32.hip has the measurement): a resource per operand based at the tile's first row, a
+    // per-lane byte offset fixed for the tile, one scalar offset that walks K.
+    constexpr int UA = C_::NA / C_::NWAVES;            // pieces u < UA are A pieces for every wave
+    static_assert(C_::NA % C_::NWAVES == 0, "A pieces must divide evenly over the waves");
+    constexpr int EB = ET == 1 ? 1 : 2;                // bytes per operand element
+    int voff[C_::NI], dst[C_::NI];
 #pragma unroll
     for (int u = 0; u < C_::NI; ++u) {
         const int pq = wave + C_::NWAVES * u;
         const int prow = lane >> 2, pc = lane & 3;
-        isa[u] = pq < C_::NA;
-        const int trow = 16 * (isa[u] ? pq : pq - C_::NA) + prow;
+        const bool isa = u < UA;
+        const int trow = 16 * (isa ? pq : pq - C_::NA) + prow;
         const int gch = pc ^ ((trow >> 2) & 3);
-        if (isa[u]) {
-            int grow = m0 + trow;
-            grow = grow < p.M ? grow : p.M - 1;
-            src[u] = reinterpret_cast<const char*>(p.A) + (size_t)grow * p.lda * (ET == 1 ? 1 : 2) + 16 * gch;
+        if (isa) {
+            voff[u] = min(trow, p.M - 1 - m0) * p.lda * EB + 16 * gch;
             dst[u] = 16 * pq * 16;
         } else {
-            int grow = n0 + trow;
-            grow = grow < p.N ? grow : p.N - 1;
-            src[u] = reinterpret_cast<const char*>(p.W) + (size_t)grow * p.ldw * (ET == 1 ? 1 : 2) + 16 * gch;
+            voff[u] = min(trow, p.N - 1 - n0) * p.ldw * EB + 16 * gch;
             dst[u] = 2 * C_::A_FLOATS + 16 * (pq - C_::NA) * 16;
         }
     }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) + (size_t)m0 * p.lda * EB, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.W)) + (size_t)n0 * p.ldw * EB, 0, 0xffffffff, 0x00020000);
+    int koff = 0;
     auto stage = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < C_::NI; ++u) {
-            const int boff = isa[u] ? buf * C_::A_FLOATS : buf * C_::B_FLOATS;
-            __builtin_amdgcn_global_load_lds((gptr_t)src[u], (lptr_t)(smem + dst[u] + boff), 16, 0, 0);
-            src[u] += 64;
+            const int boff = u < UA ? buf * C_::A_FLOATS : buf * C_::B_FLOATS;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(u < UA ? rsA : rsW, (lptr_t)(smem + dst[u] + boff), 16, voff[u], koff, 0, 0);
         }
+        koff += 64;
     };
 
     // Accumulators start as bias (+ residual / + PE row).  All loads are issued back to back behind WAVE-UNIFORM branches and waited for
@@ -216,45 +221,67 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS)) void gemm_bf16_kernel(BA
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
 
+    // Activation, output form (fp32 / bf16 / fp8) and the optional bf16 copy are chosen ONCE per tile, outside the element loops (see
+    // gemm_f32.hip: with the runtime tests inside them the epilogue was tens of KB of branchy code).
+    auto finish = [&](auto act_c, auto out_c, auto sec_c) {
+        constexpr int ACT = decltype(act_c)::value, OUT = decltype(out_c)::value;
+        constexpr bool SEC = decltype(sec_c)::value;
+        const bool ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = m0 + wm * (32 * TM) + i * 32 + l31;
-        if (row >= p.M) continue;
-        float sa = 1.f;
-        if constexpr (ET == 1) sa = p.a_scale ? p.a_scale[row] : p.a_const;
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * (32 * TM) + i * 32 + l31;
+            if (row >= p.M) continue;
+            float sa = 1.f;
+            if constexpr (ET == 1) sa = p.a_scale ? p.a_scale[row] : p.a_const;
+            const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
-                if (col >= p.N) continue;
-                f32x4 v, add = {0.f, 0.f, 0.f, 0.f}, sw4 = {1.f, 1.f, 1.f, 1.f};
-                if constexpr (ET == 1) {            // de-quantise, then bias (+ residual / PE row) as the bf16 form's accumulator start does
-                    if (p.w_scale) sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + col);
-                    if (p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + col);
-                    if (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) {
-                        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
-                        add += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
+                    if (col >= p.N) continue;
+                    f32x4 v, add = {0.f, 0.f, 0.f, 0.f}, sw4 = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (ET == 1) {            // de-quantise, then bias (+ residual / PE row) as the bf16 form's accumulator start does
+                        if (p.w_scale) sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + col);
+                        if (p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + col);
+                        if (ext) add += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
                     }
-                }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float t = acc[i][j][4 * qd + c];
-                    if constexpr (ET == 1) t = t * (sa * sw4[c]) + add[c];
-                    if (p.epilogue == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
-                    else if (p.epilogue == MMDM_EPI_BIAS_SILU) t = silu(t);
-                    v[c] = t;
+                    for (int c = 0; c < 4; ++c) {
+                        float t = acc[i][j][4 * qd + c];
+                        if constexpr (ET == 1) t = t * (sa * sw4[c]) + add[c];
+                        if constexpr (ACT == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
+                        else if constexpr (ACT == MMDM_EPI_BIAS_SILU) t = silu(t);
+                        v[c] = t;
+                    }
+                    if constexpr (OUT == 1 || SEC) {
+                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        if constexpr (OUT == 1) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col) = o;
+                        if constexpr (SEC) {
+                            if (col < p.p2_cols) *reinterpret_cast<bf16x4*>(p.P2 + (size_t)row * p.ld2 + col) = o;
+                        }
+                    }
+                    if constexpr (OUT == 2) *reinterpret_cast<unsigned*>(static_cast<unsigned char*>(p.C) + (size_t)row * p.ldc + col) = pack_fp8x4(v * p.out_scale);
+                    if constexpr (OUT == 0) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
                 }
-                const bool second = p.P2 && col < p.p2_cols;
-                if (p.out_bf16 == 1 || second) {
-                    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    if (p.out_bf16 == 1) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col) = o;
-                    if (second) *reinterpret_cast<bf16x4*>(p.P2 + (size_t)row * p.ld2 + col) = o;
-                }
-                if (p.out_bf16 == 2) *reinterpret_cast<unsigned*>(static_cast<unsigned char*>(p.C) + (size_t)row * p.ldc + col) = pack_fp8x4(v * p.out_scale);
-                if (!p.out_bf16) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
-            }
-    }
+        }
+    };
+    auto finish_out = [&](auto act_c) {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        if (p.P2) {
+            if (p.out_bf16 == 1) finish(act_c, I1{}, std::true_type{});
+            else if (p.out_bf16 == 2) finish(act_c, I2{}, std::true_type{});
+            else finish(act_c, I0{}, std::true_type{});
+        } else {
+            if (p.out_bf16 == 1) finish(act_c, I1{}, std::false_type{});
+            else if (p.out_bf16 == 2) finish(act_c, I2{}, std::false_type{});
+            else finish(act_c, I0{}, std::false_type{});
+        }
+    };
+    if (p.epilogue == MMDM_EPI_BIAS_GELU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_GELU>{});
+    else if (p.epilogue == MMDM_EPI_BIAS_SILU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_SILU>{});
+    else finish_out(std::integral_constant<int, MMDM_EPI_BIAS>{});
+#endif
 }
 
 template <int TM_, int TN_, int ET = 0>
