@@ -28,7 +28,6 @@ struct GemmArgs {
     int M, N, K, Kw, epilogue, period;   // Kw >= K: readable columns of W (zero beyond K)
     int mt, nt;
     int ablate;                          // timing experiments only (tools/gemm_bench.py); 0 in production
-    int stagger, stagger_slots;          // first-round workgroups of CU slot s = 1 .. stagger_slots wait s * stagger ticks (100 MHz) before they start; 0 = off
     unsigned long long* stamps;          // diagnostic builds of a launch only (tools/gemm_timeline.py): per-workgroup {start, loop start, loop end, placement, kernel end, kernel entry, -, -}
                                          // in 100 MHz s_memrealtime ticks; nullptr in production (one never-taken scalar branch per workgroup)
 };
@@ -542,10 +541,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
     if (p.stamps && tid == 0) p.stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
-    // The epilogue (accumulator reads, activation, stores) runs beside a co-resident workgroup that is inside its K loop and keeps
-    // the SIMD's issue port busy with MFMAs; at equal priority the epilogue wave only gets the leftovers (measured with the launch
-    // staggered: 27-35 us for 16 stores per lane; tools/gemm_timeline.py).  It is ~300 instructions: let it go first.
-    if (p.ablate & 64) __builtin_amdgcn_s_setprio(3);
     if (p.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) p.stamps[8 * (size_t)bid + 6] = __builtin_amdgcn_s_memrealtime();
@@ -630,20 +625,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void 
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    // Stagger.  On an idle chip the dispatcher puts workgroups b, b + 256, b + 512 .. on the same CU at the same instant, and equal
-    // tiles then stay in lock-step for the whole launch: every co-resident workgroup is in its prologue (an HBM burst of the whole
-    // chip), and later in its epilogue, at the same time, with the matrix pipe idle (tools/gemm_timeline.py: two co-resident
-    // 128x128x1024 tiles took 133-139 us against 109 at the MFMA peak, the next pair started 4 us later).  Holding the first-round
-    // workgroup of CU slot s back by s/occupancy of a tile's duration puts the co-resident tiles out of phase for the rest of the
-    // launch: one is always in its K loop.  The held-back slot costs nothing: a lone workgroup has the CU's matrix pipes to itself.
     const unsigned long long t_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
-    if (p.stagger > 0 && bid >= 256) {
-        const int slot = bid >> 8;
-        if (slot <= p.stagger_slots) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)slot * p.stagger;
-            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     if (p.stamps && threadIdx.x == 0) p.stamps[8 * (size_t)bid + 5] = t_entry;
     gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_>(p, smem, swz, bid);
     if (p.stamps) {
@@ -669,14 +651,6 @@ int launch_glds(GemmArgs a, hipStream_t st) {
     // measured (tools/gemm_bench.py): the 16-byte epilogue pays where the accumulators are initialised from memory (+10 % on
     // the K = 1024 residual GEMMs) and is neutral-to-slightly-negative for bias/GELU-only epilogues
     const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
-    a.stagger = a.stagger_slots = 0;
-    if ((a.ablate & 32) && PIPE_ == 1) {
-        // co-resident workgroups by LDS footprint (tools/lds_census.hip) and registers (<= 168: 3 waves per SIMD)
-        const int occ = C_::SMEM_BYTES > 48 * 1024 ? 2 : (C_::SMEM_BYTES > 32 * 1024 ? 3 : 4);
-        const double tile_us = 2.0 * C_::BM * C_::BN * a.K / (157.3e12 / 256 * 0.9) * 1e6;      // one tile alone on a CU
-        a.stagger = (int)(tile_us * 100.0 / occ);
-        a.stagger_slots = occ - 1;
-    }
     mmdm_note_gemm("%s<%d,%d,%d,%d,%s>", PIPE_ ? "gemm_pipe" : "gemm_glds", TM_, TN_, BK_, NBUF_, (ext && vepi_ok(a) && !(a.ablate & 16)) ? "vepi" : "scalar");
     if (ext && vepi_ok(a) && !(a.ablate & 16))
         hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);

@@ -22,9 +22,35 @@ int mmdm_gemm_split_init(void);
 // Activations of the GEMM epilogues, one definition for every kernel.  Each is a FIXED sequence of operations (explicit fma, no
 // expression the compiler may or may not contract), so two instantiations of an epilogue -- fp32 rows vs bf16 planes, one tile shape vs
 // another -- produce the same bits for the same accumulator value.
+// erf(a), branch-free, <= 1 ulp on each of its two ranges (minimax polynomials: N. Juffa's single-precision erff, published under the
+// BSD 2-clause licence): both ranges are evaluated and one is selected, so a wave never diverges -- the library erff branches on |a|,
+// and the 32-64 copies of it in a GEMM epilogue are what that epilogue spends its time in (tools/gemm_timeline.py: 39 us per 128 x 64
+// tile beside co-resident workgroups in their K loops, 8.6 us with the activation removed).
+__device__ __forceinline__ float erf_bf(float a) {
+    const float t = __builtin_fabsf(a), s = a * a;
+    // |a| > 0.927734375:  1 - exp(p(t))
+    float r = __builtin_fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = __builtin_fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = __builtin_fmaf(r, s, u);
+    r = __builtin_fmaf(r, t, -1.06777877e-1f);
+    r = __builtin_fmaf(r, t, -6.34846687e-1f);
+    r = __builtin_fmaf(r, t, -1.28717512e-1f);
+    r = __builtin_fmaf(r, t, -t);
+    r = 1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896340736f);
+    r = __builtin_copysignf(r, a);
+    // |a| <= 0.927734375:  a + a q(a^2)
+    float q = -5.96761703e-4f;
+    q = __builtin_fmaf(q, s, 4.99119423e-3f);
+    q = __builtin_fmaf(q, s, -2.67681349e-2f);
+    q = __builtin_fmaf(q, s, 1.12819925e-1f);
+    q = __builtin_fmaf(q, s, -3.76125336e-1f);
+    q = __builtin_fmaf(q, s, 1.28379166e-1f);
+    q = __builtin_fmaf(q, a, a);
+    return t > 0.927734375f ? r : q;
+}
 __device__ __forceinline__ float gelu_erf(float x) {            // F.gelu (erf form): 0.5 x (1 + erf(x / sqrt 2))   src/models/utils/layers.py:104
     const float h = 0.5f * x;
-    return __builtin_fmaf(h, erff(x * 0.70710678118654752440f), h);
+    return __builtin_fmaf(h, erf_bf(x * 0.70710678118654752440f), h);
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
