@@ -22,7 +22,7 @@ MIN_OUTLIERS = 4
 #     person to face +Z, so person 2 of a pair facing each other -- where these trajectories sit for many late steps -- is exactly that
 #     half turn.  kappa = sqrt(3e-4 / w) (10x margin on the figure above).
 # Persons with kappa > KAPPA_MASK are on the branch point: their position / velocity channels are compared for sanity only (finite,
-# |err| <= 1).  Rotation-6D and foot-contact channels are never affected and always meet the plain tolerance.
+# |err| within the motion's own extent).  Rotation-6D and foot-contact channels are never affected and always meet the plain tolerance.
 KAPPA_MASK = 25.0
 
 
@@ -67,6 +67,8 @@ def compare_step(out, refs, what, hist, tol=STEP_TOL):
         assert frac <= tol["frac"], f"{what} {nm}: {frac:.2e} of the elements outside tolerance, max err {d[keep].max().item():.2e} {note}"
         if keep.any():
             assert (d[keep] / scale[keep]).max().item() <= tol["hard"], f"{what} {nm}: max err {d[keep].max().item():.2e} {note}"
-        assert d.max().item() <= 1.0, f"{what} {nm}: an element on a branch point is off by {d.max().item():.2e}"
+        # masked persons sit on the rotation's branch point: any rounding turns them by an arbitrary angle about the pivot, so their
+        # position / velocity channels can only be checked for sanity -- finite, and inside the motion's own extent
+        assert d.max().item() <= 2.0 * ref.abs().max().item() + 1.0, f"{what} {nm}: an element on a branch point is off by {d.max().item():.2e}"
         worst = max(worst, frac)
     return worst, masked
