@@ -64,6 +64,7 @@ struct AttnArgs {
     int nseq, Tq, Tk, H, shift, qtiles, pairs_per_xcd;
     float scale, scale2;
     int out_bf16;      // 1: O written as bf16 (feeds the bf16 out-projection GEMM); 2: as three bf16 planes (exact split, plane stride nseq*Tq*ldo)
+    int ablate;        // timing experiments only (tools/attn_bench.py, mmdmx_set_attn_ablate); 0 in production
     int flags;         // MMDM_ATTN_NO_ZERO_KEY: plain softmax (nn.MultiheadAttention default); MMDM_ATTN_CAUSAL: key <= query only
     int dh;            // real head width (<= the kernel's DH, multiple of 4): heads narrower than the template (the 96-wide heads of the
                        // 768 / 8 clipTransEncoder text heads on the DH = 128 kernel) are zero-padded in registers -- Q columns >= dh are
@@ -74,6 +75,8 @@ struct AttnArgs {
     size_t q_plane, k_plane;
     int ldqp, ldkp;
 };
+
+int g_attn_ablate = 0;
 
 typedef __bf16 bf16x4a __attribute__((ext_vector_type(4)));
 
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (ci + NST - 1 < nchunks) stage(c0 + (NST - 1) * KC, stg);
+        if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();
+        if (ci + NST - 1 < nchunks && !(p.ablate & 1)) stage(c0 + (NST - 1) * KC, stg);
         const float* Ks = smem + cur * STAGE;
         const float* Vs = Ks + KC * DH;
 
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int cb = j & 1;
-            if (j + 1 < NJ) {
+            if (j + 1 < NJ && !(p.ablate & 8)) {
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
                     kf[cb ^ 1][kt] = *reinterpret_cast<const f32x4*>(&Ks[(16 * kt + lq) * DH + 4 * ((4 * (j + 1) + g) ^ lq)]);
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
                 for (int r = 0; r < 4; ++r)
                     if (c0 + 16 * kt + 4 * g + r > kmax) st[kt][r] = -INFINITY;
         }
+        if (!(p.ablate & 4)) {
         float cmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
 #pragma unroll
         for (int kt = 1; kt < NKT; ++kt) cmax = fmaxf(cmax, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
@@ -276,14 +280,19 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         l_run = l_run * alpha + lsum;
         m_run = m_new;
 
-        // rescale O: accumulator rows are queries 4g + r, whose alpha lives in lanes with (lane&15) == 4g + r
-        float ar[4];
+        // rescale O: accumulator rows are queries 4g + r, whose alpha lives in lanes with (lane&15) == 4g + r.  Once the running maxima
+        // of a wave's 16 queries have stopped moving -- the usual case after the first chunks -- every alpha is exactly 1 and the 4
+        // cross-lane reads + 4*NJ multiplies are skipped (wave-uniform branch; x * 1.0f is exact, so the result is unchanged).
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+            float ar[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r);
+            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];       // (the PV MFMAs of the previous chunk retired long ago: barrier + QK^T in between)
+                for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];   // (the PV MFMAs of the previous chunk retired long ago: barrier + QK^T in between)
+        }
+        }
 
         // O[q][n] += sum_key P[q][key] V[key][n]:  A = P (lane-local: st[kt][r] is P[q=lq][key=16kt+4g+r]),
         // B = V[key = 16kt + 4g + r][this lane's NJ contiguous columns] (load_v_row)
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
         for (int idx = 0; idx < 4 * NKT; ++idx) {
             const int kt = idx >> 2, r = idx & 3, cb = idx & 1;
-            if (idx + 1 < 4 * NKT) {
+            if (idx + 1 < 4 * NKT && !(p.ablate & 16)) {
                 const int kt1 = (idx + 1) >> 2, r1 = (idx + 1) & 3;
                 load_v_row<DH>(&Vs[(16 * kt1 + 4 * g + r1) * DH], lq, vb[cb ^ 1]);
             }
@@ -674,7 +683,7 @@ extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int 
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_f32: row strides must cover H*dh=%d", H * dh);
     AttnArgs a;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
-    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags; a.dh = dh;
+    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate;
     a.Qp = a.Kp = nullptr; a.q_plane = a.k_plane = 0; a.ldqp = a.ldkp = 0;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
@@ -721,7 +730,7 @@ extern "C" int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, c
     AttnArgs a;
     a.Q = nullptr; a.K = nullptr; a.V = V; a.O = static_cast<float*>(Ov); a.ldq = 0; a.ldk = 0; a.ldv = ldv; a.ldo = ldo;
     a.Qp = static_cast<const __bf16*>(Qp); a.Kp = static_cast<const __bf16*>(Kp); a.q_plane = (size_t)q_plane; a.k_plane = (size_t)k_plane; a.ldqp = ldq; a.ldkp = ldk;
-    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags; a.dh = dh;
+    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
     a.pairs_per_xcd = (nseq * H + 7) / 8;
@@ -731,3 +740,5 @@ extern "C" int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, c
     if (nplanes == 3) return dh == 128 ? launch_qkp<128, 3>(a, st) : launch_qkp<64, 3>(a, st);
     return dh == 128 ? launch_qkp<128, 1>(a, st) : launch_qkp<64, 1>(a, st);
 }
+
+extern "C" void mmdmx_set_attn_ablate(int a) { g_attn_ablate = a; }

@@ -1,6 +1,9 @@
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, statistics
-from mixermdm_amd import ops
+from mixermdm_amd import ops, load_library
+import os
+ops.attention(torch.zeros(1,16,64,device="cuda:0"),torch.zeros(1,16,64,device="cuda:0"),torch.zeros(1,16,64,device="cuda:0"),1)
+load_library().mmdmx_set_attn_ablate(int(os.environ.get("ABL","0")))
 d = torch.device("cuda:0")
 for nseq,T,H,dh,name in [(64,300,8,128,"d.sa"),(64,300,8,64,"m.sa")]:
     D=H*dh
