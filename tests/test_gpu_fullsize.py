@@ -125,3 +125,30 @@ def test_full_size_fp32_split_mode_is_deterministic_batch_independent_and_tracks
         one, _ = run(s, cond[k:k + 1], xT[k:k + 1], STEPS)
         assert torch.equal(one["x"][0], a["x"][k]) and torch.equal(one["x2"][0], a["x2"][k]), k
     s.close()
+
+
+def test_configs3_shard_of_32_motions_equals_its_motions_sampled_alone():
+    """BASELINE configs[3] (B = 256 over 8 GPUs): the per-GPU shard of 32 motions, the batch `bench.py --gpus 8` runs -- M = 38 400 GEMM rows,
+    5120 attention workgroups.  Finite, deterministic under graph replay, and motions 0 / 17 / 31 of the shard are bit-identical to the same
+    motions sampled alone (so the 8-way split of the 256 requests cannot change a result), in fp32 and fp32_split."""
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_stats, synthetic_inputs, FULL_DIMS
+    sd = synthetic_state_dict(seed=0, std=0.02, bias_std=0.02, **FULL_DIMS)
+    st = synthetic_stats()
+    B3 = 32
+    cond, xT = synthetic_inputs(B3, T, seed_cond=61, seed_x=62)
+    for mode in ("fp32", "fp32_split"):
+        s = Sampler(d_heads=8, m_heads=8, max_batch=B3, max_frames=T, precision=mode, **FULL_DIMS)
+        s.load_state_dict(sd)
+        s.set_norm_stats(st["mean_hml"], st["std_hml"], st["mean_ih"], st["std_ih"])
+        s.prepare()
+        s.set_schedule("ddim1000")
+        a, _ = run(s, cond, xT, 2, graph=True)
+        b, _ = run(s, cond, xT, 2, graph=True)
+        for k in ("x", "x2", "pred_xstart2"):
+            assert torch.isfinite(a[k]).all() and torch.equal(a[k], b[k]), (mode, k)
+        assert a["x"].shape == (B3, T, 524)
+        for k in (0, 17, 31):
+            one, _ = run(s, cond[k:k + 1], xT[k:k + 1], 2)
+            assert torch.equal(one["x"][0], a["x"][k]) and torch.equal(one["x2"][0], a["x2"][k]), (mode, k)
+        s.close()
