@@ -112,6 +112,63 @@ def test_linear_strided_slices_k262():
     assert torch.count_nonzero(out[:, :262]).item() == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(777, 520, 1024), (130, 136, 128), (1000, 3000, 512), (129, 68, 2048), (19, 1028, 96)])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "resid", "pe"])
+def test_linear_writes_only_its_window(M, N, K, epi):
+    """Ragged M and N on the pipelined kernels (rows past M are dropped by the buffer resource's range check, columns past N by a lane
+    mask): the result goes into an interior window of a sentinel-filled buffer (ldc > N, rows above and below), and nothing outside
+    the window may change -- in particular not the rows below it, which a store clipped only by its vector offset would reach."""
+    from mixermdm_amd import ops
+    from mixermdm_amd._lib import load_library
+    d = dev()
+    x, w, b = rnd(31, M, K), rnd(32, N, K, scale=1 / math.sqrt(K)), rnd(33, N)
+    y = F.linear(x.double(), w.double(), b.double())
+    extra = None
+    if epi == "gelu":
+        y = F.gelu(y)
+    elif epi == "resid":
+        extra = rnd(34, M, N)
+        y = y + extra.double()
+    elif epi == "pe":
+        extra = rnd(35, 40, N)
+        y = y + extra.double()[torch.arange(M) % 40]
+    PADR, PADC = 70, 12                                   # 12 floats keep the window's rows 16-byte aligned (the 16-byte epilogue stays eligible)
+    buf = torch.full((M + 2 * PADR, N + 2 * PADC), 7.25, device=d)
+    win = buf[PADR:PADR + M, PADC:PADC + N]
+    ops.linear(x.to(d), w.to(d), b.to(d), epi, extra.to(d) if extra is not None else None, period=40 if epi == "pe" else 0, out=win)
+    kern = load_library().mmdm_last_gemm_kernel().decode()
+    assert kern.startswith("gemm_pipe<"), kern
+    assert_close(win, y.float(), atol=2e-5 * math.sqrt(max(1.0, K / 1024)), rtol=1e-5, what=f"{M}x{N}x{K} {epi} on {kern}")
+    chk = buf.clone()
+    chk[PADR:PADR + M, PADC:PADC + N] = 7.25
+    assert bool((chk == 7.25).all()), f"{kern}: wrote outside its {M}x{N} window"
+
+
+def test_linear_split_and_bf16_write_only_their_window():
+    """Same for the fp32-split kernel (buffer-store fp32 rows, hybrid 256x128 + 128x64 tiling) at a ragged M: rows past M untouched."""
+    from mixermdm_amd import ops
+    d = dev()
+    M, N, K = 19200 + 77, 1024, 512
+    x, w, b = rnd(36, M, K), rnd(37, N, K, scale=1 / math.sqrt(K)), rnd(38, N)
+    xs, ws = ops.split3(x.to(d)), ops.split3(w.to(d))
+    ref = F.linear(x[-300:].double(), w.double(), b.double()).float()
+    got = ops.linear_split(xs, ws, b.to(d))
+    assert got.shape == (M, N)
+    assert_close(got[-300:], ref, atol=2e-5, rtol=1e-5, what="linear_split tail rows")
+    # the allocation behind `got` ends with row M-1: a write past it would have faulted or hit the caching allocator's next block; check the
+    # block that follows in a fresh sentinel-filled arena instead
+    arena = torch.full((M + 256, N), 3.5, device=d)
+    import ctypes as C
+    from mixermdm_amd._lib import load_library
+    from mixermdm_amd.ops import EPI
+    lib = load_library()
+    rc = lib.mmdm_linear_split(C.c_void_p(xs.data_ptr()), K, M * K, C.c_void_p(ws.data_ptr()), K, N * K, C.c_void_p(b.to(d).data_ptr()),
+                               C.c_void_p(arena.data_ptr()), N, 0, 0, M, N, K, EPI["bias"], None, 0, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(arena[:M], got) and bool((arena[M:] == 3.5).all())
+
+
 def test_linear_empty_and_errors():
     from mixermdm_amd import ops, MMDMError
     d = dev()
