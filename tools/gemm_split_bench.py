@@ -29,6 +29,10 @@ nat = ops.linear(x, w, b)
 sc = ref.abs().mean()
 print(f"err/mean|ref|: split mean {(out.double()-ref).abs().mean()/sc:.3e} max {(out.double()-ref).abs().max()/sc:.3e} | native fp32 MFMA mean {(nat.double()-ref).abs().mean()/sc:.3e} max {(nat.double()-ref).abs().max()/sc:.3e}")
 cfgs = [int(c) for c in os.environ.get("CFGS","-1,1").split(",")]
+# clock ramp: the first ~30 launches after an idle period run at lower clocks; warm up, or the first configuration reads ~10 % low
+_w = torch.randn(4096, 4096, device=d)
+for _ in range(60): ops.linear(_w, _w)
+torch.cuda.synchronize()
 for M,N,K,name,epi in shapes:
     x = torch.randn(M,K,device=d); w = torch.randn(N,K,device=d)/math.sqrt(K); b = torch.randn(N,device=d)
     out = torch.empty(M,N,device=d); extra = out if epi=="resid" else None
