@@ -128,6 +128,12 @@ int mmdm_attention_opts(const float* Q, int ldq, const float* K, int ldk, const 
 int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
                           void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
 
+/* The all-bf16 form (BASELINE configs[4] path): as mmdm_attention_planes with nplanes = 1 and V given as bf16 rows [rows][ldv] as well
+ * (the projection GEMM's bf16 copy); P.V also runs on the bf16 matrix cores (v_mfma_f32_16x16x16_bf16, probabilities rounded to bf16,
+ * V read transposed from its row-major LDS image by ds_read_b64_tr_b16), fp32 accumulation and softmax.  dh = 64 or 128. */
+int mmdm_attention_bf16(const void* Qp, int ldq, const void* Kp, int ldk, const void* Vp, int ldv, void* O, int ldo, int out_mode, int flags,
+                        int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
+
 /* out[r,:] = silu(time_row[:] + txt[r,:]) for r < rows; time_row = time_tab + (*step_idx) * D.
  * Replaces `embed_timestep(t) + text_embed(c)` followed by AdaLN's SiLU  in2in.py:415-422, layers.py:9-10. */
 int mmdm_cond_silu_f32(const float* time_tab, const int* step_idx, const float* txt, float* out, int rows, int D, void* stream);

@@ -74,6 +74,7 @@ struct AttnArgs {
     const __bf16* Qp; const __bf16* Kp;
     size_t q_plane, k_plane;
     int ldqp, ldkp;
+    const __bf16* Vp; int ldvp;        // bf16 V rows (attn_qkp_kernel<DH, 1, true>: P.V on the bf16 matrix cores); nullptr = fp32 V
 };
 
 int g_attn_ablate = 0;
@@ -331,6 +332,23 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+__device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y) {
+    if (p.out_bf16 == 2) {
+        __bf16* op = reinterpret_cast<__bf16*>(p.O) + idx;
+        const size_t plane = (size_t)p.nseq * p.Tq * p.ldo;
+        const __bf16 b1 = (__bf16)y;
+        const float r1 = y - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        op[0] = b1;
+        op[plane] = b2;
+        op[2 * plane] = (__bf16)(r1 - (float)b2);
+    } else if (p.out_bf16) {
+        reinterpret_cast<__bf16*>(p.O)[idx] = (__bf16)y;
+    } else {
+        p.O[idx] = y;
+    }
+}
+
 // Q K^T on the bf16 matrix cores, everything else as attn_mfma_kernel.
 // NP = 3: Q and K arrive as exact 3-way bf16 splits of the fp32 projections (written by the QKV GEMM's epilogue) and every score is the
 // six-term sum q1k1 + q1k2 + q2k1 + q1k3 + q3k1 + q2k2 accumulated in fp32 -- fp32-accurate scores (gemm_split.hip has the argument) from
@@ -338,20 +356,30 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // NP = 1: plain bf16 Q and K (the bf16 path).  The 16x16 C/D register map is the same for every 16x16 MFMA (col = lane & 15 = query,
 // row = 4 * (lane >> 4) + reg = key), so the softmax and the fp32 P.V half of the kernel are untouched; V stays fp32.
 // K planes in LDS: [plane][16 keys][DH bf16], 16-byte chunk c of key row r stored at c ^ (r & (chunks_per_row - 1)).
-template <int DH, int NP>
+// PVB (NP = 1 only): P.V on the bf16 matrix cores as well.  V arrives as bf16 rows (the projection GEMM's bf16 copy) and is staged
+// row-major [16 keys][DH bf16]; the B operand of v_mfma_f32_16x16x16_bf16 -- lane (n, kg) holds V[keys 4kg .. 4kg+3][column n] -- is a
+// COLUMN of four rows, which gfx950's ds_read_b64_tr_b16 delivers straight from the row-major image: per 16-lane group it reads a
+// 4-row x 16-column block, lane 4q + p supplying the address of row q / columns 4p .. 4p+3 and lane i receiving column i of the four
+// rows.  The A operand is this lane's own four probabilities (keys 4g .. 4g+3 of query lq) rounded to bf16; the accumulator map is the
+// 16x16 one (column = lane & 15, rows 4 (lane >> 4) + reg), so the running rescale is unchanged and element (j, r) is
+// O[query 4g + r][column 16 j + lq].  One MFMA of 16 cycles per 16 output columns and 16 keys instead of four of 32.
+// V image swizzle (16-byte chunk c of key row r at c ^ x(r)): 256-byte rows (DH = 128) x = ((r & 3) << 2) | ((r >> 2) & 3), 128-byte rows
+// (DH = 64) x = ((r >> 1) & 3) << 1 -- without it the eight rows a 32-lane half reads sit on the same banks.
+template <int DH, int NP, bool PVB = false>
 __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
+    static_assert(!PVB || NP == 1, "bf16 P.V goes with bf16 scores");
     constexpr int NJ = DH / 16;                 // 16-wide output column tiles (PV)
     constexpr int NS = DH / 32;                 // 32-deep reduction steps of Q K^T
     constexpr int CPRK = DH / 8;                // 16-byte chunks per K row (bf16)
     constexpr int RPPK = 64 / CPRK;             // K rows per 1-KiB DMA piece
     constexpr int NPK = KC / RPPK;              // pieces per K plane
-    constexpr int CPR = DH / 4;                 // 16-byte chunks per V row (fp32)
+    constexpr int CPR = PVB ? DH / 8 : DH / 4;  // 16-byte chunks per V row (bf16 / fp32)
     constexpr int RPP = 64 / CPR;
     constexpr int NPV = KC / RPP;
     constexpr int NPIECE = NP * NPK + NPV;
     constexpr int NI = (NPIECE + 3) / 4;
     constexpr int KPLANE = KC * DH / 2;         // floats per K plane
-    constexpr int STAGE = NP * KPLANE + KC * DH;
+    constexpr int STAGE = NP * KPLANE + (PVB ? KC * DH / 2 : KC * DH);
     constexpr int NT = NP == 3 ? 6 : 1;
     constexpr int TK[6] = {1, 2, 0, 1, 0, 0}, TQ[6] = {1, 0, 2, 0, 1, 0};      // (K plane, Q plane) per term, small terms first
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 stages][K planes | V]
@@ -410,11 +438,17 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
                 const int pp = pq - NP * NPK;
                 const int trow = RPP * pp + lane / CPR;
                 const int pos = lane % CPR;
-                const int src_chunk = pos;                                  // V rows are stored unswizzled (load_v_row)
                 int krow = c0 + trow;
                 krow = krow < p.Tk ? krow : p.Tk - 1;
-                const float* src = Vg + (size_t)krow * p.ldv + 4 * src_chunk;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + NP * KPLANE + RPP * pp * DH), 16, 0, 0);
+                if constexpr (PVB) {
+                    const int xv = DH == 128 ? (((trow & 3) << 2) | ((trow >> 2) & 3)) : (((trow >> 1) & 3) << 1);
+                    const __bf16* src = p.Vp + ((size_t)kvseq * p.Tk + krow) * p.ldvp + head * DH + 8 * (pos ^ xv);
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + NP * KPLANE + RPP * pp * (DH / 2)), 16, 0, 0);
+                } else {
+                    const int src_chunk = pos;                              // V rows are stored unswizzled (load_v_row)
+                    const float* src = Vg + (size_t)krow * p.ldv + 4 * src_chunk;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + NP * KPLANE + RPP * pp * DH), 16, 0, 0);
+                }
             }
         }
     };
@@ -486,6 +520,21 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];
 
+        if constexpr (PVB) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+            const bf16x4a pb = {(__bf16)st[0][0], (__bf16)st[0][1], (__bf16)st[0][2], (__bf16)st[0][3]};
+            const s16x4 pa = __builtin_bit_cast(s16x4, pb);
+            // transposed-read address of this lane: row 4g + q of the stage, columns 16 j + 4 pp .. + 3 (q = (lane & 15) >> 2, pp = lane & 3)
+            const int vrow = 4 * g + (lq >> 2), pp = lq & 3;
+            const int xv = DH == 128 ? (((vrow & 3) << 2) | ((vrow >> 2) & 3)) : (((vrow >> 1) & 3) << 1);
+            const char* vbase = reinterpret_cast<const char*>(Vs) + vrow * (DH * 2) + 8 * (pp & 1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vbase + 16 * ((2 * j + (pp >> 1)) ^ xv)));
+                o[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, vb, o[j], 0, 0, 0);
+            }
+        } else {
         float vb[2][NJ];
         load_v_row<DH>(&Vs[(4 * g) * DH], lq, vb[0]);
 #pragma unroll
@@ -495,6 +544,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[0][r], vb[cb][j], o[j], 0, 0, 0);
+        }
         }
     }
 
@@ -507,35 +557,25 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
     for (int r = 0; r < 4; ++r) {
         const int qrow = q0 + 4 * g + r;
         if (qrow >= p.Tq) continue;
-        store_o_row<DH>(p, o, r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH, lq);
+        if constexpr (PVB) {                        // element (j, r) is column 16 j + lq of row 4g + r
+            const float inv = 1.0f / lr[r];
+            const size_t off = ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH + lq;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) store_out(p, off + 16 * j, o[j][r] * inv);
+        } else {
+            store_o_row<DH>(p, o, r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH, lq);
+        }
     }
 }
 
-template <int DH, int NP>
-constexpr int qkp_smem() { return 2 * (NP * KC * DH / 2 + KC * DH) * 4; }
+template <int DH, int NP, bool PVB = false>
+constexpr int qkp_smem() { return 2 * (NP * KC * DH / 2 + (PVB ? KC * DH / 2 : KC * DH)) * 4; }
 
-template <int DH, int NP>
+template <int DH, int NP, bool PVB = false>
 int launch_qkp(const AttnArgs& a, hipStream_t st) {
-    constexpr int smem_bytes = qkp_smem<DH, NP>();
-    hipLaunchKernelGGL((attn_qkp_kernel<DH, NP>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), smem_bytes, st, a);
+    constexpr int smem_bytes = qkp_smem<DH, NP, PVB>();
+    hipLaunchKernelGGL((attn_qkp_kernel<DH, NP, PVB>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), smem_bytes, st, a);
     return mmdm_check_launch("attn_qkp");
-}
-
-__device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y) {
-    if (p.out_bf16 == 2) {
-        __bf16* op = reinterpret_cast<__bf16*>(p.O) + idx;
-        const size_t plane = (size_t)p.nseq * p.Tq * p.ldo;
-        const __bf16 b1 = (__bf16)y;
-        const float r1 = y - (float)b1;
-        const __bf16 b2 = (__bf16)r1;
-        op[0] = b1;
-        op[plane] = b2;
-        op[2 * plane] = (__bf16)(r1 - (float)b2);
-    } else if (p.out_bf16) {
-        reinterpret_cast<__bf16*>(p.O)[idx] = (__bf16)y;
-    } else {
-        p.O[idx] = y;
-    }
 }
 
 // Small-head fallback (dh in {4,8,16,32}): one thread per (sequence, head, query); used by tiny test configurations.
@@ -682,7 +722,7 @@ extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int 
     if (ldq < H * dh || ldk < H * dh || ldv < H * dh || ldo < H * dh)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_f32: row strides must cover H*dh=%d", H * dh);
     AttnArgs a;
-    a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.Vp = nullptr; a.ldvp = 0;
     a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate;
     a.Qp = a.Kp = nullptr; a.q_plane = a.k_plane = 0; a.ldqp = a.ldkp = 0;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
@@ -714,6 +754,20 @@ extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int 
 
 extern "C" int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
                                      void* Ov, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
+    return mmdm_attention_planes_ex(Qp, ldq, q_plane, Kp, ldk, k_plane, nplanes, V, ldv, nullptr, 0, Ov, ldo, out_mode, flags, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);
+}
+
+extern "C" int mmdm_attention_bf16(const void* Qp, int ldq, const void* Kp, int ldk, const void* Vp, int ldv, void* O, int ldo, int out_mode, int flags,
+                                   int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
+    if (!Vp) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_bf16: V is null");
+    // the fp32 V argument of the shared path is unused by the bf16 P.V kernel: any non-null 16-byte aligned pointer passes its checks
+    return mmdm_attention_planes_ex(Qp, ldq, 8, Kp, ldk, 8, 1, static_cast<const float*>(Vp), 4 * ((ldv + 3) / 4) < H * dh ? H * dh : 4 * ((ldv + 3) / 4), Vp, ldv,
+                                    O, ldo, out_mode, flags, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);
+}
+
+// Vp != nullptr (one plane only): V also as bf16 rows [rows][ldvp] -> P.V on the bf16 matrix cores (attn_qkp_kernel<DH, 1, true>)
+int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
+                             const void* Vp, int ldvp, void* Ov, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
     if (nseq == 0 || Tq == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
     if (!Qp || !Kp || !V || !Ov || nseq < 0 || Tq < 0 || Tk <= 0 || H <= 0 || (nplanes != 1 && nplanes != 3))
@@ -730,6 +784,9 @@ extern "C" int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, c
     AttnArgs a;
     a.Q = nullptr; a.K = nullptr; a.V = V; a.O = static_cast<float*>(Ov); a.ldq = 0; a.ldk = 0; a.ldv = ldv; a.ldo = ldo;
     a.Qp = static_cast<const __bf16*>(Qp); a.Kp = static_cast<const __bf16*>(Kp); a.q_plane = (size_t)q_plane; a.k_plane = (size_t)k_plane; a.ldqp = ldq; a.ldkp = ldk;
+    a.Vp = static_cast<const __bf16*>(Vp); a.ldvp = ldvp;
+    if (Vp && (nplanes != 1 || (reinterpret_cast<uintptr_t>(Vp) & 15) || (ldvp & 7) || ldvp < H * dh))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: bf16 V needs one plane, 16-byte aligned rows and a row stride >= H*dh");
     a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
@@ -738,6 +795,7 @@ extern "C" int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, c
     a.scale2 = a.scale * 1.4426950408889634f;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (nplanes == 3) return dh == 128 ? launch_qkp<128, 3>(a, st) : launch_qkp<64, 3>(a, st);
+    if (Vp) return dh == 128 ? launch_qkp<128, 1, true>(a, st) : launch_qkp<64, 1, true>(a, st);
     return dh == 128 ? launch_qkp<128, 1>(a, st) : launch_qkp<64, 1>(a, st);
 }
 

@@ -475,9 +475,9 @@ int linear_s(const Ctx& c, const void* A, int lda, size_t a_plane, const void* W
 
 // attention whose Q K^T runs on the bf16 matrix cores from the plane copies written by the projection GEMMs
 int attention_p(const Ctx& c, const void* Qp, int ldq, size_t q_plane, const void* Kp, int ldk, size_t k_plane, int np, const float* V, int ldv, void* O, int ldo,
-                int out_mode, int nseq, int Tq, int Tk, int H, int dh, int shift) {
+                int out_mode, int nseq, int Tq, int Tk, int H, int dh, int shift, const void* Vp = nullptr, int ldvp = 0) {
     RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh, 4.0 * nseq * H * dh * (2.0 * Tq + 2.0 * Tk)));
-    RC(mmdm_attention_planes(Qp, ldq, (int64_t)q_plane, Kp, ldk, (int64_t)k_plane, np, V, ldv, O, ldo, out_mode, 0, nseq, Tq, Tk, H, dh, shift, c.st));
+    RC(mmdm_attention_planes_ex(Qp, ldq, (int64_t)q_plane, Kp, ldk, (int64_t)k_plane, np, V, ldv, Vp, ldvp, O, ldo, out_mode, 0, nseq, Tq, Tk, H, dh, shift, c.st));
     return prof_end(c, 1);
 }
 
@@ -527,24 +527,29 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         return mmdm_adaln_ex(src, ssp, r.ss_ld, rows, S.xn, ob, r.nseq, r.T, D, c.st);
     };
     auto second = [&](void* buf, int ld, int cols) { Second s2; if (qkp) { s2.p = buf; s2.ld = ld; s2.cols = cols; s2.plane = (size_t)R * ld; } return s2; };
+    // one-plane (bf16 / fp8) modes: the projection GEMMs' bf16 copy also covers V, and P.V runs on the bf16 matrix cores (attn_qkp_kernel<DH, 1, true>)
+    static const bool no_pvb = getenv("MMDM_NO_BF16_PV") != nullptr;
+    const bool pvb = qkp && np == 1 && !no_pvb;
     for (int l = r.l0; l < w.L; ++l) {
         const LayerW& lw = w.layers[l];
         const LayerWB lb = bf ? w.layers_b[l] : LayerWB();
         auto ss_at = [&](int slot, int row0) { return r.ss + (size_t)row0 * r.ss_ld + ((size_t)l * w.n_ada + slot) * 2 * D; };
         // --- self attention (layers.py:36-45)
         RC(norm(hbuf, ss_at(0, r.sa_row0), r.sa_rows));
-        if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, 2 * D, 2 * D)));
-        else RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, 2 * D, 2 * D)));
-        if (qkp) RC(attention_p(c, S.qk, 2 * D, (size_t)R * 2 * D, static_cast<const uint16_t*>(S.qk) + D, 2 * D, (size_t)R * 2 * D, np, S.qkv + 2 * D, 3 * D, S.att, D, ob,
-                                r.nseq, r.T, r.T, w.H, dh, 0));
+        const int qkld = pvb ? 3 * D : 2 * D;           // row stride of the bf16 copy of the packed projection: Q|K or Q|K|V
+        if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, qkld, qkld)));
+        else RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, qkld, qkld)));
+        if (qkp) RC(attention_p(c, S.qk, qkld, (size_t)R * qkld, static_cast<const uint16_t*>(S.qk) + D, qkld, (size_t)R * qkld, np, S.qkv + 2 * D, 3 * D, S.att, D, ob,
+                                r.nseq, r.T, r.T, w.H, dh, 0, pvb ? static_cast<const uint16_t*>(S.qk) + 2 * D : nullptr, qkld));
         else RC(attention_b(c, S.qkv, 3 * D, S.qkv + D, 3 * D, S.qkv + 2 * D, 3 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, 0));
         if (r.ca_mode) {
             // keys/values of the cross attention come from the layer INPUT of the other stream (or a fixed source):
             // project them before the residual below overwrites h.
             const float* src = r.ca_mode == 1 ? hbuf : r.kv_src;
             RC(norm(src, ss_at(2, r.ca_row0), r.ca_rows));
-            if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, D, D)));
-            else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, D, D)));
+            const int kvld = pvb ? 2 * D : D;             // bf16 copy of the cross-attention projection: K or K|V
+            if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld)));
+            else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld)));
         }
         RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         // --- cross attention (layers.py:77-88)
@@ -552,8 +557,8 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
             RC(norm(hbuf, ss_at(1, r.ca_row0), r.ca_rows));
             if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
             else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
-            if (qkp) RC(attention_p(c, S.qk, D, (size_t)R * D, S.kvp, D, (size_t)R * D, np, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
-                                    r.ca_mode == 1 ? r.nseq / 2 : 0));
+            if (qkp) RC(attention_p(c, S.qk, D, (size_t)R * D, S.kvp, pvb ? 2 * D : D, (size_t)R * (pvb ? 2 * D : D), np, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
+                                    r.ca_mode == 1 ? r.nseq / 2 : 0, pvb ? static_cast<const uint16_t*>(S.kvp) + D : nullptr, 2 * D));
             else RC(attention_b(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
             RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, (size_t)D * D, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         }
@@ -916,7 +921,9 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
         if (c.precision >= 1) {
             const size_t npl = c.precision == 2 ? 3 : 1;
             float *q1 = nullptr, *q2 = nullptr;
-            if ((rc = dalloc(h, &q1, npl * R * d)) || (rc = dalloc(h, &q2, npl * R * d / 2 + 1))) return fail(rc);     // bf16 [npl][R][2d], [npl][R][d]
+            // bf16 [npl][R][2d] (Q|K) and [npl][R][d] (cross-attention K); the one-plane modes also keep V there ([R][3d], [R][2d]): P.V on the bf16 cores
+            const size_t vx = npl == 1 ? 1 : 0;
+            if ((rc = dalloc(h, &q1, npl * R * d + vx * R * d / 2 + 1)) || (rc = dalloc(h, &q2, npl * R * d / 2 + vx * R * d / 2 + 1))) return fail(rc);
             sc->qk = q1; sc->kvp = q2;
             if (c.precision == 3 && (rc = dalloc(h, &sc->xs, R))) return fail(rc);
         }

@@ -273,6 +273,21 @@ def attention_planes(qp, kp, v, num_heads, kv_seq_shift=0, zero_key=True, causal
     return out
 
 
+def attention_bf16(qb, kb, vb, num_heads, kv_seq_shift=0, zero_key=True, causal=False, out_dtype=torch.float32):
+    """All-bf16 attention (BASELINE configs[4] path): qb [nseq, Tq, H*dh], kb / vb [nseq, Tk, H*dh] torch.bfloat16 (may be column slices of a
+    packed projection copy); Q K^T and P.V on the bf16 matrix cores, fp32 softmax and accumulation.  Returns fp32 or bf16 [nseq, Tq, H*dh]."""
+    for t in (qb, kb, vb):
+        assert t.is_cuda and t.dtype == torch.bfloat16 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1)
+    nseq, Tq, HD = qb.shape
+    Tk = kb.shape[1]
+    out = torch.empty(nseq, Tq, HD, device=qb.device, dtype=out_dtype)
+    flags = (0 if zero_key else ATTN_NO_ZERO_KEY) | (ATTN_CAUSAL if causal else 0)
+    check(load_library().mmdm_attention_bf16(C.c_void_p(qb.data_ptr()), qb.stride(1), C.c_void_p(kb.data_ptr()), kb.stride(1), C.c_void_p(vb.data_ptr()), vb.stride(1),
+                                             C.c_void_p(out.data_ptr()), HD, int(out_dtype == torch.bfloat16), flags, nseq, Tq, Tk, num_heads, HD // num_heads,
+                                             kv_seq_shift, _stream()))
+    return out
+
+
 def quantize_rows_fp8(x):
     """Row-wise OCP e4m3 quantisation of an fp32 [rows, K] tensor: returns (q uint8-viewed-as torch.float8_e4m3fn [rows, K], scale fp32 [rows])
     with x ~= q.float() * scale[:, None].  Per-output-channel weight quantisation is this on W [N, K]."""

@@ -159,3 +159,34 @@ def test_bf16_and_fp8_modes_vs_oracle_at_full_dims_T300():
         assert torch.isfinite(s.state()["x"]).all()
         s.close()
     assert not torch.equal(seen[("bf16", 999)], seen[("bf16_fp8", 999)])          # the fp8 kernels really ran
+
+
+@pytest.mark.parametrize("nseq,Tq,Tk,H,dh,zero_key,causal", [(3, 70, 70, 2, 128, True, False), (2, 300, 300, 8, 128, True, False), (2, 33, 50, 4, 64, True, False),
+                                                             (2, 64, 64, 4, 64, False, True), (1, 1, 1, 1, 128, True, False)])
+def test_attention_bf16_vs_float64_of_the_rounded_operands(nseq, Tq, Tk, H, dh, zero_key, causal):
+    """mmdm_attention_bf16 (configs[4] path): Q K^T and P.V on the bf16 matrix cores (V read transposed from its row-major LDS image by
+    ds_read_b64_tr_b16), fp32 softmax / accumulation.  Reference: float64 attention of the SAME bf16-rounded Q, K, V, so the only error left
+    is the rounding of the probabilities to bf16 (2^-9 relative each, averaging down over the keys): stated tolerance 1 % of the output's RMS
+    at the worst element (measured 0.4-0.9 %), against 4e-6 for the fp32 P.V form of the same kernel, which must stay that exact."""
+    from mixermdm_amd import ops
+    d = dev()
+    D = H * dh
+    qb, kb, vb = (rnd(90 + i, nseq, T_, D).to(d).bfloat16() for i, T_ in enumerate((Tq, Tk, Tk)))
+    Q = qb.double().view(nseq, Tq, H, dh).transpose(1, 2)
+    K = kb.double().view(nseq, Tk, H, dh).transpose(1, 2)
+    V = vb.double().view(nseq, Tk, H, dh).transpose(1, 2)
+    S = Q @ K.transpose(-1, -2) / math.sqrt(dh)
+    if causal:
+        S = S.masked_fill(torch.triu(torch.ones(Tq, Tk, device=d, dtype=torch.bool), 1), float("-inf"))
+    if zero_key:
+        S = torch.cat([S, torch.zeros(nseq, H, Tq, 1, device=d, dtype=torch.float64)], -1)
+        V = torch.cat([V, torch.zeros(nseq, H, 1, dh, device=d, dtype=torch.float64)], 2)
+    ref = (S.softmax(-1) @ V).transpose(1, 2).reshape(nseq, Tq, D)
+    rms = ref.pow(2).mean().sqrt().item()
+    got = ops.attention_bf16(qb, kb, vb, H, zero_key=zero_key, causal=causal)
+    assert torch.isfinite(got).all()
+    assert (got.double() - ref).abs().max().item() <= 1e-2 * max(rms, 0.05), ((got.double() - ref).abs().max().item(), rms)
+    exact = ops.attention_planes(qb[None], kb[None], vb.float(), H, zero_key=zero_key, causal=causal)
+    assert (exact.double() - ref).abs().max().item() <= 4e-6
+    gb = ops.attention_bf16(qb, kb, vb, H, zero_key=zero_key, causal=causal, out_dtype=torch.bfloat16)
+    assert torch.equal(gb, got.bfloat16())
