@@ -255,7 +255,7 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
     rd(0, 0, f0a, f0b);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        rd(cur, 1, f1a, f1b);
+        if (!(p.ablate & 2)) rd(cur, 1, f1a, f1b);
         mm(I0{}, I6{}, f0a, f0b);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
@@ -266,10 +266,10 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
         if (kt + 1 < nkt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // stage kt+1 landed (stage kt+2 is requested below)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                              // every wave has read all of stage kt
+            if (!(p.ablate & 16)) __builtin_amdgcn_s_barrier();        // every wave has read all of stage kt
             __builtin_amdgcn_sched_barrier(0);
-            rd(cur ^ 1, 0, f0a, f0b);
-            if (kt + 2 < nkt) stage(cur);
+            if (!(p.ablate & 2)) rd(cur ^ 1, 0, f0a, f0b);
+            if (kt + 2 < nkt && !(p.ablate & 1)) stage(cur);           // (ablate bits: timing experiments, tools/gemm_split_bench.py)
         }
         mm(I3{}, I6{}, f1a, f1b);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
