@@ -537,7 +537,11 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         // --- self attention (layers.py:36-45)
         RC(norm(hbuf, ss_at(0, r.sa_row0), r.sa_rows));
         const int qkld = pvb ? 3 * D : 2 * D;           // row stride of the bf16 copy of the packed projection: Q|K or Q|K|V
-        if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, qkld, qkld)));
+        // all-bf16 attention: nothing reads the fp32 projection, so the GEMM writes bf16 only (a third of the bytes: the fp8 QKV GEMM is output-bound)
+        if (pvb) {
+            if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qk, 3 * D, 1, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+            else RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, static_cast<float*>(S.qk), 3 * D, 1, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+        } else if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, qkld, qkld)));
         else RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, qkld, qkld)));
         if (qkp) RC(attention_p(c, S.qk, qkld, (size_t)R * qkld, static_cast<const uint16_t*>(S.qk) + D, qkld, (size_t)R * qkld, np, S.qkv + 2 * D, 3 * D, S.att, D, ob,
                                 r.nseq, r.T, r.T, w.H, dh, 0, pvb ? static_cast<const uint16_t*>(S.qk) + 2 * D : nullptr, qkld));
@@ -548,14 +552,20 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
             const float* src = r.ca_mode == 1 ? hbuf : r.kv_src;
             RC(norm(src, ss_at(2, r.ca_row0), r.ca_rows));
             const int kvld = pvb ? 2 * D : D;             // bf16 copy of the cross-attention projection: K or K|V
-            if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld)));
+            if (pvb) {
+                if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kvp, 2 * D, 1, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+                else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, static_cast<float*>(S.kvp), 2 * D, 1, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+            } else if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld)));
             else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld)));
         }
         RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         // --- cross attention (layers.py:77-88)
         if (r.ca_mode) {
             RC(norm(hbuf, ss_at(1, r.ca_row0), r.ca_rows));
-            if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
+            if (pvb) {
+                if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qk, D, 1, D, D, MMDM_EPI_BIAS, nullptr, 0));
+                else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, static_cast<float*>(S.qk), D, 1, D, D, MMDM_EPI_BIAS, nullptr, 0));
+            } else if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
             else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
             if (qkp) RC(attention_p(c, S.qk, D, (size_t)R * D, S.kvp, pvb ? 2 * D : D, (size_t)R * (pvb ? 2 * D : D), np, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
                                     r.ca_mode == 1 ? r.nseq / 2 : 0, pvb ? static_cast<const uint16_t*>(S.kvp) + D : nullptr, 2 * D));
