@@ -32,11 +32,11 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {      // OCP e4m3, RNE,
 template <int MAXV, int OMODE>
 __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h, const float* __restrict__ ss, int ss_ld, int ss_rows,
                                                      void* __restrict__ outv, int rows, int T, int D, float* __restrict__ row_scale = nullptr) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    const float* hp = h + (size_t)row * D;
     const int nv = D >> 2;                                   // float4 per row (D % 4 == 0 checked on host)
+    // persistent: a fixed grid of wave slots walks the rows (one launch of ~2000 blocks instead of rows/4 short-lived ones)
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    const float* hp = h + (size_t)row * D;
     f32x4 v[MAXV];
     float s = 0.f;
 #pragma unroll
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h,
             const int c = lane + 64 * i;
             if (c < nv) *reinterpret_cast<unsigned*>(static_cast<unsigned char*>(outv) + (size_t)row * D + 4 * c) = pack_fp8x4(v[i] * inv);
         }
-        return;
+        continue;
     }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h,
                 *reinterpret_cast<f32x4*>(static_cast<float*>(outv) + (size_t)row * D + 4 * c) = y;
             }
         }
+    }
     }
 }
 
@@ -279,7 +280,7 @@ int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void
     if (D > 64 * 4 * 8) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_adaln_f32: D=%d > 2048", D);
     const int rows = nseq * T;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    dim3 grid((rows + 3) / 4), block(256);
+    dim3 grid(min((rows + 3) / 4, 2048)), block(256);          // 256 CUs x 8 resident blocks
 #define ADALN_LAUNCH(V)                                                                                                   \
     do {                                                                                                                  \
         if (out_bf16 == 3) hipLaunchKernelGGL((adaln_kernel<V, 3>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, row_scale);       \
@@ -302,7 +303,7 @@ extern "C" int mmdm_layernorm_f32(const float* x, const float* gamma, const floa
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_layernorm_f32: D must be a multiple of 4 and pointers 16-byte aligned");
     if (D > 64 * 4 * 8) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_layernorm_f32: D=%d > 2048", D);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    dim3 grid((rows + 3) / 4), block(256);
+    dim3 grid(min((rows + 3) / 4, 2048)), block(256);          // 256 CUs x 8 resident blocks
     if (D <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, st, x, gamma, beta, out, rows, D, eps);
     else if (D <= 512) hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, st, x, gamma, beta, out, rows, D, eps);
     else if (D <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, st, x, gamma, beta, out, rows, D, eps);
