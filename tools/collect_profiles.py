@@ -1,0 +1,26 @@
+"""Copy what tools/profile_round.sh left under gpurun_out/prof_r02/ into profiles/ (tracked) and print the figures the README quotes.
+usage: python tools/collect_profiles.py [round-tag, default r02]"""
+import csv, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src, dst = os.path.join(ROOT, "gpurun_out", "prof_r02"), os.path.join(ROOT, "profiles")
+for n in ("serial", "overlap", "split_serial", "fp8_serial"):
+    shutil.copy(os.path.join(src, "summary", f"kernel_stats_{n}.csv"), os.path.join(dst, f"{tag}_kernel_stats_{n}.csv"))
+    for line in open(os.path.join(src, f"{n}.json")):
+        if line.startswith("{"):
+            d = json.loads(line)
+            json.dump(d, open(os.path.join(dst, f"{tag}_bench_{n}_under_rocprof.json"), "w"), indent=1)
+            r = d["roofline"]
+            print(f"{n:13s} {d['ms_per_step']:7.3f} ms/step  GEMM live {r['achieved']:7.2f} TFLOP/s (frac {r['frac']:.4f}, {r['avg_launch_us']:.1f} us/launch)  attention {r['attention']}")
+shutil.copy(os.path.join(src, "summary", "pmc_summary.json"), os.path.join(dst, f"{tag}_pmc_summary.json"))
+shutil.copy(os.path.join(src, "summary", "gemm_traffic.json"), os.path.join(dst, "gemm_traffic.json"))
+t = json.load(open(os.path.join(dst, "gemm_traffic.json")))
+print("traffic", t["kernel_sources_sha"], t["traffic_bytes_per_launch"], "L2 hit", t["l2_hit_rate"])
+rows = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats_serial.csv"))))
+g = [r for r in rows if r["Name"].startswith("gemm_glds_kernel")]
+tot, n = sum(float(r["TotalDurationNs"]) for r in g), sum(int(r["Calls"]) for r in g)
+steps = next(int(r["Calls"]) for r in rows if "xstart_ddim_kernel" in r["Name"])
+print(f"serial trace: {steps} steps; fp32 GEMM kernels {tot / 1e6:.1f} ms over {n} launches = {tot / n / 1e3:.1f} us average, {tot / steps / 1e6:.2f} ms/step "
+      f"= {136 * 51.453e9 / (tot / steps * 1e-9) / 1e12:.1f} TFLOP/s")
+for r in g + [r for r in rows if r["Name"].startswith(("attn_", "adaln"))]:
+    print(f"  {r['Name'][:60]:60s} x{r['Calls']:>4s}  {float(r['AverageNs']) / 1e3:7.1f} us  {r['Percentage']} %")
