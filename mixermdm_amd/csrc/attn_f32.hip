@@ -64,6 +64,7 @@ struct AttnArgs {
     int nseq, Tq, Tk, H, shift, qtiles, pairs_per_xcd;
     float scale, scale2;
     int out_bf16;      // 1: O written as bf16 (feeds the bf16 out-projection GEMM); 2: as three bf16 planes (exact split, plane stride nseq*Tq*ldo)
+    unsigned long long* stamps;   // diagnostic launches only (tools/attn_timeline.py): per workgroup {entry, loop start, loop end, kernel end, placement, qk, softmax, pv} in 100 MHz ticks
     int ablate;        // timing experiments only (tools/attn_bench.py, mmdmx_set_attn_ablate); 0 in production
     int flags;         // MMDM_ATTN_NO_ZERO_KEY: plain softmax (nn.MultiheadAttention default); MMDM_ATTN_CAUSAL: key <= query only
     int dh;            // real head width (<= the kernel's DH, multiple of 4): heads narrower than the template (the 96-wide heads of the
@@ -78,6 +79,7 @@ struct AttnArgs {
 };
 
 int g_attn_ablate = 0;
+unsigned long long* g_attn_stamps = nullptr;
 
 typedef __bf16 bf16x4a __attribute__((ext_vector_type(4)));
 
@@ -120,6 +122,27 @@ __device__ __forceinline__ void store_o_row(const P& p, const f32x4 (&o)[DH / 16
 // bank conflicts are avoided by XOR swizzles applied on the per-lane SOURCE address of the DMA and again on the read:
 //   K: 16-byte chunk c of key row r is stored at chunk (c ^ (r & 15))      (conflict-free ds_read_b128 fragment reads)
 //   V: 16-byte chunk c of key row r is stored at chunk (c ^ (4 * ((r >> 2) & 1)))  (conflict-free ds_read_b32 operand reads)
+// All-reduce over the four 16-lane rows of a wave (the four key groups g of one query lq) WITHOUT the LDS: gfx950's v_permlane16_swap /
+// v_permlane32_swap exchange rows / halves between two registers (a' = {a.r0, b.r0, a.r2, b.r2}, b' = {a.r1, b.r1, a.r3, b.r3};
+// a' = {a.lo, b.lo}, b' = {a.hi, b.hi}: tools/permlane_probe.hip), so with a = b = x one swap + one VALU op is a butterfly step.  The
+// __shfl_xor form is a ds_bpermute: an LDS round trip that queues behind the K / V fragment reads and the LDS-DMA writes of four
+// co-resident workgroups -- the softmax stretch of a chunk spent most of its 2 800 cycles in eight of them (tools/attn_timeline.py).
+// Inline asm: this compiler's two-result builtin returns the first result twice.  The s_nop cover the VALU -> permlane hazards.
+__device__ __forceinline__ float rows_max(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a = fmaxf(a, b); b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a = a + b; b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
@@ -148,6 +171,12 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 15, g = lane >> 4;
     const int q0 = qt * QB + wave * QW;
+    unsigned long long t_qk = 0, t_sm = 0, t_pv = 0, t_a = 0;
+    if (p.stamps && tid == 0) {
+        p.stamps[8 * (size_t)bid + 0] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[8 * (size_t)bid + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                                        ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
+    }
 
     // Q fragment (B operand of S^T = K Q^T): lane (q = lq, g) holds Q[q][16j + 4g + s], pre-scaled into the log2 domain.
     f32x4 qf[NJ];
@@ -227,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         if (ci + NST - 1 < nchunks && !(p.ablate & 1)) stage(c0 + (NST - 1) * KC, stg);
         const float* Ks = smem + cur * STAGE;
         const float* Vs = Ks + KC * DH;
+        if (p.stamps) { if (ci == 0 && tid == 0) p.stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime(); t_a = __builtin_amdgcn_s_memrealtime(); }
 
         // S^T tiles: st[kt][reg] = score(key = c0 + 16kt + 4g + reg, query = lq); K fragments double-buffered in registers
         f32x4 st[NKT];
@@ -252,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) MFMA_SETTLE(st[kt]);
+        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); t_qk += t - t_a; t_a = t; }
         if (c0 + KC > p.Tk || (causal && c0 + KC - 1 > q0)) {   // keys past Tk (last chunk) or above the diagonal (wave-uniform branch)
             const int kmax = causal ? min(p.Tk - 1, q0 + lq) : p.Tk - 1;
 #pragma unroll
@@ -264,9 +295,12 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         float cmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
 #pragma unroll
         for (int kt = 1; kt < NKT; ++kt) cmax = fmaxf(cmax, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const float m_new = fmaxf(m_run, cmax);
+        cmax = rows_max(cmax);
+        // Deferred reference: the running maximum only moves when the chunk's maximum exceeds it by more than 2^8 (scores are in the log2
+        // domain), so after the first chunks alpha is exactly 1 for every query of the wave and the rescale below is skipped; until
+        // then probabilities up to 2^8 enter the fp32 sums, which changes nothing but the last bits (softmax does not depend on the
+        // reference point).
+        const float m_new = cmax > m_run + 8.0f ? cmax : m_run;
         const float alpha = EXP2(m_run - m_new);
         float lsum = 0.f;
 #pragma unroll
@@ -276,8 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
                 st[kt][r] = EXP2(st[kt][r] - m_new);
                 lsum += st[kt][r];
             }
-        lsum += __shfl_xor(lsum, 16);
-        lsum += __shfl_xor(lsum, 32);
+        lsum = rows_sum(lsum);
         l_run = l_run * alpha + lsum;
         m_run = m_new;
 
@@ -297,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 
         // O[q][n] += sum_key P[q][key] V[key][n]:  A = P (lane-local: st[kt][r] is P[q=lq][key=16kt+4g+r]),
         // B = V[key = 16kt + 4g + r][this lane's NJ contiguous columns] (load_v_row)
+        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); t_sm += t - t_a; t_a = t; }
         float vb[2][NJ];
         load_v_row<DH>(&Vs[(4 * g) * DH], lq, vb[0]);
 #pragma unroll
@@ -310,12 +344,21 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
             for (int j = 0; j < NJ; ++j)
                 o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vb[cb][j], o[j], 0, 0, 0);
         }
+        if (p.stamps) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
+            t_pv += __builtin_amdgcn_s_memrealtime() - t_a;
+        }
         cur = cur + 1 == NST ? 0 : cur + 1;
         stg = stg + 1 == NST ? 0 : stg + 1;
     }
 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
+    if (p.stamps && tid == 0) {
+        p.stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[8 * (size_t)bid + 5] = t_qk; p.stamps[8 * (size_t)bid + 6] = t_sm; p.stamps[8 * (size_t)bid + 7] = t_pv;
+    }
     // normalise and store: accumulator element (j, r) belongs to query q0 + 4g + r, columns as laid out by load_v_row
     float lr[4];
 #pragma unroll
@@ -325,6 +368,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         const int qrow = q0 + 4 * g + r;
         if (qrow >= p.Tq) continue;
         store_o_row<DH>(p, o, r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * p.dh, lq);
+    }
+    if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) p.stamps[8 * (size_t)bid + 3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }
@@ -723,7 +770,7 @@ extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int 
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_f32: row strides must cover H*dh=%d", H * dh);
     AttnArgs a;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.Vp = nullptr; a.ldvp = 0;
-    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate;
+    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate; a.stamps = g_attn_stamps;
     a.Qp = a.Kp = nullptr; a.q_plane = a.k_plane = 0; a.ldqp = a.ldkp = 0;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
@@ -787,7 +834,7 @@ int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const voi
     a.Vp = static_cast<const __bf16*>(Vp); a.ldvp = ldvp;
     if (Vp && (nplanes != 1 || (reinterpret_cast<uintptr_t>(Vp) & 15) || (ldvp & 7) || ldvp < H * dh))
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: bf16 V needs one plane, 16-byte aligned rows and a row stride >= H*dh");
-    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate;
+    a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate; a.stamps = g_attn_stamps;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
     a.pairs_per_xcd = (nseq * H + 7) / 8;
@@ -800,3 +847,4 @@ int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const voi
 }
 
 extern "C" void mmdmx_set_attn_ablate(int a) { g_attn_ablate = a; }
+extern "C" void mmdmx_set_attn_stamps(void* p) { g_attn_stamps = static_cast<unsigned long long*>(p); }

