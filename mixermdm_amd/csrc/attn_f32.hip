@@ -544,9 +544,8 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
                 if (c0 + 4 * g + r > kmax) st[0][r] = -INFINITY;
         }
         float cmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const float m_new = fmaxf(m_run, cmax);
+        cmax = rows_max(cmax);
+        const float m_new = cmax > m_run + 8.0f ? cmax : m_run;        // deferred reference, as in attn_mfma_kernel
         const float alpha = EXP2(m_run - m_new);
         float lsum = 0.f;
 #pragma unroll
@@ -554,18 +553,19 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
             st[0][r] = EXP2(st[0][r] - m_new);
             lsum += st[0][r];
         }
-        lsum += __shfl_xor(lsum, 16);
-        lsum += __shfl_xor(lsum, 32);
+        lsum = rows_sum(lsum);
         l_run = l_run * alpha + lsum;
         m_run = m_new;
 
-        float ar[4];
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {          // exact skip: x * 1.0f == x
+            float ar[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r);
+            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];
+                for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];
+        }
 
         if constexpr (PVB) {
             typedef short s16x4 __attribute__((ext_vector_type(4)));

@@ -166,8 +166,10 @@ def test_bf16_and_fp8_modes_vs_oracle_at_full_dims_T300():
 def test_attention_bf16_vs_float64_of_the_rounded_operands(nseq, Tq, Tk, H, dh, zero_key, causal):
     """mmdm_attention_bf16 (configs[4] path): Q K^T and P.V on the bf16 matrix cores (V read transposed from its row-major LDS image by
     ds_read_b64_tr_b16), fp32 softmax / accumulation.  Reference: float64 attention of the SAME bf16-rounded Q, K, V, so the only error left
-    is the rounding of the probabilities to bf16 (2^-9 relative each, averaging down over the keys): stated tolerance 1 % of the output's RMS
-    at the worst element (measured 0.4-0.9 %), against 4e-6 for the fp32 P.V form of the same kernel, which must stay that exact."""
+    is the rounding of the probabilities to bf16: each carries at most 2^-9 relative error, so |out - ref| <= 2^-9 * sum_k P_k |V_k| / l <=
+    2^-9 * max|V| for every element -- the bound asserted here (measured: 0.5-1.8 % of the output's RMS at the worst element, which is a row
+    dominated by one key; the deferred softmax reference of the kernel means that key's probability is no longer exactly 1).  The fp32 P.V
+    form of the same kernel must stay within 4e-6."""
     from mixermdm_amd import ops
     d = dev()
     D = H * dh
@@ -185,7 +187,9 @@ def test_attention_bf16_vs_float64_of_the_rounded_operands(nseq, Tq, Tk, H, dh, 
     rms = ref.pow(2).mean().sqrt().item()
     got = ops.attention_bf16(qb, kb, vb, H, zero_key=zero_key, causal=causal)
     assert torch.isfinite(got).all()
-    assert (got.double() - ref).abs().max().item() <= 1e-2 * max(rms, 0.05), ((got.double() - ref).abs().max().item(), rms)
+    err = (got.double() - ref).abs().max().item()
+    print(f"attention_bf16 {nseq}x{Tq}x{Tk} H={H} dh={dh}: max err {err:.2e} = {err / max(rms, 1e-9) * 100:.2f} % of the output RMS; bound {2 ** -9 * vb.float().abs().max().item():.2e}")
+    assert err <= 2.0 ** -9 * vb.float().abs().max().item() * 1.05 + 1e-5, (err, rms)
     exact = ops.attention_planes(qb[None], kb[None], vb.float(), H, zero_key=zero_key, causal=causal)
     assert (exact.double() - ref).abs().max().item() <= 4e-6
     gb = ops.attention_bf16(qb, kb, vb, H, zero_key=zero_key, causal=causal, out_dtype=torch.bfloat16)
