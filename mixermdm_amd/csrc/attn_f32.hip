@@ -807,9 +807,7 @@ extern "C" int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, c
 extern "C" int mmdm_attention_bf16(const void* Qp, int ldq, const void* Kp, int ldk, const void* Vp, int ldv, void* O, int ldo, int out_mode, int flags,
                                    int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
     if (!Vp) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_bf16: V is null");
-    // the fp32 V argument of the shared path is unused by the bf16 P.V kernel: any non-null 16-byte aligned pointer passes its checks
-    return mmdm_attention_planes_ex(Qp, ldq, 8, Kp, ldk, 8, 1, static_cast<const float*>(Vp), 4 * ((ldv + 3) / 4) < H * dh ? H * dh : 4 * ((ldv + 3) / 4), Vp, ldv,
-                                    O, ldo, out_mode, flags, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);
+    return mmdm_attention_planes_ex(Qp, ldq, 8, Kp, ldk, 8, 1, nullptr, 0, Vp, ldv, O, ldo, out_mode, flags, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);     // no fp32 V
 }
 
 // Vp != nullptr (one plane only): V also as bf16 rows [rows][ldvp] -> P.V on the bf16 matrix cores (attn_qkp_kernel<DH, 1, true>)
@@ -817,15 +815,16 @@ int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const voi
                              const void* Vp, int ldvp, void* Ov, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
     if (nseq == 0 || Tq == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
-    if (!Qp || !Kp || !V || !Ov || nseq < 0 || Tq < 0 || Tk <= 0 || H <= 0 || (nplanes != 1 && nplanes != 3))
+    if (!Qp || !Kp || (!V && !Vp) || !Ov || nseq < 0 || Tq < 0 || Tk <= 0 || H <= 0 || (nplanes != 1 && nplanes != 3))
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: bad arguments nseq=%d Tq=%d Tk=%d H=%d planes=%d", nseq, Tq, Tk, H, nplanes);
     if (dh != 64 && dh != 128) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_attention_planes: head dim %d not supported (64, 128)", dh);
     if (flags & ~(MMDM_ATTN_NO_ZERO_KEY | MMDM_ATTN_CAUSAL)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: unknown flags 0x%x", flags);
     if ((flags & MMDM_ATTN_CAUSAL) && (Tq != Tk || !(flags & MMDM_ATTN_NO_ZERO_KEY)))
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: the causal mask needs Tq == Tk and no zero key");
-    if (ldq < H * dh || ldk < H * dh || ldv < H * dh || ldo < H * dh) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: row strides must cover H*dh=%d", H * dh);
-    const bool al = ((reinterpret_cast<uintptr_t>(Qp) | reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(V)) & 15) == 0 && ((ldq | ldk) & 7) == 0 &&
-                    (ldv & 3) == 0 && (q_plane & 7) == 0 && (k_plane & 7) == 0;
+    if (ldq < H * dh || ldk < H * dh || (!Vp && ldv < H * dh) || ldo < H * dh) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: row strides must cover H*dh=%d", H * dh);
+    // the fp32 V is not read when bf16 V rows are given (all-bf16 attention)
+    const bool al = ((reinterpret_cast<uintptr_t>(Qp) | reinterpret_cast<uintptr_t>(Kp) | (Vp ? 0 : reinterpret_cast<uintptr_t>(V))) & 15) == 0 && ((ldq | ldk) & 7) == 0 &&
+                    (Vp || (ldv & 3) == 0) && (q_plane & 7) == 0 && (k_plane & 7) == 0;
     if (!al) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: Q/K planes and V must be 16-byte aligned (bf16 strides %% 8, fp32 strides %% 4)");
     if ((reinterpret_cast<uintptr_t>(Ov) & 15) || (ldo & 3)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: O must be 16-byte aligned with a row stride %% 4 == 0");
     AttnArgs a;
