@@ -91,6 +91,13 @@ int mmdm_adaln_fp8(const float* h, const float* ss, int ss_ld, int ss_rows, void
  * Epilogues / extra / period as mmdm_linear_f32; K % 32 == 0, N % 4 == 0. */
 int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const void* W, int ldw, int64_t w_plane, const float* bias, void* C, int ldc,
                       int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
+/* The same product with W in FRAGMENT ORDER (static weights): mmdm_split_pack_weight permutes the three planes [3][N][K] inside blocks
+ * of 32 rows x 16 k so that one wave-wide 16-byte load is one MFMA operand; the kernel then takes W straight from global memory and only
+ * A goes through LDS.  Same term order per accumulator: results are bit-identical to mmdm_linear_split.  Needs N % 64 == 0, K % 64 == 0
+ * (packing alone: N % 32 == 0, K % 16 == 0); a row slice that starts at a multiple of 32 rows is the same offset as in the plane layout. */
+int mmdm_linear_split_packed(const void* A, int lda, int64_t a_plane, const void* W_packed, int64_t w_plane, const float* bias, void* C, int ldc,
+                             int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
+int mmdm_split_pack_weight(const void* W, int ldw, int64_t w_plane, void* out, int64_t out_plane, int N, int K, void* stream);
 /* Exact split of n contiguous fp32 values into three bf16 planes out[0], out[plane_stride], out[2*plane_stride] (elements). */
 int mmdm_f32_split3(const float* in, void* out, int64_t n, int64_t plane_stride, void* stream);
 

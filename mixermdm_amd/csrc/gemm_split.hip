@@ -34,6 +34,7 @@ struct SArgs {
     int M, N, K, epilogue, period, out_split;
     int mt, nt, ablate;
     int row0;                             // global index of row 0 (PE epilogue of a row-sliced launch)
+    unsigned long long* tl;               // diagnostic: per-wave phase cycle sums (tools/split_timeline.py), null in production
     __bf16* P2; size_t p2_plane; int p2_cols, ld2;   // optional second output: columns [0, p2_cols) also as three bf16 planes (attention Q/K operands)
 };
 
@@ -324,6 +325,259 @@ int set_attr() {
 }
 
 
+// ---- W straight from global memory (round 2, last experiment of the round) ------------------------------------------------------------
+// Timing ablations of the kernel above (ABL bits, tools/gemm_split_bench.py) showed that the W side of the LDS traffic -- a third of the
+// LDS-DMA pieces and half of the fragment reads -- costs 35 % of the layer shapes' rate (QKV 177 -> 238 TFLOP/s without it).  Weights
+// are static, so mmdm_prepare stores them in FRAGMENT ORDER (mmdm_split_pack_weight): block (plane, 32 rows, 16 k) is the 1 KiB that one
+// wave-wide 16-byte load delivers as the MFMA's B operand, lane (l31, lh) <- row 32*nb + l31, k = 16*kb + 8*lh .. +8.  The kernel then
+// fetches its B fragments with buffer_load_dwordx4 one whole step ahead (two register sets that swap every step), and LDS carries A only.
+// Same six-term order per accumulator: bit-identical to gemm_split_kernel.
+template <int TM_, int TN_, bool TL = false, int NV1_ = 0>
+__global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(SArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C_ = SCfg<TM_, TN_>;
+    constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
+    constexpr int NIA = C_::NA / C_::NWAVES;           // LDS-DMA pieces per wave and step (A only)
+    constexpr int NLB = 2 * 3 * TN;                    // B-fragment loads per wave and step
+    static_assert(C_::NA % C_::NWAVES == 0, "A pieces must divide evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                  // [3 stages][3 planes][BM*16]
+
+    const int nwg = p.mt * p.nt;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (swz / p.nt) * BM;
+    const int n0 = (swz % p.nt) * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C_::WGN, wn = wave % C_::WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nkt = p.K / BK;
+
+    int voff[NIA], dst[NIA];
+#pragma unroll
+    for (int u = 0; u < NIA; ++u) {
+        const int pq = wave + C_::NWAVES * u;
+        const int prow = lane >> 2, pc = lane & 3;
+        const int pl = pq / C_::NAP, pp = pq % C_::NAP;
+        const int trow = 16 * pp + prow;
+        const int gch = pc ^ ((trow >> 2) & 3);
+        const int rel = min(trow, p.M - 1 - m0);
+        voff[u] = (int)(((size_t)pl * p.pa + (size_t)rel * p.lda) * 2) + 16 * gch;
+        dst[u] = pl * C_::A_PLANE + 16 * pp * 16;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.A + (size_t)m0 * p.lda), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.W), 0, 0xffffffff, 0x00020000);
+    auto stage_part = [&](int buf, int kt, auto u0c, auto u1c) {      // kt clamped: the loop stays branch-free, a surplus request re-reads the last tile
+        const int koff = min(kt, nkt - 1) * 64;
+#pragma unroll
+        for (int u = decltype(u0c)::value; u < decltype(u1c)::value; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + dst[u] + buf * C_::A_FLOATS), 16, voff[u], koff, 0, 0);
+    };
+    auto stage = [&](int buf, int kt) { stage_part(buf, kt, std::integral_constant<int, 0>{}, std::integral_constant<int, NIA>{}); };
+    // packed W: byte offset of block (plane, nb, kb16) = plane*pw*2 + (nb*(K/16) + kb16)*1024; this wave owns nb = n0/32 + wn*TN + j
+    int voffW[3][TN];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) voffW[pl][j] = (int)((size_t)pl * p.pw * 2) + ((n0 >> 5) + wn * TN + j) * (p.K >> 4) * 1024 + lane * 16;
+    auto ldb = [&](int kt, bf16x8 (&b0)[3][TN], bf16x8 (&b1)[3][TN]) {
+        const int so = min(kt, nkt - 1) * 2048;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b0[pl][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[pl][j], so, 0));
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b1[pl][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[pl][j] + 1024, so, 0));
+    };
+
+    f32x16 acc[TM][TN];
+    {
+        f32x4 bv[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int colc = min(n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh, p.N - 4);
+                bv[j][qd] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = bv[j][qd][c];
+    }
+
+    const int sw = (l31 >> 2) & 3;
+    const int a_row = (wm * (32 * TM) + l31) * 16;
+    bf16x8 f0a[3][TM], f1a[3][TM];
+    bf16x8 bx0[3][TN], bx1[3][TN], by0[3][TN], by1[3][TN];
+    auto rda = [&](int buf, int kb, bf16x8 (&af)[3][TM]) {
+        const float* Ac = As + buf * C_::A_FLOATS + a_row;
+        const int cg = 4 * ((2 * kb + lh) ^ sw);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ac + pl * C_::A_PLANE + i * 32 * 16 + cg));
+    };
+    auto mm = [&](auto t0c, auto t1c, const bf16x8 (&af)[3][TM], const bf16x8 (&bf)[3][TN]) {
+        constexpr int t0 = decltype(t0c)::value, t1 = decltype(t1c)::value;
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = t0; t < t1; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I3 = std::integral_constant<int, 3>; using I6 = std::integral_constant<int, 6>;
+    constexpr int NRDA = 3 * TM, NT = TM * TN;
+    constexpr int NPB = NLB < 6 * NT - 1 ? NLB : 6 * NT - 1;        // B loads that get an MFMA of their own to hide behind
+    constexpr int NPA = NIA < 3 * NT - 1 ? NIA : 3 * NT - 1;        // same for the A pieces
+    // one K step: B fragments (b0, b1) of this step are in registers (or on their way: the compiler counts them), (n0_, n1_) receive the next step's
+    unsigned long long tsum[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int slot) {              // s_memtime (shader clock); the read drains lgkmcnt, so stamps sit where that is due anyway
+        if constexpr (TL) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_readcyclecounter();
+            if (slot >= 0) tsum[slot] += t - tprev;
+            tprev = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // Three A stages: the stage after next is requested DURING the step, not after its barrier.  The in-kernel timeline (tools/split_timeline.py)
+    // of the two-stage form showed why: all eight waves leave the barrier together and push their LDS-DMA requests into the CU's one address
+    // unit at once (16 cycles per 1-KiB instruction); a wave whose request cannot issue cannot issue the MFMAs behind it either -- the 12 MFMAs
+    // after the barrier took 125 cycles each instead of 32, and the waves reached the next barrier 900 cycles apart.  With a third stage
+    // buffer (kt+2) % 3 is free from the previous step's barrier on, so the step's VMEM instructions -- next step's B fragments and the A pieces of the
+    // stage after next -- are spread one by one over the 9*NT MFMAs before the barrier, NV1 of the A pieces over the 3*NT after it.
+    constexpr int NV1 = NV1_ < NIA ? NV1_ : NIA;                 // A pieces requested after the barrier
+    constexpr int NV0 = NLB + NIA - NV1;                            // VMEM instructions before it
+    constexpr int SP0 = (9 * NT - 1) / NV0 > 0 ? (9 * NT - 1) / NV0 : 1, NP0 = NV0 * SP0 <= 9 * NT - 1 ? NV0 : (9 * NT - 1) / SP0;
+    constexpr int NP1 = NV1 < 3 * NT - 1 ? NV1 : 3 * NT - 1;
+    auto step = [&](int kt, int cur, int nxt, int nn, bf16x8 (&b0)[3][TN], bf16x8 (&b1)[3][TN], bf16x8 (&n0_)[3][TN], bf16x8 (&n1_)[3][TN]) {
+        stamp(kt == 0 ? -1 : 4);
+        rda(cur, 1, f1a);
+        ldb(kt + 1, n0_, n1_);
+        stage_part(nn, kt + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, NIA - NV1>{});
+        mm(I0{}, I6{}, f0a, b0);
+        mm(I0{}, I3{}, f1a, b1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRDA, 0);
+#pragma unroll
+        for (int u = 0; u < NP0; ++u) { __builtin_amdgcn_sched_group_barrier(0x008, SP0, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x010, NV0 - NP0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 9 * NT - 1 - SP0 * NP0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV0) : "memory");     // A stage kt+1 landed (requested during step kt-1); this step's requests may be in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(2);
+        __builtin_amdgcn_s_barrier();                                   // every wave has read all of stage kt and sees stage kt+1
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(3);
+        rda(nxt, 0, f0a);
+        stage_part(nn, kt + 2, std::integral_constant<int, NIA - NV1>{}, std::integral_constant<int, NIA>{});
+        mm(I3{}, I6{}, f1a, b1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRDA, 1);
+#pragma unroll
+        for (int u = 0; u < NP1; ++u) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1); }
+        __builtin_amdgcn_sched_group_barrier(0x010, NV1 - NP1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    stage(0, 0);
+    ldb(0, bx0, bx1);
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
+    __builtin_amdgcn_s_barrier();
+    rda(0, 0, f0a);
+    int cur = 0;
+    for (int kt = 0; kt < nkt; kt += 2) {                 // nkt is even (host check): the two B register sets swap roles every step
+        const int c1 = cur == 2 ? 0 : cur + 1, c2 = c1 == 2 ? 0 : c1 + 1;
+        step(kt, cur, c1, c2, bx0, bx1, by0, by1);
+        step(kt + 1, c1, c2, cur, by0, by1, bx0, bx1);
+        cur = c2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus requests of the last steps
+    if constexpr (TL) {
+        stamp(4);
+        if (p.tl && lane == 0) {
+            unsigned long long* o = p.tl + ((size_t)blockIdx.x * C_::NWAVES + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) o[i] = tsum[i];
+            o[5] = (unsigned long long)nkt;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
+
+    if (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rowc = min(m0 + wm * (32 * TM) + i * 32 + l31, p.M - 1);
+            const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (rowc + p.row0) % p.period : rowc;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int colc = min(n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh, p.N - 4);
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + colc);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] += rv[c];
+                }
+        }
+    }
+    split_finish<TM, TN, BM>(p, acc, m0, n0, wm, wn, l31, lh);
+#endif
+}
+
+template <int TM_, int TN_, int NV1_ = 0>
+int launch_w(SArgs a, hipStream_t st) {
+    using C_ = SCfg<TM_, TN_>;
+    a.mt = (a.M + C_::BM - 1) / C_::BM;
+    a.nt = (a.N + C_::BN - 1) / C_::BN;
+    mmdm_note_gemm("gemm_splitw<%d,%d>", TM_, TN_);
+    if (a.tl) hipLaunchKernelGGL((gemm_splitw_kernel<TM_, TN_, true, NV1_>), dim3(a.mt * a.nt), dim3(C_::THREADS), 3 * C_::A_FLOATS * 4, st, a);
+    else hipLaunchKernelGGL((gemm_splitw_kernel<TM_, TN_, false, NV1_>), dim3(a.mt * a.nt), dim3(C_::THREADS), 3 * C_::A_FLOATS * 4, st, a);
+    return mmdm_check_launch("gemm_splitw");
+}
+
+template <int TM_, int TN_, int NV1_ = 0>
+int set_attr_w() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_splitw_kernel<TM_, TN_, false, NV1_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SCfg<TM_, TN_>::A_FLOATS * 4);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_splitw_kernel<TM_, TN_, true, NV1_>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SCfg<TM_, TN_>::A_FLOATS * 4);
+    if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_splitw): %s", hipGetErrorString(e));
+    return MMDM_OK;
+}
+
+// [3][N][K] planes -> fragment order (see gemm_splitw_kernel); one thread per 16-byte chunk
+__global__ void pack_split_w_kernel(const __bf16* __restrict__ in, int ldw, size_t in_plane, __bf16* __restrict__ out, size_t out_plane, int N, int K) {
+    const size_t per_plane = (size_t)N * K / 8;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < 3 * per_plane; c += (size_t)gridDim.x * blockDim.x) {
+        const int pl = (int)(c / per_plane);
+        const size_t o = c % per_plane;                       // chunk index inside the plane: ((nb*KB16 + kb16)*64 + lh*32 + l31)
+        const int ln = (int)(o & 63), l31 = ln & 31, lh = ln >> 5;
+        const size_t blk = o >> 6;
+        const int kb16 = (int)(blk % (size_t)(K >> 4)), nb = (int)(blk / (size_t)(K >> 4));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + pl * in_plane + (size_t)(nb * 32 + l31) * ldw + kb16 * 16 + lh * 8);
+        *reinterpret_cast<f32x4*>(out + pl * out_plane + o * 8) = v;
+    }
+}
+
 // x -> three bf16 planes out[0], out[plane], out[2*plane]; exact: x == out0 + out1 + out2 in real arithmetic
 __global__ void split3_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n, size_t plane) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -339,6 +593,7 @@ __global__ void split3_kernel(const float* __restrict__ in, __bf16* __restrict__
 
 int g_split_cfg = -1;
 int g_split_ablate = 0;
+unsigned long long* g_split_tl = nullptr;
 
 }  // namespace
 
@@ -348,6 +603,9 @@ int mmdm_gemm_split_init(void) {
     if ((rc = set_attr<42, 22>())) return rc;
     if ((rc = set_attr<22, 21>())) return rc;
     if ((rc = set_attr<24, 22>())) return rc;
+    if ((rc = set_attr_w<22, 21>())) return rc;
+    if ((rc = set_attr_w<12, 41>())) return rc;
+    if ((rc = set_attr_w<14, 41>())) return rc;
     const char* e = getenv("MMDM_SPLIT_CFG");
     g_split_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
@@ -355,6 +613,7 @@ int mmdm_gemm_split_init(void) {
 
 extern "C" void mmdmx_set_split_cfg(int c) { g_split_cfg = c; }
 extern "C" void mmdmx_set_split_ablate(int c) { g_split_ablate = c; }
+extern "C" void mmdmx_set_split_timeline(void* buf) { g_split_tl = static_cast<unsigned long long*>(buf); }   // 8 u64 per wave of the next packed launches
 
 extern "C" int mmdm_f32_split3(const float* in, void* out, int64_t n, int64_t plane_stride, void* stream) {
     if (n <= 0) return MMDM_OK;
@@ -368,9 +627,30 @@ extern "C" int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const 
     return mmdm_linear_split_ex(A, lda, a_plane, W, ldw, w_plane, bias, C, ldc, c_plane, out_split, M, N, K, epilogue, extra, ld_extra, period, nullptr, 0, 0, 0, stream);
 }
 
+extern "C" int mmdm_linear_split_packed(const void* A, int lda, int64_t a_plane, const void* Wp, int64_t w_plane, const float* bias, void* C, int ldc,
+                                        int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
+    return mmdm_linear_split_ex(A, lda, a_plane, Wp, 0, w_plane, bias, C, ldc, c_plane, out_split, M, N, K, epilogue, extra, ld_extra, period, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int mmdm_split_pack_weight(const void* W, int ldw, int64_t w_plane, void* out, int64_t out_plane, int N, int K, void* stream) {
+    if (N == 0) return MMDM_OK;
+    if (!W || !out || N < 0 || K <= 0 || (N & 31) || (K & 15) || ldw < K || (ldw & 7) || (w_plane & 7) || out_plane < (int64_t)N * K || (out_plane & 7))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_split_pack_weight: needs N %% 32 == 0, K %% 16 == 0, 16-byte aligned rows / planes (N=%d K=%d ldw=%d)", N, K, ldw);
+    if ((reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_split_pack_weight: unaligned pointer");
+    hipLaunchKernelGGL(pack_split_w_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(W), ldw, (size_t)w_plane,
+                       static_cast<__bf16*>(out), (size_t)out_plane, N, K);
+    return mmdm_check_launch("split_pack_weight");
+}
+
+// ldw == 0: W is in fragment order (mmdm_split_pack_weight); served by gemm_splitw_kernel
 int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W, int ldw, int64_t w_plane, const float* bias, void* C, int ldc,
                          int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period,
                          void* planes2, int ld2, int64_t plane2_stride, int planes2_cols, void* stream) {
+    const bool packed = ldw == 0;
+    if (packed) {
+        if ((N & 63) || (K & 63)) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split_packed: needs N %% 64 == 0 and K %% 64 == 0 (N=%d K=%d)", N, K);
+        ldw = K;
+    }
     mmdm_note_gemm_reset();
     if (M == 0 || N == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
@@ -392,11 +672,18 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
     a.pa = (size_t)a_plane; a.pw = (size_t)w_plane; a.pc = (size_t)c_plane;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
     a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_split = out_split;
-    a.mt = a.nt = 0; a.ablate = g_split_ablate; a.row0 = 0;
+    a.mt = a.nt = 0; a.ablate = g_split_ablate; a.row0 = 0; a.tl = packed ? g_split_tl : nullptr;
     a.P2 = static_cast<__bf16*>(planes2); a.p2_plane = (size_t)plane2_stride; a.p2_cols = planes2_cols; a.ld2 = ld2;
     if (planes2 && ((ld2 & 3) || (plane2_stride & 3) || (planes2_cols & 3) || !al16(planes2)))
         return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split: second output needs 8-byte aligned bf16 rows / planes");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (packed) {
+        // measured at M = 19 200 (tools/gemm_split_bench.py, PCFGS): 128x128 tiles of four 128x32 waves, two workgroups per CU (215-221 TFLOP/s on
+        // the layer shapes against 182-192 of the plane kernels); 64x128 tiles for the N <= 512 mixer GEMMs; 128x64 when N is not a multiple of 128
+        if (N & 127) return launch_w<22, 21>(a, st);
+        if (g_split_cfg == 5 || (g_split_cfg != 6 && N <= 512)) return launch_w<12, 41>(a, st);
+        return launch_w<14, 41>(a, st);
+    }
     switch (g_split_cfg) {
         case 0: return launch<22, 22>(a, st);
         case 1: return launch<42, 22>(a, st);

@@ -102,6 +102,7 @@ struct LayerWB {         // bf16 twins of the stack GEMM weights (precision >= 1
 struct StackW {          // a transformer stack: denoiser blocks or Influence blocks
     int D = 0, F = 0, L = 0, H = 0, n_ada = 0;
     bool has_ca = false;
+    bool w_packed = false;                      // fp32-split weights stored in MFMA fragment order (mmdm_split_pack_weight; gemm_splitw_kernel)
     float *ada_w = nullptr, *ada_b = nullptr;   // [L*n_ada*2D, D], [L*n_ada*2D]  (slots: sa, [ca_q, ca_kv,] ffn)
     std::vector<LayerW> layers;
     std::vector<LayerWB> layers_b;
@@ -502,7 +503,7 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     // wtot = elements of the whole weight matrix the twin was made from (its plane stride); the A plane stride is R*K.
     auto gemm = [&](const float* A, int lda, const float* Wf, const void* Wb, size_t woff, size_t wtot, const float* bias, float* C, int ldc, int out_b,
                     int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) -> int {
-        if (prec == 2) return linear_s(c, A, lda, (size_t)R * K, bw(Wb, woff), K, wtot, bias, C, ldc, (size_t)R * N, out_b == 2, R, N, K, epi, extra, ld_extra, s2);
+        if (prec == 2) return linear_s(c, A, lda, (size_t)R * K, bw(Wb, woff), w.w_packed ? 0 : K, wtot, bias, C, ldc, (size_t)R * N, out_b == 2, R, N, K, epi, extra, ld_extra, s2);
 
         if (bf) return linear_b(c, A, lda, bw(Wb, woff), K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra, s2);
         return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra);
@@ -1042,9 +1043,28 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
     if (h->cfg.single_only == 0 && !h->stats_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_prepare: normaliser stats not set"));
     if (h->cfg.precision >= 1) {
         const bool split = h->cfg.precision == 2;
-        auto conv = [&](const float* src, void* dst, int64_t n) { return split ? mmdm_f32_split3(src, dst, n, n, nullptr) : mmdm_f32_to_bf16(src, dst, n, nullptr); };
+        // fp32-split weights of a stack whose sizes the packed kernel covers (every N a multiple of 128, every K of 64, slices on 32-row
+        // boundaries) are stored in fragment order: split into a scratch buffer, then permuted into place (same size, same plane stride)
+        static const bool no_pack = getenv("MMDM_SPLIT_NO_PACK") != nullptr;
+        void* tmp = nullptr;
+        size_t tmp_elems = 0;
         for (ModuleW* m : {&h->d1, &h->d2, &h->mx}) {
             StackW& st = m->st;
+            st.w_packed = split && !no_pack && !st.layers_b.empty() && st.D % 128 == 0 && st.F % 128 == 0;
+            if (st.w_packed) tmp_elems = std::max(tmp_elems, (size_t)3 * std::max(3 * st.D, st.F) * st.D);
+        }
+        if (tmp_elems) HIPCHK(hipMalloc(&tmp, tmp_elems * 2));
+        struct TmpFree { void* p; ~TmpFree() { if (p) (void)hipFree(p); } } tmp_free{tmp};
+        bool pack_now = false;
+        auto conv = [&](const float* src, void* dst, int64_t n, int64_t K = 0) -> int {
+            if (!split) return mmdm_f32_to_bf16(src, dst, n, nullptr);
+            if (!pack_now) return mmdm_f32_split3(src, dst, n, n, nullptr);
+            if (int rc = mmdm_f32_split3(src, tmp, n, n, nullptr)) return rc;
+            return mmdm_split_pack_weight(tmp, (int)K, n, dst, n, (int)(n / K), (int)K, nullptr);
+        };
+        for (ModuleW* m : {&h->d1, &h->d2, &h->mx}) {
+            StackW& st = m->st;
+            pack_now = st.w_packed;
             for (size_t i = 0; i < st.layers_b.size(); ++i) {
                 const LayerW& lw = st.layers[i];
                 LayerWB& lb = st.layers_b[i];
@@ -1061,12 +1081,12 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
                     if (rc) return herr(h, rc);
                     continue;
                 }
-                rc = conv(lw.sa_in_w, lb.sa_in_w, 3 * D * D);
-                if (!rc) rc = conv(lw.sa_out_w, lb.sa_out_w, D * D);
-                if (!rc) rc = conv(lw.f1_w, lb.f1_w, F * D);
-                if (!rc) rc = conv(lw.f2_w, lb.f2_w, D * F);
-                if (!rc && st.has_ca) rc = conv(lw.ca_in_w, lb.ca_in_w, 3 * D * D);
-                if (!rc && st.has_ca) rc = conv(lw.ca_out_w, lb.ca_out_w, D * D);
+                rc = conv(lw.sa_in_w, lb.sa_in_w, 3 * D * D, D);
+                if (!rc) rc = conv(lw.sa_out_w, lb.sa_out_w, D * D, D);
+                if (!rc) rc = conv(lw.f1_w, lb.f1_w, F * D, D);
+                if (!rc) rc = conv(lw.f2_w, lb.f2_w, D * F, F);
+                if (!rc && st.has_ca) rc = conv(lw.ca_in_w, lb.ca_in_w, 3 * D * D, D);
+                if (!rc && st.has_ca) rc = conv(lw.ca_out_w, lb.ca_out_w, D * D, D);
                 if (rc) return herr(h, rc);
             }
         }

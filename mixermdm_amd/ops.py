@@ -243,9 +243,21 @@ def split3(x):
     return out
 
 
-def linear_split(xs, ws, bias=None, epilogue="bias", extra=None, period=0, split_out=False):
+def split_pack_weight(ws):
+    """Split weights ws [3, N, K] (split3) -> the same elements in MFMA fragment order, for linear_split(..., packed=True).
+    N % 32 == 0, K % 16 == 0; the result keeps the shape so that N and K can be read back from it."""
+    if not ws.is_cuda or ws.dtype != torch.bfloat16 or ws.dim() != 3 or ws.shape[0] != 3 or not ws.is_contiguous():
+        raise TypeError("split_pack_weight expects a contiguous CUDA bfloat16 [3, N, K] tensor (ops.split3)")
+    _, N, K = ws.shape
+    out = torch.empty_like(ws)
+    check(load_library().mmdm_split_pack_weight(C.c_void_p(ws.data_ptr()), K, N * K, C.c_void_p(out.data_ptr()), N * K, N, K, _stream()))
+    return out
+
+
+def linear_split(xs, ws, bias=None, epilogue="bias", extra=None, period=0, split_out=False, packed=False):
     """fp32 y = x @ w.T + bias computed on the bf16 matrix cores from exactly split operands xs [3, M, K], ws [3, N, K] (split3).
-    Returns fp32 [M, N], or its split [3, M, N] when split_out."""
+    Returns fp32 [M, N], or its split [3, M, N] when split_out.  packed: ws comes from split_pack_weight (W straight from global memory
+    in fragment order; bit-identical results)."""
     for t in (xs, ws):
         if not t.is_cuda or t.dtype != torch.bfloat16 or t.shape[0] != 3 or not t.is_contiguous():
             raise TypeError("linear_split expects contiguous CUDA bfloat16 [3, rows, K] operands (ops.split3)")
@@ -253,6 +265,10 @@ def linear_split(xs, ws, bias=None, epilogue="bias", extra=None, period=0, split
     _, M, K = xs.shape
     N = ws.shape[1]
     out = torch.empty((3, M, N) if split_out else (M, N), device=xs.device, dtype=torch.bfloat16 if split_out else torch.float32)
+    if packed:
+        check(load_library().mmdm_linear_split_packed(C.c_void_p(xs.data_ptr()), K, M * K, C.c_void_p(ws.data_ptr()), N * K, _p(bias), C.c_void_p(out.data_ptr()), N,
+                                                      M * N, int(split_out), M, N, K, EPI[epilogue], _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
+        return out
     check(load_library().mmdm_linear_split(C.c_void_p(xs.data_ptr()), K, M * K, C.c_void_p(ws.data_ptr()), K, N * K, _p(bias), C.c_void_p(out.data_ptr()), N,
                                            M * N, int(split_out), M, N, K, EPI[epilogue], _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
     return out

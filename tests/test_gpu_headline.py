@@ -278,6 +278,14 @@ def test_production_split_gemm_tiles_vs_float64(gemm_operands, N, K, epi):
     if epi == "gelu":                         # three-plane output = exact split of the fp32 output
         g3 = ops.linear_split(xs, ws, b.to(d), epi, split_out=True)
         assert torch.equal(g3[0].float() + g3[1].float() + g3[2].float(), got)
+    # the kernel the fp32-split sampler runs (weights in fragment order, W straight from global memory): same bits, and the instantiation is asserted
+    wp = ops.split_pack_weight(ws)
+    got_p = ops.linear_split(xs, wp, b.to(d), epi, r.to(d) if r is not None else None, packed=True)
+    kern_p = load_library().mmdm_last_gemm_kernel().decode()
+    assert kern_p in PRODUCTION_SPLIT_PACKED, (N, K, epi, kern_p)
+    assert torch.equal(got_p, got), f"packed fp32-split GEMM differs from the plane kernel: 19200x{N}x{K} {epi} on {kern_p}"
+    if epi == "gelu":
+        assert torch.equal(ops.linear_split(xs, wp, b.to(d), epi, split_out=True, packed=True), g3)
 
 
 @pytest.mark.parametrize("N,K,epi", SHAPES[:4])
@@ -299,6 +307,7 @@ def test_production_bf16_gemm_tiles_vs_float64_of_rounded_operands(N, K, epi):
 # instantiations the dispatch rules pick at M = 19 200 (update together with the rules in gemm_f32.hip / gemm_split.hip / gemm_bf16.hip)
 PRODUCTION_F32 = {"gemm_pipe<22,22,16,5,vepi>", "gemm_pipe<22,22,16,5,scalar>", "gemm_pipe<22,21,16,4,vepi>", "gemm_pipe<22,21,16,4,scalar>"}
 PRODUCTION_SPLIT = {"gemm_split<42,22>", "gemm_split<22,21>"}
+PRODUCTION_SPLIT_PACKED = {"gemm_splitw<14,41>", "gemm_splitw<12,41>"}
 PRODUCTION_BF16 = {"gemm_bf16<42,22>"}
 
 

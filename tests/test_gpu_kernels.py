@@ -494,3 +494,36 @@ def test_attention_with_bf16_plane_scores(dh, H, T, zero_key, causal):
     assert e3 <= 2 * en + 1e-8, (e3, en)
     got1 = ops.attention_planes(q.contiguous().bfloat16()[None], k.contiguous().bfloat16()[None], v, H, zero_key=zero_key, causal=causal)
     assert_close(got1, ref(qc.bfloat16().float(), kc.bfloat16().float(), vc), atol=2e-5, rtol=1e-4, what="attention, bf16 Q/K")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (257, 192, 128), (1000, 384, 1024), (64, 512, 512), (5, 1152, 192)])
+def test_linear_split_packed_is_bitwise_the_plane_kernel(M, N, K):
+    """W in fragment order (mmdm_split_pack_weight) and fetched straight from global memory: every tile shape of the packed dispatch
+    (128x128, 64x128 for N <= 512, 128x64 for N % 128 != 0), ragged M, every epilogue and both output forms against the plane kernel."""
+    import mixermdm_amd as mm
+    from mixermdm_amd import ops
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x, w, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    xs, ws = ops.split3(x.to(d)), ops.split3(w.to(d))
+    wp = ops.split_pack_weight(ws)
+    assert torch.equal(wp.flatten().sort().values, ws.flatten().sort().values)          # a permutation of the same elements
+    for epi, extra in [("bias", None), ("gelu", None), ("silu", None), ("resid", r.to(d))]:
+        want = ops.linear_split(xs, ws, b.to(d), epi, extra)
+        got = ops.linear_split(xs, wp, b.to(d), epi, extra, packed=True)
+        assert torch.equal(got, want), (epi, M, N, K)
+    assert torch.equal(ops.linear_split(xs, wp, None, "gelu", split_out=True, packed=True), ops.linear_split(xs, ws, None, "gelu", split_out=True))
+    # a row slice of the packed matrix that starts on a 32-row boundary is the same offset as in the plane layout (the K|V slice of a packed projection)
+    if N >= 128:
+        n0 = 64
+        lib = mm.load_library()
+        import ctypes as C
+        out = torch.empty(M, N - n0, device=d)
+        rc = lib.mmdm_linear_split_packed(C.c_void_p(xs.data_ptr()), K, M * K, C.c_void_p(wp.data_ptr() + n0 * K * 2), N * K, C.c_void_p(b.to(d)[n0:].contiguous().data_ptr()),
+                                          C.c_void_p(out.data_ptr()), N - n0, 0, 0, M, N - n0, K, ops.EPI["bias"], None, 0, 0, None)
+        assert rc == 0, lib.mmdm_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ops.linear_split(xs, ws, b.to(d))[:, n0:])
+    with pytest.raises(Exception):
+        ops.linear_split(ops.split3(x[:, :48].contiguous().to(d)), ops.split_pack_weight(ops.split3(w[:, :48].contiguous().to(d))), packed=True)   # K % 64

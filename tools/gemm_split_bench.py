@@ -38,7 +38,31 @@ for M,N,K,name,epi in shapes:
     out = torch.empty(M,N,device=d); extra = out if epi=="resid" else None
     xs, ws = split(x), split(w)
     line = f"{name:7s} {M}x{N}x{K} {epi:5s}"
-    for c in cfgs:
+    wp = torch.empty_like(ws)
+    assert lib.mmdm_split_pack_weight(vp(ws), K, N * K, vp(wp), N * K, N, K, st()) == 0, lib.mmdm_last_error()
+    def lin_packed(xs, wp, b, epi, extra, out, M, N, K):
+        rc = lib.mmdm_linear_split_packed(vp(xs), K, M * K, vp(wp), N * K, vp(b), vp(out), N, 0, 0, M, N, K, ops.EPI[epi], vp(extra), N if extra is not None else 0, 0, st())
+        assert rc == 0, lib.mmdm_last_error()
+    if epi != "resid":
+        o1 = torch.empty(M, N, device=d); o2 = torch.empty(M, N, device=d)
+        lib.mmdmx_set_split_cfg(-1)
+        lin_split(xs, ws, b, epi, None, o1, M, N, K); lin_packed(xs, wp, b, epi, None, o2, M, N, K)
+        line += " | packed==planes: " + str(torch.equal(o1, o2))
+        for c in os.environ.get("PCFGS", "p-1,p5").split(","):
+            lib.mmdmx_set_split_cfg(int(c[1:])); lin_packed(xs, wp, b, epi, None, o2, M, N, K); line += "/" + str(torch.equal(o1, o2))
+    pk = os.environ.get("PCFGS", "p-1,p5").split(",")
+    for c in cfgs + pk:
+        if isinstance(c, str):
+            lib.mmdmx_set_split_cfg(int(c[1:]))
+            ts = []
+            for r in range(5):
+                lin_packed(xs, wp, b, epi, extra, out, M, N, K)
+                e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(4): lin_packed(xs, wp, b, epi, extra, out, M, N, K)
+                e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1)/4)
+            ms = statistics.median(ts); line += f" | {c}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:6.1f}TF"
+            continue
         lib.mmdmx_set_split_cfg(c)
         ts = []
         for r in range(5):
