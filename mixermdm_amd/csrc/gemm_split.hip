@@ -347,8 +347,17 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int m0 = (swz / p.nt) * BM;
-    const int n0 = (swz % p.nt) * BN;
+    // tiles that run together on an XCD (its chunk of consecutive indices) form blocks of GM m-tiles x 8 n-tiles, so both the A rows and the
+    // W blocks they stream are shared in that XCD's L2 (with n fastest, a 24-tile-wide QKV launch had every W block used by < 3 workgroups at a time)
+    int mi, ni;
+    {
+        const int GM = p.ablate & 32 ? 1 : 8;
+        const int per_g = GM * p.nt, g = swz / per_g, rem = swz - g * per_g;
+        const int gm = min(GM, p.mt - g * GM);               // rows in this (possibly last, shorter) group
+        ni = rem / gm; mi = g * GM + rem - ni * gm;
+    }
+    const int m0 = mi * BM;
+    const int n0 = ni * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
