@@ -28,7 +28,7 @@ struct GemmArgs {
     int M, N, K, Kw, epilogue, period;   // Kw >= K: readable columns of W (zero beyond K)
     int mt, nt;
     int ablate;                          // timing experiments only (tools/gemm_bench.py); 0 in production
-    unsigned long long* stamps;          // diagnostic builds of a launch only (tools/gemm_timeline.py): per-workgroup {start, loop start, loop end, placement, kernel end, kernel entry, -, -}
+    unsigned long long* stamps;          // diagnostic builds of a launch only (tools/gemm_timeline.py): per-workgroup {start, loop start, loop end, placement, kernel end, kernel entry, residual landed, stores issued}, then {s_memtime at loop start, loop end} per workgroup
                                          // in 100 MHz s_memrealtime ticks; nullptr in production (one never-taken scalar branch per workgroup)
 };
 
@@ -376,7 +376,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
         // the accumulator-init loads above must not be counted by the pipeline's vmcnt arithmetic
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (p.stamps && tid == 0) p.stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps && tid == 0) {
+        p.stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[8 * (size_t)gridDim.x + 2 * bid] = __builtin_readcyclecounter();       // s_memtime (shader clocks) beside the 100 MHz stamp: the clock inside the loop
+    }
     // fragment read offsets (floats): row*BK + 4*((2g + lh) ^ sw)
     const int sw = swz_of<CPR>(l31);
     const int a_row = (wm * (32 * TM) + l31) * BK;
@@ -540,7 +543,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
-    if (p.stamps && tid == 0) p.stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps && tid == 0) {
+        p.stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[8 * (size_t)gridDim.x + 2 * bid + 1] = __builtin_readcyclecounter();
+    }
     if (p.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) p.stamps[8 * (size_t)bid + 6] = __builtin_amdgcn_s_memrealtime();

@@ -504,6 +504,8 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(
         __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 1);
         __builtin_amdgcn_sched_barrier(0);
     };
+    unsigned long long rt0 = 0, ct0 = 0;
+    if constexpr (TL) { rt0 = __builtin_amdgcn_s_memrealtime(); ct0 = __builtin_readcyclecounter(); }
     stage(0, 0);
     ldb(0, bx0, bx1);
     stage(1, 1);
@@ -525,6 +527,8 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(
 #pragma unroll
             for (int i = 0; i < 5; ++i) o[i] = tsum[i];
             o[5] = (unsigned long long)nkt;
+            o[6] = __builtin_amdgcn_s_memrealtime() - rt0;       // 100 MHz reference ticks over the loop
+            o[7] = __builtin_readcyclecounter() - ct0;           // s_memtime ticks over the same stretch: their ratio is the shader clock
         }
     }
 #pragma unroll
@@ -691,6 +695,8 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
         // the layer shapes against 182-192 of the plane kernels); 64x128 tiles for the N <= 512 mixer GEMMs; 128x64 when N is not a multiple of 128
         if (N & 127) return launch_w<22, 21>(a, st);
         if (g_split_cfg == 5 || (g_split_cfg != 6 && N <= 512)) return launch_w<12, 41>(a, st);
+        // (a main launch of whole rounds plus a 64x128 remainder, as the plane kernels do for N <= 1024, was measured: no gain or slower -- the
+        // kernel runs against the power-managed clock, not against the round count: tools/split_timeline.py reads 1.5 GHz inside the loop)
         return launch_w<14, 41>(a, st);
     }
     switch (g_split_cfg) {

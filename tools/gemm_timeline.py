@@ -23,9 +23,16 @@ for name in (sys.argv[1:] or ["out", "qkv"]):
     e0.record(); ops.linear(x, w, b, epi, extra, out=out); e1.record(); torch.cuda.synchronize()
     lib.mmdmx_set_gemm_stamps(C.c_void_p(0))
     kern = lib.mmdm_last_gemm_kernel().decode()
-    s = stamps.cpu().numpy().reshape(-1, 8)
-    n = int((s[:, 0] != 0).sum())
-    s = s[:n]
+    raw = stamps.cpu().numpy()
+    import re
+    tm_, tn_ = [int(v) for v in re.search(r"<(\d+),(\d+)", kern).groups()]
+    bm, bn = 32 * (tm_ // 10) * (tm_ % 10), 32 * (tn_ // 10) * (tn_ % 10)
+    n = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)                 # workgroups of the launch
+    s = raw[:8 * n].reshape(n, 8)
+    ck = raw[8 * n:10 * n].reshape(n, 2)                             # s_memtime at loop start / loop end
+    mhz = 100.0 * (ck[:, 1] - ck[:, 0]) / np.maximum(s[:, 2] - s[:, 1], 1)
+    print(f"{name}: shader clock inside the K loop (s_memtime / s_memrealtime): median {np.median(mhz):.0f} MHz, min {mhz.min():.0f}, max {mhz.max():.0f}"
+          f"  -> the fp32 matrix peak at that clock is {157.3 * np.median(mhz) / 2400:.1f} TFLOP/s")
     t0 = s[:, 0].min()
     t0 = s[:, 5].min()
     st, lp, en = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0, (s[:, 2] - t0) / 100.0      # us

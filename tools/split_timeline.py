@@ -24,14 +24,16 @@ for cfg in [int(c) for c in os.environ.get("CFGS", "-1,5").split(",")]:
       wp = torch.empty_like(ws)
       assert lib.mmdm_split_pack_weight(vp(ws), K, N * K, vp(wp), N * K, N, K, st()) == 0
       call = lambda: lib.mmdm_linear_split_packed(vp(xs), K, M * K, vp(wp), N * K, vp(b), vp(out), N, 0, 0, M, N, K, 0, None, 0, 0, st())
-      for _ in range(30): call()
-      nwg = ((M + 255) // 256) * (N // 128)
-      tl = torch.zeros(nwg * 8 * 8, device=d, dtype=torch.int64)
+      for _ in range(int(os.environ.get("WARM", "30"))): call()
+      nwg = ((M + 127) // 128) * (N // 128)
+      tl = torch.zeros(nwg * 4 * 8, device=d, dtype=torch.int64)
       lib.mmdmx_set_split_timeline(vp(tl)); assert call() == 0; torch.cuda.synchronize(); lib.mmdmx_set_split_timeline(None)
-      t = tl.view(nwg, 8, 8).double().cpu()
+      t = tl.view(nwg, 4, 8).double().cpu()
       nkt = t[0, 0, 5].item()
       per = t[:, :, :5] / nkt                     # cycles per step and phase
       mean = per.mean(dim=(0, 1)); tot = mean.sum().item()
       ideal = 48 * 32 * 2                          # 48 MFMAs x 32 cycles (8 passes x 4), two waves per SIMD
+      mhz = (t[:, :, 7] / t[:, :, 6].clamp(min=1)).median().item() * 100
+      print(f"s_memtime / s_memrealtime over the loop: {mhz:.0f} MHz; loop {t[:, :, 6].median().item() / 100:.1f} us per tile")
       print(f"{M}x{N}x{K}: {tot:.0f} shader clocks per step (MFMA-bound: {ideal}); phases " + " ".join(f"{v:.0f}" for v in mean.tolist())
             + f" | per-wave spread of the total: min {per.sum(-1).min():.0f} max {per.sum(-1).max():.0f}")
