@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-alt", action="store_true", help="skip the extra fp32_split measurement reported next to the fp32 headline (N=1 only)")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the real 1000-step sample() from x_T to x_0 reported as `full_loop`")
+    ap.add_argument("--no-clock", action="store_true", help="skip the in-loop shader-clock measurement (301 extra GEMM launches; tools/profile_round.sh passes it so that "
+                                                             "the committed kernel traces hold the step's launches only)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks meet on gloo, time a barrier, rank 0 prints a line")
     args = ap.parse_args()
 
@@ -172,7 +174,7 @@ def main():
                 "attention": {"achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a_ms / args.profile_steps, 3),
                               "launches_per_step": a_n // args.profile_steps}}
         try:
-            roof["clock"] = loop_clock(args.precision, 4 * B * T if not single else 2 * B * T, peak, ach)
+            roof["clock"] = None if args.no_clock else loop_clock(args.precision, 4 * B * T if not single else 2 * B * T, peak, ach)
         except Exception as e:          # a diagnostic next to the measurement, never a reason to lose the line
             roof["clock"] = {"error": repr(e)}
     if dist.is_initialized():

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r02
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --no-cpu-baseline --no-alt --no-full-loop"
+B="$R/bench.py --no-cpu-baseline --no-alt --no-full-loop --no-clock"
 MMDM_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -- python3 $B --steps 6 --warmup 2 > $O/serial.json 2> $O/serial.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/overlap -- python3 $B --steps 6 --warmup 2 > $O/overlap.json 2> $O/overlap.err
 MMDM_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/split_serial -- python3 $B --precision fp32_split --steps 6 --warmup 2 > $O/split_serial.json 2> $O/split_serial.err
