@@ -67,6 +67,15 @@ int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw, const floa
  * fp32 (v_mfma_f32_32x32x16_bf16), bias / residual / PE fp32, C fp32 (out_bf16 = 0) or bf16 (out_bf16 = 1); N % 4 == 0. */
 int mmdm_linear_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16,
                      int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
+/* Static weights in MFMA FRAGMENT ORDER for the bf16 / fp8 linear layers: mmdm_pack_weight_frag permutes W [N][row_bytes] (bf16: row_bytes = 2 K,
+ * fp8: K) inside blocks of 32 rows x 32 bytes so that one wave-wide 16-byte load is one MFMA operand; the *_packed entry points then take W
+ * straight from global memory (LDS carries A only; 128 x 256 tiles, K step 128 bytes).  Bit-identical to mmdm_linear_bf16 / mmdm_linear_fp8.
+ * Needs N % 256 == 0 and K % 128 == 0 (bf16) / K % 256 == 0 (fp8); a row slice starting at a multiple of 32 rows is the same byte offset. */
+int mmdm_pack_weight_frag(const void* W, int64_t ld_bytes, void* out, int N, int row_bytes, void* stream);
+int mmdm_linear_bf16_packed(const void* A, int lda, const void* W_packed, const float* bias, void* C, int ldc, int out_bf16,
+                            int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
+int mmdm_linear_fp8_packed(const void* A, int lda, const float* a_scale, const void* W_packed, const float* w_scale, const float* bias, void* C, int ldc,
+                           int out_mode, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
 /* Round-to-nearest-even fp32 -> bf16 conversion of n contiguous elements. */
 int mmdm_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 

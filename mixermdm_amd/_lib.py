@@ -65,6 +65,9 @@ SYMBOLS = {
     "mmdm_encoder_layer_workspace": (C.c_size_t, [_I, _I, _I, _I]),
     "mmdm_encoder_layer_f32": (_I, [_VP, C.POINTER(EncoderLayerWeights), _I, _I, _I, _I, _I, _I, _I, _I, C.c_float, _VP, C.c_size_t, _VP]),
     "mmdm_linear_fp8": (_I, [_VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
+    "mmdm_pack_weight_frag": (_I, [_VP, C.c_int64, _VP, _I, _I, _VP]),
+    "mmdm_linear_bf16_packed": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
+    "mmdm_linear_fp8_packed": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
     "mmdm_quantize_rows_fp8": (_I, [_VP, _I, _VP, _I, _VP, _I, _I, _VP]),
     "mmdm_adaln_fp8": (_I, [_VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _VP]),
     "mmdm_set_dual_weights": (_I, [_VP, _VP, _I]),

@@ -60,6 +60,72 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
     return (unsigned)w;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int TM, int TN, int ET>
+__device__ __forceinline__ void bf16_finish(const BArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int l31, int lh) {
+    // Activation, output form (fp32 / bf16 / fp8) and the optional bf16 copy are chosen ONCE per tile, outside the element loops (see
+    // gemm_f32.hip: with the runtime tests inside them the epilogue was tens of KB of branchy code).
+    auto finish = [&](auto act_c, auto out_c, auto sec_c) {
+        constexpr int ACT = decltype(act_c)::value, OUT = decltype(out_c)::value;
+        constexpr bool SEC = decltype(sec_c)::value;
+        const bool ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * (32 * TM) + i * 32 + l31;
+            if (row >= p.M) continue;
+            float sa = 1.f;
+            if constexpr (ET == 1) sa = p.a_scale ? p.a_scale[row] : p.a_const;
+            const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
+                    if (col >= p.N) continue;
+                    f32x4 v, add = {0.f, 0.f, 0.f, 0.f}, sw4 = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (ET == 1) {            // de-quantise, then bias (+ residual / PE row) as the bf16 form's accumulator start does
+                        if (p.w_scale) sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + col);
+                        if (p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + col);
+                        if (ext) add += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float t = acc[i][j][4 * qd + c];
+                        if constexpr (ET == 1) t = t * (sa * sw4[c]) + add[c];
+                        if constexpr (ACT == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
+                        else if constexpr (ACT == MMDM_EPI_BIAS_SILU) t = silu(t);
+                        v[c] = t;
+                    }
+                    if constexpr (OUT == 1 || SEC) {
+                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        if constexpr (OUT == 1) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col) = o;
+                        if constexpr (SEC) {
+                            if (col < p.p2_cols) *reinterpret_cast<bf16x4*>(p.P2 + (size_t)row * p.ld2 + col) = o;
+                        }
+                    }
+                    if constexpr (OUT == 2) *reinterpret_cast<unsigned*>(static_cast<unsigned char*>(p.C) + (size_t)row * p.ldc + col) = pack_fp8x4(v * p.out_scale);
+                    if constexpr (OUT == 0) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
+                }
+        }
+    };
+    auto finish_out = [&](auto act_c) {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        if (p.P2) {
+            if (p.out_bf16 == 1) finish(act_c, I1{}, std::true_type{});
+            else if (p.out_bf16 == 2) finish(act_c, I2{}, std::true_type{});
+            else finish(act_c, I0{}, std::true_type{});
+        } else {
+            if (p.out_bf16 == 1) finish(act_c, I1{}, std::false_type{});
+            else if (p.out_bf16 == 2) finish(act_c, I2{}, std::false_type{});
+            else finish(act_c, I0{}, std::false_type{});
+        }
+    };
+    if (p.epilogue == MMDM_EPI_BIAS_GELU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_GELU>{});
+    else if (p.epilogue == MMDM_EPI_BIAS_SILU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_SILU>{});
+    else finish_out(std::integral_constant<int, MMDM_EPI_BIAS>{});
+}
+#endif
+
 template <int TM_, int TN_, int ET = 0>
 // two 8-wave workgroups per CU = four waves per SIMD (<= 128 registers per wave; the second __launch_bounds__ argument is waves per SIMD): the 256 x 128 tile's 48 KB of LDS allow three, its 64 accumulators two
 __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS), (BCfg<TM_, TN_>::THREADS == 512 ? 4 : 1)) void gemm_bf16_kernel(BArgs p) {
@@ -221,66 +287,7 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS), (BCfg<TM_, TN_>::THREADS
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
 
-    // Activation, output form (fp32 / bf16 / fp8) and the optional bf16 copy are chosen ONCE per tile, outside the element loops (see
-    // gemm_f32.hip: with the runtime tests inside them the epilogue was tens of KB of branchy code).
-    auto finish = [&](auto act_c, auto out_c, auto sec_c) {
-        constexpr int ACT = decltype(act_c)::value, OUT = decltype(out_c)::value;
-        constexpr bool SEC = decltype(sec_c)::value;
-        const bool ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = m0 + wm * (32 * TM) + i * 32 + l31;
-            if (row >= p.M) continue;
-            float sa = 1.f;
-            if constexpr (ET == 1) sa = p.a_scale ? p.a_scale[row] : p.a_const;
-            const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
-                    if (col >= p.N) continue;
-                    f32x4 v, add = {0.f, 0.f, 0.f, 0.f}, sw4 = {1.f, 1.f, 1.f, 1.f};
-                    if constexpr (ET == 1) {            // de-quantise, then bias (+ residual / PE row) as the bf16 form's accumulator start does
-                        if (p.w_scale) sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + col);
-                        if (p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + col);
-                        if (ext) add += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float t = acc[i][j][4 * qd + c];
-                        if constexpr (ET == 1) t = t * (sa * sw4[c]) + add[c];
-                        if constexpr (ACT == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
-                        else if constexpr (ACT == MMDM_EPI_BIAS_SILU) t = silu(t);
-                        v[c] = t;
-                    }
-                    if constexpr (OUT == 1 || SEC) {
-                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                        if constexpr (OUT == 1) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col) = o;
-                        if constexpr (SEC) {
-                            if (col < p.p2_cols) *reinterpret_cast<bf16x4*>(p.P2 + (size_t)row * p.ld2 + col) = o;
-                        }
-                    }
-                    if constexpr (OUT == 2) *reinterpret_cast<unsigned*>(static_cast<unsigned char*>(p.C) + (size_t)row * p.ldc + col) = pack_fp8x4(v * p.out_scale);
-                    if constexpr (OUT == 0) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
-                }
-        }
-    };
-    auto finish_out = [&](auto act_c) {
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-        if (p.P2) {
-            if (p.out_bf16 == 1) finish(act_c, I1{}, std::true_type{});
-            else if (p.out_bf16 == 2) finish(act_c, I2{}, std::true_type{});
-            else finish(act_c, I0{}, std::true_type{});
-        } else {
-            if (p.out_bf16 == 1) finish(act_c, I1{}, std::false_type{});
-            else if (p.out_bf16 == 2) finish(act_c, I2{}, std::false_type{});
-            else finish(act_c, I0{}, std::false_type{});
-        }
-    };
-    if (p.epilogue == MMDM_EPI_BIAS_GELU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_GELU>{});
-    else if (p.epilogue == MMDM_EPI_BIAS_SILU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_SILU>{});
-    else finish_out(std::integral_constant<int, MMDM_EPI_BIAS>{});
+    bf16_finish<TM, TN, ET>(p, acc, m0, n0, wm, wn, l31, lh);
 #endif
 }
 
@@ -300,6 +307,225 @@ int set_attr() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, BCfg<TM_, TN_>::SMEM_BYTES);
     if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16): %s", hipGetErrorString(e));
     return MMDM_OK;
+}
+
+// ---- W in fragment order, straight from global memory (the structure that took the fp32-split GEMM from 190 to 215-220 TFLOP/s) -------------
+// Tile 128 x 256 of four waves side by side, each 128 x 64 (TM = 4, TN = 2: a k-block of 32 bytes per row is 4 A fragment reads from LDS and
+// 2 B fragment loads from global memory for 8 MFMAs -- 16 in the fp8 form).  K step = 128 bytes per row (64 bf16 / 128 fp8 = 4 k-blocks:
+// 32 / 64 MFMAs per wave between barriers instead of 8 / 16).  LDS holds A only, three stages of two 64-byte-row images; the stage after
+// next and the next step's B fragments are requested behind the MFMAs of the step's first k-block.  Two workgroups per CU (registers).
+// W: mmdm_pack_weight_frag -- block (32 rows, 32 bytes of k) = the 1 KiB one wave-wide 16-byte load delivers, lane (l31, lh) <- row l31, bytes 16 lh.
+// Accumulators start as in gemm_bf16_kernel and k ascends the same way: bit-identical results.
+template <int ET>
+__global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TM = 4, TN = 2, BM = 128, BN = 256, NW = 4, NKB = 4;
+    constexpr int HALF = BM * 16, STAGE = 2 * HALF;          // 4-byte units: one 64-byte-row image, one stage
+    constexpr int NIA = 2 * (BM / 16) / NW;                 // LDS-DMA pieces per wave and step (4)
+    constexpr int NLB = NKB * TN;                            // B fragment loads per wave and step (8)
+    constexpr int EB = ET == 1 ? 1 : 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int nwg = p.mt * p.nt;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int mi, ni;
+    {
+        const int GM = 8, per_g = GM * p.nt, g = swz / per_g, rem = swz - g * per_g;
+        const int gm = min(GM, p.mt - g * GM);
+        ni = rem / gm; mi = g * GM + rem - ni * gm;
+    }
+    const int m0 = mi * BM, n0 = ni * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = 0, wn = wave;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int kbytes = p.K * EB;
+    const int nkt = kbytes / 128;
+
+    int voff[NIA], dst[NIA];
+#pragma unroll
+    for (int u = 0; u < NIA; ++u) {
+        const int pq = wave + NW * u;                        // 0 .. 15: image (pq / 8), 16-row group (pq % 8)
+        const int half = pq >> 3, pp = pq & 7;
+        const int prow = lane >> 2, pc = lane & 3;
+        const int trow = 16 * pp + prow;
+        const int gch = pc ^ ((trow >> 2) & 3);
+        voff[u] = min(trow, p.M - 1 - m0) * p.lda * EB + 64 * half + 16 * gch;
+        dst[u] = half * HALF + 16 * pp * 16;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.A)) + (size_t)m0 * p.lda * EB, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.W)), 0, 0xffffffff, 0x00020000);
+    auto stage = [&](int buf, int kt) {                     // kt clamped: the loop stays branch-free
+        const int koff = min(kt, nkt - 1) * 128;
+#pragma unroll
+        for (int u = 0; u < NIA; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + dst[u] + buf * STAGE), 16, voff[u], koff, 0, 0);
+    };
+    int voffW[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) voffW[j] = ((n0 >> 5) + wn * TN + j) * (kbytes >> 5) * 1024 + lane * 16;
+    auto ldb = [&](int kt, bf16x8 (&b)[NKB][TN]) {
+        const int so = min(kt, nkt - 1) * (NKB * 1024);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[kb][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[j] + kb * 1024, so, 0));
+    };
+
+    f32x16 acc[TM][TN];
+    if constexpr (ET == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    } else {
+        const bool has_bias = p.bias != nullptr;
+        const bool has_ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
+        int colc[TN][4];
+        f32x4 bv[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                colc[j][qd] = min(n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh, p.N - 4);
+                bv[j][qd] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        if (has_bias) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) bv[j][qd] = *reinterpret_cast<const f32x4*>(p.bias + colc[j][qd]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rowc = min(m0 + i * 32 + l31, p.M - 1);
+            const int er = p.epilogue == MMDM_EPI_BIAS_PE ? rowc % p.period : rowc;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    f32x4 v = bv[j][qd];
+                    if (has_ext) v += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + colc[j][qd]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[i][j][4 * qd + c] = v[c];
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the pipeline below counts its own requests only
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+    }
+
+    const int sw = (l31 >> 2) & 3;
+    const int a_row = l31 * 16;
+    bf16x8 fa0[TM], fa1[TM];
+    bf16x8 bx[NKB][TN], by[NKB][TN];
+    auto rda = [&](int buf, int kb, bf16x8 (&af)[TM]) {
+        const float* Ac = smem + buf * STAGE + (kb >> 1) * HALF + a_row + 4 * ((2 * (kb & 1) + lh) ^ sw);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ac + i * 32 * 16));
+    };
+    auto mm = [&](const bf16x8 (&af)[TM], const bf16x8 (&bf)[TN]) {
+        if constexpr (ET == 1) {
+            typedef long l2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(l2, bf[j])[hh], __builtin_bit_cast(l2, af[i])[hh], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    constexpr int NM = (ET == 1 ? 2 : 1) * TM * TN;          // MFMAs per k-block
+    constexpr int NV = NLB + NIA;                            // VMEM instructions of a step, all behind the first k-block's MFMAs
+    auto step = [&](int kt, int cur, int nxt, int nn, bf16x8 (&b)[NKB][TN], bf16x8 (&bn)[NKB][TN]) {
+        rda(cur, 1, fa1);
+        ldb(kt + 1, bn);
+        stage(nn, kt + 2);
+        mm(fa0, b[0]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#pragma unroll
+        for (int u = 0; u < NM - 2; ++u) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, (NV + NM - 3) / (NM - 2), 0); }
+        __builtin_amdgcn_sched_group_barrier(0x010, NV, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rda(cur, 2, fa0);
+        mm(fa1, b[1]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        rda(cur, 3, fa1);
+        mm(fa0, b[2]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 2);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");      // A stage kt+1 landed (requested during step kt-1); this step's requests may be in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // every wave has read all of stage kt and sees stage kt+1
+        __builtin_amdgcn_sched_barrier(0);
+        rda(nxt, 0, fa0);
+        mm(fa1, b[3]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 3);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 3);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    stage(0, 0);
+    ldb(0, bx);
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
+    __builtin_amdgcn_s_barrier();
+    rda(0, 0, fa0);
+    int cur = 0;
+    for (int kt = 0; kt < nkt; kt += 2) {                  // nkt is even (host check): the two B register sets swap roles every step
+        const int c1 = cur == 2 ? 0 : cur + 1, c2 = c1 == 2 ? 0 : c1 + 1;
+        step(kt, cur, c1, c2, bx, by);
+        step(kt + 1, c1, c2, cur, by, bx);
+        cur = c2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus requests of the last steps
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
+    bf16_finish<TM, TN, ET>(p, acc, m0, n0, wm, wn, l31, lh);
+#endif
+}
+
+template <int ET>
+int launch_w(BArgs a, hipStream_t st) {
+    a.mt = (a.M + 127) / 128;
+    a.nt = a.N / 256;
+    mmdm_note_gemm("%s", ET == 1 ? "gemm_fp8w<14,42>" : "gemm_bf16w<14,42>");
+    hipLaunchKernelGGL((gemm_bf16w_kernel<ET>), dim3(a.mt * a.nt), dim3(256), 3 * 2 * 128 * 16 * 4, st, a);
+    return mmdm_check_launch(ET == 1 ? "gemm_fp8w" : "gemm_bf16w");
+}
+
+// rows of `row_bytes` operand bytes [N][ld_bytes] -> fragment order: block (32 rows, 32 bytes) = 1 KiB, chunk (lh, l31) <- row l31, bytes 16 lh
+__global__ void pack_frag_kernel(const unsigned char* __restrict__ in, size_t ld_bytes, unsigned char* __restrict__ out, int N, int row_bytes) {
+    const size_t chunks = (size_t)N * row_bytes / 16;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < chunks; o += (size_t)gridDim.x * blockDim.x) {
+        const int ln = (int)(o & 63), l31 = ln & 31, lh = ln >> 5;
+        const size_t blk = o >> 6;
+        const int kb = (int)(blk % (size_t)(row_bytes >> 5)), nb = (int)(blk / (size_t)(row_bytes >> 5));
+        *reinterpret_cast<f32x4*>(out + o * 16) = *reinterpret_cast<const f32x4*>(in + (size_t)(nb * 32 + l31) * ld_bytes + kb * 32 + lh * 16);
+    }
 }
 
 __global__ void f32_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n) {
@@ -341,6 +567,10 @@ int mmdm_gemm_bf16_init(void) {
     if ((rc = set_attr<42, 22, 1>())) return rc;
     if ((rc = set_attr<42, 42, 1>())) return rc;
     if ((rc = set_attr<22, 21, 1>())) return rc;
+    for (const void* f : {reinterpret_cast<const void*>(&gemm_bf16w_kernel<0>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1>)}) {
+        hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 128 * 16 * 4);
+        if (e2 != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16w): %s", hipGetErrorString(e2));
+    }
     const char* e = getenv("MMDM_BF16_CFG");
     g_bf16_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
@@ -355,6 +585,27 @@ extern "C" int mmdm_f32_to_bf16(const float* in, void* out, int64_t n, void* str
     return mmdm_check_launch("f32_to_bf16");
 }
 
+// W [N][row_bytes] (bf16: row_bytes = 2 K; fp8: K) -> fragment order for the *_packed entry points; N % 32 == 0, row_bytes % 32 == 0
+extern "C" int mmdm_pack_weight_frag(const void* W, int64_t ld_bytes, void* out, int N, int row_bytes, void* stream) {
+    if (N == 0) return MMDM_OK;
+    if (!W || !out || N < 0 || row_bytes <= 0 || (N & 31) || (row_bytes & 31) || ld_bytes < row_bytes || (ld_bytes & 15) ||
+        (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_pack_weight_frag: needs N %% 32 == 0, row bytes %% 32 == 0 and 16-byte aligned rows (N=%d row_bytes=%d)", N, row_bytes);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const unsigned char*>(W), (size_t)ld_bytes,
+                       static_cast<unsigned char*>(out), N, row_bytes);
+    return mmdm_check_launch("pack_weight_frag");
+}
+
+extern "C" int mmdm_linear_bf16_packed(const void* A, int lda, const void* W_packed, const float* bias, void* C, int ldc, int out_bf16,
+                                       int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
+    return mmdm_linear_bf16_ex(A, lda, W_packed, 0, bias, C, ldc, out_bf16, M, N, K, epilogue, extra, ld_extra, period, nullptr, 0, 0, stream);
+}
+
+extern "C" int mmdm_linear_fp8_packed(const void* A, int lda, const float* a_scale, const void* W_packed, const float* w_scale, const float* bias, void* C, int ldc,
+                                      int out_mode, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
+    return mmdm_linear_fp8_ex(A, lda, a_scale, W_packed, 0, w_scale, bias, C, ldc, out_mode, M, N, K, epilogue, extra, ld_extra, period, nullptr, 0, 0, 1.0f, 1.0f, stream);
+}
+
 extern "C" int mmdm_linear_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, void* C, int ldc, int out_bf16,
                                 int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
     return mmdm_linear_bf16_ex(A, lda, W, ldw, bias, C, ldc, out_bf16, M, N, K, epilogue, extra, ld_extra, period, nullptr, 0, 0, stream);
@@ -365,6 +616,11 @@ int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const fl
     mmdm_note_gemm_reset();
     if (M == 0 || N == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
+    const bool packed = ldw == 0;                 // W in fragment order (mmdm_pack_weight_frag): gemm_bf16w_kernel
+    if (packed) {
+        if ((N & 255) || (K & 127)) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16_packed: needs N %% 256 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
+        ldw = K;
+    }
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < K || ldc < N)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_bf16: bad shape M=%d N=%d K=%d lda=%d ldw=%d ldc=%d", M, N, K, lda, ldw, ldc);
     if (epilogue < MMDM_EPI_BIAS || epilogue > MMDM_EPI_BIAS_SILU) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_bf16: unknown epilogue %d", epilogue);
@@ -385,6 +641,7 @@ int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const fl
     a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (packed) return launch_w<0>(a, st);
     switch (g_bf16_cfg) {
         case 0: return launch<22, 22>(a, st);
         case 1: return launch<42, 22>(a, st);
@@ -421,6 +678,11 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
     mmdm_note_gemm_reset();
     if (M == 0 || N == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
+    const bool packed = ldw == 0;
+    if (packed) {
+        if ((N & 255) || (K & 255)) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8_packed: needs N %% 256 == 0 and K %% 256 == 0 (N=%d K=%d)", N, K);
+        ldw = K;
+    }
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < K || ldc < N)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_fp8: bad shape M=%d N=%d K=%d lda=%d ldw=%d ldc=%d", M, N, K, lda, ldw, ldc);
     if (out_mode < 0 || out_mode > 2) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_fp8: out_mode must be 0 (fp32), 1 (bf16) or 2 (fp8 at unit scale)");
@@ -443,6 +705,7 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
     a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (packed) return launch_w<1>(a, st);
     switch (g_bf16_cfg) {
         case 0: return launch<22, 22, 1>(a, st);
         case 2: return launch<42, 42, 1>(a, st);

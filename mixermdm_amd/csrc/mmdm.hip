@@ -102,7 +102,7 @@ struct LayerWB {         // bf16 twins of the stack GEMM weights (precision >= 1
 struct StackW {          // a transformer stack: denoiser blocks or Influence blocks
     int D = 0, F = 0, L = 0, H = 0, n_ada = 0;
     bool has_ca = false;
-    bool w_packed = false;                      // fp32-split weights stored in MFMA fragment order (mmdm_split_pack_weight; gemm_splitw_kernel)
+    bool w_packed = false;                      // low-precision weight twins stored in MFMA fragment order (gemm_splitw_kernel / gemm_bf16w_kernel take W straight from global memory)
     float *ada_w = nullptr, *ada_b = nullptr;   // [L*n_ada*2D, D], [L*n_ada*2D]  (slots: sa, [ca_q, ca_kv,] ffn)
     std::vector<LayerW> layers;
     std::vector<LayerWB> layers_b;
@@ -505,7 +505,7 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
                     int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) -> int {
         if (prec == 2) return linear_s(c, A, lda, (size_t)R * K, bw(Wb, woff), w.w_packed ? 0 : K, wtot, bias, C, ldc, (size_t)R * N, out_b == 2, R, N, K, epi, extra, ld_extra, s2);
 
-        if (bf) return linear_b(c, A, lda, bw(Wb, woff), K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra, s2);
+        if (bf) return linear_b(c, A, lda, bw(Wb, woff), w.w_packed ? 0 : K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra, s2);
         return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra);
     };
     // bf16 path with a head size the plane kernel covers: the projection GEMMs also emit a bf16 copy of Q and K and the scores come from
@@ -1043,21 +1043,26 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
     if (h->cfg.single_only == 0 && !h->stats_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_prepare: normaliser stats not set"));
     if (h->cfg.precision >= 1) {
         const bool split = h->cfg.precision == 2;
-        // fp32-split weights of a stack whose sizes the packed kernel covers (every N a multiple of 128, every K of 64, slices on 32-row
-        // boundaries) are stored in fragment order: split into a scratch buffer, then permuted into place (same size, same plane stride)
-        static const bool no_pack = getenv("MMDM_SPLIT_NO_PACK") != nullptr;
+        // Low-precision weights of a stack whose sizes the packed kernels cover (fp32-split: every N and K a multiple of 128; bf16 / fp8: of 256;
+        // slices on 32-row boundaries) are stored in fragment order: converted into a scratch buffer, then permuted into place (same size)
+        static const bool no_pack = getenv("MMDM_NO_PACK") != nullptr || getenv("MMDM_SPLIT_NO_PACK") != nullptr;
         void* tmp = nullptr;
         size_t tmp_elems = 0;
         for (ModuleW* m : {&h->d1, &h->d2, &h->mx}) {
             StackW& st = m->st;
-            st.w_packed = split && !no_pack && !st.layers_b.empty() && st.D % 128 == 0 && st.F % 128 == 0;
-            if (st.w_packed) tmp_elems = std::max(tmp_elems, (size_t)3 * std::max(3 * st.D, st.F) * st.D);
+            const int gran = split ? 128 : 256;             // the packed kernels' N / K granularity (gemm_split.hip: 128 x 128 tiles; gemm_bf16.hip: 128 x 256, K step 128 bytes)
+            st.w_packed = !no_pack && !st.layers_b.empty() && st.D % gran == 0 && st.F % gran == 0;
+            if (st.w_packed) tmp_elems = std::max(tmp_elems, (size_t)(split ? 3 : 1) * std::max(3 * st.D, st.F) * st.D);
         }
         if (tmp_elems) HIPCHK(hipMalloc(&tmp, tmp_elems * 2));
         struct TmpFree { void* p; ~TmpFree() { if (p) (void)hipFree(p); } } tmp_free{tmp};
         bool pack_now = false;
         auto conv = [&](const float* src, void* dst, int64_t n, int64_t K = 0) -> int {
-            if (!split) return mmdm_f32_to_bf16(src, dst, n, nullptr);
+            if (!split) {
+                if (!pack_now) return mmdm_f32_to_bf16(src, dst, n, nullptr);
+                if (int rc = mmdm_f32_to_bf16(src, tmp, n, nullptr)) return rc;
+                return mmdm_pack_weight_frag(tmp, 2 * K, dst, (int)(n / K), (int)(2 * K), nullptr);
+            }
             if (!pack_now) return mmdm_f32_split3(src, dst, n, n, nullptr);
             if (int rc = mmdm_f32_split3(src, tmp, n, n, nullptr)) return rc;
             return mmdm_split_pack_weight(tmp, (int)K, n, dst, n, (int)(n / K), (int)K, nullptr);
@@ -1071,13 +1076,16 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
                 const int64_t D = st.D, F = st.F;
                 int rc = MMDM_OK;
                 if (h->cfg.precision == 3) {          // per-output-channel e4m3 for QKV / cross-attention inputs / FFN, bf16 for the output projections
+                    // the fp8 weights stay in rows: at K = 1024 a tile is 8 steps of the packed kernel's 128-byte K step, and its prologue / epilogue
+                    // outweigh the better loop (tools/gemm_fp8_bench.py: QKV 963 vs 994 TFLOP/s, FFN-1 794 vs 909; 8192^3: 1728 vs 1508); the bf16
+                    // output projections of this mode are packed like the bf16 mode's
                     auto q8 = [&](const float* src, void* dst, float* sc, int rows, int cols) { return mmdm_quantize_rows_fp8(src, cols, dst, cols, sc, rows, cols, nullptr); };
                     rc = q8(lw.sa_in_w, lb.sa_in_8, lb.sa_in_s, (int)(3 * D), (int)D);
-                    if (!rc) rc = conv(lw.sa_out_w, lb.sa_out_w, D * D);
+                    if (!rc) rc = conv(lw.sa_out_w, lb.sa_out_w, D * D, D);
                     if (!rc) rc = q8(lw.f1_w, lb.f1_8, lb.f1_s, (int)F, (int)D);
                     if (!rc) rc = q8(lw.f2_w, lb.f2_8, lb.f2_s, (int)D, (int)F);
                     if (!rc && st.has_ca) rc = q8(lw.ca_in_w, lb.ca_in_8, lb.ca_in_s, (int)(3 * D), (int)D);
-                    if (!rc && st.has_ca) rc = conv(lw.ca_out_w, lb.ca_out_w, D * D);
+                    if (!rc && st.has_ca) rc = conv(lw.ca_out_w, lb.ca_out_w, D * D, D);
                     if (rc) return herr(h, rc);
                     continue;
                 }

@@ -217,8 +217,21 @@ def to_bf16(x):
     return out
 
 
-def linear_bf16(x, weight, bias=None, epilogue="bias", extra=None, period=0, out_dtype=torch.float32):
-    """y = x @ weight.T + bias with bf16 operands (x, weight torch.bfloat16), fp32 accumulation; fp32 or bf16 result."""
+def pack_weight_frag(w):
+    """A static bf16 or fp8 weight [N, K] -> the same bytes in MFMA fragment order (blocks of 32 rows x 32 bytes), for linear_bf16 /
+    linear_fp8 (..., packed=True).  N % 32 == 0 and 32 | bytes per row; the result keeps shape and dtype so N and K can be read back."""
+    if not w.is_cuda or w.dtype not in (torch.bfloat16, torch.float8_e4m3fn) or w.dim() != 2 or not w.is_contiguous():
+        raise TypeError("pack_weight_frag expects a contiguous CUDA bfloat16 / float8_e4m3fn [N, K] tensor")
+    N, K = w.shape
+    rb = K * w.element_size()
+    out = torch.empty_like(w)
+    check(load_library().mmdm_pack_weight_frag(C.c_void_p(w.data_ptr()), rb, C.c_void_p(out.data_ptr()), N, rb, _stream()))
+    return out
+
+
+def linear_bf16(x, weight, bias=None, epilogue="bias", extra=None, period=0, out_dtype=torch.float32, packed=False):
+    """y = x @ weight.T + bias with bf16 operands (x, weight torch.bfloat16), fp32 accumulation; fp32 or bf16 result.
+    packed: weight comes from pack_weight_frag (W straight from global memory; bit-identical results)."""
     for t in (x, weight):
         if not t.is_cuda or t.dtype != torch.bfloat16:
             raise TypeError("linear_bf16 expects CUDA torch.bfloat16 operands")
@@ -227,6 +240,11 @@ def linear_bf16(x, weight, bias=None, epilogue="bias", extra=None, period=0, out
     x2 = x.reshape(-1, K)
     M = x2.shape[0]
     out = torch.empty(M, N, device=x.device, dtype=out_dtype)
+    if packed:
+        check(load_library().mmdm_linear_bf16_packed(C.c_void_p(x2.data_ptr()), x2.stride(0), C.c_void_p(weight.data_ptr()), _p(bias),
+                                                     C.c_void_p(out.data_ptr()), out.stride(0), int(out_dtype == torch.bfloat16), M, N, K, EPI[epilogue],
+                                                     _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
+        return out.reshape(*x.shape[:-1], N)
     check(load_library().mmdm_linear_bf16(C.c_void_p(x2.data_ptr()), x2.stride(0), C.c_void_p(weight.data_ptr()), weight.stride(0), _p(bias),
                                           C.c_void_p(out.data_ptr()), out.stride(0), int(out_dtype == torch.bfloat16), M, N, K, EPI[epilogue],
                                           _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
@@ -316,7 +334,7 @@ def quantize_rows_fp8(x):
     return q.view(torch.float8_e4m3fn), scale
 
 
-def linear_fp8(xq, x_scale, wq, w_scale, bias=None, epilogue="bias", extra=None, period=0, out_dtype=torch.float32):
+def linear_fp8(xq, x_scale, wq, w_scale, bias=None, epilogue="bias", extra=None, period=0, out_dtype=torch.float32, packed=False):
     """y = (xq * x_scale[:, None]) @ (wq * w_scale[:, None]).T + bias on the fp8 matrix instructions (fp32 accumulation, de-quantised in the
     epilogue).  xq [M, K], wq [N, K] torch.float8_e4m3fn; x_scale [M] / w_scale [N] fp32 or None; out fp32, bf16 or float8_e4m3fn (unit scale)."""
     for t in (xq, wq):
@@ -328,6 +346,11 @@ def linear_fp8(xq, x_scale, wq, w_scale, bias=None, epilogue="bias", extra=None,
     M = x2.shape[0]
     out = torch.empty(M, N, device=xq.device, dtype=out_dtype)
     mode = {torch.float32: 0, torch.bfloat16: 1, torch.float8_e4m3fn: 2}[out_dtype]
+    if packed:          # wq from pack_weight_frag
+        check(load_library().mmdm_linear_fp8_packed(C.c_void_p(x2.data_ptr()), x2.stride(0), _p(x_scale), C.c_void_p(wq.data_ptr()), _p(w_scale), _p(bias),
+                                                    C.c_void_p(out.data_ptr()), out.stride(0), mode, M, N, K, EPI[epilogue],
+                                                    _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
+        return out.reshape(*xq.shape[:-1], N)
     check(load_library().mmdm_linear_fp8(C.c_void_p(x2.data_ptr()), x2.stride(0), _p(x_scale), C.c_void_p(wq.data_ptr()), wq.stride(0), _p(w_scale), _p(bias),
                                          C.c_void_p(out.data_ptr()), out.stride(0), mode, M, N, K, EPI[epilogue],
                                          _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))

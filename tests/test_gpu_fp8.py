@@ -194,3 +194,37 @@ def test_attention_bf16_vs_float64_of_the_rounded_operands(nseq, Tq, Tk, H, dh, 
     assert (exact.double() - ref).abs().max().item() <= 4e-6
     gb = ops.attention_bf16(qb, kb, vb, H, zero_key=zero_key, causal=causal, out_dtype=torch.bfloat16)
     assert torch.equal(gb, got.bfloat16())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (19, 512, 512), (1000, 768, 1024), (4800, 1024, 2048)])
+def test_packed_bf16_and_fp8_linear_are_bitwise_the_plane_kernels(M, N, K):
+    """Weights in fragment order (mmdm_pack_weight_frag), W straight from global memory (gemm_bf16w_kernel): every epilogue and output form,
+    ragged M, against the LDS-staged kernels -- the accumulators start the same way and k ascends the same way."""
+    import mixermdm_amd as mm
+    from mixermdm_amd import ops
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5 * M + N)
+    x, w, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    xb, wb = ops.to_bf16(x.to(d)), ops.to_bf16(w.to(d))
+    wp = ops.pack_weight_frag(wb)
+    assert torch.equal(wp.view(torch.int16).flatten().sort().values, wb.view(torch.int16).flatten().sort().values)
+    lib = mm.load_library()
+    for epi, extra in [("bias", None), ("gelu", None), ("silu", None), ("resid", r.to(d))]:
+        for od in (torch.float32, torch.bfloat16):
+            want = ops.linear_bf16(xb, wb, b.to(d), epi, extra, out_dtype=od)
+            got = ops.linear_bf16(xb, wp, b.to(d), epi, extra, out_dtype=od, packed=True)
+            assert lib.mmdm_last_gemm_kernel().decode() == "gemm_bf16w<14,42>"
+            assert torch.equal(got.view(torch.int16 if od == torch.bfloat16 else torch.int32), want.view(torch.int16 if od == torch.bfloat16 else torch.int32)), (epi, od)
+    xq, xs = ops.quantize_rows_fp8(x.to(d))
+    wq, ws = ops.quantize_rows_fp8(w.to(d))
+    wqp = ops.pack_weight_frag(wq)
+    for epi, extra in [("bias", None), ("gelu", None), ("resid", r.to(d))]:
+        for od in (torch.float32, torch.bfloat16, torch.float8_e4m3fn):
+            want = ops.linear_fp8(xq, xs, wq, ws, b.to(d), epi, extra, out_dtype=od)
+            got = ops.linear_fp8(xq, xs, wqp, ws, b.to(d), epi, extra, out_dtype=od, packed=True)
+            assert lib.mmdm_last_gemm_kernel().decode() == "gemm_fp8w<14,42>"
+            it = {torch.float32: torch.int32, torch.bfloat16: torch.int16, torch.float8_e4m3fn: torch.int8}[od]
+            assert torch.equal(got.view(it), want.view(it)), (epi, od)
+    with pytest.raises(Exception):
+        ops.linear_bf16(xb, ops.pack_weight_frag(wb[:96].contiguous()), packed=True)       # N % 256

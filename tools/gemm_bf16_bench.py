@@ -23,4 +23,24 @@ for M,N,K,name,epi in shapes:
             for _ in range(4): ops.linear_bf16(xb,wb,b,epi,extra)
             e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
         ms=statistics.median(res); line+=f" | cfg{c}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:7.1f}TF err {err:.1e}"
+    # weights in fragment order, W straight from global memory (gemm_bf16w_kernel): bitwise the plane kernel's result
+    if N % 256 == 0 and K % 128 == 0:
+        import ctypes as C
+        vp = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        wp = torch.empty_like(wb)
+        assert lib.mmdm_pack_weight_frag(vp(wb), 2 * K, vp(wp), N, 2 * K, st) == 0, lib.mmdm_last_error()
+        outp = torch.empty(M, N, device=d)
+        ex = extra
+        call = lambda: lib.mmdm_linear_bf16_packed(vp(xb), K, vp(wp), vp(b), vp(outp), N, 0, M, N, K, ops.EPI[epi], vp(ex), N if ex is not None else 0, 0, st)
+        assert call() == 0, lib.mmdm_last_error()
+        torch.cuda.synchronize()
+        lib.mmdmx_set_bf16_cfg(-1)
+        same = torch.equal(outp, ops.linear_bf16(xb, wb, b, epi, extra))
+        res=[]
+        for r in range(5):
+            e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e0.record()
+            for _ in range(4): call()
+            e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
+        ms=statistics.median(res); line+=f" | packed: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:7.1f}TF bitwise {same}"
     print(line, flush=True)
