@@ -143,9 +143,14 @@ __device__ __forceinline__ float rows_sum(float x) {
     return a + b;
 }
 
-template <int DH>
+// DIAG: the ablation switches and in-kernel stamps (tools/attn_bench.py ABL=, tools/attn_timeline.py) exist in a second instantiation only.  As
+// runtime tests inside the chunk loop they split its basic blocks -- the same thing cost the fp32-split GEMM 14 % -- so the
+// production instantiation sees them as compile-time zeros.
+template <int DH, bool DIAG = false>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
+    const int ablate = DIAG ? p.ablate : 0;
+    unsigned long long* const stamps = DIAG ? p.stamps : nullptr;
     constexpr int KC = KCF;
     constexpr int NJ = DH / 16;                 // d groups of 16 (QK^T) == 16-wide output column tiles (PV)
     constexpr int NKT = KC / 16;                // 16-key tiles per stage
@@ -172,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     const int lq = lane & 15, g = lane >> 4;
     const int q0 = qt * QB + wave * QW;
     unsigned long long t_qk = 0, t_sm = 0, t_pv = 0, t_a = 0;
-    if (p.stamps && tid == 0) {
-        p.stamps[8 * (size_t)bid + 0] = __builtin_amdgcn_s_memrealtime();
-        p.stamps[8 * (size_t)bid + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+    if (stamps && tid == 0) {
+        stamps[8 * (size_t)bid + 0] = __builtin_amdgcn_s_memrealtime();
+        stamps[8 * (size_t)bid + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
                                         ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
     }
 
@@ -252,11 +257,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();
-        if (ci + NST - 1 < nchunks && !(p.ablate & 1)) stage(c0 + (NST - 1) * KC, stg);
+        if (!(ablate & 2)) __builtin_amdgcn_s_barrier();
+        if (ci + NST - 1 < nchunks && !(ablate & 1)) stage(c0 + (NST - 1) * KC, stg);
         const float* Ks = smem + cur * STAGE;
         const float* Vs = Ks + KC * DH;
-        if (p.stamps) { if (ci == 0 && tid == 0) p.stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime(); t_a = __builtin_amdgcn_s_memrealtime(); }
+        if (stamps) { if (ci == 0 && tid == 0) stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime(); t_a = __builtin_amdgcn_s_memrealtime(); }
 
         // S^T tiles: st[kt][reg] = score(key = c0 + 16kt + 4g + reg, query = lq); K fragments double-buffered in registers
         f32x4 st[NKT];
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int cb = j & 1;
-            if (j + 1 < NJ && !(p.ablate & 8)) {
+            if (j + 1 < NJ && !(ablate & 8)) {
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
                     kf[cb ^ 1][kt] = *reinterpret_cast<const f32x4*>(&Ks[(16 * kt + lq) * DH + 4 * ((4 * (j + 1) + g) ^ lq)]);
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) MFMA_SETTLE(st[kt]);
-        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); t_qk += t - t_a; t_a = t; }
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); t_qk += t - t_a; t_a = t; }
         if (c0 + KC > p.Tk || (causal && c0 + KC - 1 > q0)) {   // keys past Tk (last chunk) or above the diagonal (wave-uniform branch)
             const int kmax = causal ? min(p.Tk - 1, q0 + lq) : p.Tk - 1;
 #pragma unroll
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
                 for (int r = 0; r < 4; ++r)
                     if (c0 + 16 * kt + 4 * g + r > kmax) st[kt][r] = -INFINITY;
         }
-        if (!(p.ablate & 4)) {
+        if (!(ablate & 4)) {
         float cmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
 #pragma unroll
         for (int kt = 1; kt < NKT; ++kt) cmax = fmaxf(cmax, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
@@ -330,13 +335,13 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 
         // O[q][n] += sum_key P[q][key] V[key][n]:  A = P (lane-local: st[kt][r] is P[q=lq][key=16kt+4g+r]),
         // B = V[key = 16kt + 4g + r][this lane's NJ contiguous columns] (load_v_row)
-        if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); t_sm += t - t_a; t_a = t; }
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); t_sm += t - t_a; t_a = t; }
         float vb[2][NJ];
         load_v_row<DH>(&Vs[(4 * g) * DH], lq, vb[0]);
 #pragma unroll
         for (int idx = 0; idx < 4 * NKT; ++idx) {
             const int kt = idx >> 2, r = idx & 3, cb = idx & 1;
-            if (idx + 1 < 4 * NKT && !(p.ablate & 16)) {
+            if (idx + 1 < 4 * NKT && !(ablate & 16)) {
                 const int kt1 = (idx + 1) >> 2, r1 = (idx + 1) & 3;
                 load_v_row<DH>(&Vs[(16 * kt1 + 4 * g + r1) * DH], lq, vb[cb ^ 1]);
             }
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
             for (int j = 0; j < NJ; ++j)
                 o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vb[cb][j], o[j], 0, 0, 0);
         }
-        if (p.stamps) {
+        if (stamps) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
             t_pv += __builtin_amdgcn_s_memrealtime() - t_a;
@@ -355,9 +360,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
-    if (p.stamps && tid == 0) {
-        p.stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
-        p.stamps[8 * (size_t)bid + 5] = t_qk; p.stamps[8 * (size_t)bid + 6] = t_sm; p.stamps[8 * (size_t)bid + 7] = t_pv;
+    if (stamps && tid == 0) {
+        stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
+        stamps[8 * (size_t)bid + 5] = t_qk; stamps[8 * (size_t)bid + 6] = t_sm; stamps[8 * (size_t)bid + 7] = t_pv;
     }
     // normalise and store: accumulator element (j, r) belongs to query q0 + 4g + r, columns as laid out by load_v_row
     float lr[4];
@@ -369,9 +374,9 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         if (qrow >= p.Tq) continue;
         store_o_row<DH>(p, o, r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * p.dh, lq);
     }
-    if (p.stamps) {
+    if (stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) p.stamps[8 * (size_t)bid + 3] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) stamps[8 * (size_t)bid + 3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }
@@ -719,7 +724,8 @@ constexpr int attn_smem() { return NST * 2 * KCF * DH * 4; }
 
 template <int DH>
 int launch_mfma(const AttnArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((attn_mfma_kernel<DH>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), attn_smem<DH>(), st, a);
+    if (a.ablate || a.stamps) hipLaunchKernelGGL((attn_mfma_kernel<DH, true>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), attn_smem<DH>(), st, a);
+    else hipLaunchKernelGGL((attn_mfma_kernel<DH>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), attn_smem<DH>(), st, a);
     return mmdm_check_launch("attn_mfma");
 }
 
@@ -738,6 +744,8 @@ int mmdm_attn_init(void) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<64>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem<64>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem<128>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem<64>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<128, 3>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<64, 3>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<128, 1>());
