@@ -162,10 +162,10 @@ def main():
         # cores), and a third of the mode's GEMM launches are bf16: both priced against the dense bf16 peak
         peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 6, 1), "bf16_fp8": PEAK_BF16_MFMA_TFLOPS}[args.precision]
         kname = {"fp32": "gemm_glds_kernel<..., PIPE_=1> (v_mfma_f32_32x32x2_f32; software-pipelined LDS-DMA ring: 128x128 tiles x 5 stages, 128x64 x 4 stages when N = 2048 or N, K <= 512; all instantiations of a step averaged)",
-                 "bf16": "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16, LDS-DMA staged, 256x128 tiles)",
-                 "fp32_split": "gemm_split_kernel (fp32 result from 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 operand splits; peak = 2500/6 algorithmic TFLOP/s)",
+                 "bf16": "gemm_bf16w_kernel (v_mfma_f32_32x32x16_bf16; weights in MFMA fragment order fetched straight from global memory, A through three LDS-DMA stages, 128x256 tiles, K step 128 bytes)",
+                 "fp32_split": "gemm_splitw_kernel (fp32 result from 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 operand splits; weights in MFMA fragment order fetched straight from global memory, 128x128 tiles, two workgroups per CU; peak = 2500/6 algorithmic TFLOP/s)",
                  "bf16_fp8": "gemm_bf16_kernel<ET=1> (v_mfma_f32_32x32x16_fp8_fp8: e4m3 operands, per-row / per-output-channel scales, fp32 accumulate) "
-                             "+ gemm_bf16_kernel for the attention output projections"}[args.precision]
+                             "+ gemm_bf16w_kernel (bf16, packed weights) for the attention output projections"}[args.precision]
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(single) if args.precision == "fp32" else None,
                 "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1),
