@@ -2,7 +2,7 @@ import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspa
 import torch, math, statistics
 from mixermdm_amd import ops, load_library
 lib = load_library(); d = torch.device("cuda:0")
-shapes = [(19200,3072,1024,"qkv","bias"),(19200,1024,1024,"out","resid"),(19200,2048,1024,"ffn1","gelu"),(19200,1024,2048,"ffn2","resid"),(19200,512,512,"m.out","resid"),(8192,8192,8192,"sq8k","bias")]
+shapes = [(19200,3072,1024,"qkv","bias"),(19200,1024,1024,"out","resid"),(19200,2048,1024,"ffn1","gelu"),(19200,1024,2048,"ffn2","resid"),(19200,512,512,"m.out","resid"),(19200,1536,512,"m.qkv","bias"),(19200,1024,512,"m.ffn1","gelu"),(19200,512,1024,"m.ffn2","resid"),(8192,8192,8192,"sq8k","bias")]
 cfgs = [int(c) for c in os.environ.get("CFGS", "0,1,2,3").split(",")]
 for M,N,K,name,epi in shapes:
     x = torch.randn(M,K,device=d); w = torch.randn(N,K,device=d)/math.sqrt(K); b = torch.randn(N,device=d)
