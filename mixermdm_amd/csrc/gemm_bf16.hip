@@ -316,10 +316,10 @@ int set_attr() {
 // next and the next step's B fragments are requested behind the MFMAs of the step's first k-block.  Two workgroups per CU (registers).
 // W: mmdm_pack_weight_frag -- block (32 rows, 32 bytes of k) = the 1 KiB one wave-wide 16-byte load delivers, lane (l31, lh) <- row l31, bytes 16 lh.
 // Accumulators start as in gemm_bf16_kernel and k ascends the same way: bit-identical results.
-template <int ET>
+template <int ET, int TN = 2>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int TM = 4, TN = 2, BM = 128, BN = 256, NW = 4, NKB = 4;
+    constexpr int TM = 4, BM = 128, BN = 128 * TN, NW = 4, NKB = 4;      // TN = 1: 128 x 128 tiles for the N <= 1024 GEMMs (600 tiles of 128 x 256 leave half of the second round empty)
     constexpr int HALF = BM * 16, STAGE = 2 * HALF;          // 4-byte units: one 64-byte-row image, one stage
     constexpr int NIA = 2 * (BM / 16) / NW;                 // LDS-DMA pieces per wave and step (4)
     constexpr int NLB = NKB * TN;                            // B fragment loads per wave and step (8)
@@ -508,12 +508,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #endif
 }
 
-template <int ET>
+template <int ET, int TN = 2>
 int launch_w(BArgs a, hipStream_t st) {
     a.mt = (a.M + 127) / 128;
-    a.nt = a.N / 256;
-    mmdm_note_gemm("%s", ET == 1 ? "gemm_fp8w<14,42>" : "gemm_bf16w<14,42>");
-    hipLaunchKernelGGL((gemm_bf16w_kernel<ET>), dim3(a.mt * a.nt), dim3(256), 3 * 2 * 128 * 16 * 4, st, a);
+    a.nt = a.N / (128 * TN);
+    mmdm_note_gemm("%s<14,4%d>", ET == 1 ? "gemm_fp8w" : "gemm_bf16w", TN);
+    hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN>), dim3(a.mt * a.nt), dim3(256), 3 * 2 * 128 * 16 * 4, st, a);
     return mmdm_check_launch(ET == 1 ? "gemm_fp8w" : "gemm_bf16w");
 }
 
@@ -567,7 +567,8 @@ int mmdm_gemm_bf16_init(void) {
     if ((rc = set_attr<42, 22, 1>())) return rc;
     if ((rc = set_attr<42, 42, 1>())) return rc;
     if ((rc = set_attr<22, 21, 1>())) return rc;
-    for (const void* f : {reinterpret_cast<const void*>(&gemm_bf16w_kernel<0>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1>)}) {
+    for (const void* f : {reinterpret_cast<const void*>(&gemm_bf16w_kernel<0>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1>),
+                          reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1>)}) {
         hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 128 * 16 * 4);
         if (e2 != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16w): %s", hipGetErrorString(e2));
     }
@@ -618,7 +619,7 @@ int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const fl
     if (int rc = mmdm_kernels_init()) return rc;
     const bool packed = ldw == 0;                 // W in fragment order (mmdm_pack_weight_frag): gemm_bf16w_kernel
     if (packed) {
-        if ((N & 255) || (K & 127)) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16_packed: needs N %% 256 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
+        if ((N & 127) || (K & 127)) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16_packed: needs N %% 128 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
         ldw = K;
     }
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < K || ldc < N)
@@ -641,7 +642,10 @@ int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const fl
     a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (packed) return launch_w<0>(a, st);
+    if (packed) {
+        const bool narrow = (N & 255) || (g_bf16_cfg == 11) || (g_bf16_cfg != 12 && N <= 1024);
+        return narrow ? launch_w<0, 1>(a, st) : launch_w<0, 2>(a, st);
+    }
     switch (g_bf16_cfg) {
         case 0: return launch<22, 22>(a, st);
         case 1: return launch<42, 22>(a, st);
@@ -680,7 +684,7 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
     if (int rc = mmdm_kernels_init()) return rc;
     const bool packed = ldw == 0;
     if (packed) {
-        if ((N & 255) || (K & 255)) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8_packed: needs N %% 256 == 0 and K %% 256 == 0 (N=%d K=%d)", N, K);
+        if ((N & 127) || (K & 255)) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8_packed: needs N %% 128 == 0 and K %% 256 == 0 (N=%d K=%d)", N, K);
         ldw = K;
     }
     if (!A || !W || !C || M < 0 || N < 0 || K <= 0 || lda < K || ldw < K || ldc < N)
@@ -705,7 +709,10 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
     a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (packed) return launch_w<1>(a, st);
+    if (packed) {
+        const bool narrow = (N & 255) || (g_bf16_cfg == 11) || (g_bf16_cfg != 12 && N <= 1024);
+        return narrow ? launch_w<1, 1>(a, st) : launch_w<1, 2>(a, st);
+    }
     switch (g_bf16_cfg) {
         case 0: return launch<22, 22, 1>(a, st);
         case 2: return launch<42, 42, 1>(a, st);

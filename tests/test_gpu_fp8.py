@@ -197,7 +197,7 @@ def test_attention_bf16_vs_float64_of_the_rounded_operands(nseq, Tq, Tk, H, dh, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (19, 512, 512), (1000, 768, 1024), (4800, 1024, 2048)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (19, 512, 512), (1000, 768, 1024), (4800, 1024, 2048), (520, 2048, 512), (130, 1152, 256)])
 def test_packed_bf16_and_fp8_linear_are_bitwise_the_plane_kernels(M, N, K):
     """Weights in fragment order (mmdm_pack_weight_frag), W straight from global memory (gemm_bf16w_kernel): every epilogue and output form,
     ragged M, against the LDS-staged kernels -- the accumulators start the same way and k ascends the same way."""
@@ -214,7 +214,7 @@ def test_packed_bf16_and_fp8_linear_are_bitwise_the_plane_kernels(M, N, K):
         for od in (torch.float32, torch.bfloat16):
             want = ops.linear_bf16(xb, wb, b.to(d), epi, extra, out_dtype=od)
             got = ops.linear_bf16(xb, wp, b.to(d), epi, extra, out_dtype=od, packed=True)
-            assert lib.mmdm_last_gemm_kernel().decode() == "gemm_bf16w<14,42>"
+            assert lib.mmdm_last_gemm_kernel().decode() == ("gemm_bf16w<14,42>" if N > 1024 and N % 256 == 0 else "gemm_bf16w<14,41>")
             assert torch.equal(got.view(torch.int16 if od == torch.bfloat16 else torch.int32), want.view(torch.int16 if od == torch.bfloat16 else torch.int32)), (epi, od)
     xq, xs = ops.quantize_rows_fp8(x.to(d))
     wq, ws = ops.quantize_rows_fp8(w.to(d))
@@ -223,8 +223,8 @@ def test_packed_bf16_and_fp8_linear_are_bitwise_the_plane_kernels(M, N, K):
         for od in (torch.float32, torch.bfloat16, torch.float8_e4m3fn):
             want = ops.linear_fp8(xq, xs, wq, ws, b.to(d), epi, extra, out_dtype=od)
             got = ops.linear_fp8(xq, xs, wqp, ws, b.to(d), epi, extra, out_dtype=od, packed=True)
-            assert lib.mmdm_last_gemm_kernel().decode() == "gemm_fp8w<14,42>"
+            assert lib.mmdm_last_gemm_kernel().decode() == ("gemm_fp8w<14,42>" if N > 1024 and N % 256 == 0 else "gemm_fp8w<14,41>")
             it = {torch.float32: torch.int32, torch.bfloat16: torch.int16, torch.float8_e4m3fn: torch.int8}[od]
             assert torch.equal(got.view(it), want.view(it)), (epi, od)
     with pytest.raises(Exception):
-        ops.linear_bf16(xb, ops.pack_weight_frag(wb[:96].contiguous()), packed=True)       # N % 256
+        ops.linear_bf16(xb, ops.pack_weight_frag(wb[:96].contiguous()), packed=True)       # N % 128

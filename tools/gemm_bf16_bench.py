@@ -36,11 +36,17 @@ for M,N,K,name,epi in shapes:
         assert call() == 0, lib.mmdm_last_error()
         torch.cuda.synchronize()
         lib.mmdmx_set_bf16_cfg(-1)
-        same = torch.equal(outp, ops.linear_bf16(xb, wb, b, epi, extra))
-        res=[]
-        for r in range(5):
-            e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e0.record()
-            for _ in range(4): call()
-            e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
-        ms=statistics.median(res); line+=f" | packed: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:7.1f}TF bitwise {same}"
+        ref2 = ops.linear_bf16(xb, wb, b, epi, extra)
+        for pc, tag in ((12, "128x256"), (11, "128x128")):          # forced packed tile shapes (mmdmx_set_bf16_cfg 12 / 11)
+            lib.mmdmx_set_bf16_cfg(pc)
+            assert call() == 0, lib.mmdm_last_error()
+            torch.cuda.synchronize()
+            same = torch.equal(outp, ref2)
+            res=[]
+            for r in range(5):
+                e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e0.record()
+                for _ in range(4): call()
+                e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
+            ms=statistics.median(res); line+=f" | packed {tag}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:7.1f}TF {'==' if same else '!='}"
+        lib.mmdmx_set_bf16_cfg(-1)
     print(line, flush=True)
