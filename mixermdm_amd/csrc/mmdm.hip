@@ -518,8 +518,8 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     // channel used (the K|V slice of the packed cross-attention projection); unit_a: A is the GELU output, stored at the static scale GSCALE
     constexpr float GSCALE = 1.0f;       // (a static x16 on the GELU tensor was measured: its range up to 28 saturates in these networks and doubles the error)
     auto gemm8 = [&](const void* A, bool unit_a, const void* W8, const float* Ws, size_t row0, const float* bias, void* C, int ldc, int out_mode, int N, int K,
-                     int epi, const float* extra, int ld_extra, Second s2 = Second()) -> int {
-        return linear_8(c, A, K, unit_a ? nullptr : S.xs, static_cast<const uint8_t*>(W8) + row0 * K, K, Ws + row0, bias, C, ldc, out_mode, R, N, K, epi, extra, ld_extra, s2,
+                     int epi, const float* extra, int ld_extra, Second s2 = Second(), bool w_frag = false) -> int {
+        return linear_8(c, A, K, unit_a ? nullptr : S.xs, static_cast<const uint8_t*>(W8) + row0 * K, w_frag ? 0 : K, Ws + row0, bias, C, ldc, out_mode, R, N, K, epi, extra, ld_extra, s2,
                         unit_a ? 1.0f / GSCALE : 1.0f, out_mode == 2 ? GSCALE : 1.0f);
     };
     // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / three planes, or fp8 + per-row scales
@@ -577,7 +577,7 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         RC(norm(hbuf, ss_at(w.has_ca ? 3 : 1, r.ffn_row0), r.ffn_rows));
         if (f8) {               // FFN on fp8 operands: the GELU output is written as e4m3 at unit scale and read back as the down-projection's A
             RC(gemm8(S.xn, false, lb.f1_8, lb.f1_s, 0, lw.f1_b, S.f1, F, 2, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
-            RC(gemm8(S.f1, true, lb.f2_8, lb.f2_s, 0, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
+            RC(gemm8(S.f1, true, lb.f2_8, lb.f2_s, 0, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), w.w_packed && F >= 2048));
         } else {
             RC(gemm(S.xn, D, lw.f1_w, lb.f1_w, 0, (size_t)F * D, lw.f1_b, S.f1, F, ob, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
             RC(gemm(S.f1, F, lw.f2_w, lb.f2_w, 0, (size_t)D * F, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
@@ -1076,14 +1076,17 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
                 const int64_t D = st.D, F = st.F;
                 int rc = MMDM_OK;
                 if (h->cfg.precision == 3) {          // per-output-channel e4m3 for QKV / cross-attention inputs / FFN, bf16 for the output projections
-                    // the fp8 weights stay in rows: at K = 1024 a tile is 8 steps of the packed kernel's 128-byte K step, and its prologue / epilogue
+                    // the fp8 weights with K = 1024 stay in rows: there a tile is 8 steps of the packed kernel's 128-byte K step, and its prologue / epilogue
                     // outweigh the better loop (tools/gemm_fp8_bench.py: QKV 963 vs 994 TFLOP/s, FFN-1 794 vs 909; 8192^3: 1728 vs 1508); the bf16
                     // output projections of this mode are packed like the bf16 mode's
                     auto q8 = [&](const float* src, void* dst, float* sc, int rows, int cols) { return mmdm_quantize_rows_fp8(src, cols, dst, cols, sc, rows, cols, nullptr); };
                     rc = q8(lw.sa_in_w, lb.sa_in_8, lb.sa_in_s, (int)(3 * D), (int)D);
                     if (!rc) rc = conv(lw.sa_out_w, lb.sa_out_w, D * D, D);
                     if (!rc) rc = q8(lw.f1_w, lb.f1_8, lb.f1_s, (int)F, (int)D);
-                    if (!rc) rc = q8(lw.f2_w, lb.f2_8, lb.f2_s, (int)D, (int)F);
+                    if (!rc && pack_now && F >= 2048) {       // the one fp8 GEMM with K = 2048 (16 steps of the packed kernel): 1039 vs 901 TFLOP/s
+                        rc = mmdm_quantize_rows_fp8(lw.f2_w, (int)F, tmp, (int)F, lb.f2_s, (int)D, (int)F, nullptr);
+                        if (!rc) rc = mmdm_pack_weight_frag(tmp, F, lb.f2_8, (int)D, (int)F, nullptr);
+                    } else if (!rc) rc = q8(lw.f2_w, lb.f2_8, lb.f2_s, (int)D, (int)F);
                     if (!rc && st.has_ca) rc = q8(lw.ca_in_w, lb.ca_in_8, lb.ca_in_s, (int)(3 * D), (int)D);
                     if (!rc && st.has_ca) rc = conv(lw.ca_out_w, lb.ca_out_w, D * D, D);
                     if (rc) return herr(h, rc);
