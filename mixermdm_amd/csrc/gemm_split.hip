@@ -131,10 +131,13 @@ __device__ __forceinline__ void split_finish(const SArgs& p, f32x16 (&acc)[TM][T
 }
 #endif
 
-template <int TM_, int TN_>
+// DIAG: the timing-ablation switches (tools/gemm_split_bench.py ABL=) exist in a second instantiation only -- as runtime tests inside the K loop
+// they split its basic block and the sched_group_barrier pipeline with it.
+template <int TM_, int TN_, bool DIAG = false>
 __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(SArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA / buffer-store builtins exists in the device pass only
     using C_ = SCfg<TM_, TN_>;
+    const int ablate = DIAG ? p.ablate : 0;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                              // [2][3][BM*16]
@@ -256,7 +259,7 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
     rd(0, 0, f0a, f0b);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (!(p.ablate & 2)) rd(cur, 1, f1a, f1b);
+        if (!(ablate & 2)) rd(cur, 1, f1a, f1b);
         mm(I0{}, I6{}, f0a, f0b);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
@@ -267,10 +270,10 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
         if (kt + 1 < nkt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // stage kt+1 landed (stage kt+2 is requested below)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!(p.ablate & 16)) __builtin_amdgcn_s_barrier();        // every wave has read all of stage kt
+            if (!(ablate & 16)) __builtin_amdgcn_s_barrier();        // every wave has read all of stage kt
             __builtin_amdgcn_sched_barrier(0);
-            if (!(p.ablate & 2)) rd(cur ^ 1, 0, f0a, f0b);
-            if (kt + 2 < nkt && !(p.ablate & 1)) stage(cur);           // (ablate bits: timing experiments, tools/gemm_split_bench.py)
+            if (!(ablate & 2)) rd(cur ^ 1, 0, f0a, f0b);
+            if (kt + 2 < nkt && !(ablate & 1)) stage(cur);           // (ablate bits: timing experiments, tools/gemm_split_bench.py)
         }
         mm(I3{}, I6{}, f1a, f1b);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
@@ -312,7 +315,8 @@ int launch(SArgs a, hipStream_t st) {
     a.mt = (a.M + C_::BM - 1) / C_::BM;
     a.nt = (a.N + C_::BN - 1) / C_::BN;
     mmdm_note_gemm("gemm_split<%d,%d>", TM_, TN_);
-    hipLaunchKernelGGL((gemm_split_kernel<TM_, TN_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+    if (a.ablate & 19) hipLaunchKernelGGL((gemm_split_kernel<TM_, TN_, true>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+    else hipLaunchKernelGGL((gemm_split_kernel<TM_, TN_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_split");
 }
 
@@ -320,6 +324,8 @@ template <int TM_, int TN_>
 int set_attr() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<TM_, TN_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SCfg<TM_, TN_>::SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<TM_, TN_, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, SCfg<TM_, TN_>::SMEM_BYTES);
     if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_split): %s", hipGetErrorString(e));
     return MMDM_OK;
 }
