@@ -4,7 +4,9 @@ import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = os.path.join(ROOT, "gpurun_out", "prof_r02"), os.path.join(ROOT, "profiles")
-for n in ("serial", "overlap", "split_serial", "fp8_serial"):
+for n in ("serial", "overlap", "split_serial", "bf16_serial", "fp8_serial"):
+    if not os.path.exists(os.path.join(src, "summary", f"kernel_stats_{n}.csv")):
+        continue
     shutil.copy(os.path.join(src, "summary", f"kernel_stats_{n}.csv"), os.path.join(dst, f"{tag}_kernel_stats_{n}.csv"))
     for line in open(os.path.join(src, f"{n}.json")):
         if line.startswith("{"):

@@ -24,7 +24,7 @@ def traces(d):
     return rows
 
 
-for d in ("serial", "overlap", "split_serial", "fp8_serial"):
+for d in ("serial", "overlap", "split_serial", "bf16_serial", "fp8_serial"):
     rows = traces(d)
     if not rows:
         continue

@@ -8,6 +8,7 @@ B="$R/bench.py --no-cpu-baseline --no-alt --no-full-loop --no-clock"
 MMDM_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -- python3 $B --steps 6 --warmup 2 > $O/serial.json 2> $O/serial.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/overlap -- python3 $B --steps 6 --warmup 2 > $O/overlap.json 2> $O/overlap.err
 MMDM_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/split_serial -- python3 $B --precision fp32_split --steps 6 --warmup 2 > $O/split_serial.json 2> $O/split_serial.err
+MMDM_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bf16_serial -- python3 $B --precision bf16 --steps 6 --warmup 2 > $O/bf16_serial.json 2> $O/bf16_serial.err
 MMDM_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp8_serial -- python3 $B --precision bf16_fp8 --steps 6 --warmup 2 > $O/fp8_serial.json 2> $O/fp8_serial.err
 P="$B --steps 2 --warmup 1 --no-graph --profile-steps 0"
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
