@@ -34,6 +34,7 @@ struct BArgs {
     int mt, nt;
     const float* a_scale; const float* w_scale;   // fp8 operands: per-row / per-output-channel de-quantisation scales (nullptr = 1)
     float a_const, out_scale;                     // fp8: de-quantisation factor of A when a_scale is null; fp8 output is e4m3(value * out_scale)
+    unsigned long long* tl;               // diagnostic (tools/bf16w_timeline.py): per-workgroup {loop shader clocks, loop 100 MHz ticks, whole-kernel ticks, K steps}; null in production
     __bf16* P2; int p2_cols, ld2;         // optional second output: columns [0, p2_cols) also as bf16 (attention Q/K operands)
 };
 
@@ -316,9 +317,11 @@ int set_attr() {
 // next and the next step's B fragments are requested behind the MFMAs of the step's first k-block.  Two workgroups per CU (registers).
 // W: mmdm_pack_weight_frag -- block (32 rows, 32 bytes of k) = the 1 KiB one wave-wide 16-byte load delivers, lane (l31, lh) <- row l31, bytes 16 lh.
 // Accumulators start as in gemm_bf16_kernel and k ascends the same way: bit-identical results.
-template <int ET, int TN = 2>
+template <int ET, int TN = 2, bool TL = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long t_entry = 0, t_r0 = 0, t_c0 = 0, t_r1 = 0, t_c1 = 0;
+    if constexpr (TL) t_entry = __builtin_amdgcn_s_memrealtime();
     constexpr int TM = 4, BM = 128, BN = 128 * TN, NW = 4, NKB = 4;      // TN = 1: 128 x 128 tiles for the N <= 1024 GEMMs (600 tiles of 128 x 256 leave half of the second round empty)
     constexpr int HALF = BM * 16, STAGE = 2 * HALF;          // 4-byte units: one 64-byte-row image, one stage
     constexpr int NIA = 2 * (BM / 16) / NW;                 // LDS-DMA pieces per wave and step (4)
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
         __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 3);
         __builtin_amdgcn_sched_barrier(0);
     };
+    if constexpr (TL) { t_r0 = __builtin_amdgcn_s_memrealtime(); t_c0 = __builtin_readcyclecounter(); }
     stage(0, 0);
     ldb(0, bx);
     stage(1, 1);
@@ -504,7 +508,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
+    if constexpr (TL) { t_r1 = __builtin_amdgcn_s_memrealtime(); t_c1 = __builtin_readcyclecounter(); }
     bf16_finish<TM, TN, ET>(p, acc, m0, n0, wm, wn, l31, lh);
+    if constexpr (TL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.tl && tid == 0) {
+            unsigned long long* o = p.tl + 4 * (size_t)blockIdx.x;
+            o[0] = t_c1 - t_c0; o[1] = t_r1 - t_r0; o[2] = __builtin_amdgcn_s_memrealtime() - t_entry; o[3] = (unsigned long long)nkt;
+        }
+    }
 #endif
 }
 
@@ -513,7 +525,8 @@ int launch_w(BArgs a, hipStream_t st) {
     a.mt = (a.M + 127) / 128;
     a.nt = a.N / (128 * TN);
     mmdm_note_gemm("%s<14,4%d>", ET == 1 ? "gemm_fp8w" : "gemm_bf16w", TN);
-    hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN>), dim3(a.mt * a.nt), dim3(256), 3 * 2 * 128 * 16 * 4, st, a);
+    if (a.tl) hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN, true>), dim3(a.mt * a.nt), dim3(256), 3 * 2 * 128 * 16 * 4, st, a);
+    else hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN>), dim3(a.mt * a.nt), dim3(256), 3 * 2 * 128 * 16 * 4, st, a);
     return mmdm_check_launch(ET == 1 ? "gemm_fp8w" : "gemm_bf16w");
 }
 
@@ -554,6 +567,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const float* __rest
 }
 
 int g_bf16_cfg = -1;
+unsigned long long* g_bf16_tl = nullptr;
 
 }  // namespace
 
@@ -568,7 +582,9 @@ int mmdm_gemm_bf16_init(void) {
     if ((rc = set_attr<42, 42, 1>())) return rc;
     if ((rc = set_attr<22, 21, 1>())) return rc;
     for (const void* f : {reinterpret_cast<const void*>(&gemm_bf16w_kernel<0>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1>),
-                          reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1>)}) {
+                          reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1>),
+                          reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 2, true>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 2, true>),
+                          reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1, true>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1, true>)}) {
         hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 128 * 16 * 4);
         if (e2 != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16w): %s", hipGetErrorString(e2));
     }
@@ -578,6 +594,7 @@ int mmdm_gemm_bf16_init(void) {
 }
 
 extern "C" void mmdmx_set_bf16_cfg(int c) { g_bf16_cfg = c; }
+extern "C" void mmdmx_set_bf16_timeline(void* buf) { g_bf16_tl = static_cast<unsigned long long*>(buf); }   // 4 u64 per workgroup of the next packed launches
 
 extern "C" int mmdm_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
     if (n <= 0) return MMDM_OK;
@@ -638,7 +655,7 @@ int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const fl
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
     a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_bf16 = out_bf16;
     a.mt = a.nt = 0;
-    a.a_scale = a.w_scale = nullptr; a.a_const = a.out_scale = 1.f;
+    a.a_scale = a.w_scale = nullptr; a.a_const = a.out_scale = 1.f; a.tl = packed ? g_bf16_tl : nullptr;
     a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -705,7 +722,7 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
     a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_bf16 = out_mode;
     a.mt = a.nt = 0;
     a.a_scale = a_scale; a.w_scale = w_scale;
-    a.a_const = a_const; a.out_scale = out_scale;
+    a.a_const = a_const; a.out_scale = out_scale; a.tl = packed ? g_bf16_tl : nullptr;
     a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
