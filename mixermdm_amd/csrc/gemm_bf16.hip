@@ -62,32 +62,42 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-template <int TM, int TN, int ET>
+template <int TM, int TN, int ET, int BM>
 __device__ __forceinline__ void bf16_finish(const BArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int l31, int lh) {
     // Activation, output form (fp32 / bf16 / fp8) and the optional bf16 copy are chosen ONCE per tile, outside the element loops (see
-    // gemm_f32.hip: with the runtime tests inside them the epilogue was tens of KB of branchy code).
+    // gemm_f32.hip: with the runtime tests inside them the epilogue was tens of KB of branchy code).  Results leave through buffer stores on
+    // a resource that covers the tile's rows of C: rows past M are dropped by the hardware's range check, so the row test -- a divergent
+    // branch around every store, crawled through beside co-resident workgroups' MFMA streams (tools/bf16w_timeline.py: half of a
+    // residual-shape workgroup's life was outside its K loop) -- is gone; loads of per-row / per-column operands use clamped indices.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     auto finish = [&](auto act_c, auto out_c, auto sec_c) {
         constexpr int ACT = decltype(act_c)::value, OUT = decltype(out_c)::value;
         constexpr bool SEC = decltype(sec_c)::value;
+        constexpr int EBO = OUT == 0 ? 4 : (OUT == 1 ? 2 : 1);                 // bytes per output element
         const bool ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
+        const int rows_here = min(p.M - m0, BM);
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(p.C) + (size_t)m0 * p.ldc * EBO, 0, rows_here * p.ldc * EBO, 0x00020000);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int row = m0 + wm * (32 * TM) + i * 32 + l31;
-            if (row >= p.M) continue;
+            const int rrow = wm * (32 * TM) + i * 32 + l31;                    // row inside the tile
+            const int row = m0 + rrow;
+            const bool rok = row < p.M;
+            const int rowc = min(row, p.M - 1);
             float sa = 1.f;
-            if constexpr (ET == 1) sa = p.a_scale ? p.a_scale[row] : p.a_const;
-            const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+            if constexpr (ET == 1) sa = p.a_scale ? p.a_scale[rowc] : p.a_const;
+            const int er = p.epilogue == MMDM_EPI_BIAS_PE ? rowc % p.period : rowc;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     const int col = n0 + wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;
-                    if (col >= p.N) continue;
+                    const int colc = min(col, p.N - 4);
                     f32x4 v, add = {0.f, 0.f, 0.f, 0.f}, sw4 = {1.f, 1.f, 1.f, 1.f};
                     if constexpr (ET == 1) {            // de-quantise, then bias (+ residual / PE row) as the bf16 form's accumulator start does
-                        if (p.w_scale) sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + col);
-                        if (p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + col);
-                        if (ext) add += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
+                        if (p.w_scale) sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + colc);
+                        if (p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + colc);
+                        if (ext) add += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + colc);
                     }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -97,15 +107,16 @@ __device__ __forceinline__ void bf16_finish(const BArgs& p, f32x16 (&acc)[TM][TN
                         else if constexpr (ACT == MMDM_EPI_BIAS_SILU) t = silu(t);
                         v[c] = t;
                     }
+                    const int voff = (rrow * p.ldc + col) * EBO;
                     if constexpr (OUT == 1 || SEC) {
                         const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                        if constexpr (OUT == 1) *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col) = o;
+                        if constexpr (OUT == 1) { if (col < p.N) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsC, voff, 0, 0); }
                         if constexpr (SEC) {
-                            if (col < p.p2_cols) *reinterpret_cast<bf16x4*>(p.P2 + (size_t)row * p.ld2 + col) = o;
+                            if (rok && col < p.N && col < p.p2_cols) *reinterpret_cast<bf16x4*>(p.P2 + (size_t)row * p.ld2 + col) = o;
                         }
                     }
-                    if constexpr (OUT == 2) *reinterpret_cast<unsigned*>(static_cast<unsigned char*>(p.C) + (size_t)row * p.ldc + col) = pack_fp8x4(v * p.out_scale);
-                    if constexpr (OUT == 0) *reinterpret_cast<f32x4*>(static_cast<float*>(p.C) + (size_t)row * p.ldc + col) = v;
+                    if constexpr (OUT == 2) { if (col < p.N) __builtin_amdgcn_raw_buffer_store_b32(pack_fp8x4(v * p.out_scale), rsC, voff, 0, 0); }
+                    if constexpr (OUT == 0) { if (col < p.N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff, 0, 0); }
                 }
         }
     };
@@ -288,7 +299,7 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS), (BCfg<TM_, TN_>::THREADS
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
 
-    bf16_finish<TM, TN, ET>(p, acc, m0, n0, wm, wn, l31, lh);
+    bf16_finish<TM, TN, ET, BM>(p, acc, m0, n0, wm, wn, l31, lh);
 #endif
 }
 
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
     if constexpr (TL) { t_r1 = __builtin_amdgcn_s_memrealtime(); t_c1 = __builtin_readcyclecounter(); }
-    bf16_finish<TM, TN, ET>(p, acc, m0, n0, wm, wn, l31, lh);
+    bf16_finish<TM, TN, ET, BM>(p, acc, m0, n0, wm, wn, l31, lh);
     if constexpr (TL) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (p.tl && tid == 0) {
