@@ -267,7 +267,9 @@ def loop_clock(precision, M, peak, achieved):
         call = lambda: ops.linear(x, w, b)
         for _ in range(300):
             call()
-        buf = torch.zeros(8192 * 10, dtype=torch.int64, device=d)
+        # 10 words per workgroup (8 stamps + 2 cycle counters), sized for the smallest tile the dispatch can pick (64 x 64): the stamping
+        # kernel writes without a bound check, so the buffer must cover every workgroup of this launch
+        buf = torch.zeros(10 * ((M + 63) // 64) * ((N + 63) // 64), dtype=torch.int64, device=d)
         lib.mmdmx_set_gemm_stamps(C.c_void_p(buf.data_ptr()))
         call(); torch.cuda.synchronize()
         lib.mmdmx_set_gemm_stamps(C.c_void_p(0))

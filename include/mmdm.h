@@ -13,6 +13,18 @@
  *   - return value: 0 = MMDM_OK, otherwise an mmdm_status; mmdm_last_error() gives the message
  *     (thread-local for the stateless kernels, per handle otherwise);
  *   - one handle per device, not thread-safe, no allocation after mmdm_prepare() (graph-capturable).
+ *
+ * Environment variables the library reads (all optional; nothing else in the environment changes its behaviour):
+ *   MMDM_NO_OVERLAP=1    mmdm_create: run the two denoisers and the two Influence calls of a step on ONE stream (profiling passes:
+ *                        a kernel trace without concurrent kernels); results are bit-identical either way.
+ *   MMDM_GRAPH_CACHE=n   mmdm_create: capacity (1..64, default 8) of the handle's (B, T, S)-keyed cache of captured step graphs.
+ *   MMDM_NO_PACK=1       mmdm_prepare: keep the low-precision weight twins of precision 1-3 in row-major planes instead of MFMA
+ *                        fragment order (the packed and the plane kernels are bit-identical; tests/test_gpu_packed_modes.py compares them).
+ *   MMDM_QKP / MMDM_NO_QKP / MMDM_NO_BF16_PV   precision >= 1: force / forbid the bf16-plane Q K^T and the bf16 P V forms of the attention.
+ *   MMDM_GEMM_CFG, MMDM_GEMM_TAIL, MMDM_SPLIT_CFG, MMDM_BF16_CFG   tile-selection overrides of the GEMM dispatch, for tools/ (benchmarks).
+ * The mmdmx_* symbols the library also exports (mmdmx_set_gemm_cfg, _ablate, _stamps, ...) are hooks of the scripts under tools/: timing
+ * ablations and in-kernel stamps.  They select separate DIAGNOSTIC kernel instantiations; the kernels a handle launches by default
+ * contain no diagnostic code.  They are not part of this ABI.
  */
 #ifndef MMDM_H
 #define MMDM_H

@@ -263,6 +263,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         const float* Vs = Ks + KC * DH;
         if (stamps) { if (ci == 0 && tid == 0) stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime(); t_a = __builtin_amdgcn_s_memrealtime(); }
 
+        // A wave whose 16 queries all lie past Tq (T = 300: the fourth wave of the fifth query tile, one wave in twenty) stages its
+        // pieces and keeps the barriers, but issues none of the chunk's 64 MFMAs: the matrix pipe of its SIMD goes to the co-resident
+        // workgroups' waves instead.  Wave-uniform; nothing it would have computed is ever stored.
+        if (q0 < p.Tq) {
         // S^T tiles: st[kt][reg] = score(key = c0 + 16kt + 4g + reg, query = lq); K fragments double-buffered in registers
         f32x4 st[NKT];
 #pragma unroll
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
             t_pv += __builtin_amdgcn_s_memrealtime() - t_a;
+        }
         }
         cur = cur + 1 == NST ? 0 : cur + 1;
         stg = stg + 1 == NST ? 0 : stg + 1;
@@ -519,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
         const float* Ks = smem + cur * STAGE;
         const float* Vs = Ks + NP * KPLANE;
 
+        if (q0 >= p.Tq) continue;        // a wave with no query inside Tq keeps staging and the barriers, nothing else (attn_mfma_kernel)
         // S^T tile (16 keys x 16 queries): one accumulator per 32-deep reduction step so that consecutive MFMAs are independent
         f32x4 sa[NS];
 #pragma unroll

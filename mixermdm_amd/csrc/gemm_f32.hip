@@ -251,9 +251,15 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // One output tile (`swz` = tile index after the XCD remap) from start to finish.  Device pass only: the buffer-resource type of the
 // LDS-DMA builtins does not exist in the host pass, which only needs the kernel's symbol.
 #if defined(__HIP_DEVICE_COMPILE__)
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int swz, int bid) {
+// DIAG_: the timing ablations (GemmArgs::ablate) and in-kernel stamps (GemmArgs::stamps) exist in a second instantiation only, launched
+// when a tool has set one of them (tools/gemm_bench.py ABL=, tools/gemm_timeline.py, bench.py's loop clock); the production instantiation
+// sees compile-time zeros -- no diagnostic branch, load or register in the shipped kernels.
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_, bool DIAG_>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int swz, int bid) {
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
+    const GemmArgs& p = pp;
+    unsigned long long* const p_stamps = DIAG_ ? pp.stamps : nullptr;
+    const int p_ablate = DIAG_ ? pp.ablate : 0;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN, CPR = C_::CPR, RPP = C_::RPP, NBUF = C_::NBUF;
     float* As = smem;                                   // [NBUF][BM*BK]
     float* Bs = smem + NBUF * C_::A_FLOATS;             // [NBUF][BN*BK]
@@ -266,9 +272,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C_::WGN, wn = wave % C_::WGN;
     const int l31 = lane & 31, lh = lane >> 5;
-    if (p.stamps && tid == 0) {
-        p.stamps[8 * (size_t)bid + 0] = __builtin_amdgcn_s_memrealtime();
-        p.stamps[8 * (size_t)bid + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+    if (p_stamps && tid == 0) {
+        p_stamps[8 * (size_t)bid + 0] = __builtin_amdgcn_s_memrealtime();
+        p_stamps[8 * (size_t)bid + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
                                         ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
     }
 
@@ -376,9 +382,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
         // the accumulator-init loads above must not be counted by the pipeline's vmcnt arithmetic
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (p.stamps && tid == 0) {
-        p.stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime();
-        p.stamps[8 * (size_t)gridDim.x + 2 * bid] = __builtin_readcyclecounter();       // s_memtime (shader clocks) beside the 100 MHz stamp: the clock inside the loop
+    if (p_stamps && tid == 0) {
+        p_stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime();
+        p_stamps[8 * (size_t)gridDim.x + 2 * bid] = __builtin_readcyclecounter();       // s_memtime (shader clocks) beside the 100 MHz stamp: the clock inside the loop
     }
     // fragment read offsets (floats): row*BK + 4*((2g + lh) ^ sw)
     const int sw = swz_of<CPR>(l31);
@@ -508,14 +514,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
             // raw barrier: __syncthreads() would drain vmcnt(0) while LDS-DMA is in flight and serialise the pipeline
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // everyone done reading buffer (kt+2)%3 (tile kt-1)
-            if (kt + 2 < nkt && (p.ablate & 7) < 1) stage((kt + 2) % 3);
+            if (kt + 2 < nkt && (p_ablate & 7) < 1) stage((kt + 2) % 3);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 1 < nkt && (p.ablate & 7) < 1) stage(cur ^ 1);
+            if (kt + 1 < nkt && (p_ablate & 7) < 1) stage(cur ^ 1);
         }
-        const float* Ac = As + ((p.ablate & 7) >= 1 ? 0 : cur) * C_::A_FLOATS + a_row;
-        const float* Bc = Bs + ((p.ablate & 7) >= 1 ? 0 : cur) * C_::B_FLOATS + b_row;
+        const float* Ac = As + ((p_ablate & 7) >= 1 ? 0 : cur) * C_::A_FLOATS + a_row;
+        const float* Bc = Bs + ((p_ablate & 7) >= 1 ? 0 : cur) * C_::B_FLOATS + b_row;
 #pragma unroll
         for (int g = 0; g < C_::G; ++g) {
             const int cg = 4 * ((2 * g + lh) ^ sw);
@@ -524,7 +530,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * BK + cg);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * BK + cg);
-            if (p.ablate & 8) __builtin_amdgcn_s_setprio(1);
+            if (p_ablate & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -533,23 +539,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = VEPI ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0)
                                          : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-            if (p.ablate & 8) __builtin_amdgcn_s_setprio(0);
+            if (p_ablate & 8) __builtin_amdgcn_s_setprio(0);
         }
     }
     }
-    if ((p.ablate & 7) >= 3) return;
+    if ((p_ablate & 7) >= 3) return;
     // MFMA -> VALU hazard across the loop-exit branch: see MFMA_SETTLE in attn_f32.hip
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
-    if (p.stamps && tid == 0) {
-        p.stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
-        p.stamps[8 * (size_t)gridDim.x + 2 * bid + 1] = __builtin_readcyclecounter();
+    if (p_stamps && tid == 0) {
+        p_stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
+        p_stamps[8 * (size_t)gridDim.x + 2 * bid + 1] = __builtin_readcyclecounter();
     }
-    if (p.stamps) {
+    if (p_stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) p.stamps[8 * (size_t)bid + 6] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) p_stamps[8 * (size_t)bid + 6] = __builtin_amdgcn_s_memrealtime();
     }
 
     // The activation is chosen ONCE, outside the element loops: with the runtime `p.epilogue` tests inside them every element carried all
@@ -623,7 +629,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, float* smem, int sw
 }
 #endif
 
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0>
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0, bool DIAG_ = false>
 __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void gemm_glds_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -631,13 +637,14 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void 
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const unsigned long long t_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
-    if (p.stamps && threadIdx.x == 0) p.stamps[8 * (size_t)bid + 5] = t_entry;
-    gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_>(p, smem, swz, bid);
-    if (p.stamps) {
-        if (threadIdx.x == 0) p.stamps[8 * (size_t)bid + 7] = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* const stamps = DIAG_ ? p.stamps : nullptr;
+    const unsigned long long t_entry = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+    if (stamps && threadIdx.x == 0) stamps[8 * (size_t)bid + 5] = t_entry;
+    gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_, DIAG_>(p, smem, swz, bid);
+    if (stamps) {
+        if (threadIdx.x == 0) stamps[8 * (size_t)bid + 7] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) p.stamps[8 * (size_t)bid + 4] = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) stamps[8 * (size_t)bid + 4] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }
@@ -657,22 +664,30 @@ int launch_glds(GemmArgs a, hipStream_t st) {
     // measured (tools/gemm_bench.py): the 16-byte epilogue pays where the accumulators are initialised from memory (+10 % on
     // the K = 1024 residual GEMMs) and is neutral-to-slightly-negative for bias/GELU-only epilogues
     const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
-    mmdm_note_gemm("%s<%d,%d,%d,%d,%s>", PIPE_ ? "gemm_pipe" : "gemm_glds", TM_, TN_, BK_, NBUF_, (ext && vepi_ok(a) && !(a.ablate & 16)) ? "vepi" : "scalar");
-    if (ext && vepi_ok(a) && !(a.ablate & 16))
-        hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+    const bool vepi = ext && vepi_ok(a) && !(a.ablate & 16);
+    mmdm_note_gemm("%s<%d,%d,%d,%d,%s>", PIPE_ ? "gemm_pipe" : "gemm_glds", TM_, TN_, BK_, NBUF_, vepi ? "vepi" : "scalar");
+    const dim3 grid(a.mt * a.nt), block(C_::THREADS);
+    if ((a.ablate & ~16) || a.stamps) {              // a tool asked for ablation bits / stamps: the diagnostic instantiation
+        if (vepi) hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_, true>), grid, block, C_::SMEM_BYTES, st, a);
+        else hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_, true>), grid, block, C_::SMEM_BYTES, st, a);
+    } else if (vepi)
+        hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_, false>), grid, block, C_::SMEM_BYTES, st, a);
     else
-        hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_>), dim3(a.mt * a.nt), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+        hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_, false>), grid, block, C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_glds");
 }
 
 template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2, int MINW_ = 1, int PIPE_ = 0>
 int set_attr_glds() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<TM_, TN_, BK_, NBUF_>::SMEM_BYTES);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<TM_, TN_, BK_, NBUF_>::SMEM_BYTES);
-    if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_glds): %s", hipGetErrorString(e));
+    constexpr int bytes = GCfg<TM_, TN_, BK_, NBUF_>::SMEM_BYTES;
+    const void* fns[4] = {reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_, false>),
+                          reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_, false>),
+                          reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_, true>),
+                          reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_, true>)};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_glds): %s", hipGetErrorString(e));
+    }
     return MMDM_OK;
 }
 
@@ -723,6 +738,7 @@ inline bool vec_ok(const float* p, int ld, int K) {
 }  // namespace
 
 int g_gemm_cfg = -1;
+int g_gemm_tail = 0;        // row split of the fractional last round: 0 off; t > 0: split when the fractional round holds <= t/10 of the resident slots
 int g_gemm_ablate = 0;
 unsigned long long* g_gemm_stamps = nullptr;
 
@@ -736,44 +752,26 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_cfg<22, 42, 16>())) return rc;
     if ((rc = set_attr_glds<42, 22>())) return rc;
     if ((rc = set_attr_glds<22, 22>())) return rc;
-    if ((rc = set_attr_glds<22, 22, 16, 3>())) return rc;
-    if ((rc = set_attr_glds<22, 22, 32, 2>())) return rc;
-    if ((rc = set_attr_glds<42, 22, 16, 3>())) return rc;
-    if ((rc = set_attr_glds<22, 12>())) return rc;
-    if ((rc = set_attr_glds<12, 22>())) return rc;
     if ((rc = set_attr_glds<22, 21>())) return rc;
-    if ((rc = set_attr_glds<22, 22, 16, 2, 5>())) return rc;
-    if ((rc = set_attr_glds<22, 22, 16, 2, 4>())) return rc;
-    if ((rc = set_attr_glds<42, 22, 16, 2, 4>())) return rc;
-    if ((rc = set_attr_glds<22, 22, 16, 3, 4>())) return rc;
-    if ((rc = set_attr_glds<22, 22, 16, 3, 1, 1>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 4, 1, 1>())) return rc;
     if ((rc = set_attr_glds<42, 22, 16, 3, 1, 1>())) return rc;
     if ((rc = set_attr_glds<22, 21, 16, 3, 1, 1>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 1>())) return rc;
-    if ((rc = set_attr_glds<42, 22, 16, 4, 1, 1>())) return rc;
     if ((rc = set_attr_glds<22, 21, 16, 4, 1, 1>())) return rc;
-    if ((rc = set_attr_glds<22, 42, 16, 4, 1, 1>())) return rc;
     if ((rc = set_attr_glds<22, 21, 16, 5, 1, 1>())) return rc;
-    if ((rc = set_attr_glds<21, 22, 16, 4, 1, 1>())) return rc;
     if ((rc = set_attr_glds<21, 21, 16, 4, 1, 1>())) return rc;
-    if ((rc = set_attr_glds<22, 12, 16, 4, 1, 1>())) return rc;
-    if ((rc = set_attr_glds<22, 21, 16, 6, 1, 1>())) return rc;
-    if ((rc = set_attr_glds<22, 21, 32, 3, 1, 1>())) return rc;
-    if ((rc = set_attr_glds<22, 22, 32, 3, 1, 1>())) return rc;
-    if ((rc = set_attr_glds<22, 21, 32, 4, 1, 1>())) return rc;
-    if ((rc = set_attr_glds<21, 21, 32, 4, 1, 1>())) return rc;
-    if ((rc = set_attr_glds<22, 22, 32, 4, 1, 1>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 2>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 3>())) return rc;
     const char* e = getenv("MMDM_GEMM_CFG");
     g_gemm_cfg = e ? atoi(e) : -1;
+    if (const char* t = getenv("MMDM_GEMM_TAIL")) g_gemm_tail = atoi(t);
     return MMDM_OK;
 }
 
 // tuning hook for tools/gemm_bench.py (not part of the public ABI): force a tile configuration, -1 = automatic
 extern "C" void mmdmx_set_gemm_cfg(int cfg) { g_gemm_cfg = cfg; }
 extern "C" void mmdmx_set_gemm_ablate(int a) { g_gemm_ablate = a; }
+extern "C" void mmdmx_set_gemm_tail(int t) { g_gemm_tail = t; }
 extern "C" void mmdmx_set_gemm_stamps(void* p) { g_gemm_stamps = static_cast<unsigned long long*>(p); }
 
 extern "C" int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
@@ -810,6 +808,33 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     switch (g_gemm_cfg) {
         case 10: if (glds_ok) return launch_glds<42, 22>(a, st); break;
         case -1:
+            if (glds_ok && K >= 96 && g_gemm_tail && epilogue != MMDM_EPI_BIAS_PE) {
+                // Row split ("tile list" of two entries): M = 19 200 gives 3600 / 4800 / 1200 tiles for 512 (128x128, two per CU) or 768
+                // (128x64, three per CU) resident slots = 7.03 / 6.25 / 2.34 rounds, and the fractional round costs a whole tile
+                // lifetime on a nearly empty chip.  Rows [0, M1) -- as many whole row tiles as fit into complete rounds -- go to the
+                // large tile; the remaining rows to a tile of half / a quarter of the area, whose single partial round is as short.
+                // Every pipelined instantiation accumulates an output element in the same order, so the split does not change a bit
+                // (tests: bitwise batch independence, production tiles vs float64).
+                const bool narrow = N <= 512 || K <= 512 || N == 2048;
+                const long slots = narrow ? 768 : 512, nt = (N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), mt = (M + 127) / 128;
+                const long tiles = mt * nt, full = tiles / slots, rem = tiles - full * slots;
+                const long mt1 = full * slots / nt;
+                if ((long)((M + 127) / 128) * ((N + 63) / 64) >= 512 && full >= 1 && mt1 >= 1 && mt1 < mt && rem * 10 <= slots * g_gemm_tail) {
+                    const int M1 = (int)mt1 * 128;
+                    GemmArgs b = a;
+                    a.M = M1;
+                    b.M = M - M1;
+                    b.A = A + (size_t)M1 * lda;
+                    b.C = C + (size_t)M1 * ldc;
+                    if (extra) b.extra = extra + (size_t)M1 * ld_extra;
+                    int rc = narrow ? launch_glds<22, 21, 16, 4, 1, 1>(a, st) : launch_glds<22, 22, 16, 5, 1, 1>(a, st);
+                    if (rc) return rc;
+                    // remainder: the largest tile that still gives every CU a workgroup
+                    const long r128 = (long)((b.M + 127) / 128) * ((N + 63) / 64);
+                    if (!narrow && r128 >= 256) return launch_glds<22, 21, 16, 4, 1, 1>(b, st);
+                    return launch_glds<21, 21, 16, 4, 1, 1>(b, st);
+                }
+            }
             if (glds_ok && K >= 96) {
                 // Production: the software-pipelined loop (gemm_pipe).  Tile / stage choice per shape, measured at M = 19 200 with
                 // tools/gemm_bench.py (TFLOP/s; the 2-stage kernels of round 1 reached 100-121 on the same shapes):
@@ -828,36 +853,16 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
             }
             break;
         case 11: if (glds_ok) return launch_glds<22, 22>(a, st); break;
-        case 12: if (glds_ok) return launch_glds<22, 22, 16, 3>(a, st); break;
-        case 13: if (glds_ok && K % 32 == 0) return launch_glds<22, 22, 32, 2>(a, st); break;
-        case 14: if (glds_ok) return launch_glds<42, 22, 16, 3>(a, st); break;
-        case 15: if (glds_ok) return launch_glds<22, 12>(a, st); break;     // 128 x 64 tile, 2 waves
-        case 16: if (glds_ok) return launch_glds<12, 22>(a, st); break;     // 64 x 128 tile, 2 waves
         case 17: if (glds_ok) return launch_glds<22, 21>(a, st); break;     // 128 x 64 tile, 4 waves (64 x 32 per wave)
-        case 21: if (glds_ok) return launch_glds<22, 22, 16, 2, 5>(a, st); break;   // 128 x 128, registers capped for 5 workgroups per CU
-        case 22: if (glds_ok) return launch_glds<22, 22, 16, 2, 4>(a, st); break;   // ... 4 per CU
-        case 23: if (glds_ok) return launch_glds<42, 22, 16, 2, 4>(a, st); break;   // 256 x 128 / 8 waves, 2 per CU
-        case 24: if (glds_ok) return launch_glds<22, 22, 16, 3, 4>(a, st); break;   // 128 x 128, 3 LDS stages (48 KB: 3 per CU by LDS)
-        case 30: if (glds_ok && K >= 64) return launch_glds<22, 22, 16, 3, 1, 1>(a, st); break;   // pipelined loop, 128 x 128, 3 stages
         case 31: if (glds_ok && K >= 64) return launch_glds<22, 22, 16, 4, 1, 1>(a, st); break;   // ... 4 stages (64 KB: 2 per CU)
         case 32: if (glds_ok && K >= 64) return launch_glds<42, 22, 16, 3, 1, 1>(a, st); break;   // ... 256 x 128 / 8 waves, 3 stages (72 KB: 2 per CU)
         case 33: if (glds_ok && K >= 64) return launch_glds<22, 21, 16, 3, 1, 1>(a, st); break;   // ... 128 x 64 / 4 waves
         case 34: if (glds_ok && K >= 80) return launch_glds<22, 22, 16, 5, 1, 1>(a, st); break;   // ... 128 x 128, 5 stages (80 KB: 2 per CU)
-        case 35: if (glds_ok && K >= 64) return launch_glds<42, 22, 16, 4, 1, 1>(a, st); break;   // ... 256 x 128 / 8 waves, 4 stages (96 KB: 1 per CU)
         case 36: if (glds_ok && K >= 64) return launch_glds<22, 21, 16, 4, 1, 1>(a, st); break;   // ... 128 x 64, 4 stages (48 KB: 3 per CU)
-        case 37: if (glds_ok && K >= 64) return launch_glds<22, 42, 16, 4, 1, 1>(a, st); break;   // ... 128 x 256 / 8 waves, 4 stages
         case 38: if (glds_ok && K >= 80) return launch_glds<22, 21, 16, 5, 1, 1>(a, st); break;   // ... 128 x 64, 5 stages (60 KB: 2 per CU)
-        case 40: if (glds_ok && K >= 64) return launch_glds<21, 22, 16, 4, 1, 1>(a, st); break;   // ... 64 x 128, 4 stages
         case 41: if (glds_ok && K >= 64) return launch_glds<21, 21, 16, 4, 1, 1>(a, st); break;   // ... 64 x 64 / 4 waves of 32 x 32
-        case 42: if (glds_ok && K >= 64) return launch_glds<22, 12, 16, 4, 1, 1>(a, st); break;   // ... 128 x 64 / 2 waves of 64 x 64
-        case 43: if (glds_ok && K >= 96) return launch_glds<22, 21, 16, 6, 1, 1>(a, st); break;   // ... 128 x 64, 6 stages (72 KB: 2 per CU)
-        case 50: if (glds_ok && K % 32 == 0 && K >= 128) return launch_glds<22, 21, 32, 3, 1, 1>(a, st); break;   // K step 32: 128 x 64, 3 stages (72 KB: 2 per CU)
-        case 51: if (glds_ok && K % 32 == 0 && K >= 128) return launch_glds<22, 22, 32, 3, 1, 1>(a, st); break;   // 128 x 128, 3 stages (96 KB: 1 per CU)
-        case 52: if (glds_ok && K % 32 == 0 && K >= 128) return launch_glds<22, 21, 32, 4, 1, 1>(a, st); break;   // 128 x 64, 4 stages (96 KB: 1 per CU)
-        case 53: if (glds_ok && K % 32 == 0 && K >= 128) return launch_glds<21, 21, 32, 4, 1, 1>(a, st); break;   // 64 x 64, 4 stages (64 KB: 2 per CU)
         case 60: if (glds_ok && K >= 96) return launch_glds<22, 22, 16, 5, 1, 2>(a, st); break;   // ablation: no LDS-DMA in the main loop
         case 61: if (glds_ok && K >= 96) return launch_glds<22, 22, 16, 5, 1, 3>(a, st); break;   // ablation: no barrier
-        case 54: if (glds_ok && K % 32 == 0 && K >= 128) return launch_glds<22, 22, 32, 4, 1, 1>(a, st); break;   // 128 x 128, 4 stages (128 KB: 1 per CU)
         default: break;
     }
     switch (g_gemm_cfg) {

@@ -57,7 +57,7 @@ void mmdm_note_gemm(const char* fmt, ...) {
 extern "C" const char* mmdm_last_gemm_kernel(void) { return g_gemm_note; }
 
 extern "C" const char* mmdm_last_error(void) { return g_err; }
-extern "C" const char* mmdm_version(void) { return "gfx950;mmdm-hip r2"; }
+extern "C" const char* mmdm_version(void) { return "gfx950;mmdm-hip r3"; }
 
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
@@ -524,6 +524,8 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     };
     // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / three planes, or fp8 + per-row scales
     auto norm = [&](const float* src, const float* ssp, int rows) -> int {
+        static const bool skip_exp = getenv("MMDM_EXP_SKIP_ADALN") != nullptr;      // EXPERIMENT (timing upper bound of a fused AdaLN; wrong results) -- remove
+        if (skip_exp) return MMDM_OK;
         if (f8) return mmdm_adaln_any(src, ssp, r.ss_ld, rows, S.xn, 3, S.xs, r.nseq, r.T, D, c.st);
         return mmdm_adaln_ex(src, ssp, r.ss_ld, rows, S.xn, ob, r.nseq, r.T, D, c.st);
     };
@@ -1224,11 +1226,16 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
             e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
             if (e != hipSuccess) return herr(h, mmdm_set_error(MMDM_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)));
-            if (h->graphs.size() >= h->graph_cap) {               // evict the least recently used entry (its replays may still be queued)
+            if (h->graphs.size() >= h->graph_cap) {               // evict the least recently used entry
                 size_t lru = 0;
                 for (size_t i = 1; i < h->graphs.size(); ++i)
                     if (h->graphs[i].used < h->graphs[lru].used) lru = i;
-                HIPCHK(hipStreamSynchronize(st));
+                // its replays may still be queued, and on another stream than this call's: wait for the whole device
+                e = hipDeviceSynchronize();
+                if (e != hipSuccess) {
+                    (void)hipGraphExecDestroy(exec);
+                    return herr(h, mmdm_set_error(MMDM_ERR_HIP, "mmdm_run: hipDeviceSynchronize before evicting a cached graph: %s", hipGetErrorString(e)));
+                }
                 (void)hipGraphExecDestroy(h->graphs[lru].exec);
                 h->graphs.erase(h->graphs.begin() + lru);
             }
@@ -1293,12 +1300,8 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
     if (S_keep > 0)
         for (int k = 0; k < 3; ++k)
             if (mods[k]) HIPCHK(hipMemcpyAsync(h->tt_stash + k * Dst, mods[k]->time_tab, mods[k]->st.D * sizeof(float), hipMemcpyDeviceToDevice, st));
-    h->S = 1;
-    h->begun = false;
     int rc = MMDM_OK;
-    HIPCHK(hipMemcpyAsync(h->d_tmap, &t, sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
-    RC(mmdm_set_step(h->d_step, h->d_step + 1, 0, 0, st));
+    // every exit from here on goes through `done`, which puts S, timestep_map[0] and row 0 of the time tables back
     auto done = [&](int code) {
         h->S = S_keep;
         if (S_keep > 0) {
@@ -1310,6 +1313,14 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
         }
         return herr(h, code);
     };
+    h->S = 1;
+    h->begun = false;
+    {
+        hipError_t e = hipMemcpyAsync(h->d_tmap, &t, sizeof(int), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return done(mmdm_set_error(MMDM_ERR_HIP, "mmdm_module_forward: timestep upload failed: %s", hipGetErrorString(e)));
+        if ((rc = mmdm_set_step(h->d_step, h->d_step + 1, 0, 0, st))) return done(rc);
+    }
     if (which == 3) {                         // in2INDenoiser "dual_individual": x [n,T,524], cond [n, 5*td]
         if ((rc = build_time_tab(c, h->d1))) return done(rc);
         if ((rc = text_rows(c, h->d1, cond, 5 * td, 3 * td, h->txt_d1, 0, n))) return done(rc);

@@ -118,11 +118,11 @@ __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h,
 template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ out, int rows, int D, float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    const float* xp = x + (size_t)row * D;
     const int nv = D >> 2;
+    // persistent like adaln_kernel: the host caps the grid at 2048 blocks, so every wave slot walks rows with the grid's stride
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    const float* xp = x + (size_t)row * D;
     f32x4 v[MAXV];
     float s = 0.f;
 #pragma unroll
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c);
             *reinterpret_cast<f32x4*>(out + (size_t)row * D + 4 * c) = (v[i] - mean) * rstd * g + b;
         }
+    }
     }
 }
 

@@ -50,13 +50,21 @@ def scatter_requests(cond, x_T, src=0, device=None):
     return c[lo:hi].contiguous(), x[lo:hi].contiguous(), (lo, hi, B)
 
 
-def gather_motions(local, total):
-    """All ranks receive the [total, T, F] result, rows in shard order (uneven shards are padded for the collective)."""
+def gather_motions(local, total, dst=None):
+    """The [total, T, F] result, rows in shard order (uneven shards are padded for the collective).
+    dst=None: every rank receives it (one all-gather).  dst=r: only rank r does (one gather: what a caller that owns the request needs --
+    at BASELINE configs[3] an all-gather would deliver 161 MB to each of 8 ranks of which 7 throw it away); the other ranks return None."""
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_range(total, world, r) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros(mx, *local.shape[1:], dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)
+    if dst is None:
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)
+    else:
+        bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, bufs, dst=dst)
+        if rank != dst:
+            return None
     return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)

@@ -11,6 +11,12 @@ import torch.nn.functional as F
 FACE_JOINT_INDX = [2, 1, 17, 16]  # /root/reference/src/utils/paramUtil.py:89
 
 
+def _f(t):
+    """The reference's ``.float()`` casts (no-ops on its fp32 tensors).  A float64 tensor stays float64, so that the SAME restatement run on
+    ``.double()`` weights and inputs is the high-precision yardstick of tests/parity_tol.py (what the fp32 arithmetic is an approximation of)."""
+    return t if t.dtype == torch.float64 else t.float()
+
+
 def rotation_6d_to_matrix(d6):
     """rotation_conversions.py:511-534 -- note the interleaved [0,2,4],[1,3,5] shuffle (:527-528)."""
     a1, a2 = d6[..., [0, 2, 4]], d6[..., [1, 3, 5]]
@@ -102,17 +108,17 @@ def qbetween(v0, v1):
 def ih_to_smpl(motion):
     """alignment.py:11-38: 262 -> 205 (rot6d -> -axis_angle, 6 zero pad, last 4 kept)."""
     B = motion.shape[0]
-    poses = motion[:, :, 132:132 + 126].reshape(B, -1, 21, 6).float()
+    poses = _f(motion[:, :, 132:132 + 126].reshape(B, -1, 21, 6))
     poses = quaternion_to_axis_angle(matrix_to_quaternion(rotation_6d_to_matrix(poses))) * -1
     poses = poses.reshape(B, -1, 63)
-    pad = torch.zeros(B, poses.shape[1], 6)
+    pad = torch.zeros(B, poses.shape[1], 6, dtype=poses.dtype)
     return torch.cat([motion[:, :, :132], poses, pad, motion[:, :, -4:]], dim=2)
 
 
 def smpl_to_ih(motion):
     """alignment.py:40-67: 205/201 -> 262; appends motion[..., -4:] of whatever came in."""
     B = motion.shape[0]
-    poses = motion[:, :, 132:132 + 69].reshape(B, -1, 23, 3).float() * -1
+    poses = _f(motion[:, :, 132:132 + 69].reshape(B, -1, 23, 3)) * -1
     poses = matrix_to_rotation_6d(quaternion_to_matrix(axis_angle_to_quaternion(poses)))
     poses = poses.reshape(B, -1, 138)[:, :, :-12]
     return torch.cat([motion[:, :, :132], poses, motion[:, :, -4:]], dim=2)
@@ -158,18 +164,18 @@ def center_motion(motion, diag=None):
     floor = pos.min(dim=1).values.min(dim=1).values[:, 1]
     pos[:, :, :, 1] -= floor[:, None, None]
     root_init = pos[:, 0]
-    xz = root_init[:, 0] * torch.tensor([1.0, 0.0, 1.0])
+    xz = root_init[:, 0] * torch.tensor([1.0, 0.0, 1.0], dtype=pos.dtype)
     pos2 = pos - xz[:, None, None, :]
     r_hip, l_hip = FACE_JOINT_INDX[:2]
     across = root_init[:, r_hip] - root_init[:, l_hip]
     across_len = torch.sqrt((across ** 2).sum(dim=-1))
     across = across / across_len.unsqueeze(-1)
-    fwd = torch.cross(torch.tensor([0.0, 1.0, 0.0]).expand(B, -1), across, dim=-1)
+    fwd = torch.cross(torch.tensor([0.0, 1.0, 0.0], dtype=pos.dtype).expand(B, -1), across, dim=-1)
     fwd_len = torch.sqrt((fwd ** 2).sum(dim=-1))
     fwd = fwd / fwd_len.unsqueeze(-1)
     if diag is not None:
         diag.append(dict(across=across_len, fwd=fwd_len, w=1 + fwd[:, 2], reach=pos2.abs().amax(dim=(1, 2, 3))))
-    target = torch.tensor([0.0, 0.0, 1.0]).expand(B, -1)
+    target = torch.tensor([0.0, 0.0, 1.0], dtype=pos.dtype).expand(B, -1)
     q = qbetween(fwd, target)[:, None, None, :].expand(-1, pos2.shape[1], 22, -1)
     pos2 = qrot(q, pos2)
     vel = qrot(q, vel)

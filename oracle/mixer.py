@@ -51,8 +51,8 @@ def mixer_forward(W, spec, stats, x1, timesteps, cond, x2, hist=None):
     nf, td1, td2, td = spec.nfeats, spec.d1_text_dim, spec.d2_text_dim, spec.text_dim
     mean_h, std_h, mean_i, std_i = stats
     B, T = x1.shape[:2]
-    x1 = x1.float()
-    x2 = x2.float()
+    x1 = G._f(x1)           # the reference's .float() (mixermdm.py:663-664); float64 inputs stay float64 (tests/parity_tol.py yardstick)
+    x2 = G._f(x2)
     cond1_1 = cond[:, td2 * 3:td2 * 3 + td1]
     cond1_2 = cond[:, td2 * 3 + td1:td2 * 3 + td1 * 2]
     cond2 = cond[:, :td * 3]
@@ -133,7 +133,9 @@ def process_xstart(x, stats, t0_positive, align=True, diag=None):
 
 def ddim_update(sched, i, x, x0):
     """_predict_eps_from_xstart (:558-562) + DDIM eta=0 mean (:1936-1965); tables cast to fp32 at gather (:1264-1277)."""
-    f = lambda arr: torch.tensor(arr[i], dtype=torch.float64).float()
+    # the coefficient VALUES are the fp32-rounded table entries in every case; in a float64 run they are widened again, so that run differs
+    # from the fp32 one by arithmetic rounding only
+    f = lambda arr: torch.tensor(arr[i], dtype=torch.float64).float().to(x.dtype)
     eps = (f(sched.sqrt_recip_alphas_cumprod) * x - x0) / f(sched.sqrt_recipm1_alphas_cumprod)
     ab_prev = f(sched.alphas_cumprod_prev)
     return x0 * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev - 0.0 ** 2) * eps

@@ -22,6 +22,20 @@ def pytest_sessionstart(session):
         B.build(verbose=False)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """Parity report of a GPU run (tests/parity_tol.py::REPORT): every compared step's out-of-tolerance fraction, masked persons, largest
+    conditioning factor and the float64-yardstick quantiles.  gpurun merges gpurun_out/ back; the committed copy lives under profiles/."""
+    try:
+        import json
+        import parity_tol
+        if parity_tol.REPORT:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
+                json.dump({"exitstatus": int(exitstatus), "entries": parity_tol.REPORT}, f, indent=1)
+    except Exception as e:      # the report must never turn a green run red
+        print("parity report not written:", e)
+
+
 def load_golden(name):
     """Return (arrays, weights-by-prefix-getter) for tests/golden/<name>.npz."""
     import torch

@@ -1,8 +1,29 @@
-"""Conditioning-aware comparison of one sampler step with the oracle (shared by the GPU parity tests; test infrastructure).
+"""Comparison of one sampler step with the oracle, justified by a float64 run of the same oracle (shared by the GPU parity tests; test
+infrastructure).
 
-Tolerance of a step (STEP_TOL): all but 0.2 % of the elements within atol 2e-4 + rtol 2e-4, none beyond 5e-2; the tolerance of a person's
-position / velocity channels is scaled by the conditioning factor of the global rotations that produced them.
+Two statements are made about every compared step (round 3; replaces the hand-fitted conditioning factors of round 2):
+
+1. PARITY with the fp32 oracle, element by element (`compare_step`): all but 0.2 % of the elements within atol 2e-4 + rtol 2e-4 of the
+   CPU fp32 oracle (the reference's own arithmetic: pinned to it by tests/golden), none beyond 5e-2 -- where the tolerance of an element
+   is never smaller than what fp32 arithmetic itself costs THERE: 12 x the 99.9th percentile of |CPU-fp32 - float64| over the element's
+   (sample, person, channel class) group.  The oracle runs unchanged on .double() weights and inputs (oracle/geometry.py::_f); its
+   distance from the fp32 oracle is the measured conditioning of the function at that point.  Where the reference's geometry is
+   ill-conditioned -- `qbetween` of nearly (anti-)parallel directions in align_motions / center_motion turns a whole person by an angle
+   that is rounding noise -- the CPU's own fp32 error is large in exactly that person's position / velocity channels, and the tolerance
+   follows it; everywhere else the plain tolerance applies.  No geometric formula, no mask.
+
+2. YARDSTICK (`yardstick`): the HIP path's distance from float64 is of the size of the CPU fp32 oracle's distance from float64, at the
+   quantiles p50 / p99 / p99.9 of every channel class: <= 3 x for the rotation-6D and foot-contact channels of every step, <= 12 x for the
+   position / velocity channels of a single step, and <= 3 x for EVERY class and quantile (incl. the maximum) in the median over a
+   teacher-forced sequence of steps (`yardstick_sequence`).  Why two factors: a person's position / velocity channels all pass through
+   ONE global rotation whose angle error is a single random number per person and step, so the per-step quantile ratio of that class is the
+   ratio of two random scalars -- heavy-tailed (observed up to 9.8 over 160 step x tensor samples, median 2.1) -- while its median over a
+   sequence is stable.  Measured (profiles/r03_parity_report.json): HIP / CPU medians 1.1-2.2 (fp32 and fp32_split), 2.3-2.6 on the
+   geometry-free single-person path.  The factor ~2 is the accumulation order: v_mfma_f32_32x32x2_f32 sums an output element as ONE
+   k-ordered fp32 chain of K = 1024-2048 terms, the CPU GEMM as many short chains; the oracle with its GEMMs replaced by a k-ordered fp32
+   chain shows the same 1.3-2.1 x (tools/accum_order_experiment.py).
 """
+import os
 import torch
 
 STEP_TOL = dict(atol=2e-4, rtol=2e-4, frac=2e-3, hard=5e-2)
@@ -10,74 +31,148 @@ STEP_TOL = dict(atol=2e-4, rtol=2e-4, frac=2e-3, hard=5e-2)
 # single rot6d components; `frac` allows 0.2 % of them, and never fewer than this many elements (each still inside `hard`).
 MIN_OUTLIERS = 4
 HARD_OUTLIERS = 2
+GROUP_FACTOR = 12.0        # element tolerance >= GROUP_FACTOR x p99.9 of |CPU-fp32 - float64| over the element's (sample, person, class) group
+HARD_FACTOR = 100.0        # hard bound >= HARD_FACTOR x the same figure
+AMPLIFIED = 25.0           # a group whose tolerance exceeds AMPLIFIED x the plain one is counted (and reported) as ill-conditioned
 
-# Conditioning of the reference's two global rotations (geometry near its branch points needs a discriminant-aware comparison).
-# Both are qbetween(u, v) of two directions and both are applied to whole position / velocity sequences:
-#   * align_motions turns the individual model's motion by the angle between two root-displacement DIRECTIONS (alignment.py:84-101).  A
-#     pre-geometry difference e in the root positions (HIP vs CPU rounding through 8-16 blocks: ~2e-5) turns the sequence by e / |disp| and
-#     moves a position at distance `reach` from the pivot by reach * e / |disp|: that stays inside the 2e-4 tolerance only while
-#     |disp| >= 0.1 reach.  The random-weight individual model barely moves its root (|disp| / reach = 0.04-0.07), so the factor
-#     kappa = 0.1 reach / |disp| (>= 1) scales the tolerance of that person's position / velocity channels.
-#   * qbetween is singular for anti-parallel directions: w = 1 + u.v -> 0 and |u x v| -> 0, and an fp32 rounding of w (1e-7) turns the
-#     sequence by 2e-7 / sqrt(2 w): beyond the tolerance at 8 m reach once w < 3e-5.  center_motion (alignment.py:188-206) rotates every
-#     person to face +Z, so person 2 of a pair facing each other -- where these trajectories sit for many late steps -- is exactly that
-#     half turn.  kappa = sqrt(3e-4 / w) (10x margin on the figure above).
-# Persons with kappa > KAPPA_MASK are on the branch point: their position / velocity channels are compared for sanity only (finite,
-# |err| within the motion's own extent).  Rotation-6D and foot-contact channels are never affected and always meet the plain tolerance.
-KAPPA_MASK = 25.0
+QUANTILES = (0.5, 0.99, 0.999, 1.0)
+QNAMES = ("p50", "p99", "p99.9", "max")
+YARD_FACTOR = 3.0          # rot6d / feet per step; every class in the median over a sequence
+YARD_FACTOR_POSVEL = 12.0  # position / velocity channels of a single step (one global rotation per person: see the module docstring)
+YARD_FACTOR_LOOP = 10.0    # free-running loops: S steps of compounded divergence, one sample of a chaotic process
+YARD_FLOOR = 1e-6          # two orders below atol: quantiles of exactly representable channels are rounding noise of ~1e-7
+REPORT = []                # one dict per compared step; tests/conftest.py writes it to gpurun_out/parity_report.json at session end
+REPORT_ONLY = os.environ.get("MMDM_PARITY_REPORT_ONLY") == "1"
 
 
-def kappa(hist, B):
-    """Oracle diagnostics of one step -> (kappa_chain1 [B, 2 persons], kappa_chain2 [B, 2]) tolerance factors >= 1."""
-    k_align = torch.ones(B, 2, dtype=torch.float64)
-    for p, d in enumerate(hist["align_diag"][-2:]):            # rows: B cond + B uncond of the CFG-doubled batch
-        k = torch.maximum(0.1 * d["reach"] / torch.minimum(d["disp_target"], d["disp_moved"]).clamp_min(1e-12), torch.sqrt(3e-4 / d["w"].clamp_min(1e-12))).double()
-        k_align[:, p] = torch.maximum(k[:B], k[B:]).clamp_min(1.0)
-    k_center = torch.ones(B, 2, dtype=torch.float64)
-    for p, d in enumerate(hist.get("center_diag", [])[-2:]):
-        k = torch.maximum(torch.sqrt(3e-4 / d["w"].clamp_min(1e-12)), 0.01 * d["reach"] / (d["across"] * d["fwd"]).clamp_min(1e-12)).double()
-        k_center[:, p] = k.clamp_min(1.0)
-    return torch.maximum(k_align, k_center), k_align
+def channel_classes(C):
+    ch = torch.arange(C) % 262
+    return {"posvel": ch < 132, "rot6d": (ch >= 132) & (ch < 258), "feet": ch >= 258}
 
 
+def _quant(e, qs=QUANTILES):
+    e = e.flatten().double()
+    if e.numel() == 0:
+        return [0.0] * len(qs)
+    srt = torch.sort(e).values
+    return [float(srt[min(srt.numel() - 1, int(q * (srt.numel() - 1) + 0.5))]) for q in qs]
 
-def compare_step(out, refs, what, hist, tol=STEP_TOL):
-    """out / refs: {state name: tensor [B, T, 524]}; hist: the oracle's diagnostics of this very step (``hist=`` of mixer_ddim_step).
-    Returns (worst out-of-tolerance fraction, whether a person had to be masked)."""
-    first = next(iter(refs.values()))
-    B, T = first.shape[:2]
-    k1, k2 = kappa(hist, B)
-    worst, masked = 0.0, False
-    for nm, ref in refs.items():
+
+def to64(W):
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in W.items()}
+
+
+def record(what, **kw):
+    """Extra per-test figures for the parity report."""
+    REPORT.append(dict(what=what, **kw))
+
+
+def oracle_step_pair(W, spec, stats, sched, s, i, x, x2, cond, W64=None, names=("x", "x2", "pred_xstart", "pred_xstart2")):
+    """One MixerDiffusion.ddim_sample step of the oracle in fp32 and, from the same (fp32-valued) inputs, in float64.
+    Returns ({name: fp32 tensor}, {name: float64 tensor})."""
+    from oracle import mixer as MX
+    W64 = W64 if W64 is not None else to64(W)
+    with torch.no_grad():
+        r32 = MX.mixer_ddim_step(W, spec, stats, sched, s, i, x, x2, cond)
+        r64 = MX.mixer_ddim_step(W64, spec, tuple(torch.as_tensor(t).double() for t in stats), sched, s, i, x.double(), x2.double(), cond.double())
+    return dict(zip(names, r32)), dict(zip(names, r64))
+
+
+def group_scale(e_cpu):
+    """|CPU-fp32 - float64| [B, T, C] -> (G, ngroups): G [B, T, C] = p99.9 of it over the element's (sample, person, channel class) group."""
+    B, T, C = e_cpu.shape
+    G = torch.zeros_like(e_cpu)
+    ch = torch.arange(C)
+    per_group = []
+    for p in range(C // 262):
+        for lo, hi in ((0, 132), (132, 258), (258, 262)):
+            sel = (ch >= p * 262 + lo) & (ch < p * 262 + hi)
+            k = torch.sort(e_cpu[:, :, sel].reshape(B, -1), dim=1).values
+            q = k[:, min(k.shape[1] - 1, int(0.999 * (k.shape[1] - 1) + 0.5))]
+            G[:, :, sel] = q[:, None, None]
+            per_group.append(q)
+    return G, torch.stack(per_group, dim=1)          # [B, groups]
+
+
+def compare_step(out, ref32, ref64, what, tol=STEP_TOL):
+    """out: {state name: HIP tensor [B, T, C]}; ref32 / ref64: the fp32 and the float64 oracle's outputs of this very step.
+    Asserts statement 1 of the module docstring for every tensor of ref32; returns (worst out-of-tolerance fraction, largest number of
+    ill-conditioned (sample, person, class) groups in a tensor)."""
+    worst, amplified = 0.0, 0
+    detail = {"kind": "step_vs_fp32_oracle", "tensors": {}}
+    for nm, ref in ref32.items():
         got, ref = out[nm].detach().cpu().double(), torch.as_tensor(ref).detach().cpu().double()
-        assert got.shape == ref.shape, (nm, got.shape, ref.shape)
+        r64 = torch.as_tensor(ref64[nm]).detach().cpu().double()
+        assert got.shape == ref.shape == r64.shape, (nm, got.shape, ref.shape, r64.shape)
         assert torch.isfinite(got).all(), f"{what} {nm}: non-finite"
-        kap = k1 if nm in ("x", "pred_xstart") else k2
-        scale = torch.ones(B, T, 524, dtype=torch.float64)
-        for p in range(2):
-            scale[:, :, p * 262:p * 262 + 132] = kap[:, p, None, None]
-        keep = scale <= KAPPA_MASK
-        masked |= not bool(keep.all())
+        C = got.shape[-1]
+        G, per_group = group_scale((ref - r64).abs())
+        plain = tol["atol"] + tol["rtol"] * ref.abs()
+        lim = torch.maximum(plain, GROUP_FACTOR * G)
         d = (got - ref).abs()
-        bad = (d > scale * (tol["atol"] + tol["rtol"] * ref.abs())) & keep
-        nbad = int(bad.sum())
-        frac = nbad / max(1, int(keep.sum()))
+        nbad = int((d > lim).sum())
+        frac = nbad / d.numel()
         if nbad <= MIN_OUTLIERS:          # tiny tensors (T = 1, 2): a fraction of 1048 elements is two elements; the outliers are single rot6d components
             frac = 0.0
-        note = f"(conditioning factors per [sample, person]: {[[round(v, 1) for v in r] for r in kap.tolist()]})"
-        assert frac <= tol["frac"], f"{what} {nm}: {frac:.2e} of the elements outside tolerance, max err {d[keep].max().item():.2e} {note}"
-        if keep.any():
-            rel = torch.where(keep, d / scale, torch.zeros_like(d))
-            over = rel > tol["hard"]
-            # A rot6d pair within ~1e-5 of collinear makes Gram-Schmidt amplify fp32 rounding by ~1e5 (one joint in ~1e5 on noise inputs): at
-            # most HARD_OUTLIERS rot6d components per tensor may pass the hard bound; position / velocity channels never may.
-            ch = torch.arange(524) % 262
-            rot = ((ch >= 132) & (ch < 258))[None, None, :].expand_as(over)
-            worst_idx = tuple(int(v) for v in torch.nonzero(rel == rel.max())[0])
-            assert not bool((over & ~rot).any()), f"{what} {nm}: max err {d[keep].max().item():.2e} at {worst_idx} {note}"
-            assert int(over.sum()) <= HARD_OUTLIERS, f"{what} {nm}: {int(over.sum())} rot6d components beyond the hard bound, max err {d[keep].max().item():.2e} at {worst_idx} {note}"
-        # masked persons sit on the rotation's branch point: any rounding turns them by an arbitrary angle about the pivot, so their
-        # position / velocity channels can only be checked for sanity -- finite, and inside the motion's own extent
-        assert d.max().item() <= 2.0 * ref.abs().max().item() + 1.0, f"{what} {nm}: an element on a branch point is off by {d.max().item():.2e}"
+        n_amp = int((GROUP_FACTOR * per_group > AMPLIFIED * tol["atol"]).sum())
+        note = f"(largest group tolerance {float((GROUP_FACTOR * per_group).max()):.2e}, {n_amp} ill-conditioned group(s) of {per_group.numel()})"
+        assert frac <= tol["frac"], f"{what} {nm}: {frac:.2e} of the elements outside tolerance, max err {d.max().item():.2e} {note}"
+        over = d > torch.maximum(torch.full_like(d, tol["hard"]), HARD_FACTOR * G)
+        ch = torch.arange(C) % 262
+        rot = ((ch >= 132) & (ch < 258))[None, None, :].expand_as(over)
+        # A rot6d pair within ~1e-5 of collinear makes Gram-Schmidt amplify fp32 rounding by ~1e5 (one joint in ~1e5 on noise inputs): at
+        # most HARD_OUTLIERS rot6d components per tensor may pass the hard bound; position / velocity / foot channels never may.
+        assert not bool((over & ~rot).any()), f"{what} {nm}: max err {d.max().item():.2e} {note}"
+        assert int(over.sum()) <= HARD_OUTLIERS, f"{what} {nm}: {int(over.sum())} rot6d components beyond the hard bound, max err {d.max().item():.2e} {note}"
         worst = max(worst, frac)
-    return worst, masked
+        amplified = max(amplified, n_amp)
+        detail["tensors"][nm] = {"out_of_tol_fraction": frac, "out_of_tol_elements": nbad, "elements": int(d.numel()), "max_err": float(d.max()),
+                                 "max_err_over_plain_tol": float((d / plain).max()), "largest_group_tolerance": float((GROUP_FACTOR * per_group).max()),
+                                 "ill_conditioned_groups": n_amp, "groups": int(per_group.numel())}
+    record(what, **detail)
+    return worst, amplified
+
+
+def yardstick(out, ref32, ref64, what, factor=YARD_FACTOR, factor_posvel=YARD_FACTOR_POSVEL, floor=YARD_FLOOR):
+    """Statement 2 for one step: |HIP - f64| <= factor x |fp32 oracle - f64| + floor at p50 / p99 / p99.9 of every channel class (the
+    maximum -- one element -- is recorded; it is asserted through yardstick_sequence).  Returns the figures (also appended to REPORT)."""
+    entry = {"what": what, "kind": "yardstick", "factor": factor, "factor_posvel": factor_posvel, "floor": floor, "tensors": {}}
+    fails = []
+    for nm, r64 in ref64.items():
+        if nm not in ref32 or nm not in out or out[nm] is None:
+            continue
+        got = out[nm].detach().cpu().double()
+        r32 = torch.as_tensor(ref32[nm]).detach().cpu().double()
+        r64 = torch.as_tensor(r64).detach().cpu().double()
+        e_hip, e_cpu = (got - r64).abs(), (r32 - r64).abs()
+        t = entry["tensors"][nm] = {}
+        for cname, sel in channel_classes(got.shape[-1]).items():
+            qh, qc = _quant(e_hip[..., sel]), _quant(e_cpu[..., sel])
+            t[cname] = {"hip_vs_f64": qh, "cpu32_vs_f64": qc, "ratio": [h / max(c, floor) for h, c in zip(qh, qc)]}
+            f = factor_posvel if cname == "posvel" else factor
+            for qn, h, c in list(zip(QNAMES, qh, qc))[:3]:
+                if h > f * c + floor:
+                    fails.append(f"{nm}/{cname} {qn}: HIP {h:.3e} vs CPU-fp32 {c:.3e} (factor {f})")
+    entry["ok"] = not fails
+    REPORT.append(entry)
+    if not REPORT_ONLY:
+        assert not fails, f"{what}: HIP is further from float64 than the fp32 oracle allows: " + "; ".join(fails)
+    return entry
+
+
+def yardstick_sequence(entries, what, factor=YARD_FACTOR):
+    """Statement 2 over a teacher-forced sequence: for every (tensor, class, quantile incl. max) the MEDIAN over the steps of the
+    HIP / CPU-fp32 error ratio is <= factor."""
+    acc = {}
+    for e in entries:
+        for nm, t in e["tensors"].items():
+            for cname, v in t.items():
+                for qn, r in zip(QNAMES, v["ratio"]):
+                    acc.setdefault(f"{nm}/{cname}/{qn}", []).append(r)
+    med = {k: float(torch.tensor(v).median()) for k, v in acc.items()}
+    mx = {k: float(max(v)) for k, v in acc.items()}
+    fails = [f"{k}: median ratio {m:.2f}" for k, m in med.items() if m > factor]
+    REPORT.append({"what": what, "kind": "yardstick_sequence", "steps": len(entries), "factor": factor, "median_ratio": med, "max_ratio": mx, "ok": not fails})
+    if not REPORT_ONLY:
+        assert not fails, f"{what}: " + "; ".join(fails)
+    return med

@@ -40,6 +40,8 @@ def _worker(rank, world, port, batches, out_dir):
         assert total == B and (lo, hi) == shard_range(B, world, rank) and c.shape[0] == hi - lo
         full = gather_motions(_row_fn(c, x), total)
         torch.save(full, os.path.join(out_dir, f"B{B}_r{rank}.pt"))
+        only1 = gather_motions(_row_fn(c, x), total, dst=1)          # rank-1-only gather: the owner gets the same rows, the others nothing
+        assert (only1 is None) == (rank != 1) and (only1 is None or torch.equal(only1, full))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -200,6 +200,33 @@ def test_scatter_sample_gather_on_rccl_world_1():
         full = gather_motions(s.sample(c, x), total)
         dist.barrier()
         assert torch.equal(full, ref)
+        assert torch.equal(gather_motions(s.sample(c, x), total, dst=0), ref)       # rank-0-only gather (dist.gather on RCCL)
         s.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_runs_its_rccl_path_under_torchrun_on_the_gpu_box():
+    """`bench.py` as the driver launches it for N > 1 -- `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` -- with
+    N = 1 and MMDM_BENCH_FORCE_DIST=1, as a CHILD process: the RCCL init -> weight broadcast -> barrier -> all_gather / all_reduce of the
+    timings really execute on this box (the CPU suite only covers the launcher with --dry-run on gloo), at the per-GPU batch of BASELINE
+    configs[3] (32 motions), and the JSON line names that workload."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MMDM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt", "--no-full-loop",
+           "--profile-steps", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["batch_per_gpu"] == 32 and line["scaling"] == "weak" and line["outputs_finite"]
+    assert "2-person MixerMDM" in line["config"]["workload"] and "batch 32 per GPU" in line["config"]["workload"]
+    assert line["ms_per_step"] > 0 and abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3 * 1000)) < 1e-3
+    assert line["ms_per_step_ranks"]["min"] == line["ms_per_step_ranks"]["max"]          # the all_gather of the per-rank timings ran (one rank)

@@ -26,7 +26,7 @@ from test_gpu_sampler import STEP_TOL     # noqa: E402
 
 
 # ---- kernels ----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("rows,D", [(5, 16), (77, 768), (301, 256), (9, 1024), (3, 2048)])
+@pytest.mark.parametrize("rows,D", [(5, 16), (77, 768), (301, 256), (9, 1024), (3, 2048), (20000, 1024), (8193, 64)])
 def test_layernorm(rows, D):
     from mixermdm_amd import ops
     x, g, b = rnd(1, rows, D) * 3 + 0.5, rnd(2, D), rnd(3, D)

@@ -3,9 +3,10 @@ ddim1000 schedule -- in the native fp32 mode and in fp32_split, against (1) the 
 itself at these sizes (tests/golden/fulldims.npz), plus float64 checks of the GEMM instantiations the B=16 step actually launches
 (M = 19 200 rows), with the launched kernel asserted through the mmdm_last_gemm_kernel() debug getter.
 
-Tolerance of a step (tests/parity_tol.py::STEP_TOL): all but 0.2 % of the elements within atol 2e-4 + rtol 2e-4, none beyond 5e-2
-(a handful of near-degenerate joints amplify rounding through the rot6d -> quaternion round trip); the tolerance of a person's position /
-velocity channels is scaled by the conditioning factor of the global rotations that produced them (tests/parity_tol.py).
+Tolerance of a step (tests/parity_tol.py): all but 0.2 % of the elements within atol 2e-4 + rtol 2e-4 of the fp32 oracle, none beyond 5e-2
+(a handful of near-degenerate joints amplify rounding through the rot6d -> quaternion round trip), the tolerance of an element never
+smaller than 12 x what fp32 arithmetic costs the CPU oracle itself in that (sample, person, channel class) group -- measured against a
+float64 run of the same oracle; and the float64 yardstick: the HIP path is as far from float64 as the CPU fp32 oracle is, within 3 x.
 """
 import math
 import os
@@ -19,7 +20,7 @@ pytestmark = pytest.mark.gpu
 from oracle import mixer as MX            # noqa: E402  (checker only)
 from oracle import schedule as OS         # noqa: E402
 from test_gpu_kernels import assert_close, rnd, dev   # noqa: E402
-from parity_tol import STEP_TOL, compare_step, KAPPA_MASK      # noqa: E402,F401
+from parity_tol import STEP_TOL, compare_step, yardstick, yardstick_sequence, to64, record      # noqa: E402,F401
 from conftest import fulldims_case         # noqa: E402
 
 MODES = ["fp32", "fp32_split"]
@@ -39,6 +40,23 @@ class _Threads:
 def case():
     """(golden arrays, state dict, oracle weights incl. pe tables, stats tuple, seeded inputs) of fulldims.npz."""
     return fulldims_case()
+
+
+@pytest.fixture(scope="module")
+def case64(case):
+    """The same weights and statistics in float64: the oracle run on them is the yardstick of tests/parity_tol.py::yardstick."""
+    _, _, W, stats, _ = case
+    return to64(W), tuple(t.double() for t in stats)
+
+
+NAMES = ("x", "x2", "pred_xstart", "pred_xstart2")
+
+
+def _step64(case64, sch, i, x, x2, cond):
+    """One oracle step in float64 from the same (fp32-valued) inputs -> {state name: float64 tensor}."""
+    W64, stats64 = case64
+    with _Threads(), torch.no_grad():
+        return dict(zip(NAMES, MX.mixer_ddim_step(W64, MX.MixerSpec(d_heads=8, m_heads=8), stats64, sch, 3.5, i, x.double(), x2.double(), cond.double(), {})))
 
 
 @pytest.fixture(scope="module")
@@ -67,11 +85,14 @@ def _step(s, x, x2, i, names=("x", "x2", "pred_xstart", "pred_xstart2")):
     return {k: st[k].clone() for k in names}
 
 
-def _check_step(s, x, x2, i, refs, what, hist):
-    """refs: {state name: reference tensor}; hist: the oracle's diagnostics of this very step (conditioning factors)."""
+def _check_step(s, x, x2, i, refs, what, ref64):
+    """refs: {state name: fp32 reference tensor} (the oracle's, or the reference's own captured output); ref64: the float64 oracle's
+    outputs of the same step.  Element-wise parity with `refs` at the float64-derived tolerance, and the float64 yardstick
+    (tests/parity_tol.py).  Returns (HIP outputs, worst out-of-tolerance fraction, ill-conditioned groups, yardstick entry)."""
     out = _step(s, x, x2, i)
-    worst, masked = compare_step(out, refs, what, hist)
-    return out, worst, masked
+    r64 = {k: ref64[k] for k in refs}
+    worst, amplified = compare_step(out, refs, r64, what)
+    return out, worst, amplified, yardstick(out, refs, r64, what)
 
 
 def _force(s, x, x2, i):
@@ -87,28 +108,25 @@ def _force(s, x, x2, i):
 # (d) the reference itself at the real sizes
 # ---------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
-def golden_diag(case):
-    """The oracle's conditioning diagnostics for the fixture's steps (the expected VALUES stay the reference's own outputs)."""
+def golden_f64(case, case64):
+    """The float64 oracle's outputs of the fixture's steps: the yardstick the reference's own fp32 outputs (the expected VALUES) and the HIP
+    outputs are both measured against."""
     g, _, W, stats, inp = case
-    spec = MX.MixerSpec(d_heads=8, m_heads=8)
     out = {}
-    with _Threads(), torch.no_grad():
-        cb, xT, xb2 = inp["step"]
-        for i in (32, 0):
-            out[f"ddim50:{i}"] = h = {}
-            MX.mixer_ddim_step(W, spec, stats, OS.make_schedule("cosine", 1000, "ddim50"), 3.5, i, xT, xb2, cb, h)
-        c300, x300 = inp["t300"]
-        xa, xb = inp["late"]
-        sch = OS.make_schedule("cosine", 1000, "ddim1000")
-        out["t300:999"] = h = {}
-        MX.mixer_ddim_step(W, spec, stats, sch, 3.5, 999, x300, x300, c300, h)
-        out["t300:3"] = h = {}
-        MX.mixer_ddim_step(W, spec, stats, sch, 3.5, 3, xa, xb, c300, h)
+    cb, xT, xb2 = inp["step"]
+    s50 = OS.make_schedule("cosine", 1000, "ddim50")
+    for i in (32, 0):
+        out[f"ddim50:{i}"] = _step64(case64, s50, i, xT, xb2, cb)
+    c300, x300 = inp["t300"]
+    xa, xb = inp["late"]
+    sch = OS.make_schedule("cosine", 1000, "ddim1000")
+    out["t300:999"] = _step64(case64, sch, 999, x300, x300, c300)
+    out["t300:3"] = _step64(case64, sch, 3, xa, xb, c300)
     return out
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_reference_golden_at_full_dims(case, samplers, golden_diag, mode):
+def test_reference_golden_at_full_dims(case, samplers, golden_f64, mode):
     """Mixer.forward, ddim_sample at i=32 / i=0 (B=2, T=32) and two ddim1000 steps at T=300 (B=1): HIP == reference outputs captured at
     D=1024/512 with the seeded weights (tests/golden/make_golden.py::g_fulldims)."""
     g, _, _, _, inp = case
@@ -119,53 +137,52 @@ def test_reference_golden_at_full_dims(case, samplers, golden_diag, mode):
     cb, xT, xb2 = inp["step"]
     s.set_schedule("ddim50")
     s.begin(cb, xT)
-    diag = golden_diag
+    f64 = golden_f64
     for i in (32, 0):
         refs = {nm: torch.from_numpy(g[f"ddim50:i{i}:{key}"]) for nm, key in (("x", "sample"), ("x2", "sample2"), ("pred_xstart2", "pred_xstart2"))}
-        _check_step(s, xT, xb2, i, refs, f"ddim50 i={i} [{mode}]", diag[f"ddim50:{i}"])
+        _check_step(s, xT, xb2, i, refs, f"reference golden ddim50 i={i} B=2 T=32 [{mode}]", f64[f"ddim50:{i}"])
     c300, x300 = inp["t300"]
     s.set_schedule("ddim1000")
     s.begin(c300, x300)
     _check_step(s, x300, x300, 999, {"x": torch.from_numpy(g["ddim1000:T300:i999:sample"]), "x2": torch.from_numpy(g["ddim1000:T300:i999:sample2"])},
-                f"T=300 i=999 [{mode}]", diag["t300:999"])
+                f"reference golden T=300 i=999 [{mode}]", f64["t300:999"])
     xa, xb = inp["late"]
     _check_step(s, xa, xb, 3, {"x": torch.from_numpy(g["ddim1000:T300:i3:sample"]), "x2": torch.from_numpy(g["ddim1000:T300:i3:sample2"])},
-                f"T=300 i=3 [{mode}]", diag["t300:3"])
+                f"reference golden T=300 i=3 [{mode}]", f64["t300:3"])
 
 
 # ---------------------------------------------------------------------------------------------------
 # (a) one full-dims DDIM step at T = 300, B = 2 against the oracle
 # ---------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
-def oracle_t300_b2(case):
+def oracle_t300_b2(case, case64):
     from mixermdm_amd.synthetic import synthetic_inputs
     _, _, W, stats, _ = case
     cond, xT = synthetic_inputs(2, 300, seed_cond=41, seed_x=42)
     x2 = rnd(43, 2, 300, 524)
     sch = OS.make_schedule("cosine", 1000, "ddim1000")
-    h1, h2 = {}, {}
     with _Threads(), torch.no_grad():
-        first = MX.mixer_ddim_step(W, MX.MixerSpec(d_heads=8, m_heads=8), stats, sch, 3.5, 999, xT, xT, cond, h1)
-        mid = MX.mixer_ddim_step(W, MX.MixerSpec(d_heads=8, m_heads=8), stats, sch, 3.5, 500, xT, x2, cond, h2)
-    return cond, xT, x2, (first, h1), (mid, h2)
+        first = MX.mixer_ddim_step(W, MX.MixerSpec(d_heads=8, m_heads=8), stats, sch, 3.5, 999, xT, xT, cond)
+        mid = MX.mixer_ddim_step(W, MX.MixerSpec(d_heads=8, m_heads=8), stats, sch, 3.5, 500, xT, x2, cond)
+    return cond, xT, x2, (first, _step64(case64, sch, 999, xT, xT, cond)), (mid, _step64(case64, sch, 500, xT, x2, cond))
 
 
 @pytest.mark.parametrize("mode", MODES)
 def test_full_dims_T300_B2_step_vs_oracle(samplers, oracle_t300_b2, mode):
-    cond, xT, x2, (first, h1), (mid, h2) = oracle_t300_b2
+    cond, xT, x2, (first, f64a), (mid, f64b) = oracle_t300_b2
     s = samplers[mode]
     s.set_schedule("ddim1000")
     s.begin(cond, xT)
     names = ("x", "x2", "pred_xstart", "pred_xstart2")
-    _check_step(s, xT, xT, 999, dict(zip(names, first)), f"T=300 B=2 i=999 [{mode}]", h1)
-    _check_step(s, xT, x2, 500, dict(zip(names, mid)), f"T=300 B=2 i=500 [{mode}]", h2)      # chains that differ, mid-schedule coefficients
+    _check_step(s, xT, xT, 999, dict(zip(names, first)), f"T=300 B=2 i=999 [{mode}]", f64a)
+    _check_step(s, xT, x2, 500, dict(zip(names, mid)), f"T=300 B=2 i=500 [{mode}]", f64b)      # chains that differ, mid-schedule coefficients
 
 
 # ---------------------------------------------------------------------------------------------------
 # (b) ddim1000: first 20 and last 20 steps, teacher-forced, B = 1, T = 300
 # ---------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
-def oracle_chains(case, samplers):
+def oracle_chains(case, case64, samplers):
     """Oracle trajectories: 20 free-running steps from x_T (i = 999..980), and 20 from the state the HIP fp32 sampler reaches at
     i = 19 after 980 steps of its own loop (i = 19..0, incl. the un-normalised i == 0 branch).  states[k] -> states[k+1] is one oracle
     step; every HIP mode is forced to states[k] before its step k, so one oracle pass serves both modes."""
@@ -185,9 +202,9 @@ def oracle_chains(case, samplers):
         for name, i0, (x, x2) in (("first", 999, (xT, xT)), ("last", 19, late0)):
             states = [(x, x2, None, None, None)]
             for k in range(20):
-                h = {}
-                nx, nx2, p1, p2 = MX.mixer_ddim_step(W, spec, stats, sch, 3.5, i0 - k, states[-1][0], states[-1][1], cond, h)
-                states.append((nx, nx2, p1, p2, {"align_diag": h["align_diag"], "center_diag": h.get("center_diag", [])}))
+                nx, nx2, p1, p2 = MX.mixer_ddim_step(W, spec, stats, sch, 3.5, i0 - k, states[-1][0], states[-1][1], cond)
+                f64 = _step64(case64, sch, i0 - k, states[-1][0], states[-1][1], cond)      # the same step from the same state, in float64
+                states.append((nx, nx2, p1, p2, f64))
             chains[name] = (i0, states)
     return cond, xT, chains
 
@@ -200,17 +217,22 @@ def test_ddim1000_teacher_forced_20_steps(samplers, oracle_chains, mode, which):
     s = samplers[mode]
     s.set_schedule("ddim1000")
     s.begin(cond, xT)
-    worst, masked = 0.0, 0
+    worst, amplified, yards = 0.0, 0, []
     for k in range(20):
         x, x2 = states[k][:2]
-        rx, rx2, rp1, rp2, h = states[k + 1]
-        out, w, m = _check_step(s, x, x2, i0 - k, {"x": rx, "x2": rx2, "pred_xstart": rp1, "pred_xstart2": rp2}, f"ddim1000 {which} i={i0 - k} [{mode}]", h)
+        rx, rx2, rp1, rp2, f64 = states[k + 1]
+        out, w, a, y = _check_step(s, x, x2, i0 - k, {"x": rx, "x2": rx2, "pred_xstart": rp1, "pred_xstart2": rp2}, f"ddim1000 {which} i={i0 - k} [{mode}]", f64)
         worst = max(worst, w)
-        masked += int(m)
+        amplified += int(a > 0)
+        yards.append(y)
     if which == "last":                       # quirk 6: the final step returns the raw (un-normalised) blend in both pred_xstart
         assert torch.equal(out["pred_xstart"], out["pred_xstart2"])
-    print(f"{mode} {which}: worst out-of-tolerance fraction over 20 steps {worst:.2e}; steps with a masked (branch-point) person: {masked}")
-    assert masked <= 16                    # the comparison must not be vacuous: a rotation on a branch point is the exception
+    med = yardstick_sequence(yards, f"ddim1000 {which} 20 teacher-forced steps [{mode}]")
+    print(f"{mode} {which}: worst out-of-tolerance fraction over 20 steps {worst:.2e}; steps with an ill-conditioned group: {amplified}; "
+          f"largest median HIP/CPU error ratio vs float64 {max(med.values()):.2f}")
+    record(f"ddim1000 {which} 20 teacher-forced steps [{mode}]", kind="summary", worst_out_of_tol_fraction=worst, steps_with_an_ill_conditioned_group=amplified)
+    # the float64-derived tolerance must stay the exception, not the rule: observed 1 (last) / 0 (first) of 20 steps
+    assert amplified <= 3
 
 
 # ---------------------------------------------------------------------------------------------------

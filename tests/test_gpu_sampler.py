@@ -19,8 +19,18 @@ from test_gpu_kernels import assert_close, rnd, dev   # noqa: E402
 # frac: the golden inputs are N(0,1) noise, so a few rot6d vectors are nearly collinear and their Gram-Schmidt /
 # quaternion round trip amplifies 1e-7 rounding differences to 1e-3 (the CPU oracle shows the same handful of outliers
 # against the reference: tests/test_oracle_golden.py::close_frac); everything else must agree to 2e-4.  Steps compared with the ORACLE
-# use compare_step: same tolerance, scaled per person by the conditioning of the reference's global rotations (tests/parity_tol.py).
-from parity_tol import STEP_TOL, compare_step      # noqa: E402
+# use compare_step: same tolerance, never smaller than 12 x the fp32 oracle's own distance from a float64 run of the same step in the
+# element's (sample, person, channel class) group, plus the float64 yardstick (tests/parity_tol.py).
+from parity_tol import STEP_TOL, compare_step, yardstick, oracle_step_pair      # noqa: E402
+
+
+def check_vs_oracle(st, W, spec, ostats, osch, i, x, x2, cond, what, names=("x", "x2", "pred_xstart2")):
+    """HIP state `st` after one step from (x, x2) at respaced index i  vs  the fp32 oracle (element-wise) and the float64 oracle (yardstick)."""
+    r32, r64 = oracle_step_pair(W, spec, ostats, osch, 3.5, i, x, x2, cond)
+    r32, r64 = {k: r32[k] for k in names}, {k: r64[k] for k in names}
+    compare_step(st, r32, r64, what)
+    yardstick(st, r32, r64, what)
+    return r32
 
 
 def golden_sampler(golden, mode=4, align=True, force=None, model2_kind=0, max_batch=2, out1=False):
@@ -177,18 +187,15 @@ def test_full_size_step_vs_oracle(full):
     s.begin(cond, xT)
     s.run(1, use_graph=False)
     st = s.state()
-    h = {}
-    rx, rx2, p1, p2 = MX.mixer_ddim_step(W, spec, ostats, osch, 3.5, 49, xT, xT, cond, hist=h)
-    compare_step(st, {"x": rx, "x2": rx2, "pred_xstart": p1, "pred_xstart2": p2}, "full-size step", h)
+    r = check_vs_oracle(st, W, spec, ostats, osch, 49, xT, xT, cond, "full-size step B=2 T=40", ("x", "x2", "pred_xstart", "pred_xstart2"))
+    rx, rx2 = r["x"], r["x2"]
     # second step from the oracle's state (teacher forced) exercises chains that differ
     st["x"].copy_(rx.to(dev()))
     st["x2"].copy_(rx2.to(dev()))
     torch.cuda.synchronize()
     s.run(1, use_graph=False)
     st = s.state()
-    h = {}
-    rx, rx2, p1, p2 = MX.mixer_ddim_step(W, spec, ostats, osch, 3.5, 48, rx, rx2, cond, hist=h)
-    compare_step(st, {"x": rx, "x2": rx2}, "full-size step 2", h)
+    check_vs_oracle(st, W, spec, ostats, osch, 48, rx, rx2, cond, "full-size step 2 B=2 T=40", ("x", "x2"))
 
 
 def test_graph_replay_equals_eager_and_is_deterministic(full):
@@ -305,9 +312,7 @@ def test_ragged_shapes_match_oracle_one_step(full_small, B, T):
     s.begin(cond, xT)
     s.run(1, use_graph=True)
     st = s.state()
-    h = {}
-    rx, rx2, p1, p2 = MX.mixer_ddim_step(W, spec, ostats, osch, 3.5, 19, xT, xT, cond, hist=h)
-    compare_step(st, {"x": rx, "x2": rx2, "pred_xstart2": p2}, f"B={B} T={T}", h)
+    check_vs_oracle(st, W, spec, ostats, osch, 19, xT, xT, cond, f"ragged shape B={B} T={T}")
 
 
 @pytest.fixture(scope="module")
@@ -414,8 +419,6 @@ def test_fp32_split_path_matches_oracle_like_the_fp32_path(full_small, B, T):
     cond, xT = synthetic_inputs(B, T, seed_cond=21, seed_x=22)
     spec = MX.MixerSpec(d_heads=4, m_heads=4)
     osch = OS.make_schedule("cosine", 1000, "ddim20")
-    h = {}
-    rx, rx2, p1, p2 = MX.mixer_ddim_step(W, spec, ostats, osch, 3.5, 19, xT, xT, cond, hist=h)
     s = Sampler(d_heads=4, m_heads=4, max_batch=B, max_frames=T, precision="fp32_split", **dims)
     s.load_state_dict({k: v for k, v in W.items() if not k.endswith("sequence_pos_encoder.pe")})
     s.set_norm_stats(*[t.numpy() for t in ostats])
@@ -426,7 +429,7 @@ def test_fp32_split_path_matches_oracle_like_the_fp32_path(full_small, B, T):
         smp.begin(cond, xT)
         smp.run(1, use_graph=(nm == "split"))
         outs[nm] = {k: v.clone() for k, v in smp.state().items() if v is not None}
-    compare_step(outs["split"], {"x": rx, "x2": rx2, "pred_xstart2": p2}, f"fp32_split B={B} T={T}", h)
+    rx2 = check_vs_oracle(outs["split"], W, spec, ostats, osch, 19, xT, xT, cond, f"fp32_split B={B} T={T}")["x2"]
     med = lambda a, b: (a.cpu() - b).abs().median().item()
     assert med(outs["split"]["x2"], rx2) <= 2 * med(outs["native"]["x2"], rx2) + 1e-7
     s.close()
@@ -476,9 +479,7 @@ def test_long_sequence_beyond_the_reference_default(full_small):
     s.begin(cond, xT)
     s.run(1, use_graph=True)
     st = s.state()
-    h = {}
-    rx, rx2, p1, p2 = MX.mixer_ddim_step(W, MX.MixerSpec(d_heads=4, m_heads=4), ostats, OS.make_schedule("cosine", 1000, "ddim20"), 3.5, 19, xT, xT, cond, hist=h)
-    compare_step(st, {"x": rx, "x2": rx2, "pred_xstart2": p2}, "T=700", h)
+    check_vs_oracle(st, W, MX.MixerSpec(d_heads=4, m_heads=4), ostats, OS.make_schedule("cosine", 1000, "ddim20"), 19, xT, xT, cond, "T=700 B=1")
     from mixermdm_amd._lib import MMDMError
     with pytest.raises(MMDMError, match="exceed"):
         s.begin(*synthetic_inputs(1, 701))

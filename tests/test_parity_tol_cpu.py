@@ -1,0 +1,66 @@
+"""CPU: the float64-derived step comparison (tests/parity_tol.py) is neither vacuous nor brittle -- checked on the oracle itself at small sizes:
+an fp32 evaluation with rounding-level noise passes, a real alignment error (one person turned by half a degree, a wrong foot-contact
+channel, a mis-scaled rotation block) fails."""
+import math
+import pytest
+import torch
+
+from oracle import mixer as MX, schedule as OS
+from oracle.layers import pe_table
+from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_inputs, synthetic_stats
+from parity_tol import compare_step, yardstick, yardstick_sequence, oracle_step_pair
+
+DIMS = dict(d_latent=64, d_ff=128, d_layers=2, m_latent=32, m_ff=64, m_layers=2)
+
+
+@pytest.fixture(scope="module")
+def pair():
+    sd = synthetic_state_dict(seed=0, std=0.05, bias_std=0.02, **DIMS)
+    W = dict(sd)
+    W["sequence_pos_encoder.pe"], W["denoiser1.sequence_pos_encoder.pe"], W["denoiser2.sequence_pos_encoder.pe"] = pe_table(32), pe_table(64), pe_table(64)
+    st = synthetic_stats()
+    stats = tuple(st[k] for k in ("mean_hml", "std_hml", "mean_ih", "std_ih"))
+    cond, xT = synthetic_inputs(2, 24)
+    x2 = torch.randn(2, 24, 524, generator=torch.Generator().manual_seed(9))
+    sch = OS.make_schedule("cosine", 1000, "ddim50")
+    r32, r64 = oracle_step_pair(W, MX.MixerSpec(d_heads=4, m_heads=4), stats, sch, 3.5, 30, xT, x2, cond)
+    return r32, r64, stats
+
+
+def _noisy(r32, rel):
+    g = torch.Generator().manual_seed(1)
+    return {k: v * (1 + rel * torch.randn(v.shape, generator=g)) for k, v in r32.items()}
+
+
+def test_rounding_level_noise_passes(pair):
+    r32, r64, _ = pair
+    out = _noisy(r32, 2e-7)
+    worst, amp = compare_step(out, r32, r64, "noise")
+    assert worst <= 2e-3
+    e = yardstick(out, r32, r64, "noise")
+    assert e["ok"]
+    assert max(yardstick_sequence([e, e, e], "noise x3").values()) <= 3.0
+
+
+def test_a_person_turned_by_half_a_degree_fails(pair):
+    """pred_xstart is in normalised HumanML3D space: de-normalise person 1, turn positions about Y by 0.5 degrees, normalise again."""
+    r32, r64, stats = pair
+    mean, std = stats[0], stats[1]
+    out = {k: v.clone() for k, v in r32.items()}
+    p = out["pred_xstart"][..., :66] * std[:66] + mean[:66]
+    j = p.reshape(*p.shape[:-1], 22, 3)
+    a = math.radians(0.5)
+    x, z = j[..., 0].clone(), j[..., 2].clone()
+    j[..., 0], j[..., 2] = math.cos(a) * x + math.sin(a) * z, -math.sin(a) * x + math.cos(a) * z
+    out["pred_xstart"][..., :66] = (j.reshape(p.shape) - mean[:66]) / std[:66]
+    with pytest.raises(AssertionError, match="pred_xstart"):
+        compare_step(out, r32, r64, "turned person")
+
+
+@pytest.mark.parametrize("lo,hi,what", [(258, 262, "feet"), (132, 258, "rot6d"), (262 + 66, 262 + 132, "velocities of person 2")])
+def test_a_wrong_channel_block_fails(pair, lo, hi, what):
+    r32, r64, _ = pair
+    out = {k: v.clone() for k, v in r32.items()}
+    out["x2"][..., lo:hi] += 1e-2
+    with pytest.raises(AssertionError, match="x2"):
+        compare_step(out, r32, r64, what)
