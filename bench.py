@@ -167,7 +167,7 @@ def main():
                  "bf16_fp8": "gemm_bf16_kernel<ET=1> (v_mfma_f32_32x32x16_fp8_fp8: e4m3 operands, per-row / per-output-channel scales, fp32 accumulate) "
                              "+ gemm_bf16w_kernel (bf16, packed weights) for the attention output projections"}[args.precision]
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(single) if args.precision == "fp32" else None,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(single, args.precision),
                 "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1),
                 "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
                 "gflop_per_launch": round(g_fl / g_n / 1e9, 3), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
@@ -204,6 +204,24 @@ def main():
         alt = {"mode": "fp32_split (exact 3-way bf16 operand split, six bf16 MFMAs per product, fp32 accumulate)", "ms_per_step": round(a_ms, 3),
                "value": round(B / (a_ms * 1e-3 * S), 5), "unit": "motions/s", "rel_rms_vs_fp32_after_2_steps": rel,
                "achieved_tflops_algorithmic": round(algorithmic_flops_per_motion_step(T, single=single) * B / (a_ms * 1e-3) / 1e12, 2)}
+        # its own roofline: live HIP-event pairs around every GEMM launch of an eager pass, against 2500 / 6 algorithmic TFLOP/s
+        if args.profile_steps > 0:
+            alt_smp.profile(True)
+            alt_smp.run(args.profile_steps, use_graph=False)
+            g_ms, g_n, g_fl, g_by = alt_smp.profile_read(0)
+            a2_ms, a2_n, a2_fl, _ = alt_smp.profile_read(1)
+            alt_smp.profile(False)
+            pk = round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
+            ach2 = g_fl / (g_ms * 1e-3) / 1e12
+            alt["roofline"] = {"bound": "mfma", "kernel": "gemm_splitw_kernel (fp32 result from 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 operand splits; packed weights straight from global memory, 128x128 tiles, two workgroups per CU)",
+                               "achieved": round(ach2, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach2 / pk, 4), "traffic": measured_traffic(single, "fp32_split"),
+                               "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1), "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
+                               "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
+                               "attention": {"achieved": round(a2_fl / (a2_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a2_ms / args.profile_steps, 3), "launches_per_step": a2_n // args.profile_steps}}
+            try:
+                alt["roofline"]["clock"] = None if args.no_clock else loop_clock("fp32_split", 4 * B * T, pk, ach2)
+            except Exception as e:
+                alt["roofline"]["clock"] = {"error": repr(e)}
         alt_smp.close()
 
     # The metric itself, not an extrapolation: one whole sample() from x_T to x_0 (S graph replays + the begin() set-up), every rank
@@ -303,19 +321,20 @@ def loop_clock(precision, M, peak, achieved):
                    "`peak` above is the guide's 2.4 GHz figure" % (M, N, K)}
 
 
-def measured_traffic(single):
-    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this workload (profiles/gemm_traffic.json, written by
-    tools/pmc_summary.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    16-byte-per-lane streams on gfx950).  bench.py cannot collect PMC counters itself.  The artefact records the hash of the kernel
-    sources it was measured on: null when it is absent, for another workload, or was taken on different kernel sources than the
-    ones this run executes."""
+def measured_traffic(single, precision="fp32"):
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this workload and precision mode (profiles/gemm_traffic.json
+    for fp32, profiles/gemm_traffic_<mode>.json otherwise; written by tools/pmc_summary.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streams on gfx950).  bench.py cannot collect PMC counters
+    itself.  The artefact records the hash of the kernel sources it was measured on: null when it is absent, for another workload, or
+    was taken on different kernel sources than the ones this run executes."""
     from mixermdm_amd.build import sources_sha
-    path = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "gemm_traffic.json" if precision == "fp32" else "gemm_traffic_%s.json" % precision)
     if single or not os.path.exists(path):
         return None
     with open(path) as f:
         rec = json.load(f)
-    if rec.get("kernel_sources_sha") != sources_sha():
+    if rec.get("kernel_sources_sha") != sources_sha(precision):
+        print("bench.py: %s was measured on other kernel sources (%s != %s): roofline.traffic = null" % (os.path.basename(path), rec.get("kernel_sources_sha"), sources_sha(precision)), file=sys.stderr)
         return None
     return rec["traffic_bytes_per_launch"]
 
@@ -358,11 +377,32 @@ def cpu_baseline(sd_cpu, stats, T, nsteps, single=False):
         for k in range(nsteps):
             x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 998 - k, x, x2, cond)
         dt = (time.perf_counter() - t0) / nsteps
-    return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "host_threads": ncpu, "kind": "port",
+        # SURVEY 8d also asks the GPU's own batch on the CPU: B = 16 is one more calibration (the larger GEMMs want more threads) and two
+        # timed steps, extrapolated x1000 like the B = 1 figure; it says how much batch efficiency the CPU gets (the GPU needs the batch, the CPU barely gains)
+        b16 = None
+        if nsteps >= 4:
+            c16, x16 = synthetic_inputs(16, T)
+            best16 = (None, 1e30)
+            for nt in sorted({min(ncpu, c) for c in (16, 32, 64, 128)}):
+                torch.set_num_threads(nt)
+                t0 = time.perf_counter()
+                MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 999, x16, x16, c16)
+                d16 = time.perf_counter() - t0
+                if d16 < best16[1]:
+                    best16 = (nt, d16)
+            torch.set_num_threads(best16[0])
+            xa, xb = x16, x16
+            t0 = time.perf_counter()
+            for k in range(2):
+                xa, xb, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 998 - k, xa, xb, c16)
+            d16 = (time.perf_counter() - t0) / 2
+            b16 = {"s_per_step": round(d16, 3), "cores": best16[0], "motions_per_s": round(16.0 / (d16 * 1000), 7),
+                   "sample": "2 consecutive DDIM steps at B=16 (the GPU's batch), thread count calibrated over {16, 32, 64, 128}, extrapolated x1000 steps"}
+    return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": best[0], "host_threads": ncpu, "kind": "port",
             "sample": "%d consecutive DDIM steps (i=998..) of the same workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), "
                       "%.3f s/step, extrapolated x1000 steps; thread count calibrated over {8, 16, 32, 64} of the host's %d hardware threads: %d fastest (one step: %s)"
                       % (nsteps, T, torch.__version__, dt, ncpu, best[0], ", ".join("%d thr %.2f s" % kv for kv in sorted(calib.items()))),
-            "s_per_step_b1": round(dt, 4)}
+            "s_per_step_b1": round(dt, 4), "b16": b16}
 
 
 def cpu_baseline_single(sd_cpu, T, nsteps):

@@ -9,13 +9,18 @@ LIB = os.path.join(HERE, "libmmdm_hip.so")
 SOURCES = ["mmdm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "attn_f32.hip", "rowops.hip", "geometry.hip"]
 
 
-def sources_sha():
-    """sha256 over the sources of the kernel the committed PMC traffic figure belongs to (the fp32 GEMM: csrc/gemm_f32.hip, plus the
-    host orchestration csrc/mmdm.hip that decides which GEMMs a step launches, and csrc/kernels.h): profiles/gemm_traffic.json records
-    it so that bench.py can tell whether that measurement describes the kernels it is running."""
+SHA_FILES = {"fp32": ("gemm_f32.hip", "mmdm.hip", "kernels.h"), "fp32_split": ("gemm_split.hip", "mmdm.hip", "kernels.h"),
+             "bf16": ("gemm_bf16.hip", "mmdm.hip", "kernels.h"), "bf16_fp8": ("gemm_bf16.hip", "mmdm.hip", "kernels.h")}
+
+
+def sources_sha(precision="fp32"):
+    """sha256 over the sources of the kernel a committed PMC traffic figure belongs to -- the dominant GEMM of the precision mode
+    (csrc/gemm_f32.hip / gemm_split.hip / gemm_bf16.hip), the host orchestration csrc/mmdm.hip that decides which GEMMs a step launches,
+    and csrc/kernels.h: profiles/gemm_traffic*.json record it so that bench.py can tell whether that measurement describes the kernels
+    it is running."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm_f32.hip", "mmdm.hip", "kernels.h"):
+    for f in SHA_FILES[precision]:
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]

@@ -738,7 +738,10 @@ inline bool vec_ok(const float* p, int ld, int K) {
 }  // namespace
 
 int g_gemm_cfg = -1;
-int g_gemm_tail = 0;        // row split of the fractional last round: 0 off; t > 0: split when the fractional round holds <= t/10 of the resident slots
+int g_gemm_tail = -1;       // row split of the fractional last round: t > 0: split when the fractional round holds <= t/10 of the resident slots; 0 off;
+                            // -1 (default): what the caller's handle asked for through mmdm_gemm_set_tail (one-stream samplers: 10, two-stream: 0)
+static thread_local int t_gemm_tail = 0;
+void mmdm_gemm_set_tail(int t) { t_gemm_tail = t; }
 int g_gemm_ablate = 0;
 unsigned long long* g_gemm_stamps = nullptr;
 
@@ -764,7 +767,7 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 3>())) return rc;
     const char* e = getenv("MMDM_GEMM_CFG");
     g_gemm_cfg = e ? atoi(e) : -1;
-    if (const char* t = getenv("MMDM_GEMM_TAIL")) g_gemm_tail = atoi(t);
+    if (const char* t = getenv("MMDM_GEMM_TAIL")) g_gemm_tail = atoi(t);       // forces the rule for every caller (tools)
     return MMDM_OK;
 }
 
@@ -805,21 +808,24 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     const bool av = vec_ok(A, lda, K), wv = vec_ok(W, ldw, Kw);
     const bool glds_ok = av && wv && (K % 16 == 0) && Kw == K;
     // production choice: LDS-DMA kernel, 128x128 tile / 4 waves (5 workgroups per CU) whenever the operands allow it
+    const int tail = g_gemm_tail >= 0 ? g_gemm_tail : t_gemm_tail;
     switch (g_gemm_cfg) {
         case 10: if (glds_ok) return launch_glds<42, 22>(a, st); break;
         case -1:
-            if (glds_ok && K >= 96 && g_gemm_tail && epilogue != MMDM_EPI_BIAS_PE) {
-                // Row split ("tile list" of two entries): M = 19 200 gives 3600 / 4800 / 1200 tiles for 512 (128x128, two per CU) or 768
-                // (128x64, three per CU) resident slots = 7.03 / 6.25 / 2.34 rounds, and the fractional round costs a whole tile
-                // lifetime on a nearly empty chip.  Rows [0, M1) -- as many whole row tiles as fit into complete rounds -- go to the
-                // large tile; the remaining rows to a tile of half / a quarter of the area, whose single partial round is as short.
+            if (glds_ok && K >= 96 && tail && epilogue != MMDM_EPI_BIAS_PE) {
+                // Row split ("tile list" of two entries) for callers that run ONE stream of kernels: M = 12 544 (configs[1]) gives 2352 / 3136 /
+                // 784 tiles for 512 (128x128, two per CU) or 768 (128x64, three per CU) resident slots = 4.6 / 4.1 / 1.5 rounds, and the
+                // fractional round costs a whole tile lifetime on a partly empty chip.  Rows [0, M1) -- as many whole row tiles as fit into
+                // complete rounds -- go to the large tile; the remaining rows to a tile of half / a quarter of the area, whose single
+                // partial round is as short.  Measured: configs[1] 15.35 -> 14.45 ms/step; QKV at M = 19 200 stand-alone 894 -> 857 us.
+                // The two-stream MixerMDM step does NOT use it (59.2 vs 59.5 ms/step: the other stream's kernels already fill a tail).
                 // Every pipelined instantiation accumulates an output element in the same order, so the split does not change a bit
                 // (tests: bitwise batch independence, production tiles vs float64).
                 const bool narrow = N <= 512 || K <= 512 || N == 2048;
                 const long slots = narrow ? 768 : 512, nt = (N + (narrow ? 63 : 127)) / (narrow ? 64 : 128), mt = (M + 127) / 128;
                 const long tiles = mt * nt, full = tiles / slots, rem = tiles - full * slots;
                 const long mt1 = full * slots / nt;
-                if ((long)((M + 127) / 128) * ((N + 63) / 64) >= 512 && full >= 1 && mt1 >= 1 && mt1 < mt && rem * 10 <= slots * g_gemm_tail) {
+                if ((long)((M + 127) / 128) * ((N + 63) / 64) >= 512 && full >= 1 && mt1 >= 1 && mt1 < mt && rem * 10 <= slots * tail) {
                     const int M1 = (int)mt1 * 128;
                     GemmArgs b = a;
                     a.M = M1;

@@ -16,6 +16,9 @@ int mmdm_kernels_init(void);
 void mmdm_note_gemm(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 void mmdm_note_gemm_reset(void);
 int mmdm_gemm_init(void);
+// Row split of a GEMM's fractional last round of tiles (gemm_f32.hip): t/10 = the largest fraction of a round that is split off; 0 = never.
+// Thread-local; the sampler sets it per handle before it launches a step (one-stream samplers benefit, the two-stream step does not).
+void mmdm_gemm_set_tail(int t);
 int mmdm_gemm_bf16_init(void);
 int mmdm_gemm_split_init(void);
 

@@ -524,8 +524,6 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     };
     // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / three planes, or fp8 + per-row scales
     auto norm = [&](const float* src, const float* ssp, int rows) -> int {
-        static const bool skip_exp = getenv("MMDM_EXP_SKIP_ADALN") != nullptr;      // EXPERIMENT (timing upper bound of a fused AdaLN; wrong results) -- remove
-        if (skip_exp) return MMDM_OK;
         if (f8) return mmdm_adaln_any(src, ssp, r.ss_ld, rows, S.xn, 3, S.xs, r.nseq, r.T, D, c.st);
         return mmdm_adaln_ex(src, ssp, r.ss_ld, rows, S.xn, ob, r.nseq, r.T, D, c.st);
     };
@@ -760,6 +758,8 @@ int ss_ld_of(const ModuleW& m) { return m.st.L * m.st.n_ada * 2 * m.st.D; }
 int run_step(const Ctx& c) {
     mmdm_handle H = c.h;
     const int B = H->B, T = H->T, n = 2 * B;
+    // the single-chain samplers run ONE stream of kernels: split the GEMMs' fractional last round (gemm_f32.hip; results are bit-identical)
+    mmdm_gemm_set_tail((H->cfg.single_only == 1 || H->cfg.single_only == 2) ? 10 : 0);
     if (H->cfg.single_only == 1) {
         if (H->d1.kind == 1) {
             RC(run_denoiser_mdm(c, H->d1, H->x, B, 1, NF, n, T, H->cond_cat, H->td1, H->o1, NF));
@@ -1291,6 +1291,7 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
     Ctx c{h, st, &h->sa};
     const int td = h->cfg.text_dim;
     ProfPause pause(h->prof);
+    mmdm_gemm_set_tail((so_ == 1 || so_ == 2) ? 10 : 0);
     // The forward borrows slot 0 of the schedule tables (timestep_map[0] and row 0 of every time_tab) for a one-entry schedule
     // time_tab[0] = time_embed(pe[t]) and puts the caller's entries back afterwards, so a schedule set before survives the call
     // (a sampling call in progress does not: text embeddings, scratch and the step index are overwritten -- mmdm_begin again).

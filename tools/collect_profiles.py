@@ -1,23 +1,31 @@
-"""Copy what tools/profile_round.sh left under gpurun_out/prof_r02/ into profiles/ (tracked) and print the figures the README quotes.
-usage: python tools/collect_profiles.py [round-tag, default r02]"""
+"""Copy what tools/profile_round.sh left under gpurun_out/prof_<tag>/ into profiles/ (tracked) and print the figures DESIGN.md quotes.
+usage: python tools/collect_profiles.py [round-tag, default r03]"""
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src, dst = os.path.join(ROOT, "gpurun_out", "prof_r02"), os.path.join(ROOT, "profiles")
-for n in ("serial", "overlap", "split_serial", "bf16_serial", "fp8_serial"):
-    if not os.path.exists(os.path.join(src, "summary", f"kernel_stats_{n}.csv")):
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles")
+for n in ("serial", "overlap", "fp32_split_serial", "bf16_serial", "bf16_fp8_serial", "single_serial"):
+    st = os.path.join(src, "summary", f"kernel_stats_{n}.csv")
+    if not os.path.exists(st):
         continue
-    shutil.copy(os.path.join(src, "summary", f"kernel_stats_{n}.csv"), os.path.join(dst, f"{tag}_kernel_stats_{n}.csv"))
+    shutil.copy(st, os.path.join(dst, f"{tag}_kernel_stats_{n}.csv"))
     for line in open(os.path.join(src, f"{n}.json")):
         if line.startswith("{"):
             d = json.loads(line)
             json.dump(d, open(os.path.join(dst, f"{tag}_bench_{n}_under_rocprof.json"), "w"), indent=1)
             r = d["roofline"]
-            print(f"{n:13s} {d['ms_per_step']:7.3f} ms/step  GEMM live {r['achieved']:7.2f} TFLOP/s (frac {r['frac']:.4f}, {r['avg_launch_us']:.1f} us/launch)  attention {r['attention']}")
-shutil.copy(os.path.join(src, "summary", "pmc_summary.json"), os.path.join(dst, f"{tag}_pmc_summary.json"))
-shutil.copy(os.path.join(src, "summary", "gemm_traffic.json"), os.path.join(dst, "gemm_traffic.json"))
-t = json.load(open(os.path.join(dst, "gemm_traffic.json")))
-print("traffic", t["kernel_sources_sha"], t["traffic_bytes_per_launch"], "L2 hit", t["l2_hit_rate"])
+            print(f"{n:18s} {d['ms_per_step']:7.3f} ms/step  GEMM live {r['achieved']:7.2f} TFLOP/s (frac {r['frac']:.4f}, {r['avg_launch_us']:.1f} us/launch)  attention {r['attention']}")
+for p in ("fp32", "fp32_split", "bf16_fp8"):
+    sm = os.path.join(src, f"summary_{p}")
+    if not os.path.exists(os.path.join(sm, "pmc_summary.json")):
+        continue
+    shutil.copy(os.path.join(sm, "pmc_summary.json"), os.path.join(dst, f"{tag}_pmc_{'summary' if p == 'fp32' else p.replace('bf16_fp8', 'fp8')}.json"))
+    if os.path.exists(os.path.join(sm, "gemm_traffic.json")):
+        out = os.path.join(dst, "gemm_traffic.json" if p == "fp32" else f"gemm_traffic_{p}.json")
+        shutil.copy(os.path.join(sm, "gemm_traffic.json"), out)
+        t = json.load(open(out))
+        print(f"traffic {p:11s} sha {t['kernel_sources_sha']}  {t['traffic_bytes_per_launch'] / 1e6:.0f} MB/launch  L2 hit {t['l2_hit_rate']}  MFMA busy {t.get('mfma_busy_frac')}  "
+              f"clock {t.get('clock_ghz')} GHz  {t.get('hbm_side_TBps')} TB/s beyond L2")
 rows = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats_serial.csv"))))
 g = [r for r in rows if r["Name"].startswith("gemm_glds_kernel")]
 tot, n = sum(float(r["TotalDurationNs"]) for r in g), sum(int(r["Calls"]) for r in g)
