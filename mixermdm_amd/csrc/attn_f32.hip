@@ -15,6 +15,7 @@
 // QK^T is permuted identically for both operands so that one 16-byte LDS read feeds four MFMAs.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace {
@@ -146,19 +147,28 @@ __device__ __forceinline__ float rows_sum(float x) {
 // DIAG: the ablation switches and in-kernel stamps (tools/attn_bench.py ABL=, tools/attn_timeline.py) exist in a second instantiation only.  As
 // runtime tests inside the chunk loop they split its basic blocks -- the same thing cost the fp32-split GEMM 14 % -- so the
 // production instantiation sees them as compile-time zeros.
-template <int DH, bool DIAG = false>
+//
+// QT = query tiles of 16 per wave.  Production runs QT = 1 (a workgroup = 64 queries, four workgroups per CU at 112 registers).  QT = 2 --
+// 128 queries per workgroup, tile-major so that the last workgroup's live tiles spread over its waves, K fragments and V rows shared by
+// the two tiles, 3 workgroups per (sequence, head) instead of 5 = exactly three rounds of 512 slots at T = 300 -- was built and measured
+// in round 3: bit-identical results, but 192 registers leave two waves per SIMD and the kernel is 19 % SLOWER (246.6 vs 207.7 us at
+// 64 x 8 x 300 x 128 with warm clocks; 138 vs 129 us at dh = 64, where both forms keep four waves per SIMD): what this kernel needs is
+// waves per SIMD, not fewer fixed costs per MFMA (LAB_NOTES.md).  The template parameter stays (the code is the same), QT = 2 is not
+// instantiated.  A tile whose 16 queries all lie past Tq is never computed (wave-uniform: `NA` live tiles, one chunk loop per count).
+template <int DH, bool DIAG = false, int QT = 1>
 __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
     const int ablate = DIAG ? p.ablate : 0;
     unsigned long long* const stamps = DIAG ? p.stamps : nullptr;
     constexpr int KC = KCF;
     constexpr int NJ = DH / 16;                 // d groups of 16 (QK^T) == 16-wide output column tiles (PV)
-    constexpr int NKT = KC / 16;                // 16-key tiles per stage
+    static_assert(KC == 16, "one 16-key tile per stage");
     constexpr int CPR = DH / 4;                 // 16-byte chunks per row
     constexpr int RPP = 64 / CPR;               // rows per 1-KiB DMA piece
     constexpr int NPIECE = 2 * KC / RPP;        // pieces per stage (K then V)
     constexpr int NI = NPIECE / 4;              // pieces per wave
     constexpr int STAGE = 2 * KC * DH;          // floats per stage
+    constexpr int QBW = QB * QT;                // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [NST stages][K: KC*DH | V: KC*DH]
 
     // XCD-aware mapping: blocks b and b+8 share an XCD (private L2), so all query tiles of one (sequence, head) are given to
@@ -175,7 +185,12 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 15, g = lane >> 4;
-    const int q0 = qt * QB + wave * QW;
+    const int q0 = qt * QBW + wave * QW;        // first query of this wave's tile 0; tile t starts at q0 + QB * t
+    // live tiles of this wave: tiles are ordered by query, so tile t live implies tile t - 1 live
+    int nact = 0;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) nact += (q0 + QB * t < p.Tq) ? 1 : 0;
+    nact = __builtin_amdgcn_readfirstlane(nact);
     unsigned long long t_qk = 0, t_sm = 0, t_pv = 0, t_a = 0;
     if (stamps && tid == 0) {
         stamps[8 * (size_t)bid + 0] = __builtin_amdgcn_s_memrealtime();
@@ -183,27 +198,32 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
                                         ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
     }
 
-    // Q fragment (B operand of S^T = K Q^T): lane (q = lq, g) holds Q[q][16j + 4g + s], pre-scaled into the log2 domain.
-    f32x4 qf[NJ];
-    {
-        int qrow = q0 + lq;
+    // Q fragments (B operand of S^T = K Q^T): lane (q = lq, g) holds Q[q][16j + 4g + s], pre-scaled into the log2 domain.
+    f32x4 qf[QT][NJ];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        int qrow = q0 + QB * t + lq;
         if (qrow >= p.Tq) qrow = p.Tq - 1;
         const float* qp = p.Q + ((size_t)seq * p.Tq + qrow) * p.ldq + head * p.dh + 4 * g;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const bool in = 16 * j + 4 * g < p.dh;                       // dh % 4 == 0: a 16-byte group is wholly inside or outside
             f32x4 v = *reinterpret_cast<const f32x4*>(qp + (in ? 16 * j : 0));
-            qf[j] = in ? v * p.scale2 : f32x4{0.f, 0.f, 0.f, 0.f};
+            qf[t][j] = in ? v * p.scale2 : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 
-    f32x4 o[NJ];
+    f32x4 o[QT][NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) o[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // add_zero_attn: one key with logit 0, value 0 already absorbed in the initial state; without it the state starts empty
     // (m = -inf, l = 0: the first chunk always holds a visible key, so alpha = 2^(-inf) = 0 and no NaN can form).
     const bool nozero = (p.flags & MMDM_ATTN_NO_ZERO_KEY) != 0, causal = (p.flags & MMDM_ATTN_CAUSAL) != 0;
-    float m_run = nozero ? -INFINITY : 0.f, l_run = nozero ? 0.f : 1.f;
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { m_run[t] = nozero ? -INFINITY : 0.f; l_run[t] = nozero ? 0.f : 1.f; }
 
     const float* Kg = p.K + (size_t)kvseq * p.Tk * p.ldk + head * p.dh;
     const float* Vg = p.V + (size_t)kvseq * p.Tk * p.ldv + head * p.dh;
@@ -238,9 +258,102 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 
     int nchunks = (p.Tk + KC - 1) / KC;
     if (causal) {                               // keys past the workgroup's last query are never visible (same count for all 4 waves: barriers)
-        const int last_q = min(qt * QB + QB - 1, p.Tq - 1);
+        const int last_q = min(qt * QBW + QBW - 1, p.Tq - 1);
         nchunks = min(nchunks, last_q / KC + 1);
     }
+
+    // One chunk for the first NA tiles of this wave.  K fragments and V rows are read once and feed every live tile.
+    auto chunk = [&](auto na_c, int c0, const float* Ks, const float* Vs) {
+        constexpr int NA = decltype(na_c)::value;
+        // S^T tiles: st[t][reg] = score(key = c0 + 4g + reg, query = lq of tile t); K fragments double-buffered in registers
+        f32x4 st[NA];
+#pragma unroll
+        for (int t = 0; t < NA; ++t) st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 kf[2];
+        kf[0] = *reinterpret_cast<const f32x4*>(&Ks[lq * DH + 4 * (g ^ lq)]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int cb = j & 1;
+            if (j + 1 < NJ && !(ablate & 8)) kf[cb ^ 1] = *reinterpret_cast<const f32x4*>(&Ks[lq * DH + 4 * ((4 * (j + 1) + g) ^ lq)]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < NA; ++t)
+                    st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[cb][s], qf[t][j][s], st[t], 0, 0, 0);
+            // keep the hand-made double buffer: without the fence the scheduler hoists every fragment read of the chunk to its top,
+            // which at two tiles per wave costs 24 more live registers than the 256 of two waves per SIMD (17 spills, reloaded -- with
+            // vmcnt(0) -- inside the loop)
+            if constexpr (QT > 1) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < NA; ++t) MFMA_SETTLE(st[t]);
+        if (stamps) { const unsigned long long tt = __builtin_amdgcn_s_memrealtime(); t_qk += tt - t_a; t_a = tt; }
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            const int q0t = q0 + QB * t;
+            if (c0 + KC > p.Tk || (causal && c0 + KC - 1 > q0t)) {   // keys past Tk (last chunk) or above the diagonal (wave-uniform branch)
+                const int kmax = causal ? min(p.Tk - 1, q0t + lq) : p.Tk - 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + 4 * g + r > kmax) st[t][r] = -INFINITY;
+            }
+            if (!(ablate & 4)) {
+                float cmax = fmaxf(fmaxf(st[t][0], st[t][1]), fmaxf(st[t][2], st[t][3]));
+                cmax = rows_max(cmax);
+                // Deferred reference: the running maximum only moves when the chunk's maximum exceeds it by more than 2^8 (scores are in the log2
+                // domain), so after the first chunks alpha is exactly 1 for every query of the wave and the rescale below is skipped; until
+                // then probabilities up to 2^8 enter the fp32 sums, which changes nothing but the last bits (softmax does not depend on the
+                // reference point).
+                const float m_new = cmax > m_run[t] + 8.0f ? cmax : m_run[t];
+                const float alpha = EXP2(m_run[t] - m_new);
+                float lsum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[t][r] = EXP2(st[t][r] - m_new);
+                    lsum += st[t][r];
+                }
+                lsum = rows_sum(lsum);
+                l_run[t] = l_run[t] * alpha + lsum;
+                m_run[t] = m_new;
+                // rescale O: accumulator rows are queries 4g + r, whose alpha lives in lanes with (lane&15) == 4g + r.  Once the running maxima
+                // of a tile's 16 queries have stopped moving -- the usual case after the first chunks -- every alpha is exactly 1 and the 4
+                // cross-lane reads + 4*NJ multiplies are skipped (wave-uniform branch; x * 1.0f is exact, so the result is unchanged).
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+                    float ar[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[t][j][r] *= ar[r];   // (the PV MFMAs of the previous chunk retired long ago: barrier + QK^T in between)
+                }
+            }
+        }
+        // O[q][n] += sum_key P[q][key] V[key][n]:  A = P (lane-local: st[t][r] is P[q = lq of tile t][key = 4g + r]),
+        // B = V[key = 4g + r][this lane's NJ contiguous columns] (load_v_row), shared by the tiles
+        if (stamps) { const unsigned long long tt = __builtin_amdgcn_s_memrealtime(); t_sm += tt - t_a; t_a = tt; }
+        float vb[2][NJ];
+        load_v_row<DH>(&Vs[(4 * g) * DH], lq, vb[0]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cb = r & 1;
+            if (r + 1 < 4 && !(ablate & 16)) load_v_row<DH>(&Vs[(4 * g + r + 1) * DH], lq, vb[cb ^ 1]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int t = 0; t < NA; ++t)
+                    o[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[t][r], vb[cb][j], o[t][j], 0, 0, 0);
+            if constexpr (QT > 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (stamps) {
+#pragma unroll
+            for (int t = 0; t < NA; ++t)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[t][j]);
+            t_pv += __builtin_amdgcn_s_memrealtime() - t_a;
+        }
+    };
+
     // NST-stage ring: chunks 0 .. NST-2 are requested up front; in iteration ci the wave waits until at most the NST-2 newest of its
     // chunks are still in flight (= chunk ci has landed), the raw barrier makes that true for every wave and proves that chunk ci-1 --
     // whose buffer is restaged next -- has been read by all of them (their ds_reads were retired by lgkmcnt(0) before the barrier).
@@ -248,136 +361,54 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nchunks) stage(t * KC, t);
-    int cur = 0, stg = NST - 1;
-    for (int ci = 0; ci < nchunks; ++ci) {
-        const int c0 = ci * KC;
-        const int left = nchunks - 1 - ci;                     // chunks requested behind this one (capped at NST - 2 by the ring)
-        if (left >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NI) : "memory");
-        else if (left == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
-        else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(ablate & 2)) __builtin_amdgcn_s_barrier();
-        if (ci + NST - 1 < nchunks && !(ablate & 1)) stage(c0 + (NST - 1) * KC, stg);
-        const float* Ks = smem + cur * STAGE;
-        const float* Vs = Ks + KC * DH;
-        if (stamps) { if (ci == 0 && tid == 0) stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime(); t_a = __builtin_amdgcn_s_memrealtime(); }
-
-        // A wave whose 16 queries all lie past Tq (T = 300: the fourth wave of the fifth query tile, one wave in twenty) stages its
-        // pieces and keeps the barriers, but issues none of the chunk's 64 MFMAs: the matrix pipe of its SIMD goes to the co-resident
-        // workgroups' waves instead.  Wave-uniform; nothing it would have computed is ever stored.
-        if (q0 < p.Tq) {
-        // S^T tiles: st[kt][reg] = score(key = c0 + 16kt + 4g + reg, query = lq); K fragments double-buffered in registers
-        f32x4 st[NKT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 kf[2][NKT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) kf[0][kt] = *reinterpret_cast<const f32x4*>(&Ks[(16 * kt + lq) * DH + 4 * (g ^ lq)]);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int cb = j & 1;
-            if (j + 1 < NJ && !(ablate & 8)) {
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
-                    kf[cb ^ 1][kt] = *reinterpret_cast<const f32x4*>(&Ks[(16 * kt + lq) * DH + 4 * ((4 * (j + 1) + g) ^ lq)]);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
-                    st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[cb][kt][s], qf[j][s], st[kt], 0, 0, 0);
+    // The chunk loop exists once per number of live tiles (wave-uniform choice OUTSIDE the loop): with both bodies inside one loop the
+    // register allocator keeps the state of both alive across the branch (263 registers instead of 184 at DH = 128, QT = 2).
+    auto run = [&](auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
+        int cur = 0, stg = NST - 1;
+        for (int ci = 0; ci < nchunks; ++ci) {
+            const int c0 = ci * KC;
+            const int left = nchunks - 1 - ci;                     // chunks requested behind this one (capped at NST - 2 by the ring)
+            if (left >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NI) : "memory");
+            else if (left == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+            else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!(ablate & 2)) __builtin_amdgcn_s_barrier();
+            if (ci + NST - 1 < nchunks && !(ablate & 1)) stage(c0 + (NST - 1) * KC, stg);
+            const float* Ks = smem + cur * STAGE;
+            const float* Vs = Ks + KC * DH;
+            if (stamps) { if (ci == 0 && tid == 0) stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime(); t_a = __builtin_amdgcn_s_memrealtime(); }
+            // a wave without a live tile (T = 300, QT = 2: wave 3 of the last workgroup) stages its pieces and keeps the barriers, nothing else
+            if constexpr (NA > 0) chunk(na_c, c0, Ks, Vs);
+            cur = cur + 1 == NST ? 0 : cur + 1;
+            stg = stg + 1 == NST ? 0 : stg + 1;
         }
+    };
+    if (nact == QT) run(std::integral_constant<int, QT>{});
+    else if (QT > 1 && nact == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
 
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) MFMA_SETTLE(st[kt]);
-        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); t_qk += t - t_a; t_a = t; }
-        if (c0 + KC > p.Tk || (causal && c0 + KC - 1 > q0)) {   // keys past Tk (last chunk) or above the diagonal (wave-uniform branch)
-            const int kmax = causal ? min(p.Tk - 1, q0 + lq) : p.Tk - 1;
+    for (int t = 0; t < QT; ++t)
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c0 + 16 * kt + 4 * g + r > kmax) st[kt][r] = -INFINITY;
-        }
-        if (!(ablate & 4)) {
-        float cmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
-#pragma unroll
-        for (int kt = 1; kt < NKT; ++kt) cmax = fmaxf(cmax, fmaxf(fmaxf(st[kt][0], st[kt][1]), fmaxf(st[kt][2], st[kt][3])));
-        cmax = rows_max(cmax);
-        // Deferred reference: the running maximum only moves when the chunk's maximum exceeds it by more than 2^8 (scores are in the log2
-        // domain), so after the first chunks alpha is exactly 1 for every query of the wave and the rescale below is skipped; until
-        // then probabilities up to 2^8 enter the fp32 sums, which changes nothing but the last bits (softmax does not depend on the
-        // reference point).
-        const float m_new = cmax > m_run + 8.0f ? cmax : m_run;
-        const float alpha = EXP2(m_run - m_new);
-        float lsum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                st[kt][r] = EXP2(st[kt][r] - m_new);
-                lsum += st[kt][r];
-            }
-        lsum = rows_sum(lsum);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-
-        // rescale O: accumulator rows are queries 4g + r, whose alpha lives in lanes with (lane&15) == 4g + r.  Once the running maxima
-        // of a wave's 16 queries have stopped moving -- the usual case after the first chunks -- every alpha is exactly 1 and the 4
-        // cross-lane reads + 4*NJ multiplies are skipped (wave-uniform branch; x * 1.0f is exact, so the result is unchanged).
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-            float ar[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];   // (the PV MFMAs of the previous chunk retired long ago: barrier + QK^T in between)
-        }
-        }
-
-        // O[q][n] += sum_key P[q][key] V[key][n]:  A = P (lane-local: st[kt][r] is P[q=lq][key=16kt+4g+r]),
-        // B = V[key = 16kt + 4g + r][this lane's NJ contiguous columns] (load_v_row)
-        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); t_sm += t - t_a; t_a = t; }
-        float vb[2][NJ];
-        load_v_row<DH>(&Vs[(4 * g) * DH], lq, vb[0]);
-#pragma unroll
-        for (int idx = 0; idx < 4 * NKT; ++idx) {
-            const int kt = idx >> 2, r = idx & 3, cb = idx & 1;
-            if (idx + 1 < 4 * NKT && !(ablate & 16)) {
-                const int kt1 = (idx + 1) >> 2, r1 = (idx + 1) & 3;
-                load_v_row<DH>(&Vs[(16 * kt1 + 4 * g + r1) * DH], lq, vb[cb ^ 1]);
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vb[cb][j], o[j], 0, 0, 0);
-        }
-        if (stamps) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
-            t_pv += __builtin_amdgcn_s_memrealtime() - t_a;
-        }
-        }
-        cur = cur + 1 == NST ? 0 : cur + 1;
-        stg = stg + 1 == NST ? 0 : stg + 1;
-    }
-
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
+        for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[t][j]);
     if (stamps && tid == 0) {
         stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
         stamps[8 * (size_t)bid + 5] = t_qk; stamps[8 * (size_t)bid + 6] = t_sm; stamps[8 * (size_t)bid + 7] = t_pv;
     }
-    // normalise and store: accumulator element (j, r) belongs to query q0 + 4g + r, columns as laid out by load_v_row
-    float lr[4];
+    // normalise and store: accumulator element (j, r) of tile t belongs to query q0 + QB t + 4g + r, columns as laid out by load_v_row
 #pragma unroll
-    for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run, 4 * g + r);
+    for (int t = 0; t < QT; ++t) {
+        float lr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qrow = q0 + 4 * g + r;
-        if (qrow >= p.Tq) continue;
-        store_o_row<DH>(p, o, r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * p.dh, lq);
+        for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run[t], 4 * g + r);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qrow = q0 + QB * t + 4 * g + r;
+            if (qrow >= p.Tq) continue;
+            store_o_row<DH>(p, o[t], r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * p.dh, lq);
+        }
     }
     if (stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -730,8 +761,9 @@ constexpr int attn_smem() { return NST * 2 * KCF * DH * 4; }
 
 template <int DH>
 int launch_mfma(const AttnArgs& a, hipStream_t st) {
-    if (a.ablate || a.stamps) hipLaunchKernelGGL((attn_mfma_kernel<DH, true>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), attn_smem<DH>(), st, a);
-    else hipLaunchKernelGGL((attn_mfma_kernel<DH>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), attn_smem<DH>(), st, a);
+    const dim3 grid(8 * a.pairs_per_xcd * a.qtiles), block(256);
+    if (a.ablate || a.stamps) hipLaunchKernelGGL((attn_mfma_kernel<DH, true>), grid, block, attn_smem<DH>(), st, a);
+    else hipLaunchKernelGGL((attn_mfma_kernel<DH>), grid, block, attn_smem<DH>(), st, a);
     return mmdm_check_launch("attn_mfma");
 }
 
@@ -745,13 +777,10 @@ int launch_small(const AttnArgs& a, hipStream_t st) {
 }  // namespace
 
 int mmdm_attn_init(void) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<128>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem<128>());
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<64>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem<64>());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem<128>());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem<64>());
+    hipError_t e = hipSuccess;
+    const void* fns[4] = {reinterpret_cast<const void*>(&attn_mfma_kernel<128, false>), reinterpret_cast<const void*>(&attn_mfma_kernel<128, true>),
+                          reinterpret_cast<const void*>(&attn_mfma_kernel<64, false>), reinterpret_cast<const void*>(&attn_mfma_kernel<64, true>)};
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 2 ? attn_smem<128>() : attn_smem<64>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<128, 3>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<64, 3>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<128, 1>());

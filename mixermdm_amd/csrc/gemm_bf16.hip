@@ -267,6 +267,33 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS), (BCfg<TM_, TN_>::THREADS
         if (kt + 1 < nkt) stage(cur ^ 1);
         const float* Ac = As + cur * C_::A_FLOATS + a_row;
         const float* Bc = Bs + cur * C_::B_FLOATS + b_row;
+        if constexpr (ET == 1) {
+            // fp8: ONE v_mfma_scale_f32_32x32x64_f8f6f4 per output tile and 64-byte row step (e4m3 on both sides, unit E8M0 scales): the
+            // block-scaled form runs the 64-deep product in the time of two K = 16 fp8 MFMAs, i.e. at twice the non-scaled fp8 / bf16
+            // rate (MI355X_MICROARCH.md, Matrix cores).  A lane's 32 operand bytes are its two 16-byte fragments of the step (chunks lh and
+            // 2 + lh of the row); A and W use the same positions, so every product pairs the same k on both sides.
+            typedef int v8i __attribute__((ext_vector_type(8)));
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            v8i af8[TM], bf8[TN];
+            const int c0 = 4 * (lh ^ sw), c1 = 4 * ((2 + lh) ^ sw);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const v4i lo = __builtin_bit_cast(v4i, *reinterpret_cast<const f32x4*>(Ac + i * 32 * 16 + c0));
+                const v4i hi = __builtin_bit_cast(v4i, *reinterpret_cast<const f32x4*>(Ac + i * 32 * 16 + c1));
+                af8[i] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const v4i lo = __builtin_bit_cast(v4i, *reinterpret_cast<const f32x4*>(Bc + j * 32 * 16 + c0));
+                const v4i hi = __builtin_bit_cast(v4i, *reinterpret_cast<const f32x4*>(Bc + j * 32 * 16 + c1));
+                bf8[j] = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bf8[j], af8[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        } else {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int cg = 4 * ((2 * kb + lh) ^ sw);
@@ -275,22 +302,12 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS), (BCfg<TM_, TN_>::THREADS
             for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ac + i * 32 * 16 + cg));
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bc + j * 32 * 16 + cg));
-            if constexpr (ET == 1) {
-                typedef long l2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(l2, bf[j])[hh], __builtin_bit_cast(l2, af[i])[hh], acc[i][j], 0, 0, 0);
-            } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-            }
+        }
         }
     }
     // MFMA -> VALU hazard across the loop-exit branch: see MFMA_SETTLE in attn_f32.hip
@@ -447,24 +464,54 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
         for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ac + i * 32 * 16));
     };
     auto mm = [&](const bf16x8 (&af)[TM], const bf16x8 (&bf)[TN]) {
-        if constexpr (ET == 1) {
-            typedef long l2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(l2, bf[j])[hh], __builtin_bit_cast(l2, af[i])[hh], acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        }
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     };
-    constexpr int NM = (ET == 1 ? 2 : 1) * TM * TN;          // MFMAs per k-block
+    // fp8: the block-scaled 64-deep MFMA takes the fragments of TWO k-blocks (this lane's 16 bytes of each) per operand, exactly as the
+    // staged kernel pairs the two fragments of its 64-byte row step -- same products, same order: the two kernels stay bit-identical.
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    auto cat = [](const bf16x8& lo, const bf16x8& hi) {
+        const v4i a = __builtin_bit_cast(v4i, lo), b = __builtin_bit_cast(v4i, hi);
+        return v8i{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    };
+    auto mm64 = [&](const bf16x8 (&al)[TM], const bf16x8 (&ah)[TM], const bf16x8 (&bl)[TN], const bf16x8 (&bh)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat(bl[j], bh[j]), cat(al[i], ah[i]), acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    };
+    constexpr int NM = TM * TN;                              // MFMAs per k-block (bf16) / per pair of k-blocks (fp8)
     constexpr int NV = NLB + NIA;                            // VMEM instructions of a step, all behind the first k-block's MFMAs
+    // fp8 step: f0 holds the fragments of k-block 0 on entry and f2 receives those of the next step's k-block 0
+    auto step8 = [&](int kt, int cur, int nxt, int nn, bf16x8 (&b)[NKB][TN], bf16x8 (&bn)[NKB][TN], bf16x8 (&f0)[TM], bf16x8 (&f1)[TM], bf16x8 (&f2)[TM]) {
+        rda(cur, 1, f1);
+        ldb(kt + 1, bn);
+        stage(nn, kt + 2);
+        mm64(f0, f1, b[0], b[1]);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int u = 0; u < NM - 2; ++u) { __builtin_amdgcn_sched_group_barrier(0x010, (NV + NM - 3) / (NM - 2), 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x010, NV, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rda(cur, 2, f0);
+        rda(cur, 3, f1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");      // A stage kt+1 landed (requested during step kt-1); this step's requests may be in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // every wave has read all of stage kt and sees stage kt+1
+        __builtin_amdgcn_sched_barrier(0);
+        rda(nxt, 0, f2);
+        mm64(f0, f1, b[2], b[3]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto step = [&](int kt, int cur, int nxt, int nn, bf16x8 (&b)[NKB][TN], bf16x8 (&bn)[NKB][TN]) {
         rda(cur, 1, fa1);
         ldb(kt + 1, bn);
@@ -508,10 +555,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
     __builtin_amdgcn_s_barrier();
     rda(0, 0, fa0);
     int cur = 0;
+    bf16x8 fa2[TM];
     for (int kt = 0; kt < nkt; kt += 2) {                  // nkt is even (host check): the two B register sets swap roles every step
         const int c1 = cur == 2 ? 0 : cur + 1, c2 = c1 == 2 ? 0 : c1 + 1;
-        step(kt, cur, c1, c2, bx, by);
-        step(kt + 1, c1, c2, cur, by, bx);
+        if constexpr (ET == 1) {
+            step8(kt, cur, c1, c2, bx, by, fa0, fa1, fa2);
+            step8(kt + 1, c1, c2, cur, by, bx, fa2, fa1, fa0);
+        } else {
+            step(kt, cur, c1, c2, bx, by);
+            step(kt + 1, c1, c2, cur, by, bx);
+        }
         cur = c2;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus requests of the last steps
@@ -592,9 +645,9 @@ int mmdm_gemm_bf16_init(void) {
     if ((rc = set_attr<42, 22, 1>())) return rc;
     if ((rc = set_attr<42, 42, 1>())) return rc;
     if ((rc = set_attr<22, 21, 1>())) return rc;
-    for (const void* f : {reinterpret_cast<const void*>(&gemm_bf16w_kernel<0>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1>),
+    for (const void* f : {reinterpret_cast<const void*>(&gemm_bf16w_kernel<0>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1>),
-                          reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 2, true>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 2, true>),
+                          reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 2, true>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1, true>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1, true>)}) {
         hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 128 * 16 * 4);
         if (e2 != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16w): %s", hipGetErrorString(e2));
@@ -738,8 +791,10 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (packed) {
-        const bool narrow = (N & 255) || (g_bf16_cfg == 11) || (g_bf16_cfg != 12 && N <= 1024);
-        return narrow ? launch_w<1, 1>(a, st) : launch_w<1, 2>(a, st);
+        // fp8 packed: the 128 x 128 tile only (the block-scaled MFMA takes 32-byte operands: with 128 x 256 tiles the paired fragments
+        // of both operands no longer fit next to 128 accumulators at two waves per SIMD; the sampler uses this kernel for the K = 2048
+        // FFN-2 GEMM, N = 1024, which is a 128 x 128 shape anyway)
+        return launch_w<1, 1>(a, st);
     }
     switch (g_bf16_cfg) {
         case 0: return launch<22, 22, 1>(a, st);
