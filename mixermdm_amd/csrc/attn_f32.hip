@@ -155,8 +155,12 @@ __device__ __forceinline__ float rows_sum(float x) {
 // 64 x 8 x 300 x 128 with warm clocks; 138 vs 129 us at dh = 64, where both forms keep four waves per SIMD): what this kernel needs is
 // waves per SIMD, not fewer fixed costs per MFMA (LAB_NOTES.md).  The template parameter stays (the code is the same), QT = 2 is not
 // instantiated.  A tile whose 16 queries all lie past Tq is never computed (wave-uniform: `NA` live tiles, one chunk loop per count).
-template <int DH, bool DIAG = false, int QT = 1>
-__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
+// NW = waves per workgroup.  Production runs NW = 4.  NW = 8 (round 3: 128 queries per workgroup at ONE tile per wave, so registers and the
+// four waves per SIMD stay; two 8-wave workgroups per CU share each K / V stage among twice as many waves and T = 300 gives exactly three
+// rounds of 512 slots) was measured 13 % SLOWER (236 vs 209 us at 64 x 8 x 300 x 128; bit-identical results): four independent
+// workgroups per CU de-synchronise, two 8-wave ones put pairs of lock-stepped waves on every SIMD.  Not instantiated (LAB_NOTES.md).
+template <int DH, bool DIAG = false, int QT = 1, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
     const int ablate = DIAG ? p.ablate : 0;
     unsigned long long* const stamps = DIAG ? p.stamps : nullptr;
@@ -166,9 +170,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     constexpr int CPR = DH / 4;                 // 16-byte chunks per row
     constexpr int RPP = 64 / CPR;               // rows per 1-KiB DMA piece
     constexpr int NPIECE = 2 * KC / RPP;        // pieces per stage (K then V)
-    constexpr int NI = NPIECE / 4;              // pieces per wave
+    constexpr int NI = NPIECE / NW;             // pieces per wave
+    static_assert(NPIECE % NW == 0 && NI >= 1, "pieces of a stage divide evenly over the waves");
     constexpr int STAGE = 2 * KC * DH;          // floats per stage
-    constexpr int QBW = QB * QT;                // queries per workgroup
+    constexpr int QBT = QW * NW;                // queries per tile row of the workgroup (one tile per wave)
+    constexpr int QBW = QBT * QT;               // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [NST stages][K: KC*DH | V: KC*DH]
 
     // XCD-aware mapping: blocks b and b+8 share an XCD (private L2), so all query tiles of one (sequence, head) are given to
@@ -185,11 +191,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 15, g = lane >> 4;
-    const int q0 = qt * QBW + wave * QW;        // first query of this wave's tile 0; tile t starts at q0 + QB * t
+    const int q0 = qt * QBW + wave * QW;        // first query of this wave's tile 0; tile t starts at q0 + QBT * t
     // live tiles of this wave: tiles are ordered by query, so tile t live implies tile t - 1 live
     int nact = 0;
 #pragma unroll
-    for (int t = 0; t < QT; ++t) nact += (q0 + QB * t < p.Tq) ? 1 : 0;
+    for (int t = 0; t < QT; ++t) nact += (q0 + QBT * t < p.Tq) ? 1 : 0;
     nact = __builtin_amdgcn_readfirstlane(nact);
     unsigned long long t_qk = 0, t_sm = 0, t_pv = 0, t_a = 0;
     if (stamps && tid == 0) {
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     f32x4 qf[QT][NJ];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        int qrow = q0 + QB * t + lq;
+        int qrow = q0 + QBT * t + lq;
         if (qrow >= p.Tq) qrow = p.Tq - 1;
         const float* qp = p.Q + ((size_t)seq * p.Tq + qrow) * p.ldq + head * p.dh + 4 * g;
 #pragma unroll
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
     int voff[NI], dsto[NI];
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
-        const int pq = wave + 4 * u;
+        const int pq = wave + NW * u;
         const bool isk = pq < NPIECE / 2;
         const int trow = RPP * (isk ? pq : pq - NPIECE / 2) + lane / CPR;
         const int pos = lane % CPR;
@@ -247,11 +253,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         voff[u] = (trow * (isk ? p.ldk : p.ldv) + 4 * src_chunk) * 4;
         dsto[u] = (isk ? 0 : KC * DH) + RPP * (isk ? pq : pq - NPIECE / 2) * DH;
     }
-    static_assert(NPIECE / 2 % 4 == 0, "K and V pieces split evenly over the four waves: piece u is a K piece for every wave or for none");
+    // piece u of this wave is a K piece or a V piece: wave-uniform (for NPIECE / 2 % NW == 0 the same for every wave)
     auto stage = [&](int c0, int buf) {
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
-            const bool isk = u < NPIECE / 8;
+            const bool isk = wave + NW * u < NPIECE / 2;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(isk ? rsK : rsV, (lptr_t)(smem + buf * STAGE + dsto[u]), 16, voff[u], c0 * (isk ? p.ldk : p.ldv) * 4, 0, 0);
         }
     };
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         if (stamps) { const unsigned long long tt = __builtin_amdgcn_s_memrealtime(); t_qk += tt - t_a; t_a = tt; }
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
-            const int q0t = q0 + QB * t;
+            const int q0t = q0 + QBT * t;
             if (c0 + KC > p.Tk || (causal && c0 + KC - 1 > q0t)) {   // keys past Tk (last chunk) or above the diagonal (wave-uniform branch)
                 const int kmax = causal ? min(p.Tk - 1, q0t + lq) : p.Tk - 1;
 #pragma unroll
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         stamps[8 * (size_t)bid + 2] = __builtin_amdgcn_s_memrealtime();
         stamps[8 * (size_t)bid + 5] = t_qk; stamps[8 * (size_t)bid + 6] = t_sm; stamps[8 * (size_t)bid + 7] = t_pv;
     }
-    // normalise and store: accumulator element (j, r) of tile t belongs to query q0 + QB t + 4g + r, columns as laid out by load_v_row
+    // normalise and store: accumulator element (j, r) of tile t belongs to query q0 + QBT t + 4g + r, columns as laid out by load_v_row
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         float lr[4];
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnArgs p) {
         for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run[t], 4 * g + r);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int qrow = q0 + QB * t + 4 * g + r;
+            const int qrow = q0 + QBT * t + 4 * g + r;
             if (qrow >= p.Tq) continue;
             store_o_row<DH>(p, o[t], r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * p.dh, lq);
         }

@@ -540,9 +540,9 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         const int qkld = pvb ? 3 * D : 2 * D;           // row stride of the bf16 copy of the packed projection: Q|K or Q|K|V
         // all-bf16 attention: nothing reads the fp32 projection, so the GEMM writes bf16 only (a third of the bytes: the fp8 QKV GEMM is output-bound)
         if (pvb) {
-            if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qk, 3 * D, 1, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+            if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qk, 3 * D, 1, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, Second(), w.w_packed));
             else RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, static_cast<float*>(S.qk), 3 * D, 1, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0));
-        } else if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, qkld, qkld)));
+        } else if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, qkld, qkld), w.w_packed));
         else RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, qkld, qkld)));
         if (qkp) RC(attention_p(c, S.qk, qkld, (size_t)R * qkld, static_cast<const uint16_t*>(S.qk) + D, qkld, (size_t)R * qkld, np, S.qkv + 2 * D, 3 * D, S.att, D, ob,
                                 r.nseq, r.T, r.T, w.H, dh, 0, pvb ? static_cast<const uint16_t*>(S.qk) + 2 * D : nullptr, qkld));
@@ -554,9 +554,9 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
             RC(norm(src, ss_at(2, r.ca_row0), r.ca_rows));
             const int kvld = pvb ? 2 * D : D;             // bf16 copy of the cross-attention projection: K or K|V
             if (pvb) {
-                if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kvp, 2 * D, 1, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+                if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kvp, 2 * D, 1, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, Second(), w.w_packed));
                 else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, static_cast<float*>(S.kvp), 2 * D, 1, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0));
-            } else if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld)));
+            } else if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld), w.w_packed));
             else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld)));
         }
         RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
@@ -564,9 +564,9 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         if (r.ca_mode) {
             RC(norm(hbuf, ss_at(1, r.ca_row0), r.ca_rows));
             if (pvb) {
-                if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qk, D, 1, D, D, MMDM_EPI_BIAS, nullptr, 0));
+                if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qk, D, 1, D, D, MMDM_EPI_BIAS, nullptr, 0, Second(), w.w_packed));
                 else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, static_cast<float*>(S.qk), D, 1, D, D, MMDM_EPI_BIAS, nullptr, 0));
-            } else if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
+            } else if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D), w.w_packed));
             else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
             if (qkp) RC(attention_p(c, S.qk, D, (size_t)R * D, S.kvp, pvb ? 2 * D : D, (size_t)R * (pvb ? 2 * D : D), np, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
                                     r.ca_mode == 1 ? r.nseq / 2 : 0, pvb ? static_cast<const uint16_t*>(S.kvp) + D : nullptr, 2 * D));
@@ -1078,18 +1078,23 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
                 const int64_t D = st.D, F = st.F;
                 int rc = MMDM_OK;
                 if (h->cfg.precision == 3) {          // per-output-channel e4m3 for QKV / cross-attention inputs / FFN, bf16 for the output projections
-                    // the fp8 weights with K = 1024 stay in rows: there a tile is 8 steps of the packed kernel's 128-byte K step, and its prologue / epilogue
-                    // outweigh the better loop (tools/gemm_fp8_bench.py: QKV 963 vs 994 TFLOP/s, FFN-1 794 vs 909; 8192^3: 1728 vs 1508); the bf16
-                    // output projections of this mode are packed like the bf16 mode's
+                    // the bf16 output projections of this mode are packed like the bf16 mode's
                     auto q8 = [&](const float* src, void* dst, float* sc, int rows, int cols) { return mmdm_quantize_rows_fp8(src, cols, dst, cols, sc, rows, cols, nullptr); };
-                    rc = q8(lw.sa_in_w, lb.sa_in_8, lb.sa_in_s, (int)(3 * D), (int)D);
+                    // quantise into the scratch buffer, then permute into MFMA fragment order (the packed kernel takes W straight from global memory)
+                    auto q8p = [&](const float* src, void* dst, float* sc, int rows, int cols) {
+                        int r2 = mmdm_quantize_rows_fp8(src, cols, tmp, cols, sc, rows, cols, nullptr);
+                        return r2 ? r2 : mmdm_pack_weight_frag(tmp, cols, dst, rows, cols, nullptr);
+                    };
+                    // Round 3, with the block-scaled 64-deep fp8 MFMA in both kernels (tools/gemm_fp8_bench.py, M = 19 200): the packed kernel now wins
+                    // on the projections (QKV 1203 vs 988 TFLOP/s) and on K = 2048 (FFN-2 917 vs 685); FFN-1 stays staged (1048 vs 988)
+                    rc = pack_now ? q8p(lw.sa_in_w, lb.sa_in_8, lb.sa_in_s, (int)(3 * D), (int)D) : q8(lw.sa_in_w, lb.sa_in_8, lb.sa_in_s, (int)(3 * D), (int)D);
                     if (!rc) rc = conv(lw.sa_out_w, lb.sa_out_w, D * D, D);
                     if (!rc) rc = q8(lw.f1_w, lb.f1_8, lb.f1_s, (int)F, (int)D);
                     if (!rc && pack_now && F >= 2048) {       // the one fp8 GEMM with K = 2048 (16 steps of the packed kernel): 1039 vs 901 TFLOP/s
                         rc = mmdm_quantize_rows_fp8(lw.f2_w, (int)F, tmp, (int)F, lb.f2_s, (int)D, (int)F, nullptr);
                         if (!rc) rc = mmdm_pack_weight_frag(tmp, F, lb.f2_8, (int)D, (int)F, nullptr);
                     } else if (!rc) rc = q8(lw.f2_w, lb.f2_8, lb.f2_s, (int)D, (int)F);
-                    if (!rc && st.has_ca) rc = q8(lw.ca_in_w, lb.ca_in_8, lb.ca_in_s, (int)(3 * D), (int)D);
+                    if (!rc && st.has_ca) rc = pack_now ? q8p(lw.ca_in_w, lb.ca_in_8, lb.ca_in_s, (int)(3 * D), (int)D) : q8(lw.ca_in_w, lb.ca_in_8, lb.ca_in_s, (int)(3 * D), (int)D);
                     if (!rc && st.has_ca) rc = conv(lw.ca_out_w, lb.ca_out_w, D * D, D);
                     if (rc) return herr(h, rc);
                     continue;

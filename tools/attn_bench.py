@@ -15,7 +15,7 @@ for nseq,T,H,dh,name in [(64,300,8,128,"d.sa"),(64,300,8,64,"m.sa"),(128,300,8,1
     qkv = torch.randn(nseq,T,3*D,device=d)
     line = f"{name} nseq={nseq} T={T} H={H} dh={dh}:"
     outs = []
-    for qt in (1,):
+    for nw in (4,):
         res=[]
         for r in range(7):
             o = ops.attention(qkv[...,:D],qkv[...,D:2*D],qkv[...,2*D:],H)
