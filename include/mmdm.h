@@ -21,6 +21,8 @@
  *   MMDM_NO_PACK=1       mmdm_prepare: keep the low-precision weight twins of precision 1-3 in row-major planes instead of MFMA
  *                        fragment order (the packed and the plane kernels are bit-identical; tests/test_gpu_packed_modes.py compares them).
  *   MMDM_QKP / MMDM_NO_QKP / MMDM_NO_BF16_PV   precision >= 1: force / forbid the bf16-plane Q K^T and the bf16 P V forms of the attention.
+ *   MMDM_FUSE_ADALN=1    precision 0, two-chain samplers: apply AdaLN inside the GEMM that consumes it (mmdm_linear_adaln_f32's kernel) instead
+ *                        of as a pass of its own.  Off by default: measured slower (LAB_NOTES.md, "AdaLN in the GEMM"); results agree to fp32 rounding.
  *   MMDM_GEMM_CFG, MMDM_GEMM_TAIL, MMDM_SPLIT_CFG, MMDM_BF16_CFG   tile-selection overrides of the GEMM dispatch, for tools/ (benchmarks).
  * The mmdmx_* symbols the library also exports (mmdmx_set_gemm_cfg, _ablate, _stamps, ...) are hooks of the scripts under tools/: timing
  * ablations and in-kernel stamps.  They select separate DIAGNOSTIC kernel instantiations; the kernels a handle launches by default
@@ -81,8 +83,8 @@ int mmdm_linear_bf16(const void* A, int lda, const void* W, int ldw, const float
                      int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
 /* Static weights in MFMA FRAGMENT ORDER for the bf16 / fp8 linear layers: mmdm_pack_weight_frag permutes W [N][row_bytes] (bf16: row_bytes = 2 K,
  * fp8: K) inside blocks of 32 rows x 32 bytes so that one wave-wide 16-byte load is one MFMA operand; the *_packed entry points then take W
- * straight from global memory (LDS carries A only; 128 x 256 tiles, K step 128 bytes).  Bit-identical to mmdm_linear_bf16 / mmdm_linear_fp8.
- * Needs N % 256 == 0 and K % 128 == 0 (bf16) / K % 256 == 0 (fp8); a row slice starting at a multiple of 32 rows is the same byte offset. */
+ * straight from global memory (LDS carries A only; 128 x 256 or 128 x 128 tiles for bf16, 128 x 128 for fp8, K step 128 bytes).  Bit-identical to
+ * mmdm_linear_bf16 / mmdm_linear_fp8.  Needs N % 128 == 0 and K % 128 == 0 (bf16) / K % 256 == 0 (fp8); a row slice starting at a multiple of 32 rows is the same byte offset. */
 int mmdm_pack_weight_frag(const void* W, int64_t ld_bytes, void* out, int N, int row_bytes, void* stream);
 int mmdm_linear_bf16_packed(const void* A, int lda, const void* W_packed, const float* bias, void* C, int ldc, int out_bf16,
                             int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
@@ -92,7 +94,7 @@ int mmdm_linear_fp8_packed(const void* A, int lda, const float* a_scale, const v
 int mmdm_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 
 /* fp8 operands (OCP e4m3; BASELINE configs[4] "fp8 MFMA QKV/FFN GEMMs", mmdm_config.precision = 3): A [M,K] and W [N,K] are fp8 bytes
- * (16-byte aligned rows, K % 64 == 0), accumulated in fp32 on v_mfma_f32_32x32x16_fp8_fp8 and de-quantised in the epilogue:
+ * (16-byte aligned rows, K % 64 == 0), accumulated in fp32 on v_mfma_scale_f32_32x32x64_f8f6f4 (block-scaled form, unit scales) and de-quantised in the epilogue:
  *   C[m][n] = acc[m][n] * a_scale[m] * w_scale[n] + bias[n] (+ residual / PE row), then the activation;
  * a_scale [M] per-row activation scales, w_scale [N] per-output-channel weight scales (either may be NULL = 1).
  * out_mode: 0 fp32, 1 bf16, 2 fp8 at unit scale (values saturate at +-448).  Epilogues / extra / period as mmdm_linear_f32; N % 4 == 0. */
@@ -126,6 +128,21 @@ int mmdm_f32_split3(const float* in, void* out, int64_t n, int64_t plane_stride,
  * row(s) = s % ss_rows.  ss is the output of Linear(SiLU(emb)) (scale first, shift second), row stride ss_ld.
  * Replaces AdaLN.forward  src/models/utils/layers.py:15-25. */
 int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss_rows, float* out, int nseq, int T, int D, void* stream);
+
+/* AdaLN fused around the fp32 GEMM (no stand-alone pass, no normalised copy of the residual stream).
+ * Reference: AdaLN.forward feeding nn.Linear / MultiheadAttention.in_proj -- src/models/utils/layers.py:15-25, 36-44, 77-87, 99-104.
+ *
+ * mmdm_linear_f32_stats: mmdm_linear_f32 with a residual (MMDM_EPI_BIAS_RESID) or positional (MMDM_EPI_BIAS_PE) epilogue that ALSO writes,
+ *   for every output row and 32-column block, (mean, sum of squared deviations) of the stored values: stats [M][N/32][2] floats.
+ *   Needs N % 32 == 0, K % 16 == 0, K >= 96 and 16-byte aligned rows (MMDM_ERR_UNSUPPORTED otherwise).
+ * mmdm_linear_adaln_f32: C = epilogue( AdaLN(H) W^T + b ), epilogue MMDM_EPI_BIAS or MMDM_EPI_BIAS_GELU.  H [M,K] row stride ldh is the
+ *   un-normalised input, stats [M][K/32][2] what mmdm_linear_f32_stats wrote for it, ss / ss_ld / ss_rows / T as in mmdm_adaln_f32 (row m
+ *   takes (scale | shift) row (m / T) % ss_rows).  LN eps 1e-6, biased variance, no affine.  Needs K % 128 == 0, 128 <= K <= 1024 and
+ *   T >= 128 (a 128-row tile then touches at most two sequences). */
+int mmdm_linear_f32_stats(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+                          int epilogue, const float* extra, int ld_extra, int period, float* stats, void* stream);
+int mmdm_linear_adaln_f32(const float* H, int ldh, const float* stats, const float* ss, int ss_ld, int ss_rows, int T,
+                          const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K, int epilogue, void* stream);
 
 /* Same with a selectable output type: out_bf16 != 0 writes `out` as bf16 (operand of the next bf16 GEMM). */
 int mmdm_adaln_ex(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, int nseq, int T, int D, void* stream);

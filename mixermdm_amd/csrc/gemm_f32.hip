@@ -27,6 +27,14 @@ struct GemmArgs {
     int lda, ldw, ldc, ld_extra;
     int M, N, K, Kw, epilogue, period;   // Kw >= K: readable columns of W (zero beyond K)
     int mt, nt;
+    // AdaLN fused around the GEMM (mmdm_gemm_fuse, kernels.h).  Producer side (16-byte epilogue of the pipelined kernel): per output row
+    // and 32-column block the pair (mean, M2 = sum of squared deviations) of the values just stored -> stats_out [M][N/32][2].
+    // Consumer side (NORM_ instantiation): A holds the un-normalised residual stream; its rows' statistics are combined from nstats
+    // [M][K/32][2] and the fragments are modulated after their LDS read: a <- ((a - mean) rstd) (1 + scale[seq][k]) + shift[seq][k],
+    // seq = row / T, (scale | shift) = nss + (seq % nss_rows) * nss_ld (reference: AdaLN.forward src/models/utils/layers.py:15-25).
+    float* stats_out;
+    const float* nstats; const float* nss;
+    int nss_ld, nss_rows, nT;
     int ablate;                          // timing experiments only (tools/gemm_bench.py); 0 in production
     unsigned long long* stamps;          // diagnostic builds of a launch only (tools/gemm_timeline.py): per-workgroup {start, loop start, loop end, placement, kernel end, kernel entry, residual landed, stores issued}, then {s_memtime at loop start, loop end} per workgroup
                                          // in 100 MHz s_memrealtime ticks; nullptr in production (one never-taken scalar branch per workgroup)
@@ -205,6 +213,7 @@ __global__ __launch_bounds__((Cfg<TM_, TN_, BK_>::THREADS)) void gemm_f32_kernel
 // read (16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3)): a 16-lane read group then covers 16 distinct
 // 16-byte bank slots.  Rows past M / N are clamped on load (their results are never stored).
 // ---------------------------------------------------------------------------------------------------------
+constexpr int NORM_MAX_K = 1024;      // fused AdaLN: the conditioning table in LDS is [2 sequences][(1 + scale) | shift][NORM_MAX_K floats] = 16 KB
 template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2>
 struct GCfg {
     static constexpr int WGM = TM_ / 10, WGN = TN_ / 10, TM = TM_ % 10, TN = TN_ % 10;
@@ -254,8 +263,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // DIAG_: the timing ablations (GemmArgs::ablate) and in-kernel stamps (GemmArgs::stamps) exist in a second instantiation only, launched
 // when a tool has set one of them (tools/gemm_bench.py ABL=, tools/gemm_timeline.py, bench.py's loop clock); the production instantiation
 // sees compile-time zeros -- no diagnostic branch, load or register in the shipped kernels.
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_, bool DIAG_>
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_, bool DIAG_, bool NORM_ = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int swz, int bid) {
+    static_assert(!NORM_ || (PIPE_ == 1 && !VEPI), "the AdaLN prologue exists in the pipelined kernel with the scalar epilogue (bias / GELU consumers)");
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
     const GemmArgs& p = pp;
     unsigned long long* const p_stamps = DIAG_ ? pp.stamps : nullptr;
@@ -371,12 +381,83 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
         }
     }
 
+    // ---- fused AdaLN, consumer side: row statistics and the conditioning rows of this tile ----------------------------------------
+    // LDS behind the operand ring: [2 sequences][(1 + scale) | shift][NORM_MAX_K floats].  A 128-row tile touches at most two sequences
+    // (host: T >= 128).  The prologue's global loads are ISSUED here, before the operand ring's first requests, and CONSUMED behind them
+    // (in-order retirement: waiting for these loads never waits for a ring tile), so the ring's latency covers the prologue's.
+    float nr_a[NORM_ ? TM : 1], nr_b[NORM_ ? TM : 1];          // per row tile of this lane: rstd, -mean * rstd
+    int nss_off[NORM_ ? TM : 1];                                 // LDS byte address of the lane's (sequence block, k = 4 lh) in the table
+    float* const SS = smem + NBUF * (C_::A_FLOATS + C_::B_FLOATS);
+    constexpr int NLD = NORM_MAX_K / 128;                        // 16-byte statistics loads per row and lane half at the largest K (two partials each)
+    constexpr int NSS = NORM_MAX_K / 2 / C_::THREADS;            // conditioning float4 pairs per thread at the largest K
+    f32x4 pv[NORM_ ? TM : 1][NORM_ ? NLD : 1], ssv[NORM_ ? NSS : 1][2];
+    if constexpr (NORM_) {
+        const int K = p.K, nblk = K >> 5, nh = nblk >> 1, T = p.nT;       // nh partials per lane half (host: K % 128 == 0 -> nh even)
+        // (a) statistics: lane half lh combines half of the row's 32-column partials, the partner lane (lane ^ 32) the other half;
+        //     compile-time load count, addresses clamped into the half (one wait for the lot, not one per load)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = min(m0 + wm * (32 * TM) + i * 32 + l31, p.M - 1);
+            const float* sp = p.nstats + ((size_t)row * nblk + (size_t)lh * nh) * 2;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) pv[i][u] = *reinterpret_cast<const f32x4*>(sp + 4 * min(u, (nh >> 1) - 1));
+        }
+        // (b) conditioning rows of the tile's two sequences: entry e = (sequence, float4 column)
+        const int q0 = m0 / T, q1 = min(m0 + BM - 1, p.M - 1) / T;
+#pragma unroll
+        for (int u = 0; u < NSS; ++u) {
+            const int e = min(tid + u * C_::THREADS, (K >> 1) - 1);
+            const int sidx = e / (K >> 2), c4 = e - sidx * (K >> 2);
+            const float* src = p.nss + (size_t)((sidx ? q1 : q0) % p.nss_rows) * p.nss_ld + 4 * c4;
+            ssv[u][0] = *reinterpret_cast<const f32x4*>(src);
+            ssv[u][1] = *reinterpret_cast<const f32x4*>(src + K);
+        }
+    }
+    auto norm_consume = [&]() {
+        if constexpr (NORM_) {
+            const int K = p.K, nblk = K >> 5, nh = nblk >> 1, T = p.nT, q0 = m0 / T;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                // within this half: block means relative to the half's first block mean (pivot: no cancellation in the squares), Chan's
+                // combination over equal blocks of 32: M2_half = sum M2_b + 32 (S2 - S1^2 / nh); then the two halves (nh * 32 elements each)
+                const float piv = pv[i][0][0];
+                float s1 = 0.f, s2 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int u = 0; u < NLD; ++u) {
+                    const f32x4 v = pv[i][u];                        // (mean, M2) of two blocks
+                    const float wgt = 2 * u < nh ? 1.0f : 0.0f;     // loads past the half repeat its last pair: weight 0
+                    const float d0 = v[0] - piv, d1 = v[2] - piv;
+                    s1 += wgt * (d0 + d1); s2 += wgt * (d0 * d0 + d1 * d1); m2 += wgt * (v[1] + v[3]);
+                }
+                const float mean_h = piv + s1 / (float)nh;
+                const float m2_h = m2 + 32.0f * fmaxf(s2 - s1 * s1 / (float)nh, 0.f);
+                const float mean_o = __shfl_xor(mean_h, 32), m2_o = __shfl_xor(m2_h, 32);
+                const float mean = 0.5f * (mean_h + mean_o), dm = mean_h - mean_o;
+                const float var = (m2_h + m2_o + 0.25f * (float)K * dm * dm) / (float)K;      // n0 n1 / (n0 + n1) = K / 4
+                const float rstd = 1.0f / sqrtf(var + 1e-6f);
+                nr_a[i] = rstd; nr_b[i] = -mean * rstd;
+                // the loop advances the address by one K step (64 bytes) per tile
+                nss_off[i] = (int)(size_t)(lptr_t)SS + ((min(m0 + wm * (32 * TM) + i * 32 + l31, p.M - 1) / T - q0) * 2 * NORM_MAX_K + 4 * lh) * 4;
+            }
+#pragma unroll
+            for (int u = 0; u < NSS; ++u) {
+                const int e = tid + u * C_::THREADS;
+                if (e < (K >> 1)) {
+                    const int sidx = e / (K >> 2), c4 = e - sidx * (K >> 2);
+                    *reinterpret_cast<f32x4*>(SS + sidx * 2 * NORM_MAX_K + 4 * c4) = 1.0f + ssv[u][0];
+                    *reinterpret_cast<f32x4*>(SS + sidx * 2 * NORM_MAX_K + NORM_MAX_K + 4 * c4) = ssv[u][1];
+                }
+            }
+        }
+    };
+
     if constexpr (PIPE_ != 0) {
         // The first NBUF-1 operand tiles are requested behind the accumulator-initialisation loads; vmcnt retires in order, so
         // "at most the NBUF-2 newest tiles outstanding" means the initialisation values and tile 0 have landed: the loop starts on
         // tile 0 while the others are still on their way (the host side guarantees nkt >= NBUF).
 #pragma unroll
         for (int t = 0; t < NBUF - 1; ++t) stage(t);
+        norm_consume();
         wait_vm<(NBUF - 2) * C_::NI>();
     } else {
         // the accumulator-init loads above must not be counted by the pipeline's vmcnt arithmetic
@@ -397,6 +478,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
         static_assert((C_::NI + 1) / 2 <= 4 * TM * TN - 1, "LDS-DMA pieces of a tile must fit behind the MFMAs of two k-groups");
         constexpr int NI = C_::NI;
         f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+        f32x4 s0[NORM_ ? TM : 1][2], s1[NORM_ ? TM : 1][2];      // (1 + scale), shift of the fragments' four k (NORM_ only)
         auto rd = [&](int buf, int g, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
             const int cg = 4 * ((2 * g + lh) ^ sw);
             const float* Ac = As + buf * C_::A_FLOATS + a_row + cg;
@@ -406,9 +488,32 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * BK);
         };
-        auto mm = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+        // NORM_: the conditioning values of a fragment: logical k = k0 + 4 (2 g + lh) + s of this lane's sequence
+        // `next` = the fragments belong to the tile after the current one; every offset besides the running nss_off is an immediate
+        auto rdss = [&](bool next, int g, f32x4 (&sf)[NORM_ ? TM : 1][2]) {
+            if constexpr (NORM_) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int i = 0; i < TM; ++i) {
+                    typedef __attribute__((address_space(3))) const f32x4* lds_f4;
+                    const int a = nss_off[i] + (next ? BK * 4 : 0) + 32 * g;         // an LDS byte address: the table base is folded in
+                    sf[i][0] = *(lds_f4)(size_t)a;
+                    sf[i][1] = *(lds_f4)(size_t)(a + NORM_MAX_K * 4);
+                }
+            }
+        };
+        auto modulate = [&](f32x4 (&af)[TM], const f32x4 (&sf)[NORM_ ? TM : 1][2]) {
+            if constexpr (NORM_) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        af[i][s] = __builtin_fmaf(__builtin_fmaf(af[i][s], nr_a[i], nr_b[i]), sf[i][0][s], sf[i][1][s]);
+                }
+            }
+        };
+        auto mm_s = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], auto s0c, auto s1c) {
+#pragma unroll
+            for (int s = decltype(s0c)::value; s < decltype(s1c)::value; ++s)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -416,6 +521,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                         acc[i][j] = VEPI ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0)
                                          : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         };
+        auto mm = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) { mm_s(af, bf, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); };
         // `left` = tiles that may stay in flight behind the one being waited for (+ the NR residual loads issued at the start of the drain)
         constexpr int NR = LATE_R ? TM * TN * 4 : 0;
         auto wait_left = [&](int left) {
@@ -425,8 +531,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
             else if (left == 1) wait_vm<NI + NR>();
             else wait_vm<NR>();
         };
-        __builtin_amdgcn_s_barrier();                        // tile 0 has landed for every wave
+        if constexpr (NORM_) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's writes of the conditioning table
+        __builtin_amdgcn_s_barrier();                        // tile 0 has landed for every wave (and the conditioning table is complete)
         rd(0, 0, a0, b0);
+        rdss(false, 0, s0);
+        modulate(a0, s0);
         int cur = 0, nxt = 1, stg = NBUF - 1;
         const int n_main = nkt - (NBUF - 1);                 // steps that still issue a new tile
         constexpr int G = C_::G, NMM = 4 * TM * TN;          // k-groups per step (even), MFMAs per group
@@ -450,6 +559,43 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if constexpr (NORM_) {
+                // Fused AdaLN: the group in two scheduling regions.  (A) this group's first two k-steps (8 MFMAs for a 2 x 2 wave tile) with
+                // the fragment reads of the FOLLOWING group behind the first MFMA and the LDS-DMA pieces behind the next ones, as in the
+                // plain loop; (B) behind a scheduling fence, the modulation of those fragments -- 8 TM fma in one cluster behind the region's
+                // first MFMA -- and the last two k-steps.  Measured (LAB_NOTES.md, "AdaLN in the GEMM"): every VALU instruction in this loop
+                // costs about one MFMA pass whatever it depends on (16 independent dummy fma per group: +6 %), so the fused GEMM is slower
+                // than the plain one by more than the stand-alone pass costs wherever N >= 2048; the sampler therefore keeps the pass
+                // unless MMDM_FUSE_ADALN=1.
+                static_assert(TM == 2 && TN == 2, "the fused consumer is the 128 x 128 kernel");
+                constexpr std::integral_constant<int, 0> c0{}; constexpr std::integral_constant<int, 2> c2{}; constexpr std::integral_constant<int, 4> c4{};
+                const bool follow = g < G - 1 || more;
+                if constexpr (g % 2 == 0) {
+                    if constexpr (g < G - 1) { rd(cur, g + 1, a1, b1); rdss(false, g + 1, s1); }
+                    else if (more) { rd(nxt, 0, a1, b1); rdss(true, 0, s1); }
+                    if constexpr (STG && g == 0) stage_part(stg, std::integral_constant<int, 0>{}, std::integral_constant<int, D0>{});
+                    mm_s(a0, b0, c0, c2);
+                } else {
+                    if constexpr (g < G - 1) { rd(cur, g + 1, a0, b0); rdss(false, g + 1, s0); }
+                    else if (more) { rd(nxt, 0, a0, b0); rdss(true, 0, s0); }
+                    if constexpr (STG && g == 1) stage_part(stg, std::integral_constant<int, D0>{}, std::integral_constant<int, NI>{});
+                    mm_s(a1, b1, c0, c2);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, g);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN + 2 * TM, g);
+#pragma unroll
+                for (int u = 0; u < dma_here; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, g);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, g);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMM / 2 - 1 - dma_here, g);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (g % 2 == 0) { if (follow) modulate(a1, s1); mm_s(a0, b0, c2, c4); }
+                else { if (follow) modulate(a0, s0); mm_s(a1, b1, c2, c4); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, g);
+                __builtin_amdgcn_sched_group_barrier(0x002, 16, g);
+                __builtin_amdgcn_sched_group_barrier(0x008, NMM / 2 - 1, g);
+            } else {
             if constexpr (g % 2 == 0) {
                 if constexpr (g < G - 1) rd(cur, g + 1, a1, b1);
                 else if (more) rd(nxt, 0, a1, b1);
@@ -469,6 +615,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                 __builtin_amdgcn_sched_group_barrier(0x010, 1, g);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, NMM - 1 - dma_here, g);
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         auto step = [&](auto do_stage, int left, bool more) {
@@ -479,6 +626,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                 group(std::integral_constant<int, 3>{}, do_stage, left, more);
             }
             cur = nxt; nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+            if constexpr (NORM_) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) nss_off[i] += BK * 4;
+            }
         };
         for (int kt = 0; kt < n_main; ++kt) {
             step(std::true_type{}, 0, true);
@@ -583,10 +734,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
             // D^T map: lane&31 = output row inside the 32-row tile, register 4*qd + c = output column 8*qd + 4*(lane>>5) + c
             const int col0 = n0 + wn * (32 * TN) + 4 * lh;
             const int voff = (wm * (32 * TM) + l31) * ldc4 + col0 * 4;
+            // Fused AdaLN, producer side (identity epilogues = rows of the residual stream; wave-uniform switch): (mean, M2) of every stored
+            // row over each 32-column block -- this lane holds 16 of the block's values, its partner (lane ^ 32) the other 16 -- for the
+            // GEMM that consumes the row next (NORM_).  One pass beside the stores: deviations from the lane's first value (pivot), then
+            // Chan's combination of the two lanes' halves.
+            const bool want_stats = ACT == MMDM_EPI_BIAS && p.stats_out != nullptr;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) {
+                    float piv = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         f32x4 v;
@@ -595,11 +752,29 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                             float t = acc[i][j][4 * qd + c];
                             if constexpr (LATE_R) t += rv[i][j][qd][c];
                             v[c] = act(t);
+                            if constexpr (ACT == MMDM_EPI_BIAS) {
+                                if (qd == 0 && c == 0) piv = t;
+                                const float dv = t - piv;
+                                s1 += dv; s2 = __builtin_fmaf(dv, dv, s2);
+                            }
                         }
                         // the row step is part of the VECTOR offset: only that (plus the immediate) takes part in the range check
                         if (FULLN || col0 + j * 32 + 8 * qd < p.N)
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4, 0, 0);
                     }
+                    if constexpr (ACT == MMDM_EPI_BIAS) {
+                        if (want_stats) {
+                            const float mean_l = piv + s1 * (1.0f / 16.0f), m2_l = fmaxf(s2 - s1 * s1 * (1.0f / 16.0f), 0.f);
+                            const float mean_o = __shfl_xor(mean_l, 32), m2_o = __shfl_xor(m2_l, 32), dm = mean_l - mean_o;
+                            const int row = m0 + wm * (32 * TM) + i * 32 + l31, blk = (n0 + wn * (32 * TN) + j * 32) >> 5, nblk = p.N >> 5;
+                            if (lh == 0 && row < p.M && blk < nblk) {
+                                float* d = p.stats_out + ((size_t)row * nblk + blk) * 2;
+                                d[0] = 0.5f * (mean_l + mean_o);
+                                d[1] = m2_l + m2_o + 8.0f * dm * dm;          // n0 n1 / (n0 + n1) = 16 * 16 / 32
+                            }
+                        }
+                    }
+                }
         } else {
             const int col0 = n0 + wn * (32 * TN) + l31;
             const int voff = (wm * (32 * TM) + 4 * lh) * ldc4 + col0 * 4;
@@ -629,7 +804,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
 }
 #endif
 
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0, bool DIAG_ = false>
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0, bool DIAG_ = false, bool NORM_ = false>
 __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void gemm_glds_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -640,7 +815,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void 
     unsigned long long* const stamps = DIAG_ ? p.stamps : nullptr;
     const unsigned long long t_entry = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     if (stamps && threadIdx.x == 0) stamps[8 * (size_t)bid + 5] = t_entry;
-    gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_, DIAG_>(p, smem, swz, bid);
+    gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_, DIAG_, NORM_>(p, smem, swz, bid);
     if (stamps) {
         if (threadIdx.x == 0) stamps[8 * (size_t)bid + 7] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -675,6 +850,18 @@ int launch_glds(GemmArgs a, hipStream_t st) {
     else
         hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_, false>), grid, block, C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_glds");
+}
+
+// The AdaLN-consuming GEMM (NORM_): 128 x 128 tiles, FOUR stages (64 KB) + the conditioning table of the tile's two sequences (16 KB at
+// K = 1024) = 80 KB: two workgroups per CU, like the five-stage kernel it replaces (four stages measured equal: LAB_NOTES.md).
+inline int norm_smem(int) { return GCfg<22, 22, 16, 4>::SMEM_BYTES + 4 * NORM_MAX_K * (int)sizeof(float); }
+int launch_norm(GemmArgs a, hipStream_t st) {
+    using C_ = GCfg<22, 22, 16, 4>;
+    a.mt = (a.M + C_::BM - 1) / C_::BM;
+    a.nt = (a.N + C_::BN - 1) / C_::BN;
+    mmdm_note_gemm("gemm_pipe_adaln<22,22,16,4,scalar>");
+    hipLaunchKernelGGL((gemm_glds_kernel<22, 22, 16, 4, false, 1, 1, false, true>), dim3(a.mt * a.nt), dim3(C_::THREADS), norm_smem(a.K), st, a);
+    return mmdm_check_launch("gemm_pipe_adaln");
 }
 
 template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2, int MINW_ = 1, int PIPE_ = 0>
@@ -737,6 +924,8 @@ inline bool vec_ok(const float* p, int ld, int K) {
 
 }  // namespace
 
+bool mmdm_gemm_fuse_ok(int K, int T) { return K >= 128 && K <= NORM_MAX_K && (K & 127) == 0 && T >= 128; }
+
 int g_gemm_cfg = -1;
 int g_gemm_tail = -1;       // row split of the fractional last round: t > 0: split when the fractional round holds <= t/10 of the resident slots; 0 off;
                             // -1 (default): what the caller's handle asked for through mmdm_gemm_set_tail (one-stream samplers: 10, two-stream: 0)
@@ -765,6 +954,11 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_glds<21, 21, 16, 4, 1, 1>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 2>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 3>())) return rc;
+    {
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<22, 22, 16, 4, false, 1, 1, false, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, norm_smem(NORM_MAX_K));
+        if (e2 != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_pipe_adaln): %s", hipGetErrorString(e2));
+    }
     const char* e = getenv("MMDM_GEMM_CFG");
     g_gemm_cfg = e ? atoi(e) : -1;
     if (const char* t = getenv("MMDM_GEMM_TAIL")) g_gemm_tail = atoi(t);       // forces the rule for every caller (tools)
@@ -786,6 +980,14 @@ extern "C" int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw,
 // handle stores zero-padded to 264 columns be fetched with 16-byte loads.
 int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
+    return mmdm_linear_f32_fused(A, lda, W, ldw, Kw, bias, C, ldc, M, N, K, epilogue, extra, ld_extra, period, nullptr, stream);
+}
+
+// `fuse` (kernels.h): stats_out -- the 16-byte-epilogue kernel also writes the rows' partial LayerNorm statistics; norm_stats / norm_ss --
+// A is the un-normalised residual stream and AdaLN is applied to its fragments inside the GEMM.  Both need the shapes the pipelined
+// kernel covers; a request it cannot honour is an error (the caller decides up front: mmdm_gemm_fuse_ok).
+int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
+                          int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, const mmdm_gemm_fuse* fuse, void* stream) {
     mmdm_note_gemm_reset();
     if (M == 0 || N == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
@@ -804,9 +1006,24 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     a.mt = a.nt = 0;
     a.ablate = g_gemm_ablate;
     a.stamps = g_gemm_stamps;
+    a.stats_out = fuse ? fuse->stats_out : nullptr;
+    a.nstats = fuse ? fuse->norm_stats : nullptr; a.nss = fuse ? fuse->norm_ss : nullptr;
+    a.nss_ld = fuse ? fuse->ss_ld : 0; a.nss_rows = fuse ? fuse->ss_rows : 1; a.nT = fuse ? fuse->T : 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool av = vec_ok(A, lda, K), wv = vec_ok(W, ldw, Kw);
     const bool glds_ok = av && wv && (K % 16 == 0) && Kw == K;
+    if (a.stats_out) {              // producer: needs the pipelined kernel's 16-byte epilogue and whole 32-column blocks
+        const bool ext = epilogue == MMDM_EPI_BIAS_RESID || epilogue == MMDM_EPI_BIAS_PE;
+        if (!(glds_ok && K >= 96 && ext && vepi_ok(a) && (N & 31) == 0 && g_gemm_cfg == -1))
+            return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: row statistics need the pipelined residual / PE GEMM (K >= 96, K %% 16, N %% 32, 16-byte aligned rows)");
+    }
+    if (a.nstats) {                 // consumer
+        if (!(glds_ok && mmdm_gemm_fuse_ok(K, a.nT) && a.nss && a.nss_rows > 0 && a.nss_ld >= 2 * K && (a.nss_ld & 3) == 0 &&
+              (reinterpret_cast<uintptr_t>(a.nss) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.nstats) & 15) == 0 &&
+              (epilogue == MMDM_EPI_BIAS || epilogue == MMDM_EPI_BIAS_GELU) && !a.stats_out))
+            return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: fused AdaLN needs K %% 128 == 0, 128 <= K <= %d, T >= 128, a bias / GELU epilogue and 16-byte aligned tables (K=%d T=%d)", NORM_MAX_K, K, a.nT);
+        return launch_norm(a, st);
+    }
     // production choice: LDS-DMA kernel, 128x128 tile / 4 waves (5 workgroups per CU) whenever the operands allow it
     const int tail = g_gemm_tail >= 0 ? g_gemm_tail : t_gemm_tail;
     switch (g_gemm_cfg) {
@@ -833,6 +1050,7 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
                     b.A = A + (size_t)M1 * lda;
                     b.C = C + (size_t)M1 * ldc;
                     if (extra) b.extra = extra + (size_t)M1 * ld_extra;
+                    if (a.stats_out) b.stats_out = a.stats_out + (size_t)M1 * (N >> 5) * 2;
                     int rc = narrow ? launch_glds<22, 21, 16, 4, 1, 1>(a, st) : launch_glds<22, 22, 16, 5, 1, 1>(a, st);
                     if (rc) return rc;
                     // remainder: the largest tile that still gives every CU a workgroup
@@ -879,4 +1097,20 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
         case 4: return launch_cfg<42, 22, 16>(a, av, wv, st);
         default: return launch_cfg<22, 22, 16>(a, av, wv, st);
     }
+}
+
+extern "C" int mmdm_linear_f32_stats(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+                                     int epilogue, const float* extra, int ld_extra, int period, float* stats, void* stream) {
+    if (!stats) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32_stats: null stats");
+    mmdm_gemm_fuse f;
+    f.stats_out = stats;
+    return mmdm_linear_f32_fused(A, lda, W, ldw, K, bias, C, ldc, M, N, K, epilogue, extra, ld_extra, period, &f, stream);
+}
+
+extern "C" int mmdm_linear_adaln_f32(const float* H, int ldh, const float* stats, const float* ss, int ss_ld, int ss_rows, int T,
+                                     const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K, int epilogue, void* stream) {
+    if (!stats || !ss || T <= 0 || ss_rows <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_adaln_f32: bad arguments");
+    mmdm_gemm_fuse f;
+    f.norm_stats = stats; f.norm_ss = ss; f.ss_ld = ss_ld; f.ss_rows = ss_rows; f.T = T;
+    return mmdm_linear_f32_fused(H, ldh, W, ldw, K, bias, C, ldc, M, N, K, epilogue, nullptr, 0, 0, &f, stream);
 }

@@ -79,6 +79,19 @@ int mmdm_blend_cfg_dyn(const float* out1, const float* out2, const float* w, int
                        float* model_out, const mmdm_hist_desc* hd, const int* loop_pos, int B, int T, hipStream_t st);
 int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
+// AdaLN fused around the fp32 GEMM (gemm_f32.hip).  A residual / PE GEMM that produces rows of the residual stream also writes their
+// partial LayerNorm statistics (stats_out [M][N/32][2]: mean and sum of squared deviations per 32-column block); the GEMM that consumes
+// AdaLN(h) takes h itself plus those statistics (norm_stats, over its K) and the conditioning rows (norm_ss: scale | shift of row
+// (m / T) % ss_rows, row stride ss_ld) and modulates its A fragments in registers -- no stand-alone AdaLN pass, no normalised copy.
+struct mmdm_gemm_fuse {
+    float* stats_out = nullptr;
+    const float* norm_stats = nullptr;
+    const float* norm_ss = nullptr;
+    int ss_ld = 0, ss_rows = 1, T = 1;
+};
+bool mmdm_gemm_fuse_ok(int K, int T);      // shapes the fused consumer covers: K % 128 == 0, 128 <= K <= 1024, T >= 128
+int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
+                          int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, const mmdm_gemm_fuse* fuse, void* stream);
 int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
                   int nseq, int T, int D, hipStream_t st);
 int mmdm_mdm_unpack(const float* src, float* dst, int nseq, int T, int D, hipStream_t st);

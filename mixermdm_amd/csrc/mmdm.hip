@@ -129,6 +129,7 @@ struct Scratch {          // transformer-stack work buffers (one set per concurr
     float *xp = nullptr;      // [2][rows][NFP] repacked pose operands of the embedding GEMMs
     void *qk = nullptr, *kvp = nullptr;   // precision >= 1: bf16 plane copies of the attention's Q|K ([planes][R][2D]) and cross-attention K ([planes][R][D])
     float* xs = nullptr;                  // precision == 3: per-row scales of the fp8 AdaLN output in xn
+    float* hstat = nullptr;               // precision == 0: partial LayerNorm statistics of the rows of h, [R][D/32][2] (fused AdaLN, gemm_f32.hip)
 };
 
 struct Prof {
@@ -414,9 +415,9 @@ int prof_end(const Ctx& c, int cls) {
 }
 
 int linear(const Ctx& c, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
-           int epi = MMDM_EPI_BIAS, const float* extra = nullptr, int ld_extra = 0, int period = 0, int Kw = 0) {
+           int epi = MMDM_EPI_BIAS, const float* extra = nullptr, int ld_extra = 0, int period = 0, int Kw = 0, const mmdm_gemm_fuse* fuse = nullptr) {
     RC(prof_begin(c, 0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1))));
-    RC(mmdm_linear_f32_ex(A, lda, W, ldw, Kw ? Kw : K, bias, C, ldc, M, N, K, epi, extra, ld_extra, period, c.st));
+    RC(mmdm_linear_f32_fused(A, lda, W, ldw, Kw ? Kw : K, bias, C, ldc, M, N, K, epi, extra, ld_extra, period, fuse, c.st));
     return prof_end(c, 0);
 }
 
@@ -440,6 +441,8 @@ struct StackRun {
     int ca_mode;            // 0 none; 1 keys/values = the other half of the layer INPUT (in2in.py:439-440); 2 = fixed `kv_src`
     const float* kv_src;
     int l0 = 0;             // first block to run (the "dual_individual" quirk runs only the last block on person b)
+    float* hstat = nullptr; // fp32, AdaLN fused into the GEMMs: partial LayerNorm statistics [rows of hbuf][D/32][2], written by the GEMM that
+                            // produced hbuf and rewritten by every residual GEMM of the stack (nullptr = stand-alone AdaLN passes)
 };
 
 // h [nseq*T, D] is updated in place through the L blocks (TransformerBlockDoubleCond / TransformerBlock / InfluenceBlockCross).
@@ -501,11 +504,28 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     auto bw = [](const void* base, size_t elems) { return static_cast<const void*>(static_cast<const uint16_t*>(base) + elems); };
     // one GEMM of the stack: fp32 (A fp32, W fp32), bf16 (A bf16 from the producer, W twin) or fp32-split (three planes each).
     // wtot = elements of the whole weight matrix the twin was made from (its plane stride); the A plane stride is R*K.
+    // fused AdaLN (fp32, StackRun::hstat): norm() only remembers its arguments and the GEMM that would have read S.xn applies it to its A
+    // fragments
+    const float *pend_src = nullptr, *pend_ss = nullptr;
+    int pend_rows = 0;
+    float* const hst = r.hstat;
+    const bool fused = hst != nullptr;
     auto gemm = [&](const float* A, int lda, const float* Wf, const void* Wb, size_t woff, size_t wtot, const float* bias, float* C, int ldc, int out_b,
                     int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) -> int {
         if (prec == 2) return linear_s(c, A, lda, (size_t)R * K, bw(Wb, woff), w.w_packed ? 0 : K, wtot, bias, C, ldc, (size_t)R * N, out_b == 2, R, N, K, epi, extra, ld_extra, s2);
 
         if (bf) return linear_b(c, A, lda, bw(Wb, woff), w.w_packed ? 0 : K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra, s2);
+        if (fused) {
+            mmdm_gemm_fuse f;
+            if (A == S.xn) {              // the operand would have been AdaLN(pend_src): take the residual stream itself + its statistics
+                f.norm_stats = hst; f.norm_ss = pend_ss; f.ss_ld = r.ss_ld; f.ss_rows = pend_rows; f.T = r.T;
+                return linear(c, pend_src, D, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra, 0, 0, &f);
+            }
+            if (C == hbuf && epi == MMDM_EPI_BIAS_RESID) {      // a new version of the residual stream: leave its rows' statistics behind
+                f.stats_out = hst;
+                return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra, 0, 0, &f);
+            }
+        }
         return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra);
     };
     // bf16 path with a head size the plane kernel covers: the projection GEMMs also emit a bf16 copy of Q and K and the scores come from
@@ -524,6 +544,11 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     };
     // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / three planes, or fp8 + per-row scales
     auto norm = [&](const float* src, const float* ssp, int rows) -> int {
+        if (fused) {
+            if (src != hbuf) return mmdm_set_error(MMDM_ERR_STATE, "run_stack: fused AdaLN has statistics for the residual stream only");
+            pend_src = src; pend_ss = ssp; pend_rows = rows;
+            return MMDM_OK;
+        }
         if (f8) return mmdm_adaln_any(src, ssp, r.ss_ld, rows, S.xn, 3, S.xs, r.nseq, r.T, D, c.st);
         return mmdm_adaln_ex(src, ssp, r.ss_ld, rows, S.xn, ob, r.nseq, r.T, D, c.st);
     };
@@ -596,8 +621,22 @@ int cond_vectors(const Ctx& c, const ModuleW& m, const float* txt, float* se, fl
 
 // motion_embed + positional encoding of one person slice (in2in.py:426-431): x [nb*T rows, ld 524 or 262] -> h rows
 // xpad: one person's repacked rows [nb*T, NFP] (mmdm_repack_pose); pe_row0 = 1 for MDMDenoiser (token 0 is the conditioning token)
-int embed(const Ctx& c, const ModuleW& m, const float* xpad, float* hdst, int nb, int T, int pe_row0 = 0) {
-    return linear(c, xpad, NFP, m.me_w, NFP, m.me_b, hdst, m.st.D, nb * T, m.st.D, NFP, MMDM_EPI_BIAS_PE, m.pe + (size_t)pe_row0 * m.st.D, m.st.D, T, NFP);
+int embed(const Ctx& c, const ModuleW& m, const float* xpad, float* hdst, int nb, int T, int pe_row0 = 0, float* stats = nullptr) {
+    mmdm_gemm_fuse f;
+    f.stats_out = stats;
+    return linear(c, xpad, NFP, m.me_w, NFP, m.me_b, hdst, m.st.D, nb * T, m.st.D, NFP, MMDM_EPI_BIAS_PE, m.pe + (size_t)pe_row0 * m.st.D, m.st.D, T, NFP, stats ? &f : nullptr);
+}
+
+// fp32 handles: AdaLN applied inside the denoisers' GEMMs instead of as a pass of its own -- OFF unless MMDM_FUSE_ADALN=1 (or the tools'
+// mmdmx_set_fuse_adaln): measured slower (61.2 vs 59.4 ms/step; LAB_NOTES.md, "AdaLN in the GEMM").  The fused consumer is one kernel
+// shape (128 x 128 tiles, no row split of the last round), so the one-stream samplers would keep the stand-alone pass in any case.
+static int g_fuse_adaln = -1;
+extern "C" void mmdmx_set_fuse_adaln(int on) { g_fuse_adaln = on; }
+bool fuse_adaln(mmdm_handle h, const StackW& w, int T) {
+    static const bool env_on = getenv("MMDM_FUSE_ADALN") != nullptr && atoi(getenv("MMDM_FUSE_ADALN")) != 0;
+    const bool off = g_fuse_adaln >= 0 ? g_fuse_adaln == 0 : !env_on;
+    return !off && h->cfg.precision == 0 && (h->cfg.single_only == 0 || h->cfg.single_only == 3) && w.D >= 1024 && (w.D & 31) == 0 &&
+           mmdm_gemm_fuse_ok(w.D, T) && h->sa.hstat != nullptr;
 }
 
 // denoiser1 on the CFG-doubled batch n; xa [B or n rows...]: source rows are taken from `x` with `xrows` samples, repeated to n.
@@ -607,11 +646,15 @@ int run_denoiser(const Ctx& c, const ModuleW& m, bool interaction, const float* 
     mmdm_handle H = c.h;
     const int D = m.st.D;
     // embed: `x` holds xb samples (xb == n, or xb == n/2 when cond/uncond halves share the same x: cfg_sampler.py:41-42)
+    const bool fused = fuse_adaln(H, m.st, T);
     RC(mmdm_repack_pose(x, ldx, c.s->xp, npers, xb * T, NFP, c.st));
     for (int p = 0; p < npers; ++p)
-        for (int rep = 0; rep < n / xb; ++rep)
-            RC(embed(c, m, c.s->xp + (size_t)p * xb * T * NFP, c.s->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
+        for (int rep = 0; rep < n / xb; ++rep) {
+            const size_t row0 = ((size_t)p * n + (size_t)rep * xb) * T;
+            RC(embed(c, m, c.s->xp + (size_t)p * xb * T * NFP, c.s->h + row0 * D, xb, T, 0, fused ? c.s->hstat + row0 * (D / 32) * 2 : nullptr));
+        }
     StackRun r;
+    r.hstat = fused ? c.s->hstat : nullptr;
     r.nseq = npers * n; r.T = T; r.ss = ss; r.ss_ld = ss_ld;
     r.sa_row0 = 0; r.sa_rows = npers * n;
     r.ffn_row0 = 0; r.ffn_rows = npers * n;
@@ -931,6 +974,7 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
             (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f * opx / 2)) ||
             (rc = dalloc(h, &sc->xp, (size_t)2 * n * T * NFP)))
             return fail(rc);
+        if (c.precision == 0 && (rc = dalloc(h, &sc->hstat, R * (d / 32 + 1) * 2))) return fail(rc);
         if (c.precision >= 1) {
             const size_t npl = c.precision == 2 ? 3 : 1;
             float *q1 = nullptr, *q2 = nullptr;

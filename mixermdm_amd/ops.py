@@ -46,6 +46,33 @@ def linear(x, weight, bias=None, epilogue="bias", extra=None, period=0, out=None
     return out.reshape(*x.shape[:-1], N) if x.is_contiguous() else out
 
 
+def linear_stats(x, weight, bias=None, epilogue="resid", extra=None, period=0, out=None):
+    """linear() with a residual / PE epilogue that also returns the partial LayerNorm statistics of the rows it wrote:
+    (y [M, N], stats [M, N/32, 2]) -- the producer half of the fused AdaLN (mmdm_linear_f32_stats)."""
+    _chk(x, weight, bias, extra)
+    K, N = x.shape[-1], weight.shape[0]
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    stats = torch.empty(M, N // 32, 2, device=x.device, dtype=torch.float32)
+    check(load_library().mmdm_linear_f32_stats(_p(x2), x2.stride(0), _p(weight), weight.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                               EPI[epilogue], _p(extra), extra.stride(0) if extra is not None else 0, period, _p(stats), _stream()))
+    return out, stats
+
+
+def linear_adaln(h, stats, ss, T, weight, bias=None, epilogue="bias", ss_rows=None):
+    """epilogue(AdaLN(h) @ weight.T + bias) with the normalisation applied inside the GEMM: h [M, K] un-normalised, stats from
+    linear_stats, ss [rows, 2K] (scale | shift), row m uses ss[(m // T) % ss_rows] (mmdm_linear_adaln_f32)."""
+    _chk(h, stats, ss, weight, bias)
+    M, K = h.shape
+    N = weight.shape[0]
+    out = torch.empty(M, N, device=h.device, dtype=torch.float32)
+    check(load_library().mmdm_linear_adaln_f32(_p(h), h.stride(0), _p(stats), _p(ss), ss.stride(0), ss_rows or ss.shape[0], T, _p(weight), weight.stride(0),
+                                               _p(bias), _p(out), out.stride(0), M, N, K, EPI[epilogue], _stream()))
+    return out
+
+
 def adaln(h, ss, ss_rows=None):
     """h [nseq, T, D]; ss [rows, 2D] (scale | shift); row(s) = s % ss_rows."""
     _chk(h, ss)

@@ -527,3 +527,53 @@ def test_linear_split_packed_is_bitwise_the_plane_kernel(M, N, K):
         assert torch.equal(out, ops.linear_split(xs, ws, b.to(d))[:, n0:])
     with pytest.raises(Exception):
         ops.linear_split(ops.split3(x[:, :48].contiguous().to(d)), ops.split_pack_weight(ops.split3(w[:, :48].contiguous().to(d))), packed=True)   # K % 64
+
+
+# ---- AdaLN fused around the fp32 GEMM (producer statistics + consumer prologue) -------------------------------------------------------
+@pytest.mark.parametrize("nseq,T,K,N,epi", [(2, 300, 1024, 3072, "bias"), (5, 150, 1024, 1024, "gelu"), (3, 128, 512, 1536, "bias"), (1, 700, 256, 128, "gelu"),
+                                            (7, 131, 128, 2048, "bias")])
+def test_linear_with_fused_adaln_matches_adaln_then_linear(nseq, T, K, N, epi):
+    """h = resid + x W0^T (producer: writes h and the partial row statistics), then epilogue(AdaLN(h) W1^T + b) inside the consumer GEMM --
+    against the stand-alone AdaLN pass followed by the plain GEMM, and against float64.  Tiles that straddle a sequence boundary (T not a
+    multiple of 128), ragged M, rows of h with a large common offset (variance by Chan's combination, not E[x^2] - E[x]^2)."""
+    from mixermdm_amd import ops
+    M = nseq * T
+    x, w0, b0 = rnd(1, M, 256), rnd(2, K, 256, scale=1 / 16), rnd(3, K)
+    resid = rnd(4, M, K) * 2 + 30.0                        # mean >> std: the statistics must not cancel
+    w1, b1 = rnd(5, N, K, scale=1 / math.sqrt(K)), rnd(6, N)
+    ss = rnd(7, 3, 2 * K) * 0.5
+    d = dev()
+    h, stats = ops.linear_stats(x.to(d), w0.to(d), b0.to(d), "resid", resid.to(d))
+    assert torch.equal(h, ops.linear(x.to(d), w0.to(d), b0.to(d), "resid", resid.to(d)))          # the statistics are a side output
+    hb = h.cpu().double().view(M, K // 32, 32)
+    assert_close(stats[..., 0], hb.mean(-1).float(), atol=1e-5, rtol=1e-6, what="block means")
+    assert_close(stats[..., 1], ((hb - hb.mean(-1, keepdim=True)) ** 2).sum(-1).float(), atol=1e-3, rtol=1e-4, what="block M2")
+    got = ops.linear_adaln(h, stats, ss.to(d), T, w1.to(d), b1.to(d), epi, ss_rows=3)
+    assert load_library_kernel().startswith("gemm_pipe_adaln<")
+    xn = ops.adaln(h.view(nseq, T, K), ss.to(d), 3).view(M, K)
+    want = ops.linear(xn, w1.to(d), b1.to(d), epi)
+    assert_close(got, want, atol=3e-5, rtol=1e-5, what="fused vs AdaLN pass + GEMM")
+    # float64: LN(eps 1e-6, biased variance) * (1 + scale) + shift with row m -> ss[(m // T) % 3]
+    h64 = h.cpu().double()
+    sel = (torch.arange(M) // T) % 3
+    ln = (h64 - h64.mean(-1, keepdim=True)) / torch.sqrt(h64.var(-1, unbiased=False, keepdim=True) + 1e-6)
+    y = F.linear(ln * (1 + ss.double()[sel, :K]) + ss.double()[sel, K:], w1.double(), b1.double())
+    if epi == "gelu":
+        y = F.gelu(y)
+    assert_close(got, y.float(), atol=5e-5, rtol=2e-5, what="fused vs float64")
+
+
+def load_library_kernel():
+    from mixermdm_amd._lib import load_library
+    return load_library().mmdm_last_gemm_kernel().decode()
+
+
+def test_fused_adaln_rejects_what_it_does_not_cover():
+    from mixermdm_amd import ops, MMDMError
+    d = dev()
+    h, w = torch.zeros(256, 1024, device=d), torch.zeros(64, 1024, device=d)
+    st, ss = torch.zeros(256, 32, 2, device=d), torch.zeros(1, 2048, device=d)
+    with pytest.raises(MMDMError, match="T >= 128"):
+        ops.linear_adaln(h, st, ss, 64, w)                      # a tile would span more than two sequences
+    with pytest.raises(MMDMError, match="statistics need"):
+        ops.linear_stats(torch.zeros(8, 64, device=d), torch.zeros(40, 64, device=d), None, "resid", torch.zeros(8, 40, device=d))
