@@ -21,6 +21,8 @@
  *   MMDM_NO_PACK=1       mmdm_prepare: keep the low-precision weight twins of precision 1-3 in row-major planes instead of MFMA
  *                        fragment order (the packed and the plane kernels are bit-identical; tests/test_gpu_packed_modes.py compares them).
  *   MMDM_QKP / MMDM_NO_QKP / MMDM_NO_BF16_PV   precision >= 1: force / forbid the bf16-plane Q K^T and the bf16 P V forms of the attention.
+ *   MMDM_LN_PRODUCER=1   precision 0: let the residual GEMM that produces rows of the residual stream also write their AdaLN for the next block
+ *                        (mmdm_linear_f32_ln's kernel) instead of a pass of its own.  Off by default: measured slower (LAB_NOTES.md).
  *   MMDM_FUSE_ADALN=1    precision 0, two-chain samplers: apply AdaLN inside the GEMM that consumes it (mmdm_linear_adaln_f32's kernel) instead
  *                        of as a pass of its own.  Off by default: measured slower (LAB_NOTES.md, "AdaLN in the GEMM"); results agree to fp32 rounding.
  *   MMDM_GEMM_CFG, MMDM_GEMM_TAIL, MMDM_SPLIT_CFG, MMDM_BF16_CFG   tile-selection overrides of the GEMM dispatch, for tools/ (benchmarks).
@@ -139,6 +141,16 @@ int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss_rows, floa
  *   un-normalised input, stats [M][K/32][2] what mmdm_linear_f32_stats wrote for it, ss / ss_ld / ss_rows / T as in mmdm_adaln_f32 (row m
  *   takes (scale | shift) row (m / T) % ss_rows).  LN eps 1e-6, biased variance, no affine.  Needs K % 128 == 0, 128 <= K <= 1024 and
  *   T >= 128 (a 128-row tile then touches at most two sequences). */
+/* mmdm_linear_f32_ln: mmdm_linear_f32 with a residual / positional epilogue that ALSO writes ln_out [M][ldc] = AdaLN of the rows it just
+ *   produced (ss / ss_ld / ss_rows / T as in mmdm_adaln_f32) -- what the next block's first GEMM reads -- so that the stand-alone pass
+ *   (one more read and write of the residual stream) disappears.  A row's statistics span all column tiles: each tile leaves its rows'
+ *   (mean, M2) in `work`, counts itself and waits for the other tiles of its row block (consecutive workgroups of one XCD), then
+ *   normalises from registers.  work: mmdm_linear_f32_ln_work_bytes(M, N) bytes, zeroed once by the caller; one launch per work buffer
+ *   in flight at a time.  Needs N a multiple of the tile width (128; 64 if N <= 512 or K <= 512), K % 16 == 0, K >= 96, 16-byte aligned rows. */
+size_t mmdm_linear_f32_ln_work_bytes(int M, int N);
+int mmdm_linear_f32_ln(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+                       int epilogue, const float* extra, int ld_extra, int period, const float* ss, int ss_ld, int ss_rows, int T,
+                       float* ln_out, void* work, void* stream);
 int mmdm_linear_f32_stats(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
                           int epilogue, const float* extra, int ld_extra, int period, float* stats, void* stream);
 int mmdm_linear_adaln_f32(const float* H, int ldh, const float* stats, const float* ss, int ss_ld, int ss_rows, int T,

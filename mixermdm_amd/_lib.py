@@ -37,6 +37,8 @@ SYMBOLS = {
     "mmdm_version": (C.c_char_p, []),
     "mmdm_linear_f32": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
     "mmdm_linear_f32_stats": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP, _VP]),
+    "mmdm_linear_f32_ln_work_bytes": (C.c_size_t, [_I, _I]),
+    "mmdm_linear_f32_ln": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "mmdm_linear_adaln_f32": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "mmdm_linear_bf16": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
     "mmdm_f32_to_bf16": (_I, [_VP, _VP, C.c_int64, _VP]),

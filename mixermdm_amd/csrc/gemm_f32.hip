@@ -35,6 +35,12 @@ struct GemmArgs {
     float* stats_out;
     const float* nstats; const float* nss;
     int nss_ld, nss_rows, nT;
+    // AdaLN of the NEXT block written by the GEMM that produces the residual stream (LNP_ instantiation, N == nt * BN): besides C = the new
+    // rows of h, ln_out = ((h - mean) rstd) (1 + scale) + shift with (scale | shift) = nss + ((row / nT) % nss_rows) * nss_ld.  A row's
+    // statistics need all nt column tiles: every tile leaves (mean, M2) of its BN columns per row in ln_part [mt][nt][BM][2], counts itself
+    // in ln_cnt[m tile] (monotonic across launches) and waits until the row block's nt tiles have arrived (they are consecutive workgroups
+    // of one XCD, see the kernel's tile map), then combines the nt partials.  ln_err: set if the bounded wait expires (never observed).
+    float* ln_out; float* ln_part; unsigned* ln_cnt; int* ln_err;
     int ablate;                          // timing experiments only (tools/gemm_bench.py); 0 in production
     unsigned long long* stamps;          // diagnostic builds of a launch only (tools/gemm_timeline.py): per-workgroup {start, loop start, loop end, placement, kernel end, kernel entry, residual landed, stores issued}, then {s_memtime at loop start, loop end} per workgroup
                                          // in 100 MHz s_memrealtime ticks; nullptr in production (one never-taken scalar branch per workgroup)
@@ -263,9 +269,10 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // DIAG_: the timing ablations (GemmArgs::ablate) and in-kernel stamps (GemmArgs::stamps) exist in a second instantiation only, launched
 // when a tool has set one of them (tools/gemm_bench.py ABL=, tools/gemm_timeline.py, bench.py's loop clock); the production instantiation
 // sees compile-time zeros -- no diagnostic branch, load or register in the shipped kernels.
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_, bool DIAG_, bool NORM_ = false>
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_, bool DIAG_, bool NORM_ = false, bool LNP_ = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int swz, int bid) {
     static_assert(!NORM_ || (PIPE_ == 1 && !VEPI), "the AdaLN prologue exists in the pipelined kernel with the scalar epilogue (bias / GELU consumers)");
+    static_assert(!LNP_ || (PIPE_ == 1 && VEPI && !NORM_), "the AdaLN-producing epilogue exists in the pipelined kernel with the 16-byte epilogue (residual / PE producers)");
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
     const GemmArgs& p = pp;
     unsigned long long* const p_stamps = DIAG_ ? pp.stamps : nullptr;
@@ -739,6 +746,120 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
             // GEMM that consumes the row next (NORM_).  One pass beside the stores: deviations from the lane's first value (pivot), then
             // Chan's combination of the two lanes' halves.
             const bool want_stats = ACT == MMDM_EPI_BIAS && p.stats_out != nullptr;
+            if constexpr (LNP_ && ACT == MMDM_EPI_BIAS) {
+                // ---- the residual stream's new rows AND their AdaLN for the next block (GemmArgs::ln_out) ----
+                // Order: (A) row partials of this tile -> memory, arrive at the row block's counter; (B) the stores of h, which cover the
+                // rendezvous' round trips; (C) wait for the block's other tiles; (D) one thread per row combines the nt partials;
+                // (E) normalise + modulate from the registers, store.  Every global round trip is taken once per tile, never per element.
+                constexpr int NL = 16 * TN;                          // values of a row this lane holds; its partner lane (lane ^ 32) holds the other NL
+                typedef unsigned long long u64;
+                float* const xs = smem;                              // [WGN][BM][2], then [BM][2] (rstd, -mean rstd): the operand ring is idle
+                __builtin_amdgcn_s_barrier();                        // ... once every wave has left the K loop
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float piv = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            float t = acc[i][j][e];
+                            if constexpr (LATE_R) t += rv[i][j][e >> 2][e & 3];
+                            acc[i][j][e] = t;
+                            if (j == 0 && e == 0) piv = t;
+                            const float dv = t - piv;
+                            s1 += dv; s2 = __builtin_fmaf(dv, dv, s2);
+                        }
+                    const float mean_l = piv + s1 * (1.0f / NL), m2_l = fmaxf(s2 - s1 * s1 * (1.0f / NL), 0.f);
+                    const float mean_o = __shfl_xor(mean_l, 32), m2_o = __shfl_xor(m2_l, 32), dm = mean_l - mean_o;
+                    if (lh == 0) {
+                        const int rr = wm * (32 * TM) + i * 32 + l31;
+                        xs[(wn * BM + rr) * 2] = 0.5f * (mean_l + mean_o);
+                        xs[(wn * BM + rr) * 2 + 1] = m2_l + m2_o + (0.5f * NL) * dm * dm;     // n0 n1 / (n0 + n1), n0 = n1 = NL
+                    }
+                }
+                __syncthreads();
+                const int mtile = m0 / BM, ntile = n0 / BN, nt = p.nt;
+                if (tid < BM) {
+                    float mean = xs[tid * 2], m2 = xs[tid * 2 + 1];
+                    if constexpr (C_::WGN == 2) {
+                        const float mb = xs[(BM + tid) * 2], m2b = xs[(BM + tid) * 2 + 1], dm = mean - mb;
+                        m2 = m2 + m2b + (0.5f * 32 * TN) * dm * dm;
+                        mean = 0.5f * (mean + mb);
+                    }
+                    const u64 both = (u64)__builtin_bit_cast(unsigned, mean) | ((u64)__builtin_bit_cast(unsigned, m2) << 32);
+                    __hip_atomic_store(reinterpret_cast<u64*>(p.ln_part) + (size_t)(mtile * nt + ntile) * BM + tid, both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partials have reached memory (agent scope) ...
+                __syncthreads();
+                unsigned target = 0;
+                if (tid == 0)                                        // ... before this tile counts itself
+                    target = (__hip_atomic_fetch_add(p.ln_cnt + mtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned)nt + 1u) * (unsigned)nt;
+                // (B) h
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int qd = 0; qd < 4; ++qd) {
+                            const f32x4 v = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4, 0, 0);
+                        }
+                // (C)
+                if (tid == 0) {
+                    int it = 0;
+                    while ((int)(__hip_atomic_load(p.ln_cnt + mtile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++it > (1 << 23)) { *p.ln_err = 1; break; }          // ~1 s: bounded, so that a protocol error cannot hang the device
+                    }
+                }
+                __syncthreads();
+                // (D) equal counts BN per partial: mean = average of the means, M2 = sum M2 + BN sum (mean_t - mean)^2 (pivoted)
+                if (tid < BM) {
+                    const u64* pr = reinterpret_cast<const u64*>(p.ln_part) + (size_t)mtile * nt * BM + tid;
+                    const float piv = __builtin_bit_cast(float, (unsigned)__hip_atomic_load(pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    float sm = 0.f, sq = 0.f, m2 = 0.f;
+                    for (int t0 = 0; t0 < nt; t0 += 8) {             // eight loads in flight per round trip (the register budget is the K loop's)
+                        u64 raw[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) raw[t] = __hip_atomic_load(pr + (size_t)min(t0 + t, nt - 1) * BM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const float wgt = t0 + t < nt ? 1.0f : 0.0f;
+                            const float dv = __builtin_bit_cast(float, (unsigned)raw[t]) - piv;
+                            sm += wgt * dv; sq += wgt * dv * dv; m2 += wgt * __builtin_bit_cast(float, (unsigned)(raw[t] >> 32));
+                        }
+                    }
+                    const float inv_nt = 1.0f / (float)nt;
+                    const float mean = piv + sm * inv_nt;
+                    const float var = (m2 + (float)BN * fmaxf(sq - sm * sm * inv_nt, 0.f)) / (float)p.N;
+                    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+                    xs[tid * 2] = rstd; xs[tid * 2 + 1] = -mean * rstd;
+                }
+                __syncthreads();
+                // (E)
+                const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(p.ln_out + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int rr = wm * (32 * TM) + i * 32 + l31;
+                    const float rstd = xs[rr * 2], nb = xs[rr * 2 + 1];
+                    const int row = min(m0 + rr, p.M - 1);
+                    const float* ssr = p.nss + (size_t)((row / p.nT) % p.nss_rows) * p.nss_ld + col0;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int qd = 0; qd < 4; ++qd) {
+                            const f32x4 sc = *reinterpret_cast<const f32x4*>(ssr + j * 32 + 8 * qd);
+                            const f32x4 sh = *reinterpret_cast<const f32x4*>(ssr + p.N + j * 32 + 8 * qd);
+                            f32x4 v;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                v[c] = __builtin_fmaf(__builtin_fmaf(acc[i][j][4 * qd + c], rstd, nb), 1.0f + sc[c], sh[c]);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsX, voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4, 0, 0);
+                            if (qd == 3) __builtin_amdgcn_sched_barrier(0);       // at most eight table loads in flight: the kernel's register budget is the K loop's
+                        }
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -804,18 +925,27 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
 }
 #endif
 
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0, bool DIAG_ = false, bool NORM_ = false>
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0, bool DIAG_ = false, bool NORM_ = false, bool LNP_ = false>
 __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void gemm_glds_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nwg = p.mt * p.nt;
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    if constexpr (LNP_) {
+        // WHOLE row blocks per XCD (the grid is 8 x the largest share; surplus workgroups leave): the nt tiles of a row block are consecutive
+        // workgroups of one XCD's in-order dispatch, so a tile that waits for its row block waits for workgroups that are already resident
+        // or next in line -- never for the end of another XCD's list.
+        const int qm = p.mt >> 3, rm = p.mt & 7;
+        const int rows_x = qm + (xcd < rm ? 1 : 0), row0_x = xcd * qm + min(xcd, rm), j = bid >> 3;
+        if (j >= rows_x * p.nt) return;
+        swz = row0_x * p.nt + j;
+    }
     unsigned long long* const stamps = DIAG_ ? p.stamps : nullptr;
     const unsigned long long t_entry = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     if (stamps && threadIdx.x == 0) stamps[8 * (size_t)bid + 5] = t_entry;
-    gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_, DIAG_, NORM_>(p, smem, swz, bid);
+    gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_, DIAG_, NORM_, LNP_>(p, smem, swz, bid);
     if (stamps) {
         if (threadIdx.x == 0) stamps[8 * (size_t)bid + 7] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -862,6 +992,27 @@ int launch_norm(GemmArgs a, hipStream_t st) {
     mmdm_note_gemm("gemm_pipe_adaln<22,22,16,4,scalar>");
     hipLaunchKernelGGL((gemm_glds_kernel<22, 22, 16, 4, false, 1, 1, false, true>), dim3(a.mt * a.nt), dim3(C_::THREADS), norm_smem(a.K), st, a);
     return mmdm_check_launch("gemm_pipe_adaln");
+}
+
+// The AdaLN-producing GEMM (LNP_): the production residual kernels with the row-block rendezvous in the epilogue; grid = 8 x the largest
+// per-XCD share of whole row blocks.
+constexpr int LN_HDR_BYTES = 64 * 1024;          // ln_work: [counters: one unsigned per row block | error flag at the end of the header][partials]
+template <int TM_, int TN_, int NBUF_>
+int launch_lnp(GemmArgs a, hipStream_t st) {
+    using C_ = GCfg<TM_, TN_, 16, NBUF_>;
+    a.mt = (a.M + C_::BM - 1) / C_::BM;
+    a.nt = a.N / C_::BN;
+    const int share = ((a.mt + 7) / 8) * a.nt;
+    mmdm_note_gemm("gemm_pipe_ln<%d,%d,16,%d,vepi>", TM_, TN_, NBUF_);
+    hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, 16, NBUF_, true, 2, 1, false, false, true>), dim3(8 * share), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
+    return mmdm_check_launch("gemm_pipe_ln");
+}
+template <int TM_, int TN_, int NBUF_>
+int set_attr_lnp() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, 16, NBUF_, true, 2, 1, false, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<TM_, TN_, 16, NBUF_>::SMEM_BYTES);
+    if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_pipe_ln): %s", hipGetErrorString(e));
+    return MMDM_OK;
 }
 
 template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2, int MINW_ = 1, int PIPE_ = 0>
@@ -924,6 +1075,13 @@ inline bool vec_ok(const float* p, int ld, int K) {
 
 }  // namespace
 
+// producer-side AdaLN: the tile the dispatch would pick for (N, K) must divide N; the row-block counters must fit the header
+static bool ln_narrow(int N, int K) { return N <= 512 || K <= 512; }
+bool mmdm_gemm_ln_ok(int M, int N, int K) {
+    const int bn = ln_narrow(N, K) ? 64 : 128;
+    return M > 0 && K >= 96 && (K & 15) == 0 && N % bn == 0 && (M + 127) / 128 <= (LN_HDR_BYTES - 64) / 4;
+}
+size_t mmdm_gemm_ln_work_bytes(int M, int N) { return LN_HDR_BYTES + (size_t)((M + 127) / 128) * 128 * (N / 64) * 2 * sizeof(float); }
 bool mmdm_gemm_fuse_ok(int K, int T) { return K >= 128 && K <= NORM_MAX_K && (K & 127) == 0 && T >= 128; }
 
 int g_gemm_cfg = -1;
@@ -954,6 +1112,8 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_glds<21, 21, 16, 4, 1, 1>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 2>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 3>())) return rc;
+    if ((rc = set_attr_lnp<22, 22, 5>())) return rc;
+    if ((rc = set_attr_lnp<22, 21, 4>())) return rc;
     {
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<22, 22, 16, 4, false, 1, 1, false, true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, norm_smem(NORM_MAX_K));
@@ -1009,6 +1169,10 @@ int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int 
     a.stats_out = fuse ? fuse->stats_out : nullptr;
     a.nstats = fuse ? fuse->norm_stats : nullptr; a.nss = fuse ? fuse->norm_ss : nullptr;
     a.nss_ld = fuse ? fuse->ss_ld : 0; a.nss_rows = fuse ? fuse->ss_rows : 1; a.nT = fuse ? fuse->T : 1;
+    a.ln_out = fuse ? fuse->ln_out : nullptr;
+    a.ln_cnt = fuse ? static_cast<unsigned*>(fuse->ln_work) : nullptr;
+    a.ln_err = fuse && fuse->ln_work ? reinterpret_cast<int*>(static_cast<char*>(fuse->ln_work) + LN_HDR_BYTES - 64) : nullptr;
+    a.ln_part = fuse && fuse->ln_work ? reinterpret_cast<float*>(static_cast<char*>(fuse->ln_work) + LN_HDR_BYTES) : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool av = vec_ok(A, lda, K), wv = vec_ok(W, ldw, Kw);
     const bool glds_ok = av && wv && (K % 16 == 0) && Kw == K;
@@ -1016,6 +1180,15 @@ int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int 
         const bool ext = epilogue == MMDM_EPI_BIAS_RESID || epilogue == MMDM_EPI_BIAS_PE;
         if (!(glds_ok && K >= 96 && ext && vepi_ok(a) && (N & 31) == 0 && g_gemm_cfg == -1))
             return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: row statistics need the pipelined residual / PE GEMM (K >= 96, K %% 16, N %% 32, 16-byte aligned rows)");
+    }
+    if (a.ln_out) {                 // producer of the next block's AdaLN
+        const bool ext = epilogue == MMDM_EPI_BIAS_RESID || epilogue == MMDM_EPI_BIAS_PE;
+        if (!(glds_ok && ext && vepi_ok(a) && mmdm_gemm_ln_ok(M, N, K) && fuse->ln_work && a.nss && a.nss_rows > 0 && a.nT > 0 && a.nss_ld >= 2 * N &&
+              (a.nss_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.nss) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.ln_out) & 15) == 0 && !a.stats_out &&
+              !a.nstats && g_gemm_cfg == -1))
+            return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: producer-side AdaLN needs the pipelined residual / PE GEMM with N a multiple of its tile width, "
+                                  "16-byte aligned rows and tables and a work buffer (M=%d N=%d K=%d)", M, N, K);
+        return ln_narrow(N, K) ? launch_lnp<22, 21, 4>(a, st) : launch_lnp<22, 22, 5>(a, st);
     }
     if (a.nstats) {                 // consumer
         if (!(glds_ok && mmdm_gemm_fuse_ok(K, a.nT) && a.nss && a.nss_rows > 0 && a.nss_ld >= 2 * K && (a.nss_ld & 3) == 0 &&
@@ -1104,6 +1277,16 @@ extern "C" int mmdm_linear_f32_stats(const float* A, int lda, const float* W, in
     if (!stats) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32_stats: null stats");
     mmdm_gemm_fuse f;
     f.stats_out = stats;
+    return mmdm_linear_f32_fused(A, lda, W, ldw, K, bias, C, ldc, M, N, K, epilogue, extra, ld_extra, period, &f, stream);
+}
+
+extern "C" size_t mmdm_linear_f32_ln_work_bytes(int M, int N) { return mmdm_gemm_ln_work_bytes(M, N); }
+extern "C" int mmdm_linear_f32_ln(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+                                  int epilogue, const float* extra, int ld_extra, int period, const float* ss, int ss_ld, int ss_rows, int T,
+                                  float* ln_out, void* work, void* stream) {
+    if (!ss || !ln_out || !work || T <= 0 || ss_rows <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32_ln: bad arguments");
+    mmdm_gemm_fuse f;
+    f.norm_ss = ss; f.ss_ld = ss_ld; f.ss_rows = ss_rows; f.T = T; f.ln_out = ln_out; f.ln_work = work;
     return mmdm_linear_f32_fused(A, lda, W, ldw, K, bias, C, ldc, M, N, K, epilogue, extra, ld_extra, period, &f, stream);
 }
 

@@ -88,7 +88,14 @@ struct mmdm_gemm_fuse {
     const float* norm_stats = nullptr;
     const float* norm_ss = nullptr;
     int ss_ld = 0, ss_rows = 1, T = 1;
+    // Producer-side AdaLN: the residual / PE GEMM also writes ln_out [M][ldc] = AdaLN(C rows; norm_ss, ss_ld, ss_rows, T) -- the operand of
+    // the next block's first GEMM -- through a row-block rendezvous of its column tiles (gemm_f32.hip, LNP_).  ln_work: mmdm_gemm_ln_work_bytes
+    // bytes, zeroed ONCE by the caller (counters are monotonic across launches); at most one such GEMM per ln_work in flight at a time.
+    float* ln_out = nullptr;
+    void* ln_work = nullptr;
 };
+size_t mmdm_gemm_ln_work_bytes(int M, int N);
+bool mmdm_gemm_ln_ok(int M, int N, int K);   // shapes the producer-side AdaLN covers (N % 128 == 0 or N % 64 == 0 per the tile the dispatch picks)
 bool mmdm_gemm_fuse_ok(int K, int T);      // shapes the fused consumer covers: K % 128 == 0, 128 <= K <= 1024, T >= 128
 int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                           int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, const mmdm_gemm_fuse* fuse, void* stream);

@@ -130,6 +130,7 @@ struct Scratch {          // transformer-stack work buffers (one set per concurr
     void *qk = nullptr, *kvp = nullptr;   // precision >= 1: bf16 plane copies of the attention's Q|K ([planes][R][2D]) and cross-attention K ([planes][R][D])
     float* xs = nullptr;                  // precision == 3: per-row scales of the fp8 AdaLN output in xn
     float* hstat = nullptr;               // precision == 0: partial LayerNorm statistics of the rows of h, [R][D/32][2] (fused AdaLN, gemm_f32.hip)
+    float* ln_work = nullptr;             // precision == 0: rendezvous counters + per-tile row partials of the AdaLN-producing residual GEMMs (gemm_f32.hip, LNP_)
 };
 
 struct Prof {
@@ -495,6 +496,17 @@ int attention_b(const Ctx& c, const float* Q, int ldq, const float* K, int ldk, 
 // h [nseq*T, D] is updated in place through the L blocks (TransformerBlockDoubleCond / TransformerBlock / InfluenceBlockCross).
 // precision == 1: the GEMM operands xn / att / f1 are written as bf16 by their producers and the weights come from the bf16 twins;
 // the residual stream h, the Q/K/V projections, softmax and all accumulation stay fp32.
+// fp32 handles: the residual GEMMs also write the AdaLN of the block that follows -- OFF unless MMDM_LN_PRODUCER=1 (or the tools'
+// mmdmx_set_ln_producer): measured slower (60.2 vs 59.5 ms/step; LAB_NOTES.md, "AdaLN written by the producer").  Every GEMM shape of the
+// stack that would carry it must be covered (gemm_f32.hip: mmdm_gemm_ln_ok).
+static int g_ln_producer = -1;
+extern "C" void mmdmx_set_ln_producer(int on) { g_ln_producer = on; }
+bool ln_producer(mmdm_handle h, int R, int D, int F) {
+    static const int env = getenv("MMDM_LN_PRODUCER") ? atoi(getenv("MMDM_LN_PRODUCER")) : 0;
+    const int on = g_ln_producer >= 0 ? g_ln_producer : env;
+    return on != 0 && h->cfg.precision == 0 && mmdm_gemm_ln_ok(R, D, D) && mmdm_gemm_ln_ok(R, D, F);
+}
+
 int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     const Scratch& S = *c.s;
     const int D = w.D, F = w.F, R = r.nseq * r.T, dh = D / w.H;
@@ -508,10 +520,20 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     // fragments
     const float *pend_src = nullptr, *pend_ss = nullptr;
     int pend_rows = 0;
-    float* const hst = r.hstat;
+    // AdaLN written by the PRODUCER of the residual stream (fp32, ln_producer()): a residual GEMM whose output the next norm() reads also
+    // writes that norm's result into S.xn (gemm_f32.hip, LNP_); norm() then finds its work done (`ready_ss`).
+    const bool lnp = ln_producer(c.h, R, D, F) && S.ln_work != nullptr;
+    const float* ready_ss = nullptr;
+    float* const hst = lnp ? nullptr : r.hstat;
     const bool fused = hst != nullptr;
     auto gemm = [&](const float* A, int lda, const float* Wf, const void* Wb, size_t woff, size_t wtot, const float* bias, float* C, int ldc, int out_b,
-                    int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) -> int {
+                    int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second(), const float* next_ss = nullptr, int next_rows = 0) -> int {
+        if (lnp && next_ss && C == hbuf && epi == MMDM_EPI_BIAS_RESID) {
+            mmdm_gemm_fuse f;
+            f.norm_ss = next_ss; f.ss_ld = r.ss_ld; f.ss_rows = next_rows; f.T = r.T; f.ln_out = S.xn; f.ln_work = S.ln_work;
+            ready_ss = next_ss;
+            return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra, 0, 0, &f);
+        }
         if (prec == 2) return linear_s(c, A, lda, (size_t)R * K, bw(Wb, woff), w.w_packed ? 0 : K, wtot, bias, C, ldc, (size_t)R * N, out_b == 2, R, N, K, epi, extra, ld_extra, s2);
 
         if (bf) return linear_b(c, A, lda, bw(Wb, woff), w.w_packed ? 0 : K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra, s2);
@@ -544,6 +566,12 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     };
     // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / three planes, or fp8 + per-row scales
     auto norm = [&](const float* src, const float* ssp, int rows) -> int {
+        if (ready_ss) {
+            const bool done = src == hbuf && ssp == ready_ss;
+            ready_ss = nullptr;
+            if (done) return MMDM_OK;          // S.xn already holds it
+            return mmdm_set_error(MMDM_ERR_STATE, "run_stack: the residual GEMM prepared a different AdaLN than the one requested next");
+        }
         if (fused) {
             if (src != hbuf) return mmdm_set_error(MMDM_ERR_STATE, "run_stack: fused AdaLN has statistics for the residual stream only");
             pend_src = src; pend_ss = ssp; pend_rows = rows;
@@ -584,7 +612,9 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
             } else if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld), w.w_packed));
             else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld)));
         }
-        RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+        const int ffn_slot = w.has_ca ? 3 : 1;
+        if (r.ca_mode) RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), ss_at(1, r.ca_row0), r.ca_rows));
+        else RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), ss_at(ffn_slot, r.ffn_row0), r.ffn_rows));
         // --- cross attention (layers.py:77-88)
         if (r.ca_mode) {
             RC(norm(hbuf, ss_at(1, r.ca_row0), r.ca_rows));
@@ -596,16 +626,18 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
             if (qkp) RC(attention_p(c, S.qk, D, (size_t)R * D, S.kvp, pvb ? 2 * D : D, (size_t)R * (pvb ? 2 * D : D), np, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
                                     r.ca_mode == 1 ? r.nseq / 2 : 0, pvb ? static_cast<const uint16_t*>(S.kvp) + D : nullptr, 2 * D));
             else RC(attention_b(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
-            RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, (size_t)D * D, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+            RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, (size_t)D * D, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), ss_at(ffn_slot, r.ffn_row0), r.ffn_rows));
         }
         // --- FFN (layers.py:99-106)
-        RC(norm(hbuf, ss_at(w.has_ca ? 3 : 1, r.ffn_row0), r.ffn_rows));
+        RC(norm(hbuf, ss_at(ffn_slot, r.ffn_row0), r.ffn_rows));
         if (f8) {               // FFN on fp8 operands: the GELU output is written as e4m3 at unit scale and read back as the down-projection's A
             RC(gemm8(S.xn, false, lb.f1_8, lb.f1_s, 0, lw.f1_b, S.f1, F, 2, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
             RC(gemm8(S.f1, true, lb.f2_8, lb.f2_s, 0, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), w.w_packed && F >= 2048));
         } else {
             RC(gemm(S.xn, D, lw.f1_w, lb.f1_w, 0, (size_t)F * D, lw.f1_b, S.f1, F, ob, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
-            RC(gemm(S.f1, F, lw.f2_w, lb.f2_w, 0, (size_t)D * F, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
+            // the next block starts with sa_block.norm of these rows
+            const float* nx = l + 1 < w.L ? r.ss + (size_t)r.sa_row0 * r.ss_ld + ((size_t)(l + 1) * w.n_ada) * 2 * D : nullptr;
+            RC(gemm(S.f1, F, lw.f2_w, lb.f2_w, 0, (size_t)D * F, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), nx, r.sa_rows));
         }
     }
     return MMDM_OK;
@@ -975,6 +1007,11 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
             (rc = dalloc(h, &sc->xp, (size_t)2 * n * T * NFP)))
             return fail(rc);
         if (c.precision == 0 && (rc = dalloc(h, &sc->hstat, R * (d / 32 + 1) * 2))) return fail(rc);
+        if (c.precision == 0) {
+            const size_t nb = mmdm_gemm_ln_work_bytes((int)R, (int)d);
+            if ((rc = dalloc(h, &sc->ln_work, nb / sizeof(float)))) return fail(rc);
+            if (hipMemset(sc->ln_work, 0, nb) != hipSuccess) return fail(mmdm_set_error(MMDM_ERR_HIP, "hipMemset(ln_work)"));
+        }
         if (c.precision >= 1) {
             const size_t npl = c.precision == 2 ? 3 : 1;
             float *q1 = nullptr, *q2 = nullptr;

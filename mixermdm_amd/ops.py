@@ -61,6 +61,23 @@ def linear_stats(x, weight, bias=None, epilogue="resid", extra=None, period=0, o
     return out, stats
 
 
+def linear_ln(x, weight, bias, epilogue, extra, ss, T, period=0, ss_rows=None, work=None):
+    """linear() with a residual / PE epilogue that also returns AdaLN(y; ss) of the rows it produced (mmdm_linear_f32_ln):
+    (y [M, N], xn [M, N], work).  `work` is the rendezvous buffer (zeroed once; pass it back to reuse it)."""
+    _chk(x, weight, bias, extra, ss)
+    K, N = x.shape[-1], weight.shape[0]
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    lib = load_library()
+    if work is None:
+        work = torch.zeros(lib.mmdm_linear_f32_ln_work_bytes(M, N), dtype=torch.uint8, device=x.device)
+    out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    xn = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    check(lib.mmdm_linear_f32_ln(_p(x2), x2.stride(0), _p(weight), weight.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, EPI[epilogue],
+                                 _p(extra), extra.stride(0), period, _p(ss), ss.stride(0), ss_rows or ss.shape[0], T, _p(xn), _p(work), _stream()))
+    return out, xn, work
+
+
 def linear_adaln(h, stats, ss, T, weight, bias=None, epilogue="bias", ss_rows=None):
     """epilogue(AdaLN(h) @ weight.T + bias) with the normalisation applied inside the GEMM: h [M, K] un-normalised, stats from
     linear_stats, ss [rows, 2K] (scale | shift), row m uses ss[(m // T) % ss_rows] (mmdm_linear_adaln_f32)."""

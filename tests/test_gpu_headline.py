@@ -178,27 +178,31 @@ def test_full_dims_T300_B2_step_vs_oracle(samplers, oracle_t300_b2, mode):
     _check_step(s, xT, x2, 500, dict(zip(names, mid)), f"T=300 B=2 i=500 [{mode}]", f64b)      # chains that differ, mid-schedule coefficients
 
 
-def test_full_dims_step_with_adaln_inside_the_gemm(samplers, oracle_t300_b2):
-    """MMDM_FUSE_ADALN (off by default: slower, LAB_NOTES.md): the denoisers' AdaLN applied to the A fragments of the consuming GEMM from
-    the producer's partial row statistics.  Same parity bar as the default path; not bit-identical to it (proof that the path ran)."""
+@pytest.mark.parametrize("which", ["consumer", "producer"])
+def test_full_dims_step_with_adaln_inside_the_gemm(samplers, oracle_t300_b2, which):
+    """The two fused forms of AdaLN, both off by default because they measured slower (LAB_NOTES.md).  consumer (MMDM_FUSE_ADALN): applied to
+    the A fragments of the GEMM that reads it, from the producer's partial row statistics; producer (MMDM_LN_PRODUCER): written by the
+    residual GEMM that produces the rows, through a row-block rendezvous of its column tiles.  Same parity bar as the default path; not
+    bit-identical to it (proof that the path ran)."""
     from mixermdm_amd._lib import load_library
     cond, xT, x2, _, (mid, f64b) = oracle_t300_b2
     s = samplers["fp32"]
     s.set_schedule("ddim1000")
     s.begin(cond, xT)
     lib = load_library()
+    hook = lib.mmdmx_set_fuse_adaln if which == "consumer" else lib.mmdmx_set_ln_producer
     outs = {}
     try:
         for on in (0, 1):
-            lib.mmdmx_set_fuse_adaln(on)
+            hook(on)
             _force(s, xT, x2, 500)
             s.run(1, use_graph=False)                   # eager: a captured step graph would replay the kernels it was captured with
             outs[on] = {k: v.clone() for k, v in s.state().items() if k in NAMES}
     finally:
-        lib.mmdmx_set_fuse_adaln(-1)
+        hook(-1)
     refs = dict(zip(NAMES, mid))
-    compare_step(outs[1], refs, f64b, "T=300 B=2 i=500 [fp32, AdaLN in the GEMM]")
-    yardstick(outs[1], refs, f64b, "T=300 B=2 i=500 [fp32, AdaLN in the GEMM]")
+    compare_step(outs[1], refs, f64b, f"T=300 B=2 i=500 [fp32, AdaLN in the GEMM: {which}]")
+    yardstick(outs[1], refs, f64b, f"T=300 B=2 i=500 [fp32, AdaLN in the GEMM: {which}]")
     assert not torch.equal(outs[0]["pred_xstart2"], outs[1]["pred_xstart2"])
     assert_close(outs[1]["pred_xstart2"], outs[0]["pred_xstart2"], atol=2e-3, rtol=2e-3, frac=1e-3, what="AdaLN in the GEMM vs the stand-alone pass")
 

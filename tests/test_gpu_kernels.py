@@ -563,6 +563,46 @@ def test_linear_with_fused_adaln_matches_adaln_then_linear(nseq, T, K, N, epi):
     assert_close(got, y.float(), atol=5e-5, rtol=2e-5, what="fused vs float64")
 
 
+@pytest.mark.parametrize("nseq,T,N,K,epi", [(64, 300, 1024, 1024, "resid"), (8, 300, 1024, 2048, "resid"), (4, 300, 512, 512, "resid"), (64, 196, 1024, 1024, "resid"),
+                                            (3, 131, 1024, 256, "pe"), (5, 77, 512, 1024, "resid"), (1, 40, 128, 128, "resid")])
+def test_linear_with_ln_output_matches_linear_then_adaln(nseq, T, N, K, epi):
+    """The residual / PE GEMM that also writes the AdaLN of the rows it produced (row-block rendezvous of its column tiles) against the
+    plain GEMM followed by the stand-alone pass and against float64: rows bit-identical to the plain GEMM's, ragged M, tiles that straddle
+    sequences, a large common offset in the rows, and the rendezvous buffer reused by later launches (monotonic counters)."""
+    from mixermdm_amd import ops
+    M = nseq * T
+    d = dev()
+    x, w, b = rnd(1, M, K).to(d), rnd(2, N, K, scale=1 / math.sqrt(K)).to(d), rnd(3, N).to(d)
+    extra = (rnd(4, M if epi == "resid" else T, N) * 2 + 30.0).to(d)
+    ss = (rnd(5, 3, 2 * N) * 0.5).to(d)
+    period = T if epi == "pe" else 0
+    want_y = ops.linear(x, w, b, epi, extra, period)
+    want_xn = ops.adaln(want_y.view(nseq, T, N), ss, 3).view(M, N)
+    work = None
+    for rep in range(3):
+        y, xn, work = ops.linear_ln(x, w, b, epi, extra, ss, T, period=period, ss_rows=3, work=work)
+        assert load_library_kernel().startswith("gemm_pipe_ln<")
+        assert torch.equal(y, want_y), f"rows differ from the plain GEMM (launch {rep})"
+        assert_close(xn, want_xn, atol=2e-5, rtol=2e-5, what=f"AdaLN written by the GEMM vs the stand-alone pass (launch {rep})")
+    err = work[64 * 1024 - 64:64 * 1024 - 60].view(torch.int32).item()
+    assert err == 0, "the bounded rendezvous wait expired"
+    h64 = want_y.cpu().double()
+    sel = (torch.arange(M) // T) % 3
+    ln = (h64 - h64.mean(-1, keepdim=True)) / torch.sqrt(h64.var(-1, unbiased=False, keepdim=True) + 1e-6)
+    ref = ln * (1 + ss.cpu().double()[sel, :N]) + ss.cpu().double()[sel, N:]
+    assert_close(xn, ref.float(), atol=2e-5, rtol=2e-5, what="AdaLN written by the GEMM vs float64")
+
+
+def test_ln_output_rejects_what_it_does_not_cover():
+    from mixermdm_amd import ops, MMDMError
+    d = dev()
+    x, ss = torch.zeros(256, 1024, device=d), torch.zeros(1, 2 * 960, device=d)
+    with pytest.raises(MMDMError):            # N = 960 is not a multiple of the 128-wide tile
+        ops.linear_ln(x, torch.zeros(960, 1024, device=d), torch.zeros(960, device=d), "resid", torch.zeros(256, 960, device=d), ss, 128)
+    with pytest.raises(MMDMError):            # not a residual / PE epilogue
+        ops.linear_ln(x, torch.zeros(1024, 1024, device=d), torch.zeros(1024, device=d), "gelu", torch.zeros(256, 1024, device=d), torch.zeros(1, 2048, device=d), 128)
+
+
 def load_library_kernel():
     from mixermdm_amd._lib import load_library
     return load_library().mmdm_last_gemm_kernel().decode()
