@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round bench lines (GPU box): every bench.py line profiles/README.md quotes, at HEAD.  Output: gpurun_out/bench_$TAG/*.json
+# (then: python tools/collect_bench.py $TAG, here).  usage: tools/bench_round.sh [tag, default r03]   (~15 minutes)
+TAG=${1:-r03}
+O=gpurun_out/bench_$TAG; rm -rf $O; mkdir -p $O
+Q="--no-cpu-baseline --no-alt --no-full-loop"
+python bench.py > $O/default.json 2> $O/default.err                                    # the driver's command: headline + fp32_split + full loop + CPU port
+python bench.py --workload single $Q > $O/single.json 2> $O/single.err                  # configs[1]
+python bench.py --precision bf16 $Q > $O/bf16.json 2> $O/bf16.err
+python bench.py --precision bf16_fp8 $Q > $O/bf16_fp8.json 2> $O/bf16_fp8.err           # configs[4] arithmetic at B = 16
+python bench.py --precision bf16_fp8 --batch 64 $Q > $O/fp8_b64.json 2> $O/fp8_b64.err  # configs[4] per-GPU shard
+python bench.py --batch 32 $Q > $O/b32.json 2> $O/b32.err                               # configs[3] per-GPU shard
+python bench.py --batch 32 --precision fp32_split $Q > $O/b32_split.json 2> $O/b32_split.err
+python tools/full_loop.py > $O/full_loops.txt 2> $O/full_loops.err
+for f in $O/*.json; do echo $(basename $f) $(grep -o '"ms_per_step": [0-9.]*' $f | head -1) $(grep -o '"value": [0-9.]*' $f | head -1); done
+tail -6 $O/full_loops.txt
