@@ -13,9 +13,9 @@ for n in ("default", "single", "bf16", "bf16_fp8", "fp8_b64", "b32", "b32_split"
     json.dump(d, open(os.path.join(dst, f"{tag}_bench_{n}.json"), "w"), indent=1)
     r = d["roofline"]
     extra = ""
-    if "fp32_split" in d:
+    if d.get("fp32_split"):
         s = d["fp32_split"]; extra += f"  | fp32_split {s['ms_per_step']} ms/step frac {s['roofline']['frac']}"
-    if "full_loop" in d:
+    if d.get("full_loop"):
         extra += f"  | full loop {d['full_loop']}"
     if d.get("cpu_baseline"):
         extra += f"  | cpu {d['cpu_baseline'].get('value')} {d['cpu_baseline'].get('unit')}"
