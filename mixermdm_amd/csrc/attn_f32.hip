@@ -129,12 +129,17 @@ __device__ __forceinline__ void store_o_row(const P& p, const f32x4 (&o)[DH / 16
 // __shfl_xor form is a ds_bpermute: an LDS round trip that queues behind the K / V fragment reads and the LDS-DMA writes of four
 // co-resident workgroups -- the softmax stretch of a chunk spent most of its 2 800 cycles in eight of them (tools/attn_timeline.py).
 // Inline asm: this compiler's two-result builtin returns the first result twice.  The s_nop cover the VALU -> permlane hazards.
+// v_max_f32 / v_max3_f32 as such: fmaxf() of values the compiler cannot prove quiet (MFMA results, permlane outputs) is preceded by a
+// canonicalising v_max x, x per operand -- six extra VALU instructions per chunk, and in this loop a VALU instruction costs matrix-pipe time
+// (LAB_NOTES.md).  Same result for every input but a signalling NaN, which is returned as it is instead of quieted.
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float rows_max(float x) {
     float a = x, b = x;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    a = fmaxf(a, b); b = a;
+    a = vmax(a, b); b = a;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return fmaxf(a, b);
+    return vmax(a, b);
 }
 __device__ __forceinline__ float rows_sum(float x) {
     float a = x, b = x;
@@ -204,21 +209,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
                                         ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32);   // HW_ID, XCC_ID
     }
 
-    // Q fragments (B operand of S^T = K Q^T): lane (q = lq, g) holds Q[q][16j + 4g + s], pre-scaled into the log2 domain.
-    f32x4 qf[QT][NJ];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        int qrow = q0 + QBT * t + lq;
-        if (qrow >= p.Tq) qrow = p.Tq - 1;
-        const float* qp = p.Q + ((size_t)seq * p.Tq + qrow) * p.ldq + head * p.dh + 4 * g;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const bool in = 16 * j + 4 * g < p.dh;                       // dh % 4 == 0: a 16-byte group is wholly inside or outside
-            f32x4 v = *reinterpret_cast<const f32x4*>(qp + (in ? 16 * j : 0));
-            qf[t][j] = in ? v * p.scale2 : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-
+    f32x4 qf[QT][NJ];                           // Q fragments: loaded behind the first K / V stage's requests (below)
     f32x4 o[QT][NJ];
 #pragma unroll
     for (int t = 0; t < QT; ++t)
@@ -304,20 +295,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
                     if (c0 + 4 * g + r > kmax) st[t][r] = -INFINITY;
             }
             if (!(ablate & 4)) {
-                float cmax = fmaxf(fmaxf(st[t][0], st[t][1]), fmaxf(st[t][2], st[t][3]));
+                float cmax = vmax3(st[t][0], st[t][1], vmax(st[t][2], st[t][3]));
                 cmax = rows_max(cmax);
                 // Deferred reference: the running maximum only moves when the chunk's maximum exceeds it by more than 2^8 (scores are in the log2
                 // domain), so after the first chunks alpha is exactly 1 for every query of the wave and the rescale below is skipped; until
                 // then probabilities up to 2^8 enter the fp32 sums, which changes nothing but the last bits (softmax does not depend on the
-                // reference point).
+                // reference point).  (A speculative form -- probabilities against the current reference first, the cross-lane maximum only
+                // when one exceeds 2^8, row sums reduced after the loop: 14 VALU instructions per chunk instead of 40 -- measured the same
+                // 200 us at 128 registers: what is left of the softmax stretch is its dependent chain, not its instruction count.)
                 const float m_new = cmax > m_run[t] + 8.0f ? cmax : m_run[t];
                 const float alpha = EXP2(m_run[t] - m_new);
-                float lsum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    st[t][r] = EXP2(st[t][r] - m_new);
-                    lsum += st[t][r];
-                }
+                for (int r = 0; r < 4; ++r) st[t][r] = EXP2(st[t][r] - m_new);
+                float lsum = ((st[t][0] + st[t][1]) + st[t][2]) + st[t][3];      // (0 + p0 is p0: the same bits without the add)
                 lsum = rows_sum(lsum);
                 l_run[t] = l_run[t] * alpha + lsum;
                 m_run[t] = m_new;
@@ -367,12 +357,35 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nchunks) stage(t * KC, t);
+    static_assert(NST == 2, "the Q loads are younger than the first stage's requests: the loop's first wait must be vmcnt(0)");
+    // (the first chunk's K / V rows are on their way: the Q loads below share that latency instead of preceding it -- the prologue was 9 us
+    // of a 69 us workgroup at dh = 128, tools/attn_timeline.py)
+    // Q fragments (B operand of S^T = K Q^T): lane (q = lq, g) holds Q[q][16j + 4g + s], pre-scaled into the log2 domain.
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        int qrow = q0 + QBT * t + lq;
+        if (qrow >= p.Tq) qrow = p.Tq - 1;
+        const float* qp = p.Q + ((size_t)seq * p.Tq + qrow) * p.ldq + head * p.dh + 4 * g;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool in = 16 * j + 4 * g < p.dh;                       // dh % 4 == 0: a 16-byte group is wholly inside or outside
+            f32x4 v = *reinterpret_cast<const f32x4*>(qp + (in ? 16 * j : 0));
+            qf[t][j] = in ? v * p.scale2 : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
     // The chunk loop exists once per number of live tiles (wave-uniform choice OUTSIDE the loop): with both bodies inside one loop the
     // register allocator keeps the state of both alive across the branch (263 registers instead of 184 at DH = 128, QT = 2).
     auto run = [&](auto na_c) {
         constexpr int NA = decltype(na_c)::value;
-        int cur = 0, stg = NST - 1;
-        for (int ci = 0; ci < nchunks; ++ci) {
+        // the stage index is a compile-time constant (the loop body exists NST times): the K / V fragment reads then address LDS with their
+        // per-lane offset + an immediate instead of one VALU add per read (a VALU instruction in this loop costs matrix-pipe time)
+        for (int cb = 0; cb < nchunks; cb += NST) {
+#pragma unroll
+          for (int cur = 0; cur < NST; ++cur) {
+            const int ci = cb + cur;
+            if (ci >= nchunks) break;
+            const int stg = (cur + NST - 1) % NST;
             const int c0 = ci * KC;
             const int left = nchunks - 1 - ci;                     // chunks requested behind this one (capped at NST - 2 by the ring)
             if (left >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NI) : "memory");
@@ -387,8 +400,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
             if (stamps) { if (ci == 0 && tid == 0) stamps[8 * (size_t)bid + 1] = __builtin_amdgcn_s_memrealtime(); t_a = __builtin_amdgcn_s_memrealtime(); }
             // a wave without a live tile (T = 300, QT = 2: wave 3 of the last workgroup) stages its pieces and keeps the barriers, nothing else
             if constexpr (NA > 0) chunk(na_c, c0, Ks, Vs);
-            cur = cur + 1 == NST ? 0 : cur + 1;
-            stg = stg + 1 == NST ? 0 : stg + 1;
+          }
         }
     };
     if (nact == QT) run(std::integral_constant<int, QT>{});
@@ -591,16 +603,13 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
             for (int r = 0; r < 4; ++r)
                 if (c0 + 4 * g + r > kmax) st[0][r] = -INFINITY;
         }
-        float cmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+        float cmax = vmax3(st[0][0], st[0][1], vmax(st[0][2], st[0][3]));
         cmax = rows_max(cmax);
         const float m_new = cmax > m_run + 8.0f ? cmax : m_run;        // deferred reference, as in attn_mfma_kernel
         const float alpha = EXP2(m_run - m_new);
-        float lsum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            st[0][r] = EXP2(st[0][r] - m_new);
-            lsum += st[0][r];
-        }
+        for (int r = 0; r < 4; ++r) st[0][r] = EXP2(st[0][r] - m_new);
+        float lsum = ((st[0][0] + st[0][1]) + st[0][2]) + st[0][3];
         lsum = rows_sum(lsum);
         l_run = l_run * alpha + lsum;
         m_run = m_new;
