@@ -473,6 +473,7 @@ __device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y
 // (DH = 64) x = ((r >> 1) & 3) << 1 -- without it the eight rows a 32-lane half reads sit on the same banks.
 template <int DH, int NP, bool PVB = false>
 __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
     static_assert(!PVB || NP == 1, "bf16 P.V goes with bf16 scores");
     constexpr int NJ = DH / 16;                 // 16-wide output column tiles (PV)
     constexpr int NS = DH / 32;                 // 32-deep reduction steps of Q K^T
@@ -525,37 +526,41 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
     const __bf16* Kg = p.Kp + (size_t)kvseq * p.Tk * p.ldkp + head * DH;
     const float* Vg = p.V + (size_t)kvseq * p.Tk * p.ldv + head * DH;
 
+    // DMA pieces of this wave (piece pq = wave + 4u): buffer-addressed as in attn_mfma_kernel -- one resource per piece over this (sequence,
+    // head)'s rows of its operand (a K plane, or V), a per-lane byte offset that is fixed for the whole launch and ONE scalar offset per
+    // chunk.  (The pointer form computed a clamped row, a 64-bit product and a 64-bit sum per lane, piece and chunk: 40 VALU instructions
+    // per chunk beside 12 short MFMAs.)  Rows past Tk fall outside the resource and arrive as zeros; their scores are masked below.
+    __amdgpu_buffer_rsrc_t rsp[NI];
+    int voff[NI], dsto[NI], rstep[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int pq = wave + 4 * u;                                   // wave-uniform
+        const bool isk = pq < NP * NPK;
+        const int pl = isk ? pq / NPK : 0, pp = isk ? pq % NPK : pq - NP * NPK;
+        const int trow = isk ? RPPK * pp + lane / CPRK : RPP * pp + lane / CPR;
+        const int pos = isk ? lane % CPRK : lane % CPR;
+        const void* base; unsigned bytes;
+        if (isk) {
+            base = Kg + (size_t)pl * p.k_plane; bytes = (unsigned)(((size_t)(p.Tk - 1) * p.ldkp + DH) * 2);
+            voff[u] = (trow * p.ldkp + 8 * (pos ^ (trow & (CPRK - 1)))) * 2; rstep[u] = p.ldkp * 2;
+            dsto[u] = pl * KPLANE + RPPK * pp * (DH / 2);
+        } else if constexpr (PVB) {
+            const int xv = DH == 128 ? (((trow & 3) << 2) | ((trow >> 2) & 3)) : (((trow >> 1) & 3) << 1);
+            base = p.Vp + (size_t)kvseq * p.Tk * p.ldvp + head * DH; bytes = (unsigned)(((size_t)(p.Tk - 1) * p.ldvp + DH) * 2);
+            voff[u] = (trow * p.ldvp + 8 * (pos ^ xv)) * 2; rstep[u] = p.ldvp * 2;
+            dsto[u] = NP * KPLANE + RPP * pp * (DH / 2);
+        } else {
+            base = Vg; bytes = (unsigned)(((size_t)(p.Tk - 1) * p.ldv + DH) * 4);
+            voff[u] = (trow * p.ldv + 4 * pos) * 4; rstep[u] = p.ldv * 4;              // V rows are stored unswizzled (load_v_row)
+            dsto[u] = NP * KPLANE + RPP * pp * DH;
+        }
+        rsp[u] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+    }
     auto stage = [&](int c0, int buf) {
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
-            const int pq = wave + 4 * u;
-            if (pq >= NPIECE) break;                                   // wave-uniform
-            float* base = smem + buf * STAGE;
-            if (pq < NP * NPK) {
-                const int pl = pq / NPK, pp = pq % NPK;
-                const int trow = RPPK * pp + lane / CPRK;
-                const int pos = lane % CPRK;
-                const int src_chunk = pos ^ (trow & (CPRK - 1));
-                int krow = c0 + trow;
-                krow = krow < p.Tk ? krow : p.Tk - 1;
-                const __bf16* src = Kg + (size_t)pl * p.k_plane + (size_t)krow * p.ldkp + 8 * src_chunk;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + pl * KPLANE + RPPK * pp * (DH / 2)), 16, 0, 0);
-            } else {
-                const int pp = pq - NP * NPK;
-                const int trow = RPP * pp + lane / CPR;
-                const int pos = lane % CPR;
-                int krow = c0 + trow;
-                krow = krow < p.Tk ? krow : p.Tk - 1;
-                if constexpr (PVB) {
-                    const int xv = DH == 128 ? (((trow & 3) << 2) | ((trow >> 2) & 3)) : (((trow >> 1) & 3) << 1);
-                    const __bf16* src = p.Vp + ((size_t)kvseq * p.Tk + krow) * p.ldvp + head * DH + 8 * (pos ^ xv);
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + NP * KPLANE + RPP * pp * (DH / 2)), 16, 0, 0);
-                } else {
-                    const int src_chunk = pos;                              // V rows are stored unswizzled (load_v_row)
-                    const float* src = Vg + (size_t)krow * p.ldv + 4 * src_chunk;
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + NP * KPLANE + RPP * pp * DH), 16, 0, 0);
-                }
-            }
+            if (wave + 4 * u >= NPIECE) break;                         // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp[u], (lptr_t)(smem + buf * STAGE + dsto[u]), 16, voff[u], c0 * rstep[u], 0, 0);
         }
     };
 
@@ -565,8 +570,13 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
         nchunks = min(nchunks, last_q / KC + 1);
     }
     stage(0, 0);
-    for (int ci = 0; ci < nchunks; ++ci) {
-        const int c0 = ci * KC, cur = ci & 1;
+    // the stage index is a compile-time constant (the body exists twice): fragment reads address LDS with an immediate
+    for (int cb2 = 0; cb2 < nchunks; cb2 += 2) {
+#pragma unroll
+      for (int cur = 0; cur < 2; ++cur) {
+        const int ci = cb2 + cur;
+        if (ci >= nchunks) break;
+        const int c0 = ci * KC;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (ci + 1 < nchunks) stage(c0 + KC, cur ^ 1);
@@ -650,6 +660,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
                 o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[0][r], vb[cb][j], o[j], 0, 0, 0);
         }
         }
+      }
     }
 
 #pragma unroll
@@ -670,6 +681,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
             store_o_row<DH>(p, o, r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH, lq);
         }
     }
+#endif
 }
 
 template <int DH, int NP, bool PVB = false>
