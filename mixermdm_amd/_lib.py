@@ -11,7 +11,7 @@ class MMDMError(RuntimeError):
 
 
 def lib_path():
-    return os.environ.get("MMDM_LIB_EXPERIMENT") or os.path.join(_HERE, "libmmdm_hip.so")
+    return os.path.join(_HERE, "libmmdm_hip.so")
 
 
 class Config(C.Structure):
