@@ -724,7 +724,10 @@ int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const fl
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (packed) {
-        const bool narrow = (N & 255) || (g_bf16_cfg == 11) || (g_bf16_cfg != 12 && N <= 1024);
+        // 128 x 256 tiles halve the A-fragment LDS reads per MFMA, but N <= 1024 gives them too few tiles at M = 19 200 (600 = 1.17 rounds of the
+        // 512 slots); from two rounds up they win (B = 32 / 64 shards: bf16 25.5 -> 24.8 / 50.0 -> 47.9 ms/step, bf16_fp8 21.5 -> 21.3 / 42.0 -> 41.0)
+        const bool few = (long)((M + 127) / 128) * (N / 256) < 1024;
+        const bool narrow = (N & 255) || (g_bf16_cfg == 11) || (g_bf16_cfg != 12 && N <= 1024 && few);
         return narrow ? launch_w<0, 1>(a, st) : launch_w<0, 2>(a, st);
     }
     switch (g_bf16_cfg) {
