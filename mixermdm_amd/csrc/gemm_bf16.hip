@@ -406,6 +406,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[kb][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[j] + kb * 1024, so, 0));
     };
+    // half a step of W fragments (k-blocks 2 half, 2 half + 1): the fp8 128 x 256 form keeps two HALF sets instead of two whole ones
+    auto ldbh = [&](int kt, int half, bf16x8 (&b)[2][TN]) {
+        const int so = min(kt, nkt - 1) * (NKB * 1024);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[kb][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[j] + (2 * half + kb) * 1024, so, 0));
+    };
+
 
     f32x16 acc[TM][TN];
     if constexpr (ET == 1) {
@@ -512,6 +521,38 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
         __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 1);
         __builtin_amdgcn_sched_barrier(0);
     };
+    // fp8, 128 x 256 tiles: 128 accumulators + three A fragment sets leave room for ONE step of W fragments, not two (25 spills with the
+    // whole-step double buffer).  The W fragments are therefore requested half a step ahead: k-blocks 2, 3 of this step behind the first
+    // 64-deep MFMA group (which runs on k-blocks 0, 1), k-blocks 0, 1 of the next step behind the second.  Same products in the same order.
+    auto step8h = [&](int kt, int cur, int nxt, int nn, bf16x8 (&bl)[2][TN], bf16x8 (&bh)[2][TN], bf16x8 (&f0)[TM], bf16x8 (&f1)[TM], bf16x8 (&f2)[TM]) {
+        constexpr int NVH = NLB / 2 + NIA;
+        rda(cur, 1, f1);
+        ldbh(kt, 1, bh);
+        stage(nn, kt + 2);
+        mm64(f0, f1, bl[0], bl[1]);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int u = 0; u < NM - 2; ++u) { __builtin_amdgcn_sched_group_barrier(0x010, (NVH + NM - 3) / (NM - 2), 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x010, NVH, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rda(cur, 2, f0);
+        rda(cur, 3, f1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NVH) : "memory");     // A stage kt+1 landed (requested during step kt-1); this step's requests may be in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        rda(nxt, 0, f2);
+        mm64(f0, f1, bh[0], bh[1]);
+        ldbh(kt + 1, 0, bl);                                             // (bl was consumed by the first group)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 1);
+#pragma unroll
+        for (int u = 0; u < NLB / 2; ++u) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1); }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1 - NLB / 2, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto step = [&](int kt, int cur, int nxt, int nn, bf16x8 (&b)[NKB][TN], bf16x8 (&bn)[NKB][TN]) {
         rda(cur, 1, fa1);
         ldb(kt + 1, bn);
@@ -548,8 +589,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (TL) { t_r0 = __builtin_amdgcn_s_memrealtime(); t_c0 = __builtin_readcyclecounter(); }
+    constexpr bool HALFB = ET == 1 && TN == 2;
     stage(0, 0);
-    ldb(0, bx);
+    bf16x8 bl[2][TN], bh[2][TN];                           // HALFB: the two half sets of W fragments (bx / by unused)
+    if constexpr (HALFB) ldbh(0, 0, bl);
+    else ldb(0, bx);
     stage(1, 1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -558,7 +602,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
     bf16x8 fa2[TM];
     for (int kt = 0; kt < nkt; kt += 2) {                  // nkt is even (host check): the two B register sets swap roles every step
         const int c1 = cur == 2 ? 0 : cur + 1, c2 = c1 == 2 ? 0 : c1 + 1;
-        if constexpr (ET == 1) {
+        if constexpr (HALFB) {
+            step8h(kt, cur, c1, c2, bl, bh, fa0, fa1, fa2);
+            step8h(kt + 1, c1, c2, cur, bl, bh, fa2, fa1, fa0);
+        } else if constexpr (ET == 1) {
             step8(kt, cur, c1, c2, bx, by, fa0, fa1, fa2);
             step8(kt + 1, c1, c2, cur, by, bx, fa2, fa1, fa0);
         } else {
@@ -647,6 +694,7 @@ int mmdm_gemm_bf16_init(void) {
     if ((rc = set_attr<22, 21, 1>())) return rc;
     for (const void* f : {reinterpret_cast<const void*>(&gemm_bf16w_kernel<0>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1>),
+                          reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 2>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 2, true>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 2, true>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1, true>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1, true>)}) {
         hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 128 * 16 * 4);
@@ -794,10 +842,11 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (packed) {
-        // fp8 packed: the 128 x 128 tile only (the block-scaled MFMA takes 32-byte operands: with 128 x 256 tiles the paired fragments
-        // of both operands no longer fit next to 128 accumulators at two waves per SIMD; the sampler uses this kernel for the K = 2048
-        // FFN-2 GEMM, N = 1024, which is a 128 x 128 shape anyway)
-        return launch_w<1, 1>(a, st);
+        // fp8 packed: 128 x 256 tiles (W fragments requested half a step ahead: gemm_bf16w_kernel, HALFB) for the large shards only -- measured
+        // bf16_fp8 B = 64: 41.7 -> 41.0 ms/step, B = 16: 11.07 vs 11.08 (the shorter prefetch distance costs what the halved LDS reads
+        // save) -- 128 x 128 otherwise (MMDM_BF16_CFG=12 / 13 force the wide / the narrow form)
+        const bool wide = (N & 255) == 0 && g_bf16_cfg != 11 && g_bf16_cfg != 13 && (g_bf16_cfg == 12 || (long)((M + 127) / 128) * (N / 256) >= 2400);
+        return wide ? launch_w<1, 2>(a, st) : launch_w<1, 1>(a, st);
     }
     switch (g_bf16_cfg) {
         case 0: return launch<22, 22, 1>(a, st);

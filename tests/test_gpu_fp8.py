@@ -223,8 +223,16 @@ def test_packed_bf16_and_fp8_linear_are_bitwise_the_plane_kernels(M, N, K):
         for od in (torch.float32, torch.bfloat16, torch.float8_e4m3fn):
             want = ops.linear_fp8(xq, xs, wq, ws, b.to(d), epi, extra, out_dtype=od)
             got = ops.linear_fp8(xq, xs, wqp, ws, b.to(d), epi, extra, out_dtype=od, packed=True)
-            assert lib.mmdm_last_gemm_kernel().decode() == "gemm_fp8w<14,41>"          # fp8 packed: the 128 x 128 tile only
+            assert lib.mmdm_last_gemm_kernel().decode() == "gemm_fp8w<14,41>"
             it = {torch.float32: torch.int32, torch.bfloat16: torch.int16, torch.float8_e4m3fn: torch.int8}[od]
             assert torch.equal(got.view(it), want.view(it)), (epi, od)
+            if N % 256 == 0:            # the 128 x 256 form the large shards take (W fragments requested half a step ahead): same bits
+                lib.mmdmx_set_bf16_cfg(12)
+                try:
+                    wide = ops.linear_fp8(xq, xs, wqp, ws, b.to(d), epi, extra, out_dtype=od, packed=True)
+                    assert lib.mmdm_last_gemm_kernel().decode() == "gemm_fp8w<14,42>"
+                finally:
+                    lib.mmdmx_set_bf16_cfg(-1)
+                assert torch.equal(wide.view(it), want.view(it)), (epi, od, "128x256")
     with pytest.raises(Exception):
         ops.linear_bf16(xb, ops.pack_weight_frag(wb[:96].contiguous()), packed=True)       # N % 128
