@@ -3,6 +3,11 @@
 # (then: python tools/collect_bench.py $TAG, here).  usage: tools/bench_round.sh [tag, default r03]   (~15 minutes)
 TAG=${1:-r03}
 O=gpurun_out/bench_$TAG; rm -rf $O; mkdir -p $O
+# roofline.traffic needs the PMC traffic files of THESE sources: take them from a profile round that ran in the same call (tools/profile_round.sh)
+for pm in fp32: fp32_split:_fp32_split bf16_fp8:_bf16_fp8; do
+  f=gpurun_out/prof_$TAG/summary_${pm%%:*}/gemm_traffic.json
+  [ -f $f ] && cp $f profiles/gemm_traffic${pm##*:}.json
+done
 Q="--no-cpu-baseline --no-alt --no-full-loop"
 python bench.py > $O/default.json 2> $O/default.err                                    # the driver's command: headline + fp32_split + full loop + CPU port
 python bench.py --workload single $Q > $O/single.json 2> $O/single.err                  # configs[1]
