@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (same guide)
+PEAK_FP8_MFMA_TFLOPS = 5000.0     # MI355X dense fp8 peak: the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 the fp8 GEMMs issue (same guide)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X fp32 matrix peak (/opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters)
 
 
@@ -44,6 +45,12 @@ def main():
                     help="mixer = BASELINE configs[2] (2-person MixerMDM, the headline metric); single = configs[1] (single-person in2IN, T=196, B=32)")
     ap.add_argument("--batch", type=int, default=None, help="motions per GPU (weak scaling); default 16 (mixer) / 32 (single)")
     ap.add_argument("--frames", type=int, default=None, help="default 300 (mixer) / 196 (single)")
+    ap.add_argument("--sampler", default="ddim1000", help="sampling strategy (respacing of the 1000-step schedule): ddim1000 = the headline metric; "
+                    "ddim50 = what the reference's own callers run (src/models/mixermdm.py:19, src/scripts/infer/mixermdm.py:73: B=1, T=299, ddim50)")
+    ap.add_argument("--facade", action="store_true", help="build the sampler through the reference-API mirror (mixermdm_amd.models.MixerMDM, configs/models/*.yaml) and report "
+                    "`facade`: one whole MixerMDM.forward(batch) / forward_test(batch) -- what src/scripts/infer/mixermdm.py and the evaluation datasets call")
+    ap.add_argument("--no-whole-host", action="store_true", help="skip cpu_baseline.whole_host (k concurrent 16-thread B=1 oracle processes)")
+    ap.add_argument("--cpu-worker", nargs=4, metavar=("THREADS", "STEPS", "FRAMES", "DIR"), default=None, help=argparse.SUPPRESS)
     ap.add_argument("--precision", choices=["fp32", "fp32_split", "bf16", "bf16_fp8"], default="fp32",
                     help="fp32 = the parity path and the headline metric; bf16 / bf16_fp8 = BASELINE configs[4] path (bf16 GEMM operands, fp32 accumulate; "
                          "bf16_fp8: QKV / cross-attention input / FFN GEMMs on fp8 e4m3 operands)")
@@ -57,6 +64,8 @@ def main():
                                                              "the committed kernel traces hold the step's launches only)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks meet on gloo, time a barrier, rank 0 prints a line")
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(*args.cpu_worker)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Bare `python bench.py --gpus N`: start the N ranks as FRESH child processes (one per GPU) through torch.distributed.run and
@@ -102,27 +111,42 @@ def main():
     from mixermdm_amd.distributed import broadcast_state_dict
 
     single = args.workload == "single"
-    # motions per GPU: configs[2] = 16 on one GPU (the headline); configs[3] = 256 over 8 GPUs = 32 per GPU; configs[1] (single) = 32
-    B = args.batch or (32 if single else (32 if world == 8 else 16))
+    # motions per GPU: configs[2] = 16 on one GPU (the headline); configs[3] = 256 over 8 GPUs = 32 per GPU, and the same 32 per GPU at
+    # every N > 1 so that the points of a 2 / 4 / 8-GPU curve are one per-GPU workload (`per_gpu_batch` in the line); configs[1] (single) = 32
+    B = args.batch or (32 if single else (32 if world > 1 else 16))
     T = args.frames or (196 if single else 300)
-    S = 1000
     # weights: rank 0 draws them on the host, ONE RCCL broadcast of the packed 1.46 GB vector over xGMI (no other collective on the path)
     shapes = mixer_shapes(single_only=single, **FULL_DIMS)
     sd_cpu = synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, single_only=single, **FULL_DIMS) if rank == 0 else None
     sd = broadcast_state_dict(sd_cpu, shapes, src=0, device=device)
     stats = synthetic_stats()
-    smp = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, single_only=single, precision=args.precision, **FULL_DIMS)
-    smp.load_state_dict(sd)
-    if not single:
-        smp.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
-    smp.prepare()
-    smp.set_schedule("ddim1000")
+    model = None
+    if args.facade:
+        # the reference's own entry point: MixerMDM(cfg, num_frames, sampling_strategy) over configs/models/MixerMDM.yaml; the facade owns the
+        # Sampler (same handle type), so the timed region below is the same C call either way
+        if single:
+            raise SystemExit("--facade builds the two-person MixerMDM model (use --workload mixer)")
+        from mixermdm_amd.configs import get_config
+        from mixermdm_amd.models import MixerMDM
+        model = MixerMDM(get_config(os.path.join(ROOT, "configs", "models", "MixerMDM.yaml")), num_frames=T, sampling_strategy=args.sampler, config_root=ROOT)
+        model.precision = args.precision
+        model.load_state_dict({"mixing." + k: v for k, v in sd.items()})
+        model.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+        model = model.to(device).eval()
+        smp = model._sampler_for(B, T)
+    else:
+        smp = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, single_only=single, precision=args.precision, **FULL_DIMS)
+        smp.load_state_dict(sd)
+        if not single:
+            smp.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+        smp.prepare()
+    S = smp.set_schedule(args.sampler).num_timesteps
     del sd
     cond, xT = synthetic_inputs(B, T, seed_cond=1 + 1000 * rank, seed_x=2 + 1000 * rank, single=single)   # each rank = its own shard of the batch
     cond, xT = cond.to(device), xT.to(device)
     use_graph = not args.no_graph
     if args.warmup + args.steps > S:
-        raise SystemExit("warmup + steps must be <= 1000")
+        raise SystemExit("warmup + steps must be <= %d (the steps of %s)" % (S, args.sampler))
 
     def barrier():
         if dist.is_initialized():
@@ -150,29 +174,46 @@ def main():
 
     # dominant kernel: the fp32 MFMA GEMM -- live HIP-event timing of every launch, eager, on the handle's stream
     roof = None
-    if rank == 0 and args.profile_steps > 0 and args.warmup + args.steps + args.profile_steps <= S:
+    if rank == 0 and args.profile_steps > 0:
+        if args.warmup + args.steps + args.profile_steps > S:
+            smp.begin(cond, xT)          # a short schedule (ddim50): profile the first steps of a fresh call
         smp.profile(True)
-        smp.run(args.profile_steps, use_graph=False)
+        smp.run(min(args.profile_steps, S), use_graph=False)
         g_ms, g_n, g_fl, g_by = smp.profile_read(0)
         a_ms, a_n, a_fl, _ = smp.profile_read(1)
+        f_ms, f_n, f_fl, f_by = smp.profile_read(2)      # fp8-operand launches (bf16_fp8 only): their own class, their own peak
         smp.profile(False)
+        # fp32_split executes SIX bf16 MFMAs per algorithmic multiply-add block: its roof is the dense bf16 peak / 6.
+        # bf16_fp8: two kinds of launches.  The QKV / cross-attention input / FFN GEMMs issue the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4
+        # (e4m3 operands, unit E8M0 scales: twice the bf16 rate, 5 PFLOP/s dense) and are the dominant kernel: `achieved` / `peak` / `frac` are
+        # theirs.  The attention output projections and embeddings are bf16 launches priced against 2.5 PFLOP/s in `bf16_launches`;
+        # `frac_blended` = (time both classes would take at their own peaks) / (time they took).
+        peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 6, 1), "bf16_fp8": PEAK_FP8_MFMA_TFLOPS}[args.precision]
+        other = None
+        if args.precision == "bf16_fp8" and f_n:
+            b_ach = g_fl / (g_ms * 1e-3) / 1e12
+            other = {"achieved": round(b_ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(b_ach / PEAK_BF16_MFMA_TFLOPS, 4), "launches_per_step": g_n // args.profile_steps,
+                     "avg_launch_us": round(g_ms * 1e3 / g_n, 2), "ms_per_step": round(g_ms / args.profile_steps, 3)}
+            ideal_ms = (f_fl / PEAK_FP8_MFMA_TFLOPS + g_fl / PEAK_BF16_MFMA_TFLOPS) / 1e9
+            blended = {"frac_blended": round(ideal_ms / (f_ms + g_ms), 4), "all_gemm_tflops": round((f_fl + g_fl) / ((f_ms + g_ms) * 1e-3) / 1e12, 2),
+                       "all_gemm_frac_of_bf16_peak": round((f_fl + g_fl) / ((f_ms + g_ms) * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+            g_ms, g_n, g_fl, g_by = f_ms, f_n, f_fl, f_by
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        # fp32_split executes SIX bf16 MFMAs per algorithmic multiply-add block: its roof is the dense bf16 peak / 6
-        # bf16_fp8: the non-scaled fp8 MFMA (v_mfma_f32_32x32x16_fp8_fp8) issues at the bf16 rate on gfx950 (MI355X_MICROARCH.md, Matrix
-        # cores), and a third of the mode's GEMM launches are bf16: both priced against the dense bf16 peak
-        peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 6, 1), "bf16_fp8": PEAK_BF16_MFMA_TFLOPS}[args.precision]
         kname = {"fp32": "gemm_glds_kernel<..., PIPE_=1> (v_mfma_f32_32x32x2_f32; software-pipelined LDS-DMA ring: 128x128 tiles x 5 stages, 128x64 x 4 stages when N = 2048 or N, K <= 512; all instantiations of a step averaged)",
                  "bf16": "gemm_bf16w_kernel (v_mfma_f32_32x32x16_bf16; weights in MFMA fragment order fetched straight from global memory, A through three LDS-DMA stages, 128x256 tiles, K step 128 bytes)",
                  "fp32_split": "gemm_splitw_kernel (fp32 result from 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 operand splits; weights in MFMA fragment order fetched straight from global memory, 128x128 tiles, two workgroups per CU; peak = 2500/6 algorithmic TFLOP/s)",
-                 "bf16_fp8": "gemm_bf16_kernel<ET=1> (v_mfma_f32_32x32x16_fp8_fp8: e4m3 operands, per-row / per-output-channel scales, fp32 accumulate) "
-                             "+ gemm_bf16w_kernel (bf16, packed weights) for the attention output projections"}[args.precision]
+                 "bf16_fp8": "gemm_bf16w_kernel<ET=fp8> / gemm_bf16_kernel<ET=fp8> (v_mfma_scale_f32_32x32x64_f8f6f4: e4m3 operands, unit E8M0 block scales, per-row / "
+                             "per-output-channel scales in the epilogue, fp32 accumulate; packed weights straight from global memory where the shape allows)"}[args.precision]
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(single, args.precision),
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(single, args.precision, B, T),
                 "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1),
                 "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
                 "gflop_per_launch": round(g_fl / g_n / 1e9, 3), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
                 "attention": {"achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a_ms / args.profile_steps, 3),
                               "launches_per_step": a_n // args.profile_steps}}
+        if other:
+            roof["bf16_launches"] = other
+            roof.update(blended)
         try:
             roof["clock"] = None if args.no_clock else loop_clock(args.precision, 4 * B * T if not single else 2 * B * T, peak, ach)
         except Exception as e:          # a diagnostic next to the measurement, never a reason to lose the line
@@ -188,7 +229,7 @@ def main():
         alt_smp.load_state_dict(sd_cpu)
         alt_smp.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
         alt_smp.prepare()
-        alt_smp.set_schedule("ddim1000")
+        alt_smp.set_schedule(args.sampler)
         alt_smp.begin(cond, xT)
         alt_smp.run(args.warmup, use_graph)
         torch.cuda.synchronize()
@@ -206,15 +247,16 @@ def main():
                "achieved_tflops_algorithmic": round(algorithmic_flops_per_motion_step(T, single=single) * B / (a_ms * 1e-3) / 1e12, 2)}
         # its own roofline: live HIP-event pairs around every GEMM launch of an eager pass, against 2500 / 6 algorithmic TFLOP/s
         if args.profile_steps > 0:
+            alt_smp.begin(cond, xT)
             alt_smp.profile(True)
-            alt_smp.run(args.profile_steps, use_graph=False)
+            alt_smp.run(min(args.profile_steps, S), use_graph=False)
             g_ms, g_n, g_fl, g_by = alt_smp.profile_read(0)
             a2_ms, a2_n, a2_fl, _ = alt_smp.profile_read(1)
             alt_smp.profile(False)
             pk = round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
             ach2 = g_fl / (g_ms * 1e-3) / 1e12
             alt["roofline"] = {"bound": "mfma", "kernel": "gemm_splitw_kernel (fp32 result from 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 operand splits; packed weights straight from global memory, 128x128 tiles, two workgroups per CU)",
-                               "achieved": round(ach2, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach2 / pk, 4), "traffic": measured_traffic(single, "fp32_split"),
+                               "achieved": round(ach2, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach2 / pk, 4), "traffic": measured_traffic(single, "fp32_split", B, T),
                                "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1), "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
                                "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
                                "attention": {"achieved": round(a2_fl / (a2_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a2_ms / args.profile_steps, 3), "launches_per_step": a2_n // args.profile_steps}}
@@ -236,33 +278,57 @@ def main():
         if dist.is_initialized():
             dist.all_reduce(fl, op=dist.ReduceOp.MAX)
         wall = float(fl.item())
-        full = {"steps": S, "wall_s": round(wall, 3), "motions_per_s": round(world * B / wall, 5), "outputs_finite": bool(torch.isfinite(out).all().item())}
+        full = {"steps": S, "wall_s": round(wall, 3), "motions_per_s": round(world * B / wall, 5), "seconds_per_motion": round(wall / B, 4),
+                "outputs_finite": bool(torch.isfinite(out).all().item())}
         del out
+
+    # The reference's entry points end to end: MixerMDM.forward (src/scripts/infer/mixermdm.py:119-141: every history list of the 50 steps
+    # is kept) and forward_test (src/evaluation/datasets.py:101-116), text conditioning precomputed (`cond` in the batch: the CLIP tower is
+    # upstream of this path).  Second calls: the (B, T, S) graph and the workspace exist.
+    fac = None
+    if model is not None and rank == 0:
+        batch = {"cond": cond, "x_T": xT, "motion_lens": torch.full((B, 1), T, dtype=torch.long)}
+        fac = {}
+        for name, fn in (("forward_test", model.forward_test), ("forward", model.forward)):
+            fn(batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            o = fn(batch)
+            torch.cuda.synchronize()
+            w = time.perf_counter() - t1
+            fac[name] = {"wall_s": round(w, 4), "seconds_per_motion": round(w / B, 4), "outputs_finite": bool(torch.isfinite(o["output"]).all().item()),
+                         "history_lists": {k: len(v) for k, v in o.items() if k != "output"}}
+            del o
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:       # reported at N=1 only (the other ranks of an N>1 run would idle behind it)
-        cpu = cpu_baseline(sd_cpu, stats, T, args.cpu_steps, single)
+        cpu = cpu_baseline(sd_cpu, stats, T, args.cpu_steps, single, args.sampler, S, B, whole_host=not args.no_whole_host)
 
     if rank == 0:
         flops = algorithmic_flops_per_motion_step(T, single=single)
         value = world * B / (ms_per_step * 1e-3 * S)
-        wl = ("BASELINE configs[1]: single-person in2IN (individual denoiser, CFG 3.5), T=%d, ddim1000 (eta=0), batch %d per GPU, %s, random-init weights" % (T, B, args.precision)) if single else \
+        which = "configs[1]" if single else ("configs[3] (batch 256 over 8 GPUs = 32 per GPU)" if world == 8 and B == 32 else
+                                             "configs[3]'s per-GPU shard (32) on %d GPU(s)" % world if B == 32 else "configs[2]" if (B, T, args.sampler) == (16, 300, "ddim1000") else
+                                             "the reference's own caller shape (src/scripts/infer/mixermdm.py:73,117-124; src/evaluation/datasets.py:58,100-116)" if args.sampler == "ddim50" else "configs[2] shape family")
+        wl = ("BASELINE configs[1]: single-person in2IN (individual denoiser, CFG 3.5), T=%d, %s (eta=0), batch %d per GPU, %s, random-init weights" % (T, args.sampler, B, args.precision)) if single else \
              ("BASELINE %s: 2-person MixerMDM (in2IN individual + in2IN interaction + Mixer mode 4, align, CFG 3.5), "
-              "T=%d, ddim1000 (eta=0), batch %d per GPU, %s, random-init weights" % ("configs[3] (batch 256 over 8 GPUs = 32 per GPU)" if world == 8 and B == 32 else "configs[2]", T, B, {"fp32": "fp32", "fp32_split": "fp32 via exact 3-way bf16 operand split (six bf16 MFMAs per product)", "bf16": "bf16 GEMM operands / fp32 accumulate (configs[4]-style)", "bf16_fp8": "configs[4]: bf16 path with fp8 e4m3 QKV / FFN GEMM operands, fp32 accumulate"}[args.precision]))
+              "T=%d, %s (eta=0), batch %d per GPU, %s, random-init weights" % (which, T, args.sampler, B, {"fp32": "fp32", "fp32_split": "fp32 via exact 3-way bf16 operand split (six bf16 MFMAs per product)", "bf16": "bf16 GEMM operands / fp32 accumulate (configs[4]-style)", "bf16_fp8": "configs[4]: bf16 path with fp8 e4m3 QKV / FFN GEMM operands, fp32 accumulate"}[args.precision]))
         line = {
-            "metric": "generated motions/sec (1000-step DDPM schedule sampled with DDIM eta=0, T=%d, %s)" % (T, "single-person" if single else "2-person"),
+            "metric": "generated motions/sec (1000-step DDPM schedule sampled with DDIM eta=0%s, T=%d, %s)" % ("" if S == 1000 else " on %d respaced steps (%s)" % (S, args.sampler), T, "single-person" if single else "2-person"),
             "value": round(value, 5), "unit": "motions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "ms_per_step_ranks": rank_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32_split": "f32 (3xbf16 exact operand split, fp32 accumulate)", "bf16": "bf16", "bf16_fp8": "bf16 + fp8 e4m3 QKV/FFN operands"}[args.precision], "data": "synthetic",
             "config": {"workload": wl,
-                       "batch_per_gpu": B, "frames": T, "sampler_steps": S, "hipgraph": use_graph, "parallelism": "batch-sharded x%d, no in-loop collective" % world},
+                       "batch_per_gpu": B, "frames": T, "sampler": args.sampler, "sampler_steps": S, "hipgraph": use_graph, "parallelism": "batch-sharded x%d, no in-loop collective" % world},
+            "per_gpu_batch": B,
             "achieved_tflops_algorithmic": round(flops * B * world / (ms_per_step * 1e-3) / 1e12, 2),
             "frac_of_f32_mfma_peak": round(flops * B / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if args.precision in ("fp32", "fp32_split") else None,
             "outputs_finite": finite,
-            "full_loop": full, "roofline": roof, "cpu_baseline": cpu, "fp32_split": alt,
+            "full_loop": full, "facade": fac, "roofline": roof, "cpu_baseline": cpu, "fp32_split": alt,
         }
         print(json.dumps(line), flush=True)
-    smp.close()
+    if model is None:
+        smp.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -283,16 +349,18 @@ def loop_clock(precision, M, peak, achieved):
     x = torch.randn(M, K, device=d); w = torch.randn(N, K, device=d) / K ** 0.5; b = torch.randn(N, device=d)
     if precision == "fp32":
         call = lambda: ops.linear(x, w, b)
-        lib.mmdmx_set_gemm_tail(0)          # one launch per call: the stamps are indexed by workgroup (the single-chain samplers split the last round off)
-        for _ in range(300):
-            call()
         # 10 words per workgroup (8 stamps + 2 cycle counters), sized for the smallest tile the dispatch can pick (64 x 64): the stamping
         # kernel writes without a bound check, so the buffer must cover every workgroup of this launch
         buf = torch.zeros(10 * ((M + 63) // 64) * ((N + 63) // 64), dtype=torch.int64, device=d)
-        lib.mmdmx_set_gemm_stamps(C.c_void_p(buf.data_ptr()))
-        call(); torch.cuda.synchronize()
-        lib.mmdmx_set_gemm_stamps(C.c_void_p(0))
-        lib.mmdmx_set_gemm_tail(-1)
+        lib.mmdmx_set_gemm_tail(0)          # one launch per call: the stamps are indexed by workgroup (the single-chain samplers split the last round off)
+        try:
+            for _ in range(300):
+                call()
+            lib.mmdmx_set_gemm_stamps(C.c_void_p(buf.data_ptr()))
+            call(); torch.cuda.synchronize()
+        finally:                            # the library's diagnostic switches are process-global: put them back whatever happened
+            lib.mmdmx_set_gemm_stamps(C.c_void_p(0))
+            lib.mmdmx_set_gemm_tail(-1)
         kern = lib.mmdm_last_gemm_kernel().decode()
         tm_, tn_ = [int(v) for v in re.search(r"<(\d+),(\d+)", kern).groups()]
         bm, bn = 32 * (tm_ // 10) * (tm_ % 10), 32 * (tn_ // 10) * (tn_ % 10)
@@ -312,9 +380,11 @@ def loop_clock(precision, M, peak, achieved):
         n = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
         buf = torch.zeros(n * waves * 8, dtype=torch.int64, device=d)
         lib.mmdmx_set_split_timeline.argtypes = [C.c_void_p]
-        lib.mmdmx_set_split_timeline(C.c_void_p(buf.data_ptr()))
-        call(); torch.cuda.synchronize()
-        lib.mmdmx_set_split_timeline(None)
+        try:
+            lib.mmdmx_set_split_timeline(C.c_void_p(buf.data_ptr()))
+            call(); torch.cuda.synchronize()
+        finally:
+            lib.mmdmx_set_split_timeline(None)
         t = buf.view(n * waves, 8).double().cpu()
         mhz = (100.0 * t[:, 7] / t[:, 6].clamp(min=1)).median().item()
     pk = peak * mhz / 2400.0
@@ -323,42 +393,52 @@ def loop_clock(precision, M, peak, achieved):
                    "`peak` above is the guide's 2.4 GHz figure" % (M, N, K)}
 
 
-def measured_traffic(single, precision="fp32"):
+def measured_traffic(single, precision="fp32", B=16, T=300):
     """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this workload and precision mode (profiles/gemm_traffic.json
     for fp32, profiles/gemm_traffic_<mode>.json otherwise; written by tools/pmc_summary.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streams on gfx950).  bench.py cannot collect PMC counters
-    itself.  The artefact records the hash of the kernel sources it was measured on: null when it is absent, for another workload, or
-    was taken on different kernel sources than the ones this run executes."""
+    itself.  The artefact records the hash of the kernel sources AND the workload (motions per GPU, frames) it was measured on: null when it
+    is absent, was taken at another batch / length (bytes per launch scale with M = rows of the batch), or on other kernel sources than the
+    ones this run executes."""
     from mixermdm_amd.build import sources_sha
     path = os.path.join(ROOT, "profiles", "gemm_traffic.json" if precision == "fp32" else "gemm_traffic_%s.json" % precision)
     if single or not os.path.exists(path):
         return None
     with open(path) as f:
         rec = json.load(f)
+    if (rec.get("batch", 16), rec.get("frames", 300)) != (B, T):
+        return None
     if rec.get("kernel_sources_sha") != sources_sha(precision):
         print("bench.py: %s was measured on other kernel sources (%s != %s): roofline.traffic = null" % (os.path.basename(path), rec.get("kernel_sources_sha"), sources_sha(precision)), file=sys.stderr)
         return None
     return rec["traffic_bytes_per_launch"]
 
 
-def cpu_baseline(sd_cpu, stats, T, nsteps, single=False):
-    """The oracle (a PyTorch-CPU port of the reference path, parity-pinned by tests/golden) timed on this host's cores:
-    `nsteps` consecutive DDIM steps at B=1 after one untimed step, extrapolated to the 1000-step loop."""
-    import torch
-    from oracle import mixer as MX, schedule as OS
+def _oracle_mixer(sd_cpu, stats):
+    from oracle import mixer as MX
     from oracle.layers import pe_table
-    from mixermdm_amd.synthetic import synthetic_inputs
-    if single:
-        return cpu_baseline_single(sd_cpu, T, nsteps)
     W = dict(sd_cpu)
     W["sequence_pos_encoder.pe"] = pe_table(512)
     W["denoiser1.sequence_pos_encoder.pe"] = pe_table(1024)
     W["denoiser2.sequence_pos_encoder.pe"] = pe_table(1024)
-    ostats = (stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
-    sch = OS.make_schedule("cosine", 1000, "ddim1000")
-    spec = MX.MixerSpec(d_heads=8, m_heads=8)
+    return W, (stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"]), MX.MixerSpec(d_heads=8, m_heads=8)
+
+
+def cpu_baseline(sd_cpu, stats, T, nsteps, single=False, strategy="ddim1000", S=1000, B_gpu=16, whole_host=True):
+    """The oracle (a PyTorch-CPU port of the reference path, parity-pinned by tests/golden) timed on this host's cores at B=1 on the SAME
+    workload (frames, sampling strategy): a short schedule (ddim50: the reference's own callers) is run IN FULL, the 1000-step schedule is
+    sampled -- `nsteps` consecutive DDIM steps after the thread-count calibration -- and extrapolated.  `whole_host`: the host's motions/s
+    when it runs k = host_threads / 32 such processes side by side (one process uses 16 of the box's threads)."""
+    import torch
+    from oracle import mixer as MX, schedule as OS
+    from mixermdm_amd.synthetic import synthetic_inputs
+    if single:
+        return cpu_baseline_single(sd_cpu, T, nsteps, strategy, S)
+    W, ostats, spec = _oracle_mixer(sd_cpu, stats)
+    sch = OS.make_schedule("cosine", 1000, strategy)
     cond, xT = synthetic_inputs(1, T)
     x, x2 = xT.clone(), xT.clone()
+    threads0 = torch.get_num_threads()
     with torch.no_grad():
         # thread-count calibration (one untimed step each): B=1 GEMMs are small, all cores is not always the fastest
         ncpu = os.cpu_count() or 1
@@ -368,58 +448,146 @@ def cpu_baseline(sd_cpu, stats, T, nsteps, single=False):
         for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
             torch.set_num_threads(nt)
             t0 = time.perf_counter()
-            MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 999, x, x2, cond)
+            MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, S - 1, x, x2, cond)
             dt1 = time.perf_counter() - t0
             calib[nt] = dt1
             if dt1 < best[1]:
                 best = (nt, dt1)
         torch.set_num_threads(best[0])
-        x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 999, x, x2, cond)
-        t0 = time.perf_counter()
-        for k in range(nsteps):
-            x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 998 - k, x, x2, cond)
-        dt = (time.perf_counter() - t0) / nsteps
-        # SURVEY 8d also asks the GPU's own batch on the CPU: B = 16 is one more calibration (the larger GEMMs want more threads) and two
-        # timed steps, extrapolated x1000 like the B = 1 figure; it says how much batch efficiency the CPU gets (the GPU needs the batch, the CPU barely gains)
-        b16 = None
-        if nsteps >= 4:
+        full = S * best[1] <= 45.0                    # the whole loop fits the bench's time box: time THE workload, not a sample of it
+        if full:
+            t0 = time.perf_counter()
+            for i in range(S - 1, -1, -1):
+                x, x2, _, p2 = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, i, x, x2, cond)
+            wall = time.perf_counter() - t0
+            dt, n_timed = wall / S, S
+        else:
+            x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, S - 1, x, x2, cond)
+            t0 = time.perf_counter()
+            for k in range(nsteps):
+                x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, S - 2 - k, x, x2, cond)
+            dt, n_timed = (time.perf_counter() - t0) / nsteps, nsteps
+        # SURVEY 8d also asks the GPU's own batch on the CPU: one untimed step (first touch, allocations), then one timed step at B = 16 on 32
+        # threads (64 measured slower: 25.4 vs 15.9 s), extrapolated like the B = 1 figure; it says how much batch efficiency the CPU gets
+        bN = None
+        if nsteps >= 4 and not full and B_gpu >= 16:
             c16, x16 = synthetic_inputs(16, T)
-            runs = {}
-            for nt in sorted({min(ncpu, c) for c in (32, 64)}):      # one step each (13 s on a 256-thread host): the faster one is the sample
-                torch.set_num_threads(nt)
-                t0 = time.perf_counter()
-                MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, 999, x16, x16, c16)
-                runs[nt] = time.perf_counter() - t0
-            nt16 = min(runs, key=runs.get)
-            b16 = {"s_per_step": round(runs[nt16], 3), "cores": nt16, "motions_per_s": round(16.0 / (runs[nt16] * 1000), 7),
-                   "sample": "one DDIM step at B=16 (the GPU's batch) on %s threads each (%s), the faster one extrapolated x1000 steps"
-                             % (" / ".join(str(k) for k in sorted(runs)), ", ".join("%d thr %.1f s" % kv for kv in sorted(runs.items())))}
-    return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": best[0], "host_threads": ncpu, "kind": "port",
-            "sample": "%d consecutive DDIM steps (i=998..) of the same workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), "
-                      "%.3f s/step, extrapolated x1000 steps; thread count calibrated over {8, 16, 32, 64} of the host's %d hardware threads: %d fastest (one step: %s)"
-                      % (nsteps, T, torch.__version__, dt, ncpu, best[0], ", ".join("%d thr %.2f s" % kv for kv in sorted(calib.items()))),
-            "s_per_step_b1": round(dt, 4), "b16": b16}
+            nt16 = min(ncpu, 32)
+            torch.set_num_threads(nt16)
+            MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, S - 1, x16, x16, c16)
+            t0 = time.perf_counter()
+            MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, S - 2, x16, x16, c16)
+            d16 = time.perf_counter() - t0
+            bN = {"s_per_step": round(d16, 3), "cores": nt16, "motions_per_s": round(16.0 / (d16 * S), 7),
+                  "sample": "the second of two DDIM steps at B=16 (the GPU's batch) on %d threads, extrapolated x%d steps" % (nt16, S)}
+        torch.set_num_threads(best[0])
+    out = {"value": round(1.0 / (dt * S), 7), "unit": "motions/s", "cores": best[0], "host_threads": ncpu, "kind": "port",
+           "sample": ("the WHOLE %s loop (%d DDIM steps) of the same workload at B=1, T=%d on the host CPU (PyTorch %s, fp32): %.2f s, %.3f s/step" % (strategy, S, T, torch.__version__, dt * S, dt)
+                      if full else "%d consecutive DDIM steps (i=%d..) of the same workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), %.3f s/step, extrapolated x%d steps"
+                      % (n_timed, S - 2, T, torch.__version__, dt, S)) +
+                     "; thread count calibrated over {8, 16, 32, 64} of the host's %d hardware threads: %d fastest (one step: %s)"
+                     % (ncpu, best[0], ", ".join("%d thr %.2f s" % kv for kv in sorted(calib.items()))),
+           "s_per_step_b1": round(dt, 4), "seconds_per_motion": round(dt * S, 3), "extrapolated": not full, "b16": bN}
+    if whole_host:
+        try:
+            out["whole_host"] = cpu_whole_host(T, ncpu, S, strategy)
+        except Exception as e:          # a side measurement: never a reason to lose the line
+            out["whole_host"] = {"error": repr(e)}
+    torch.set_num_threads(threads0)
+    return out
 
 
-def cpu_baseline_single(sd_cpu, T, nsteps):
+def cpu_whole_host(T, ncpu, S, strategy, threads=16, steps=2):
+    """k = host_threads / 32 concurrent oracle processes of `threads` threads each (one B=1 chain per process, as a user of the reference
+    would fill the host): every worker draws the same synthetic weights, runs one untimed step, waits for the others, then times `steps`
+    DDIM steps.  Host motions/s = sum over workers of 1 / (S x its s/step)."""
+    import tempfile
+    k = max(1, ncpu // 32)
+    d = tempfile.mkdtemp(prefix="mmdm_cpu_")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(threads), str(steps), str(T), os.path.join(d, "w%d" % i)],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS=str(threads), MMDM_CPU_STRATEGY=strategy,
+                                                                                           HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")) for i in range(k)]
+    t0 = time.perf_counter()
+    try:
+        while not all(os.path.exists(os.path.join(d, "w%d.ready" % i)) for i in range(k)):
+            if any(p.poll() not in (None, 0) for p in procs) or time.perf_counter() - t0 > 240:
+                raise RuntimeError("a cpu worker failed or did not get ready in 240 s")
+            time.sleep(0.2)
+        open(os.path.join(d, "go"), "w").close()
+        for p in procs:
+            p.wait(timeout=240)
+        per = [json.load(open(os.path.join(d, "w%d.json" % i)))["s_per_step"] for i in range(k)]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    return {"processes": k, "threads_each": threads, "s_per_step": [round(v, 3) for v in per], "motions_per_s": round(sum(1.0 / (v * S) for v in per), 7),
+            "sample": "%d concurrent B=1 oracle processes x %d threads (= %d of the host's %d hardware threads), %d timed DDIM steps each after one untimed step and a "
+                      "start barrier, extrapolated x%d steps" % (k, threads, k * threads, ncpu, steps, S)}
+
+
+def cpu_worker(threads, steps, frames, path):
+    """One process of cpu_whole_host (hidden --cpu-worker mode; never touches a GPU)."""
+    import torch
+    from oracle import mixer as MX, schedule as OS
+    from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_stats, synthetic_inputs, FULL_DIMS
+    threads, steps, T = int(threads), int(steps), int(frames)
+    torch.set_num_threads(threads)
+    W, ostats, spec = _oracle_mixer(synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, **FULL_DIMS), synthetic_stats())
+    sch = OS.make_schedule("cosine", 1000, os.environ.get("MMDM_CPU_STRATEGY", "ddim1000"))
+    S = sch.num_timesteps
+    cond, xT = synthetic_inputs(1, T)
+    with torch.no_grad():
+        x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, S - 1, xT, xT.clone(), cond)
+        open(path + ".ready", "w").close()
+        go = os.path.join(os.path.dirname(path), "go")
+        t0 = time.perf_counter()
+        while not os.path.exists(go):
+            if time.perf_counter() - t0 > 240:
+                raise SystemExit(1)
+            time.sleep(0.05)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            x, x2, _, _ = MX.mixer_ddim_step(W, spec, ostats, sch, 3.5, S - 2 - k, x, x2, cond)
+        dt = (time.perf_counter() - t0) / steps
+    with open(path + ".json", "w") as f:
+        json.dump({"s_per_step": dt, "threads": threads}, f)
+
+
+def cpu_baseline_single(sd_cpu, T, nsteps, strategy="ddim1000", S=1000):
+    """configs[0] / configs[1] on the CPU: the single-person in2IN sampler at B=1.  A short schedule (configs[0]: T=120, ddim50) is timed in
+    full, the 1000-step one is sampled and extrapolated."""
     import torch
     from oracle import mixer as MX, schedule as OS
     from oracle.layers import pe_table
     from mixermdm_amd.synthetic import synthetic_inputs
     W = dict(sd_cpu)
     W["denoiser1.sequence_pos_encoder.pe"] = pe_table(1024)
-    sch = OS.make_schedule("cosine", 1000, "ddim1000")
+    sch = OS.make_schedule("cosine", 1000, strategy)
     cond, x = synthetic_inputs(1, T, single=True)
     step = lambda i, x: MX.ddim_update(sch, i, x, MX.cfg_single(W, "denoiser1.", "individual", 3.5, x, torch.full((1,), sch.timestep_map[i], dtype=torch.long), cond, 8))
     with torch.no_grad():
-        x = step(999, x)
         t0 = time.perf_counter()
-        for k in range(nsteps):
-            x = step(998 - k, x)
-        dt = (time.perf_counter() - t0) / nsteps
-    return {"value": round(1.0 / (dt * 1000), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "host_threads": os.cpu_count(), "kind": "port",
-            "sample": "%d consecutive DDIM steps of the single-person workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), %.3f s/step, extrapolated x1000 steps" % (nsteps, T, torch.__version__, dt),
-            "s_per_step_b1": round(dt, 4)}
+        x = step(S - 1, x)
+        d0 = time.perf_counter() - t0
+        full = S * d0 <= 45.0
+        t0 = time.perf_counter()
+        if full:
+            x = synthetic_inputs(1, T, single=True)[1]
+            for i in range(S - 1, -1, -1):
+                x = step(i, x)
+            n_timed = S
+        else:
+            for k in range(nsteps):
+                x = step(S - 2 - k, x)
+            n_timed = nsteps
+        dt = (time.perf_counter() - t0) / n_timed
+    return {"value": round(1.0 / (dt * S), 7), "unit": "motions/s", "cores": torch.get_num_threads(), "host_threads": os.cpu_count(), "kind": "port",
+            "sample": ("the WHOLE %s loop (%d DDIM steps) of the single-person workload at B=1, T=%d on the host CPU (PyTorch %s, fp32): %.2f s" % (strategy, S, T, torch.__version__, dt * S)) if full else
+                      ("%d consecutive DDIM steps of the single-person workload at B=1, T=%d on the host CPU (PyTorch %s, fp32), %.3f s/step, extrapolated x%d steps" % (nsteps, T, torch.__version__, dt, S)),
+            "s_per_step_b1": round(dt, 4), "seconds_per_motion": round(dt * S, 3), "extrapolated": not full}
 
 
 if __name__ == "__main__":

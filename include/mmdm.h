@@ -394,7 +394,8 @@ int mmdm_module_forward(mmdm_handle h, int which, const float* x, const float* x
                         float* out, int n, int T, void* stream);
 
 /* Live kernel timing for bench.py: wraps hipEvents on `stream` around every launch of the kernel class `which`
- * (0 = linear/GEMM, 1 = attention) during mmdm_run(use_graph=0) and accumulates. */
+ * (0 = linear/GEMM on fp32 / bf16 / split operands, 1 = attention, 2 = fp8-operand GEMMs of precision 3 -- priced against their own
+ * matrix peak) during mmdm_run(use_graph=0) and accumulates. */
 int mmdm_profile_enable(mmdm_handle h, int on);
 int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launches, double* flops, double* algorithmic_bytes);
 

@@ -135,12 +135,11 @@ struct Scratch {          // transformer-stack work buffers (one set per concurr
 
 struct Prof {
     bool on = false;
-    std::vector<hipEvent_t> ev[2];               // pairs (start, stop) per launch, per class
-    size_t used[2] = {0, 0};
-    double flops[2] = {0, 0};
-    double bytes[2] = {0, 0};                    // algorithmic bytes (operands read once + result written once)
-    double ms[2] = {0, 0};
-    int64_t launches[2] = {0, 0};
+    static constexpr int NCLS = 3;               // 0: GEMMs (every operand type but fp8), 1: attention, 2: fp8-operand GEMMs (precision 3)
+    std::vector<hipEvent_t> ev[NCLS];            // pairs (start, stop) per launch, per class
+    size_t used[NCLS] = {0, 0, 0};
+    double flops[NCLS] = {0, 0, 0};
+    double bytes[NCLS] = {0, 0, 0};              // algorithmic bytes (operands read once + result written once)
 };
 
 }  // namespace
@@ -464,9 +463,9 @@ int linear_b(const Ctx& c, const void* A, int lda, const void* W, int ldw, const
 // fp8-operand GEMM (precision == 3): A fp8 + per-row scales (nullptr = unit), W fp8 + per-output-channel scales (gemm_bf16.hip, ET = 1)
 int linear_8(const Ctx& c, const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, const float* bias, void* C, int ldc,
              int out_mode, int M, int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second(), float a_const = 1.f, float out_scale = 1.f) {
-    RC(prof_begin(c, 0, 2.0 * M * N * K, 1.0 * ((double)M * K + (double)N * K) + (out_mode == 0 ? 4.0 : out_mode == 1 ? 2.0 : 1.0) * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
+    RC(prof_begin(c, 2, 2.0 * M * N * K, 1.0 * ((double)M * K + (double)N * K) + (out_mode == 0 ? 4.0 : out_mode == 1 ? 2.0 : 1.0) * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
     RC(mmdm_linear_fp8_ex(A, lda, a_scale, W, ldw, w_scale, bias, C, ldc, out_mode, M, N, K, epi, extra, ld_extra, 0, s2.p, s2.ld, s2.cols, a_const, out_scale, c.st));
-    return prof_end(c, 0);
+    return prof_end(c, 2);
 }
 
 // fp32-split GEMM (precision == 2): A and W as three bf16 planes, fp32 accuracy on the bf16 matrix cores (gemm_split.hip)
@@ -1080,7 +1079,7 @@ extern "C" void mmdm_destroy(mmdm_handle h) {
     if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->st2) (void)hipStreamDestroy(h->st2);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < Prof::NCLS; ++k)
         for (hipEvent_t e : h->prof.ev[k]) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     if (cur >= 0 && cur != h->device) (void)hipSetDevice(cur);
@@ -1519,12 +1518,12 @@ extern "C" int mmdm_profile_enable(mmdm_handle h, int on) {
     if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_profile_enable: null handle");
     h->prof.on = on != 0;
     if (on)
-        for (int k = 0; k < 2; ++k) { h->prof.used[k] = 0; h->prof.flops[k] = 0; h->prof.bytes[k] = 0; h->prof.ms[k] = 0; h->prof.launches[k] = 0; }
+        for (int k = 0; k < Prof::NCLS; ++k) { h->prof.used[k] = 0; h->prof.flops[k] = 0; h->prof.bytes[k] = 0; }
     return MMDM_OK;
 }
 
 extern "C" int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launches, double* flops, double* bytes) {
-    if (!h || which < 0 || which > 1) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_profile_read: bad argument");
+    if (!h || which < 0 || which >= Prof::NCLS) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_profile_read: bad argument");
     Prof& p = h->prof;
     HIPCHK(hipDeviceSynchronize());
     double ms = 0;

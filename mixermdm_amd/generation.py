@@ -42,8 +42,13 @@ def generate_one_sample(model, batch, name, save_folder, window_size=299):
     return motion
 
 
-def generate_for_evaluation(model, items, max_length=300, mm_idxs=(), mm_num_repeats=1, normalizer=None, extended=True):
+def generate_for_evaluation(model, items, max_length=300, mm_idxs=(), mm_num_repeats=1, normalizer=None, extended=True, shard_items=False):
     """Generation loop of the evaluation datasets (datasets.py:71-163).
+
+    shard_items=True under an initialised torch.distributed process group (one process per GPU): the items are dealt round-robin to the
+    ranks, every rank generates its own (no collective during sampling), and the per-item results are merged in item order on every
+    rank -- the 8 GPUs of a node do one evaluation pass instead of 8 identical ones.  x_T must then come from the items (or differ by
+    rank seed): each rank draws its own noise, as independent evaluation items do in the reference.
 
     items: iterable of dicts with 'text' (tuple/list of str), 'motion_lens' (LongTensor [1]), optionally
     'text_individual1/2', and -- since the CLIP tower is upstream -- optionally a precomputed 'cond' [1, 8*768].
@@ -51,8 +56,15 @@ def generate_for_evaluation(model, items, max_length=300, mm_idxs=(), mm_num_rep
     """
     generated, mm_generated = [], []
     mm_idxs = set(mm_idxs)
+    if shard_items:
+        from . import distributed as D
+        items = list(items)
+        mine = set(D.shard_items(len(items)))
+        gen_l, mm_l = {}, {}
     with torch.no_grad():
         for i, data in enumerate(items):
+            if shard_items and i not in mine:
+                continue
             rep = mm_num_repeats if i in mm_idxs else 1
             batch = {"text": list(data["text"]) * rep, "motion_lens": data["motion_lens"]}
             if extended:
@@ -71,10 +83,21 @@ def generate_for_evaluation(model, items, max_length=300, mm_idxs=(), mm_num_rep
             sub = {"motion1": motions[0, :, 0], "motion2": motions[0, :, 1], "motion_lens": data["motion_lens"][0], "text": data["text"][0]}
             if extended:
                 sub.update(text_individual1=data["text_individual1"][0], text_individual2=data["text_individual2"][0])
-            generated.append(sub)
+            if shard_items:
+                gen_l[i] = sub
+            else:
+                generated.append(sub)
             if i in mm_idxs:
                 mm = {"mm_motions": motions, "motion_lens": data["motion_lens"][0], "text": data["text"][0]}
                 if extended:
                     mm.update(text_individual1=data["text_individual1"][0], text_individual2=data["text_individual2"][0])
-                mm_generated.append(mm)
+                if shard_items:
+                    mm_l[i] = mm
+                else:
+                    mm_generated.append(mm)
+    if shard_items:
+        generated = D.gather_items(gen_l, len(items))
+        order = sorted(j for j in mm_idxs if j < len(items))
+        merged = D.gather_items({order.index(j): v for j, v in mm_l.items()}, len(order))
+        mm_generated = merged
     return generated, mm_generated

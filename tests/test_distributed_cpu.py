@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from mixermdm_amd.distributed import shard_range, broadcast_state_dict, scatter_requests, gather_motions
+from mixermdm_amd.distributed import shard_range, broadcast_state_dict, scatter_requests, gather_motions, sample_sharded, shard_items
 from mixermdm_amd.synthetic import mixer_shapes, synthetic_state_dict
 
 DIMS = dict(d_latent=16, d_ff=32, d_layers=1, m_latent=16, m_ff=32, m_layers=1)
@@ -44,6 +44,98 @@ def _worker(rank, world, port, batches, out_dir):
         assert (only1 is None) == (rank != 1) and (only1 is None or torch.equal(only1, full))
     dist.barrier()
     dist.destroy_process_group()
+
+
+class _StubModel:
+    """The facade's calling convention (mixermdm_amd.models.MixerMDM: .device, .nfeats, generate_cond, forward / forward_test returning the
+    reference's dictionary) with the denoising loop replaced by a deterministic per-row function: what sample_sharded moves around."""
+    nfeats = 262
+    device = torch.device("cpu")
+    steps = 3
+
+    def generate_cond(self, batch):
+        return batch["cond"]
+
+    def _hist(self, out, width):
+        b = out.shape[0]
+        rows = torch.cat([out[..., :width], -out[..., :width]], dim=0)           # cond rows, then uncond rows (quirk 12)
+        return [rows + k for k in range(self.steps)]
+
+    def forward_test(self, batch):
+        assert batch["cond"].shape[0] == batch["x_T"].shape[0] == batch["motion_lens"].shape[0] > 0
+        out = _row_fn(batch["cond"], batch["x_T"])
+        return {"output": out, "influence_i1": self._hist(out, 262), "influence_i2": self._hist(out * 3, 262)}
+
+    def forward(self, batch):
+        d = self.forward_test(batch)
+        out = d["output"]
+        d.update(out1=self._hist(out, 524), out2=self._hist(out + 1, 524), out_influenced=self._hist(out + 2, 524))
+        return d
+
+
+def _sharded_worker(rank, world, port, batches, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _StubModel()
+    for B in batches:
+        g = torch.Generator().manual_seed(11)
+        batch = {"cond": torch.randn(B, 8, generator=g), "x_T": torch.randn(B, 5, 524, generator=g), "motion_lens": torch.full((B, 1), 5)} if rank == 0 else None
+        full = sample_sharded(m, batch, fn="forward", owner=0, histories=True)                       # every rank receives everything
+        torch.save(full, os.path.join(out_dir, f"S{B}_r{rank}.pt"))
+        only = sample_sharded(m, batch, fn="forward_test", owner=0, gather_to=1)                     # only rank 1 receives; no histories asked
+        assert (only is None) == (rank != 1)
+        if only is not None:
+            assert torch.equal(only["output"], full["output"]) and only["influence_i1"] == []
+    # the evaluation loop, items dealt round-robin (generate_for_evaluation(shard_items=True))
+    from mixermdm_amd.generation import generate_for_evaluation
+    items = [{"text": ("t%d" % i,), "text_individual1": ("a%d" % i,), "text_individual2": ("b%d" % i,), "motion_lens": torch.tensor([4 + i % 3]),
+              "cond": torch.full((1, 8), float(i)), } for i in range(5)]
+
+    class _Eval(_StubModel):
+        def forward_test(self, batch):
+            B, T = batch["cond"].shape[0], int(batch["motion_lens"][0])
+            x = torch.arange(T * 524, dtype=torch.float32).reshape(1, T, 524).repeat(B, 1, 1)
+            return {"output": _row_fn(batch["cond"], x)}
+    assert shard_items(5) == list(range(rank, 5, world))
+    gen, mm = generate_for_evaluation(_Eval(), items, max_length=8, mm_idxs=(1, 4), mm_num_repeats=2, shard_items=True)
+    torch.save((gen, mm), os.path.join(out_dir, f"E_r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_facade_level_sharded_sampling_and_item_sharded_evaluation(tmp_path):
+    """sample_sharded / generate_for_evaluation(shard_items=True) on two gloo ranks against the unsharded calls: even, ragged and
+    fewer-motions-than-ranks requests; outputs and gathered history lists in the reference's [2B, T, C] row order."""
+    import numpy as np
+    batches = [4, 3, 1]
+    mp.spawn(_sharded_worker, args=(2, _free_port(), batches, str(tmp_path)), nprocs=2, join=True)
+    m = _StubModel()
+    for B in batches:
+        g = torch.Generator().manual_seed(11)
+        batch = {"cond": torch.randn(B, 8, generator=g), "x_T": torch.randn(B, 5, 524, generator=g), "motion_lens": torch.full((B, 1), 5)}
+        ref = m.forward(batch)
+        for r in range(2):
+            got = torch.load(os.path.join(tmp_path, f"S{B}_r{r}.pt"))
+            assert torch.equal(got["output"], ref["output"])
+            for nm in ("influence_i1", "influence_i2", "out1", "out2", "out_influenced"):
+                assert len(got[nm]) == len(ref[nm]) and all(torch.equal(a, b) for a, b in zip(got[nm], ref[nm])), (B, r, nm)
+    g0, m0 = torch.load(os.path.join(tmp_path, "E_r0.pt"), weights_only=False)
+    g1, m1 = torch.load(os.path.join(tmp_path, "E_r1.pt"), weights_only=False)
+    assert [d["text"] for d in g0] == ["t%d" % i for i in range(5)] == [d["text"] for d in g1]
+    assert [d["text"] for d in m0] == ["t1", "t4"] and m0[0]["mm_motions"].shape[0] == 2
+    assert all(np.array_equal(a["motion1"], b["motion1"]) for a, b in zip(g0, g1))
+    # and equal to the unsharded loop
+    from mixermdm_amd.generation import generate_for_evaluation
+    items = [{"text": ("t%d" % i,), "text_individual1": ("a%d" % i,), "text_individual2": ("b%d" % i,), "motion_lens": torch.tensor([4 + i % 3]),
+              "cond": torch.full((1, 8), float(i)), } for i in range(5)]
+
+    class _Eval(_StubModel):
+        def forward_test(self, batch):
+            B, T = batch["cond"].shape[0], int(batch["motion_lens"][0])
+            x = torch.arange(T * 524, dtype=torch.float32).reshape(1, T, 524).repeat(B, 1, 1)
+            return {"output": _row_fn(batch["cond"], x)}
+    gref, mref = generate_for_evaluation(_Eval(), items, max_length=8, mm_idxs=(1, 4), mm_num_repeats=2)
+    assert all(np.array_equal(a["motion2"], b["motion2"]) for a, b in zip(g0, gref)) and all(np.array_equal(a["mm_motions"], b["mm_motions"]) for a, b in zip(m0, mref))
 
 
 def test_shard_range_covers_everything():

@@ -206,6 +206,37 @@ def test_scatter_sample_gather_on_rccl_world_1():
         dist.destroy_process_group()
 
 
+def test_facade_level_sharded_sampling_on_rccl_world_1(tmp_path, golden):
+    """mixermdm_amd.distributed.sample_sharded around the real facade on RCCL (world size 1: broadcast, all_gather / gather execute on the GPU):
+    forward (all five history lists) and forward_test equal the unsharded calls bit for bit, in the reference's [2B, T, C] history layout.
+    World size 2 (ragged / empty shards) runs on gloo with a stub model: tests/test_distributed_cpu.py."""
+    import torch.distributed as dist
+    from mixermdm_amd.distributed import sample_sharded
+    from test_gpu_facade import tiny_model
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    m, g, t = tiny_model(tmp_path, golden, strategy="ddim20")
+    xT = t("loop:ddim20:x_T").cuda()
+    B, T = xT.shape[:2]
+    batch = {"cond": t("cfg_cond").cuda(), "x_T": xT, "motion_lens": torch.tensor([[T]] * B)}
+    ref = m.forward(dict(batch))
+    ref_t = m.forward_test(dict(batch))
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev())
+    try:
+        got = sample_sharded(m, dict(batch), fn="forward", owner=0, histories=True)
+        assert torch.equal(got["output"], ref["output"])
+        for nm in ("influence_i1", "influence_i2", "out1", "out2", "out_influenced"):
+            assert len(got[nm]) == len(ref[nm]) == 20 and all(torch.equal(a, b) for a, b in zip(got[nm], ref[nm])), nm
+        got_t = sample_sharded(m, dict(batch), fn="forward_test", owner=0, gather_to=0)
+        assert torch.equal(got_t["output"], ref_t["output"]) and got_t["influence_i1"] == []
+        d = np.abs(got["output"].cpu().numpy() - g["loop:ddim20:output"])
+        assert d.mean() <= 2e-3                                   # and it is still the reference's loop
+    finally:
+        dist.destroy_process_group()
+
+
 def test_bench_runs_its_rccl_path_under_torchrun_on_the_gpu_box():
     """`bench.py` as the driver launches it for N > 1 -- `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` -- with
     N = 1 and MMDM_BENCH_FORCE_DIST=1, as a CHILD process: the RCCL init -> weight broadcast -> barrier -> all_gather / all_reduce of the
