@@ -352,15 +352,15 @@ def loop_clock(precision, M, peak, achieved):
         # 10 words per workgroup (8 stamps + 2 cycle counters), sized for the smallest tile the dispatch can pick (64 x 64): the stamping
         # kernel writes without a bound check, so the buffer must cover every workgroup of this launch
         buf = torch.zeros(10 * ((M + 63) // 64) * ((N + 63) // 64), dtype=torch.int64, device=d)
-        lib.mmdmx_set_gemm_tail(0)          # one launch per call: the stamps are indexed by workgroup (the single-chain samplers split the last round off)
+        lib.mmdm_diag_set(b"gemm_tail", 0)          # one launch per call: the stamps are indexed by workgroup (the single-chain samplers split the last round off)
         try:
             for _ in range(300):
                 call()
-            lib.mmdmx_set_gemm_stamps(C.c_void_p(buf.data_ptr()))
+            lib.mmdm_diag_set(b"gemm_stamps", buf.data_ptr())
             call(); torch.cuda.synchronize()
         finally:                            # the library's diagnostic switches are process-global: put them back whatever happened
-            lib.mmdmx_set_gemm_stamps(C.c_void_p(0))
-            lib.mmdmx_set_gemm_tail(-1)
+            lib.mmdm_diag_set(b"gemm_stamps", 0)
+            lib.mmdm_diag_set(b"gemm_tail", -1)
         kern = lib.mmdm_last_gemm_kernel().decode()
         tm_, tn_ = [int(v) for v in re.search(r"<(\d+),(\d+)", kern).groups()]
         bm, bn = 32 * (tm_ // 10) * (tm_ % 10), 32 * (tn_ // 10) * (tn_ % 10)
@@ -379,12 +379,11 @@ def loop_clock(precision, M, peak, achieved):
         bm, bn, waves = 32 * (tm_ // 10) * (tm_ % 10), 32 * (tn_ // 10) * (tn_ % 10), (tm_ // 10) * (tn_ // 10)
         n = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
         buf = torch.zeros(n * waves * 8, dtype=torch.int64, device=d)
-        lib.mmdmx_set_split_timeline.argtypes = [C.c_void_p]
         try:
-            lib.mmdmx_set_split_timeline(C.c_void_p(buf.data_ptr()))
+            lib.mmdm_diag_set(b"split_timeline", buf.data_ptr())
             call(); torch.cuda.synchronize()
         finally:
-            lib.mmdmx_set_split_timeline(None)
+            lib.mmdm_diag_set(b"split_timeline", 0)
         t = buf.view(n * waves, 8).double().cpu()
         mhz = (100.0 * t[:, 7] / t[:, 6].clamp(min=1)).median().item()
     pk = peak * mhz / 2400.0

@@ -18,17 +18,14 @@
  *   MMDM_NO_OVERLAP=1    mmdm_create: run the two denoisers and the two Influence calls of a step on ONE stream (profiling passes:
  *                        a kernel trace without concurrent kernels); results are bit-identical either way.
  *   MMDM_GRAPH_CACHE=n   mmdm_create: capacity (1..64, default 8) of the handle's (B, T, S)-keyed cache of captured step graphs.
- *   MMDM_NO_PACK=1       mmdm_prepare: keep the low-precision weight twins of precision 1-3 in row-major planes instead of MFMA
- *                        fragment order (the packed and the plane kernels are bit-identical; tests/test_gpu_packed_modes.py compares them).
+ *   MMDM_NO_PACK=1       keep the low-precision weight twins of precision 1-3 in row-major planes instead of MFMA fragment order (the
+ *                        packed and the plane kernels are bit-identical; tests/test_gpu_packed_modes.py compares them).
  *   MMDM_QKP / MMDM_NO_QKP / MMDM_NO_BF16_PV   precision >= 1: force / forbid the bf16-plane Q K^T and the bf16 P V forms of the attention.
- *   MMDM_LN_PRODUCER=1   precision 0: let the residual GEMM that produces rows of the residual stream also write their AdaLN for the next block
- *                        (mmdm_linear_f32_ln's kernel) instead of a pass of its own.  Off by default: measured slower (LAB_NOTES.md).
- *   MMDM_FUSE_ADALN=1    precision 0, two-chain samplers: apply AdaLN inside the GEMM that consumes it (mmdm_linear_adaln_f32's kernel) instead
- *                        of as a pass of its own.  Off by default: measured slower (LAB_NOTES.md, "AdaLN in the GEMM"); results agree to fp32 rounding.
- *   MMDM_GEMM_CFG, MMDM_GEMM_TAIL, MMDM_SPLIT_CFG, MMDM_BF16_CFG   tile-selection overrides of the GEMM dispatch, for tools/ (benchmarks).
- * The mmdmx_* symbols the library also exports (mmdmx_set_gemm_cfg, _ablate, _stamps, ...) are hooks of the scripts under tools/: timing
- * ablations and in-kernel stamps.  They select separate DIAGNOSTIC kernel instantiations; the kernels a handle launches by default
- * contain no diagnostic code.  They are not part of this ABI.
+ *   MMDM_NO_LIN_ADALN=1  precision 0: keep the stand-alone AdaLN pass instead of folding AdaLN around the GEMMs by linearity
+ *                        (mmdm_linear_f32_scaled / _lnfold below); results agree to fp32 rounding (A/B measurements, tests).
+ * All of them are read ONCE, by mmdm_create, into the handle: a handle's behaviour never changes after it exists, and the stateless kernels
+ * of section 1 read no environment at all.  The library exports exactly the symbols this header declares (hidden visibility otherwise);
+ * section 4 is the one diagnostic entry point the scripts under tools/ use.
  */
 #ifndef MMDM_H
 #define MMDM_H
@@ -39,6 +36,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)      /* the library is built with -fvisibility=hidden: only what is declared here is exported */
 
 typedef enum {
     MMDM_OK = 0,
@@ -131,30 +129,26 @@ int mmdm_f32_split3(const float* in, void* out, int64_t n, int64_t plane_stride,
  * Replaces AdaLN.forward  src/models/utils/layers.py:15-25. */
 int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss_rows, float* out, int nseq, int T, int D, void* stream);
 
-/* AdaLN fused around the fp32 GEMM (no stand-alone pass, no normalised copy of the residual stream).
- * Reference: AdaLN.forward feeding nn.Linear / MultiheadAttention.in_proj -- src/models/utils/layers.py:15-25, 36-44, 77-87, 99-104.
+/* AdaLN folded around the fp32 GEMMs by linearity: no stand-alone AdaLN pass over the residual stream, no VALU work in a K loop, no
+ * rendezvous between tiles.  Reference: AdaLN.forward feeding nn.Linear / MultiheadAttention.in_proj -- src/models/utils/layers.py:13-24,
+ * 36-44, 77-87, 99-104.  With (s | t) the conditioning row of a row's sequence, mean_m / rstd_m its LayerNorm statistics (eps 1e-6):
+ *     AdaLN(h) W^T + b  =  rstd_m ( [h (1 + s)] W^T  -  mean_m u )  +  c,        u = (1 + s) W^T,   c = t W^T + b.
  *
- * mmdm_linear_f32_stats: mmdm_linear_f32 with a residual (MMDM_EPI_BIAS_RESID) or positional (MMDM_EPI_BIAS_PE) epilogue that ALSO writes,
- *   for every output row and 32-column block, (mean, sum of squared deviations) of the stored values: stats [M][N/32][2] floats.
- *   Needs N % 32 == 0, K % 16 == 0, K >= 96 and 16-byte aligned rows (MMDM_ERR_UNSUPPORTED otherwise).
- * mmdm_linear_adaln_f32: C = epilogue( AdaLN(H) W^T + b ), epilogue MMDM_EPI_BIAS or MMDM_EPI_BIAS_GELU.  H [M,K] row stride ldh is the
- *   un-normalised input, stats [M][K/32][2] what mmdm_linear_f32_stats wrote for it, ss / ss_ld / ss_rows / T as in mmdm_adaln_f32 (row m
- *   takes (scale | shift) row (m / T) % ss_rows).  LN eps 1e-6, biased variance, no affine.  Needs K % 128 == 0, 128 <= K <= 1024 and
- *   T >= 128 (a 128-row tile then touches at most two sequences). */
-/* mmdm_linear_f32_ln: mmdm_linear_f32 with a residual / positional epilogue that ALSO writes ln_out [M][ldc] = AdaLN of the rows it just
- *   produced (ss / ss_ld / ss_rows / T as in mmdm_adaln_f32) -- what the next block's first GEMM reads -- so that the stand-alone pass
- *   (one more read and write of the residual stream) disappears.  A row's statistics span all column tiles: each tile leaves its rows'
- *   (mean, M2) in `work`, counts itself and waits for the other tiles of its row block (consecutive workgroups of one XCD), then
- *   normalises from registers.  work: mmdm_linear_f32_ln_work_bytes(M, N) bytes, zeroed once by the caller; one launch per work buffer
- *   in flight at a time.  Needs N a multiple of the tile width (128; 64 if N <= 512 or K <= 512), K % 16 == 0, K >= 96, 16-byte aligned rows. */
-size_t mmdm_linear_f32_ln_work_bytes(int M, int N);
-int mmdm_linear_f32_ln(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
-                       int epilogue, const float* extra, int ld_extra, int period, const float* ss, int ss_ld, int ss_rows, int T,
-                       float* ln_out, void* work, void* stream);
-int mmdm_linear_f32_stats(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
-                          int epilogue, const float* extra, int ld_extra, int period, float* stats, void* stream);
-int mmdm_linear_adaln_f32(const float* H, int ldh, const float* stats, const float* ss, int ss_ld, int ss_rows, int T,
-                          const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K, int epilogue, void* stream);
+ * mmdm_linear_f32_scaled (producer): mmdm_linear_f32 with a residual (MMDM_EPI_BIAS_RESID) or positional (MMDM_EPI_BIAS_PE) epilogue that
+ *   ALSO writes, for every output row and 32-column block, (mean, sum of squared deviations) of the stored values -- stats [M][N/32][2] --
+ *   and the scaled copy hs1[m][n] = C[m][n] (1 + scale1[((m / T) % scale1_rows) * ss_ld + n]) (row stride ldc), optionally a second copy
+ *   hs2 with its own table (scale2 may be NULL).  Needs N % 128 == 0, K % 16 == 0, K >= 96, T >= 128, 16-byte aligned rows / tables.
+ * mmdm_linear_f32_lnfold (consumer): C = epilogue( AdaLN(h) W^T + b ), epilogue MMDM_EPI_BIAS or MMDM_EPI_BIAS_GELU, from HS = the scaled
+ *   copy of h, stats = what the producer wrote for it ([M][K/32][2]) and uc = the table whose row (m / T) % uc_rows holds u [N] | c [N]
+ *   (row stride ss_ld >= 2N; the bias is part of c).  One extra 32x32x2 MFMA per (sequence of a tile, MFMA tile) adds -mean_m u_n +
+ *   sigma_m c_n to the accumulators, the epilogue multiplies by rstd_m.  Needs K % 128 == 0, 128 <= K <= 1024, T >= 128.
+ * The sampler's fp32 stacks run on these two (u | c come out of the per-step conditioning GEMM as extra columns: W W_s and W W_t are
+ * formed once at mmdm_prepare); MMDM_NO_LIN_ADALN=1 in the environment of mmdm_create's process keeps the stand-alone pass. */
+int mmdm_linear_f32_scaled(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+                           int epilogue, const float* extra, int ld_extra, int period, float* stats, float* hs1, const float* scale1, int scale1_rows,
+                           float* hs2, const float* scale2, int scale2_rows, int ss_ld, int T, void* stream);
+int mmdm_linear_f32_lnfold(const float* HS, int lda, const float* stats, const float* uc, int uc_rows, int ss_ld, int T,
+                           const float* W, int ldw, float* C, int ldc, int M, int N, int K, int epilogue, void* stream);
 
 /* Same with a selectable output type: out_bf16 != 0 writes `out` as bf16 (operand of the next bf16 GEMM). */
 int mmdm_adaln_ex(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, int nseq, int T, int D, void* stream);
@@ -399,6 +393,20 @@ int mmdm_module_forward(mmdm_handle h, int which, const float* x, const float* x
 int mmdm_profile_enable(mmdm_handle h, int on);
 int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launches, double* flops, double* algorithmic_bytes);
 
+/* ------------------------------------------------------------------------------------------------
+ * 4. Diagnostics (tools/ and bench.py's in-loop clock measurement; not used by any product path).
+ * ---------------------------------------------------------------------------------------------- */
+/* Sets one PROCESS-GLOBAL diagnostic switch; not thread-safe, never needed to use the library.  Timing ablations and in-kernel stamps live
+ * in separate DIAGNOSTIC kernel instantiations that are only launched while a switch asks for them: the kernels a handle launches by
+ * default contain no diagnostic code.  Keys (value -1 / 0 = back to normal):
+ *   "gemm_cfg" / "split_cfg" / "bf16_cfg"       force a tile configuration of the fp32 / fp32-split / bf16-fp8 GEMM dispatch (-1 = automatic)
+ *   "gemm_tail"                                  force the row-split rule of the fp32 dispatch (t/10 of a round; -1 = the caller's handle decides)
+ *   "gemm_ablate" / "split_ablate" / "attn_ablate"   timing-ablation bits (wrong results)
+ *   "gemm_stamps" / "attn_stamps" / "split_timeline" / "bf16_timeline"   device pointer (as an integer) of a stamp buffer, 0 = off
+ * Returns MMDM_ERR_ARG for an unknown key. */
+int mmdm_diag_set(const char* key, long long value);
+
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,8 @@ class MMDMError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmmdm_hip.so")
+    # MMDM_LIB: an alternative build of the same library (A/B experiments of tools/: e.g. one translation unit compiled with another macro)
+    return os.environ.get("MMDM_LIB") or os.path.join(_HERE, "libmmdm_hip.so")
 
 
 class Config(C.Structure):
@@ -36,10 +37,8 @@ SYMBOLS = {
     "mmdm_last_error": (C.c_char_p, []),
     "mmdm_version": (C.c_char_p, []),
     "mmdm_linear_f32": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
-    "mmdm_linear_f32_stats": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP, _VP]),
-    "mmdm_linear_f32_ln_work_bytes": (C.c_size_t, [_I, _I]),
-    "mmdm_linear_f32_ln": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP, _I, _I, _I, _VP, _VP, _VP]),
-    "mmdm_linear_adaln_f32": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
+    "mmdm_linear_f32_scaled": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _I, _I, _I, _VP]),
+    "mmdm_linear_f32_lnfold": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _I, _VP, _I, _I, _I, _I, _I, _VP]),
     "mmdm_linear_bf16": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
     "mmdm_f32_to_bf16": (_I, [_VP, _VP, C.c_int64, _VP]),
     "mmdm_linear_split": (_I, [_VP, _I, C.c_int64, _VP, _I, C.c_int64, _VP, _VP, _I, C.c_int64, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
@@ -91,6 +90,7 @@ SYMBOLS = {
     "mmdm_get_state": (_I, [_VP] + [C.POINTER(_VP)] * 5),
     "mmdm_module_forward": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _VP]),
     "mmdm_profile_enable": (_I, [_VP, _I]),
+    "mmdm_diag_set": (_I, [C.c_char_p, C.c_longlong]),
     "mmdm_profile_read": (_I, [_VP, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
@@ -116,6 +116,11 @@ def load_library():
         fn.argtypes = args
     _LIB = lib
     return lib
+
+
+def diag(key, value):
+    """mmdm_diag_set (include/mmdm.h section 4): process-global diagnostic switches of tools/ and bench.py's clock measurement."""
+    check(load_library().mmdm_diag_set(key.encode(), int(value)))
 
 
 def check(rc, handle=None):

@@ -14,6 +14,7 @@
 // P.V MFMA (k index = lane group) with no cross-lane movement or LDS round trip.  The d (reduction) order of
 // QK^T is permuted identically for both operands so that one 16-byte LDS read feeds four MFMAs.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <math.h>
 #include <type_traits>
 #include "kernels.h"
@@ -66,7 +67,7 @@ struct AttnArgs {
     float scale, scale2;
     int out_bf16;      // 1: O written as bf16 (feeds the bf16 out-projection GEMM); 2: as three bf16 planes (exact split, plane stride nseq*Tq*ldo)
     unsigned long long* stamps;   // diagnostic launches only (tools/attn_timeline.py): per workgroup {entry, loop start, loop end, kernel end, placement, qk, softmax, pv} in 100 MHz ticks
-    int ablate;        // timing experiments only (tools/attn_bench.py, mmdmx_set_attn_ablate); 0 in production
+    int ablate;        // timing experiments only (tools/attn_bench.py, mmdm_diag_set "attn_ablate"); 0 in production
     int flags;         // MMDM_ATTN_NO_ZERO_KEY: plain softmax (nn.MultiheadAttention default); MMDM_ATTN_CAUSAL: key <= query only
     int dh;            // real head width (<= the kernel's DH, multiple of 4): heads narrower than the template (the 96-wide heads of the
                        // 768 / 8 clipTransEncoder text heads on the DH = 128 kernel) are zero-padded in registers -- Q columns >= dh are
@@ -915,5 +916,10 @@ int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const voi
     return dh == 128 ? launch_qkp<128, 1>(a, st) : launch_qkp<64, 1>(a, st);
 }
 
-extern "C" void mmdmx_set_attn_ablate(int a) { g_attn_ablate = a; }
-extern "C" void mmdmx_set_attn_stamps(void* p) { g_attn_stamps = static_cast<unsigned long long*>(p); }
+// diagnostics of this translation unit (mmdm_diag_set): ablation bits, in-kernel stamp buffer
+bool mmdm_diag_attn(const char* key, long long v) {
+    if (!strcmp(key, "attn_ablate")) g_attn_ablate = (int)v;
+    else if (!strcmp(key, "attn_stamps")) g_attn_stamps = reinterpret_cast<unsigned long long*>((uintptr_t)v);
+    else return false;
+    return true;
+}

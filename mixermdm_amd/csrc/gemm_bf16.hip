@@ -14,6 +14,7 @@
 // with a per-row activation scale (written by the quantising producer: AdaLN sees the whole row) and a per-output-channel weight
 // scale (mmdm_prepare).  Half the operand bytes of the bf16 form per multiply-add; the non-scaled fp8 MFMA issues at the bf16 rate.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdlib.h>
 #include <type_traits>
 #include "kernels.h"
@@ -700,13 +701,16 @@ int mmdm_gemm_bf16_init(void) {
         hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 128 * 16 * 4);
         if (e2 != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16w): %s", hipGetErrorString(e2));
     }
-    const char* e = getenv("MMDM_BF16_CFG");
-    g_bf16_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
 }
 
-extern "C" void mmdmx_set_bf16_cfg(int c) { g_bf16_cfg = c; }
-extern "C" void mmdmx_set_bf16_timeline(void* buf) { g_bf16_tl = static_cast<unsigned long long*>(buf); }   // 4 u64 per workgroup of the next packed launches
+// diagnostics of this translation unit (mmdm_diag_set): tile override; timeline buffer (4 u64 per workgroup of the next packed launches)
+bool mmdm_diag_gemm_bf16(const char* key, long long v) {
+    if (!strcmp(key, "bf16_cfg")) g_bf16_cfg = (int)v;
+    else if (!strcmp(key, "bf16_timeline")) g_bf16_tl = reinterpret_cast<unsigned long long*>((uintptr_t)v);
+    else return false;
+    return true;
+}
 
 extern "C" int mmdm_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
     if (n <= 0) return MMDM_OK;

@@ -13,10 +13,18 @@
 // Workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles that share A rows.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include "kernels.h"
 
+// cache policy of the epilogues' result stores (aux immediate of buffer_store: 0 = default write-back through L2; 2 = nt).
+#ifndef MMDM_ST_AUX
+#define MMDM_ST_AUX 0
+#endif
+
 namespace {
+
+int g_gemm_tst = 1;        // 16-byte epilogues of the pipelined kernel leave through the LDS transposition (mmdm_diag_set "gemm_tst" 0 = direct stores)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -27,20 +35,18 @@ struct GemmArgs {
     int lda, ldw, ldc, ld_extra;
     int M, N, K, Kw, epilogue, period;   // Kw >= K: readable columns of W (zero beyond K)
     int mt, nt;
-    // AdaLN fused around the GEMM (mmdm_gemm_fuse, kernels.h).  Producer side (16-byte epilogue of the pipelined kernel): per output row
-    // and 32-column block the pair (mean, M2 = sum of squared deviations) of the values just stored -> stats_out [M][N/32][2].
-    // Consumer side (NORM_ instantiation): A holds the un-normalised residual stream; its rows' statistics are combined from nstats
-    // [M][K/32][2] and the fragments are modulated after their LDS read: a <- ((a - mean) rstd) (1 + scale[seq][k]) + shift[seq][k],
-    // seq = row / T, (scale | shift) = nss + (seq % nss_rows) * nss_ld (reference: AdaLN.forward src/models/utils/layers.py:15-25).
+    // AdaLN folded around the GEMMs by linearity (mmdm_gemm_fuse, kernels.h; reference: AdaLN.forward src/models/utils/layers.py:13-24):
+    //   AdaLN(h) W^T + b = rstd_m ([h (1 + s)] W^T - mean_m u) + c,  u = (1 + s) W^T,  c = t W^T + b.
+    // Producer side (SCL_ instantiation: the 16-byte epilogue of a residual / PE GEMM that writes rows of the residual stream h): per output
+    // row and 32-column block the pair (mean, M2 = sum of squared deviations) of the values just stored -> stats_out [M][N/32][2], and up
+    // to two scaled copies hs_k[m][n] = h[m][n] (1 + sc_k[((row0 + m) / nT) % sc_rows_k][n]) (row stride ldc, table row stride nss_ld).
+    // Consumer side (LIN_ instantiation, scalar epilogue, A = a scaled copy): the prologue combines the rows' statistics from nstats
+    // [M][K/32][2]; one extra 32x32x2 MFMA per (sequence of the tile, MFMA tile) adds -mean_m u_n + sigma_m c_n to the zero-initialised
+    // accumulators (u | c = uc + (((row0 + m) / nT) % uc_rows) * nss_ld, u at [0, N), c at [N, 2N)); the epilogue multiplies by rstd_m.
     float* stats_out;
-    const float* nstats; const float* nss;
-    int nss_ld, nss_rows, nT;
-    // AdaLN of the NEXT block written by the GEMM that produces the residual stream (LNP_ instantiation, N == nt * BN): besides C = the new
-    // rows of h, ln_out = ((h - mean) rstd) (1 + scale) + shift with (scale | shift) = nss + ((row / nT) % nss_rows) * nss_ld.  A row's
-    // statistics need all nt column tiles: every tile leaves (mean, M2) of its BN columns per row in ln_part [mt][nt][BM][2], counts itself
-    // in ln_cnt[m tile] (monotonic across launches) and waits until the row block's nt tiles have arrived (they are consecutive workgroups
-    // of one XCD, see the kernel's tile map), then combines the nt partials.  ln_err: set if the bounded wait expires (never observed).
-    float* ln_out; float* ln_part; unsigned* ln_cnt; int* ln_err;
+    float* hs1; const float* sc1; float* hs2; const float* sc2;
+    const float* nstats; const float* uc;
+    int sc1_rows, sc2_rows, uc_rows, nss_ld, nT, row0;
     int ablate;                          // timing experiments only (tools/gemm_bench.py); 0 in production
     unsigned long long* stamps;          // diagnostic builds of a launch only (tools/gemm_timeline.py): per-workgroup {start, loop start, loop end, placement, kernel end, kernel entry, residual landed, stores issued}, then {s_memtime at loop start, loop end} per workgroup
                                          // in 100 MHz s_memrealtime ticks; nullptr in production (one never-taken scalar branch per workgroup)
@@ -219,7 +225,7 @@ __global__ __launch_bounds__((Cfg<TM_, TN_, BK_>::THREADS)) void gemm_f32_kernel
 // read (16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3)): a 16-lane read group then covers 16 distinct
 // 16-byte bank slots.  Rows past M / N are clamped on load (their results are never stored).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int NORM_MAX_K = 1024;      // fused AdaLN: the conditioning table in LDS is [2 sequences][(1 + scale) | shift][NORM_MAX_K floats] = 16 KB
+constexpr int LIN_MAX_K = 1024;       // AdaLN by linearity, consumer: the prologue loads LIN_MAX_K / 128 statistics quads per row and lane half
 template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2>
 struct GCfg {
     static constexpr int WGM = TM_ / 10, WGN = TN_ / 10, TM = TM_ % 10, TN = TN_ % 10;
@@ -269,10 +275,15 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // DIAG_: the timing ablations (GemmArgs::ablate) and in-kernel stamps (GemmArgs::stamps) exist in a second instantiation only, launched
 // when a tool has set one of them (tools/gemm_bench.py ABL=, tools/gemm_timeline.py, bench.py's loop clock); the production instantiation
 // sees compile-time zeros -- no diagnostic branch, load or register in the shipped kernels.
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_, bool DIAG_, bool NORM_ = false, bool LNP_ = false>
+// LIN_ / SCL_: the consumer / producer halves of AdaLN by linearity (GemmArgs) -- instantiations of their own, so the plain kernels carry
+// none of their code or registers.
+// TST_ (16-byte epilogue of the pipelined kernel): results leave through a wave-private LDS transposition, so that one store instruction
+// covers whole 128-byte lines of a few rows instead of 16 bytes of each of 32 rows (see the epilogue).
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_, bool DIAG_, bool LIN_ = false, bool SCL_ = false, bool TST_ = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int swz, int bid) {
-    static_assert(!NORM_ || (PIPE_ == 1 && !VEPI), "the AdaLN prologue exists in the pipelined kernel with the scalar epilogue (bias / GELU consumers)");
-    static_assert(!LNP_ || (PIPE_ == 1 && VEPI && !NORM_), "the AdaLN-producing epilogue exists in the pipelined kernel with the 16-byte epilogue (residual / PE producers)");
+    static_assert(!TST_ || (PIPE_ == 1 && VEPI), "transposed stores exist in the pipelined kernel's 16-byte epilogue");
+    static_assert(!LIN_ || (PIPE_ == 1 && !VEPI && !SCL_), "the AdaLN-consuming form exists in the pipelined kernel with the scalar epilogue (bias / GELU consumers)");
+    static_assert(!SCL_ || (PIPE_ == 1 && VEPI), "the AdaLN-producing form exists in the pipelined kernel with the 16-byte epilogue (residual / PE producers)");
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
     const GemmArgs& p = pp;
     unsigned long long* const p_stamps = DIAG_ ? pp.stamps : nullptr;
@@ -372,11 +383,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * (32 * TN) + j * 32 + l31;
             const bool cok = col < p.N;
-            const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+            const float bv = (!LIN_ && p.bias && cok) ? p.bias[col] : 0.f;        // LIN_: the bias is part of c (rank-2 term below)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = bv;
-                if (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) {
+                if (!LIN_ && (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE)) {
                     const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     if (cok && row < p.M) {
                         const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
@@ -388,18 +399,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
         }
     }
 
-    // ---- fused AdaLN, consumer side: row statistics and the conditioning rows of this tile ----------------------------------------
-    // LDS behind the operand ring: [2 sequences][(1 + scale) | shift][NORM_MAX_K floats].  A 128-row tile touches at most two sequences
-    // (host: T >= 128).  The prologue's global loads are ISSUED here, before the operand ring's first requests, and CONSUMED behind them
-    // (in-order retirement: waiting for these loads never waits for a ring tile), so the ring's latency covers the prologue's.
-    float nr_a[NORM_ ? TM : 1], nr_b[NORM_ ? TM : 1];          // per row tile of this lane: rstd, -mean * rstd
-    int nss_off[NORM_ ? TM : 1];                                 // LDS byte address of the lane's (sequence block, k = 4 lh) in the table
-    float* const SS = smem + NBUF * (C_::A_FLOATS + C_::B_FLOATS);
-    constexpr int NLD = NORM_MAX_K / 128;                        // 16-byte statistics loads per row and lane half at the largest K (two partials each)
-    constexpr int NSS = NORM_MAX_K / 2 / C_::THREADS;            // conditioning float4 pairs per thread at the largest K
-    f32x4 pv[NORM_ ? TM : 1][NORM_ ? NLD : 1], ssv[NORM_ ? NSS : 1][2];
-    if constexpr (NORM_) {
-        const int K = p.K, nblk = K >> 5, nh = nblk >> 1, T = p.nT;       // nh partials per lane half (host: K % 128 == 0 -> nh even)
+    // ---- AdaLN by linearity, consumer side (LIN_): row statistics and the (u | c) rows of this tile ---------------------------------
+    // The prologue's global loads are ISSUED here, before the operand ring's first requests, and CONSUMED behind them (in-order retirement:
+    // waiting for these loads never waits for a ring tile), so the ring's latency covers the prologue's.  A tile of BM <= 128 rows spans
+    // at most two sequences (host: nT >= 128): rows below the tile-relative boundary `lin_rb` belong to sequence q0, the others to q0 + 1.
+    float ln_rstd[LIN_ ? TM : 1];                                // per row tile of this lane (row = lane & 31): 1 / sqrt(var + eps)
+    float lin_b0[LIN_ ? TN : 1], lin_b1[LIN_ ? TN : 1];          // weight-side operand of the rank-2 MFMA: lane half 0: u_n, half 1: c_n; sequence q0 / q0 + 1
+    constexpr int NLD = LIN_MAX_K / 128;                         // 16-byte statistics loads per row and lane half at the largest K (two partials each)
+    f32x4 pv[LIN_ ? TM : 1][LIN_ ? NLD : 1];
+    int lin_rb = BM;
+    if constexpr (LIN_) {
+        const int K = p.K, nblk = K >> 5, nh = nblk >> 1;        // nh partials per lane half (host: K % 128 == 0 -> nh even)
         // (a) statistics: lane half lh combines half of the row's 32-column partials, the partner lane (lane ^ 32) the other half;
         //     compile-time load count, addresses clamped into the half (one wait for the lot, not one per load)
 #pragma unroll
@@ -409,20 +419,25 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
 #pragma unroll
             for (int u = 0; u < NLD; ++u) pv[i][u] = *reinterpret_cast<const f32x4*>(sp + 4 * min(u, (nh >> 1) - 1));
         }
-        // (b) conditioning rows of the tile's two sequences: entry e = (sequence, float4 column)
-        const int q0 = m0 / T, q1 = min(m0 + BM - 1, p.M - 1) / T;
+        // (b) u_n | c_n of the tile's two sequences for this lane's output columns
+        const int g0 = p.row0 + m0, q0 = g0 / p.nT;
+        lin_rb = (q0 + 1) * p.nT - g0;
+        const float* uc0 = p.uc + (size_t)(q0 % p.uc_rows) * p.nss_ld + (lh ? p.N : 0);
+        const float* uc1 = p.uc + (size_t)((q0 + 1) % p.uc_rows) * p.nss_ld + (lh ? p.N : 0);
 #pragma unroll
-        for (int u = 0; u < NSS; ++u) {
-            const int e = min(tid + u * C_::THREADS, (K >> 1) - 1);
-            const int sidx = e / (K >> 2), c4 = e - sidx * (K >> 2);
-            const float* src = p.nss + (size_t)((sidx ? q1 : q0) % p.nss_rows) * p.nss_ld + 4 * c4;
-            ssv[u][0] = *reinterpret_cast<const f32x4*>(src);
-            ssv[u][1] = *reinterpret_cast<const f32x4*>(src + K);
+        for (int j = 0; j < TN; ++j) {
+            const int col = min(n0 + wn * (32 * TN) + j * 32 + l31, p.N - 1);      // columns past N repeat the last one (never stored)
+            lin_b0[j] = uc0[col];
+            lin_b1[j] = uc1[col];
+            // issue BOTH loads here: left alone, the compiler sinks the second sequence's load into the (wave-uniform) branch that uses it, where it
+            // is followed by s_waitcnt vmcnt(0) -- one memory latency plus the drain of the whole operand ring in 43 % of the tiles
+            asm volatile("" : "+v"(lin_b0[j]), "+v"(lin_b1[j]));
         }
     }
-    auto norm_consume = [&]() {
-        if constexpr (NORM_) {
-            const int K = p.K, nblk = K >> 5, nh = nblk >> 1, T = p.nT, q0 = m0 / T;
+    auto lin_consume = [&]() {
+        if constexpr (LIN_) {
+            const int K = p.K, nblk = K >> 5, nh = nblk >> 1;
+            float a0[TM], a1[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 // within this half: block means relative to the half's first block mean (pivot: no cancellation in the squares), Chan's
@@ -441,19 +456,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                 const float mean_o = __shfl_xor(mean_h, 32), m2_o = __shfl_xor(m2_h, 32);
                 const float mean = 0.5f * (mean_h + mean_o), dm = mean_h - mean_o;
                 const float var = (m2_h + m2_o + 0.25f * (float)K * dm * dm) / (float)K;      // n0 n1 / (n0 + n1) = K / 4
-                const float rstd = 1.0f / sqrtf(var + 1e-6f);
-                nr_a[i] = rstd; nr_b[i] = -mean * rstd;
-                // the loop advances the address by one K step (64 bytes) per tile
-                nss_off[i] = (int)(size_t)(lptr_t)SS + ((min(m0 + wm * (32 * TM) + i * 32 + l31, p.M - 1) / T - q0) * 2 * NORM_MAX_K + 4 * lh) * 4;
+                const float sigma = sqrtf(var + 1e-6f);
+                ln_rstd[i] = 1.0f / sigma;
+                // activation-side operand of the rank-2 MFMA (k = lane half): -mean_m | sigma_m, zero for the rows of the other sequence
+                const float v = lh ? sigma : -mean;
+                const bool first = wm * (32 * TM) + i * 32 + l31 < lin_rb;
+                a0[i] = first ? v : 0.f;
+                a1[i] = first ? 0.f : v;
             }
 #pragma unroll
-            for (int u = 0; u < NSS; ++u) {
-                const int e = tid + u * C_::THREADS;
-                if (e < (K >> 1)) {
-                    const int sidx = e / (K >> 2), c4 = e - sidx * (K >> 2);
-                    *reinterpret_cast<f32x4*>(SS + sidx * 2 * NORM_MAX_K + 4 * c4) = 1.0f + ssv[u][0];
-                    *reinterpret_cast<f32x4*>(SS + sidx * 2 * NORM_MAX_K + NORM_MAX_K + 4 * c4) = ssv[u][1];
-                }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], lin_b0[j], acc[i][j], 0, 0, 0);
+            if (lin_rb < BM) {                                       // the tile spans a second sequence (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], lin_b1[j], acc[i][j], 0, 0, 0);
             }
         }
     };
@@ -464,7 +483,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
         // tile 0 while the others are still on their way (the host side guarantees nkt >= NBUF).
 #pragma unroll
         for (int t = 0; t < NBUF - 1; ++t) stage(t);
-        norm_consume();
+        lin_consume();
         wait_vm<(NBUF - 2) * C_::NI>();
     } else {
         // the accumulator-init loads above must not be counted by the pipeline's vmcnt arithmetic
@@ -480,12 +499,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
     const int b_row = (wn * (32 * TN) + l31) * BK;
 
     f32x4 rv[LATE_R ? TM : 1][LATE_R ? TN : 1][4];               // the late residual tile (LATE_R only)
+    // SCL_: the conditioning rows (scale part) of the tile's two sequences for both copies, restricted to this wave's 32 TN columns:
+    // [copy][sequence][32 TN] floats = ONE 16-byte load per lane, requested with the residual tile and parked in a wave-private LDS strip
+    // after the loop -- no long-lived registers, no global round trip in the epilogue.
+    f32x4 scl_q = {0.f, 0.f, 0.f, 0.f};
+    int scl_rb = BM;
     if constexpr (PIPE_ != 0) {
         static_assert((C_::G == 2 || C_::G == 4) && NBUF >= 3 && NBUF <= 6, "pipelined loop: K step 16 or 32 (two / four k-groups), 3 to 6 stages");
         static_assert((C_::NI + 1) / 2 <= 4 * TM * TN - 1, "LDS-DMA pieces of a tile must fit behind the MFMAs of two k-groups");
         constexpr int NI = C_::NI;
         f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
-        f32x4 s0[NORM_ ? TM : 1][2], s1[NORM_ ? TM : 1][2];      // (1 + scale), shift of the fragments' four k (NORM_ only)
         auto rd = [&](int buf, int g, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
             const int cg = 4 * ((2 * g + lh) ^ sw);
             const float* Ac = As + buf * C_::A_FLOATS + a_row + cg;
@@ -494,29 +517,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ac + i * 32 * BK);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bc + j * 32 * BK);
-        };
-        // NORM_: the conditioning values of a fragment: logical k = k0 + 4 (2 g + lh) + s of this lane's sequence
-        // `next` = the fragments belong to the tile after the current one; every offset besides the running nss_off is an immediate
-        auto rdss = [&](bool next, int g, f32x4 (&sf)[NORM_ ? TM : 1][2]) {
-            if constexpr (NORM_) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    typedef __attribute__((address_space(3))) const f32x4* lds_f4;
-                    const int a = nss_off[i] + (next ? BK * 4 : 0) + 32 * g;         // an LDS byte address: the table base is folded in
-                    sf[i][0] = *(lds_f4)(size_t)a;
-                    sf[i][1] = *(lds_f4)(size_t)(a + NORM_MAX_K * 4);
-                }
-            }
-        };
-        auto modulate = [&](f32x4 (&af)[TM], const f32x4 (&sf)[NORM_ ? TM : 1][2]) {
-            if constexpr (NORM_) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        af[i][s] = __builtin_fmaf(__builtin_fmaf(af[i][s], nr_a[i], nr_b[i]), sf[i][0][s], sf[i][1][s]);
-                }
-            }
         };
         auto mm_s = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], auto s0c, auto s1c) {
 #pragma unroll
@@ -530,7 +530,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
         };
         auto mm = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) { mm_s(af, bf, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); };
         // `left` = tiles that may stay in flight behind the one being waited for (+ the NR residual loads issued at the start of the drain)
-        constexpr int NR = LATE_R ? TM * TN * 4 : 0;
+        constexpr int NR = LATE_R ? TM * TN * 4 + (SCL_ ? 1 : 0) : 0;      // SCL_: + this lane's quad of the (1 + s) rows
         auto wait_left = [&](int left) {
             if (left >= 4) wait_vm<4 * NI + NR>();
             else if (left == 3) wait_vm<3 * NI + NR>();
@@ -538,11 +538,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
             else if (left == 1) wait_vm<NI + NR>();
             else wait_vm<NR>();
         };
-        if constexpr (NORM_) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's writes of the conditioning table
-        __builtin_amdgcn_s_barrier();                        // tile 0 has landed for every wave (and the conditioning table is complete)
+        __builtin_amdgcn_s_barrier();                        // tile 0 has landed for every wave
         rd(0, 0, a0, b0);
-        rdss(false, 0, s0);
-        modulate(a0, s0);
         int cur = 0, nxt = 1, stg = NBUF - 1;
         const int n_main = nkt - (NBUF - 1);                 // steps that still issue a new tile
         constexpr int G = C_::G, NMM = 4 * TM * TN;          // k-groups per step (even), MFMAs per group
@@ -566,43 +563,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if constexpr (NORM_) {
-                // Fused AdaLN: the group in two scheduling regions.  (A) this group's first two k-steps (8 MFMAs for a 2 x 2 wave tile) with
-                // the fragment reads of the FOLLOWING group behind the first MFMA and the LDS-DMA pieces behind the next ones, as in the
-                // plain loop; (B) behind a scheduling fence, the modulation of those fragments -- 8 TM fma in one cluster behind the region's
-                // first MFMA -- and the last two k-steps.  Measured (LAB_NOTES.md, "AdaLN in the GEMM"): every VALU instruction in this loop
-                // costs about one MFMA pass whatever it depends on (16 independent dummy fma per group: +6 %), so the fused GEMM is slower
-                // than the plain one by more than the stand-alone pass costs wherever N >= 2048; the sampler therefore keeps the pass
-                // unless MMDM_FUSE_ADALN=1.
-                static_assert(TM == 2 && TN == 2, "the fused consumer is the 128 x 128 kernel");
-                constexpr std::integral_constant<int, 0> c0{}; constexpr std::integral_constant<int, 2> c2{}; constexpr std::integral_constant<int, 4> c4{};
-                const bool follow = g < G - 1 || more;
-                if constexpr (g % 2 == 0) {
-                    if constexpr (g < G - 1) { rd(cur, g + 1, a1, b1); rdss(false, g + 1, s1); }
-                    else if (more) { rd(nxt, 0, a1, b1); rdss(true, 0, s1); }
-                    if constexpr (STG && g == 0) stage_part(stg, std::integral_constant<int, 0>{}, std::integral_constant<int, D0>{});
-                    mm_s(a0, b0, c0, c2);
-                } else {
-                    if constexpr (g < G - 1) { rd(cur, g + 1, a0, b0); rdss(false, g + 1, s0); }
-                    else if (more) { rd(nxt, 0, a0, b0); rdss(true, 0, s0); }
-                    if constexpr (STG && g == 1) stage_part(stg, std::integral_constant<int, D0>{}, std::integral_constant<int, NI>{});
-                    mm_s(a1, b1, c0, c2);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, g);
-                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN + 2 * TM, g);
-#pragma unroll
-                for (int u = 0; u < dma_here; ++u) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, g);
-                    __builtin_amdgcn_sched_group_barrier(0x010, 1, g);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, NMM / 2 - 1 - dma_here, g);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (g % 2 == 0) { if (follow) modulate(a1, s1); mm_s(a0, b0, c2, c4); }
-                else { if (follow) modulate(a0, s0); mm_s(a1, b1, c2, c4); }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, g);
-                __builtin_amdgcn_sched_group_barrier(0x002, 16, g);
-                __builtin_amdgcn_sched_group_barrier(0x008, NMM / 2 - 1, g);
-            } else {
             if constexpr (g % 2 == 0) {
                 if constexpr (g < G - 1) rd(cur, g + 1, a1, b1);
                 else if (more) rd(nxt, 0, a1, b1);
@@ -622,7 +582,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                 __builtin_amdgcn_sched_group_barrier(0x010, 1, g);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, NMM - 1 - dma_here, g);
-            }
             __builtin_amdgcn_sched_barrier(0);
         };
         auto step = [&](auto do_stage, int left, bool more) {
@@ -633,10 +592,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                 group(std::integral_constant<int, 3>{}, do_stage, left, more);
             }
             cur = nxt; nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
-            if constexpr (NORM_) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) nss_off[i] += BK * 4;
-            }
         };
         for (int kt = 0; kt < n_main; ++kt) {
             step(std::true_type{}, 0, true);
@@ -647,6 +602,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
             for (int i = 0; i < TM; ++i) {
                 const int row = m0 + wm * (32 * TM) + i * 32 + l31;
                 const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+                if constexpr (SCL_) {
+                    // whole column tiles (host: N % 128 == 0): one address per row tile, the column steps are immediates -- the 15 other
+                    // 64-bit addresses (and their clamps) of the general form below would not fit beside this kernel's epilogue
+                    const float* rp = p.extra + (size_t)(row < p.M ? er : 0) * p.ld_extra + n0 + wn * (32 * TN) + 4 * lh;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int qd = 0; qd < 4; ++qd) rv[i][j][qd] = *reinterpret_cast<const f32x4*>(rp + j * 32 + 8 * qd);
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -657,6 +622,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                         rv[i][j][qd] = *reinterpret_cast<const f32x4*>(p.extra + (size_t)rr * p.ld_extra + cc);
                     }
             }
+        }
+        if constexpr (SCL_) {
+            constexpr int Q = 8 * TN;                                    // quads per table row of this wave's columns
+            const int g0 = p.row0 + m0, q0 = g0 / p.nT;
+            scl_rb = (q0 + 1) * p.nT - g0;                               // tile-relative row where sequence q0 + 1 begins
+            const int qq = lane % Q, x = (lane / Q) & 1, k = (lane / (2 * Q)) & 1;
+            const bool two = k && p.sc2 != nullptr;
+            const float* tab = two ? p.sc2 : p.sc1;
+            // conditioning rows of the two sequences, per copy: four scalar remainders, selected per lane
+            const int r10 = q0 % p.sc1_rows, r11 = (q0 + 1) % p.sc1_rows, r20 = p.sc2 ? q0 % p.sc2_rows : 0, r21 = p.sc2 ? (q0 + 1) % p.sc2_rows : 0;
+            const int r = two ? (x ? r21 : r20) : (x ? r11 : r10);
+            scl_q = *reinterpret_cast<const f32x4*>(tab + (size_t)r * p.nss_ld + n0 + wn * (32 * TN) + 4 * qq);
         }
         for (int kt = n_main < 0 ? 0 : n_main; kt < nkt; ++kt)           // drain: no new tile
             step(std::false_type{}, nkt - kt - 2, kt + 1 < nkt);
@@ -727,6 +704,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
     const int rows_here = min(p.M - m0, BM);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
     const int ldc4 = p.ldc * 4;
+    // LIN_: the accumulators hold sum_k [h (1 + s)] w - mean_m u_n + sigma_m c_n; the result is rstd_m times that.  In this (scalar) map a
+    // lane's registers are 16 ROWS per MFMA tile while the prologue left rstd on the lane that owns the row: transposed through a wave-private
+    // strip of a ring stage that nobody reads any more -- stage nkt % NBUF: every wave has passed the last barrier of the loop, behind which
+    // only the last tile's stage ((nkt - 1) % NBUF) is read, and no LDS-DMA is in flight -- so no workgroup barrier is needed.
+    f32x4 lin_rs[LIN_ ? TM : 1][4];
+    if constexpr (LIN_) {
+        float* scr = smem + (nkt % NBUF) * C_::A_FLOATS + wave * (32 * TM);
+        if (lh == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) scr[i * 32 + l31] = ln_rstd[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lin_rs[i][q] = *reinterpret_cast<const f32x4*>(scr + i * 32 + 8 * q + 4 * lh);
+    }
     auto finish = [&](auto act_c, auto fulln_c) {
         constexpr int ACT = decltype(act_c)::value;
         constexpr bool FULLN = decltype(fulln_c)::value;
@@ -741,130 +735,153 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
             // D^T map: lane&31 = output row inside the 32-row tile, register 4*qd + c = output column 8*qd + 4*(lane>>5) + c
             const int col0 = n0 + wn * (32 * TN) + 4 * lh;
             const int voff = (wm * (32 * TM) + l31) * ldc4 + col0 * 4;
-            // Fused AdaLN, producer side (identity epilogues = rows of the residual stream; wave-uniform switch): (mean, M2) of every stored
-            // row over each 32-column block -- this lane holds 16 of the block's values, its partner (lane ^ 32) the other 16 -- for the
-            // GEMM that consumes the row next (NORM_).  One pass beside the stores: deviations from the lane's first value (pivot), then
-            // Chan's combination of the two lanes' halves.
-            const bool want_stats = ACT == MMDM_EPI_BIAS && p.stats_out != nullptr;
-            if constexpr (LNP_ && ACT == MMDM_EPI_BIAS) {
-                // ---- the residual stream's new rows AND their AdaLN for the next block (GemmArgs::ln_out) ----
-                // Order: (A) row partials of this tile -> memory, arrive at the row block's counter; (B) the stores of h, which cover the
-                // rendezvous' round trips; (C) wait for the block's other tiles; (D) one thread per row combines the nt partials;
-                // (E) normalise + modulate from the registers, store.  Every global round trip is taken once per tile, never per element.
-                constexpr int NL = 16 * TN;                          // values of a row this lane holds; its partner lane (lane ^ 32) holds the other NL
-                typedef unsigned long long u64;
-                float* const xs = smem;                              // [WGN][BM][2], then [BM][2] (rstd, -mean rstd): the operand ring is idle
-                __builtin_amdgcn_s_barrier();                        // ... once every wave has left the K loop
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    float piv = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            float t = acc[i][j][e];
-                            if constexpr (LATE_R) t += rv[i][j][e >> 2][e & 3];
-                            acc[i][j][e] = t;
-                            if (j == 0 && e == 0) piv = t;
-                            const float dv = t - piv;
-                            s1 += dv; s2 = __builtin_fmaf(dv, dv, s2);
-                        }
-                    const float mean_l = piv + s1 * (1.0f / NL), m2_l = fmaxf(s2 - s1 * s1 * (1.0f / NL), 0.f);
-                    const float mean_o = __shfl_xor(mean_l, 32), m2_o = __shfl_xor(m2_l, 32), dm = mean_l - mean_o;
-                    if (lh == 0) {
-                        const int rr = wm * (32 * TM) + i * 32 + l31;
-                        xs[(wn * BM + rr) * 2] = 0.5f * (mean_l + mean_o);
-                        xs[(wn * BM + rr) * 2 + 1] = m2_l + m2_o + (0.5f * NL) * dm * dm;     // n0 n1 / (n0 + n1), n0 = n1 = NL
+            if constexpr (TST_ && ACT == MMDM_EPI_BIAS) {
+                if (FULLN) {
+                    // ---- LDS-transposed stores.  In the D^T map a lane owns a ROW: a 16-byte store instruction touches 32 rows x 32 bytes (32 cache
+                    // lines, a quarter of each) -- beside a co-resident workgroup in its K loop 16 of them take ~8 us (tools/loop_bench4.hip), and the
+                    // scaled copies of SCL_ triple the count.  Here each 32-row half of the wave's tile goes through a wave-private, XOR-swizzled
+                    // [32 rows][32 TN columns] image in an idle ring stage (stage (nkt + k) % NBUF, k < NBUF - 1: see LIN_) and leaves as whole
+                    // rows: one instruction = 64 / (8 TN) rows x 128 TN bytes.  Same values, same arithmetic: bit-identical to the direct form.
+                    constexpr int WC = 32 * TN, HBF = 32 * WC, LPR = WC / 4, RPI = 64 / LPR, KA = C_::A_FLOATS / HBF;
+                    static_assert(C_::A_FLOATS % HBF == 0 && C_::B_FLOATS >= HBF && C_::B_FLOATS >= 16 * WC, "ring chunks must hold the transposition images");
+                    static_assert((C_::NWAVES + KA - 1) / KA <= 2 * (NBUF - 1) - 1, "not enough idle ring chunks for the waves' images and the scale strip");
+                    auto fst = [&](int k) { const int s0 = nkt % NBUF + k; return s0 >= NBUF ? s0 - NBUF : s0; };      // k-th idle stage
+                    const int wi = wave / KA;
+                    float* tb = wi < NBUF - 1 ? As + fst(wi) * C_::A_FLOATS + (wave % KA) * HBF : Bs + fst(wi - (NBUF - 1)) * C_::B_FLOATS;
+                    auto fsw = [](int r) { return TN == 2 ? (r & 15) : ((r ^ (r >> 3)) & 7); };                          // chunk swizzle of row r (no bank conflicts on either side)
+                    const float* strip = Bs + fst(NBUF - 2) * C_::B_FLOATS + wave * (4 * WC);                             // SCL_: [copy][sequence][WC] (1 + s is formed below)
+                    if constexpr (SCL_) {
+                        if (lane < 4 * (WC / 4)) *reinterpret_cast<f32x4*>(const_cast<float*>(strip) + 4 * lane) = scl_q;
                     }
-                }
-                __syncthreads();
-                const int mtile = m0 / BM, ntile = n0 / BN, nt = p.nt;
-                if (tid < BM) {
-                    float mean = xs[tid * 2], m2 = xs[tid * 2 + 1];
-                    if constexpr (C_::WGN == 2) {
-                        const float mb = xs[(BM + tid) * 2], m2b = xs[(BM + tid) * 2 + 1], dm = mean - mb;
-                        m2 = m2 + m2b + (0.5f * 32 * TN) * dm * dm;
-                        mean = 0.5f * (mean + mb);
-                    }
-                    const u64 both = (u64)__builtin_bit_cast(unsigned, mean) | ((u64)__builtin_bit_cast(unsigned, m2) << 32);
-                    __hip_atomic_store(reinterpret_cast<u64*>(p.ln_part) + (size_t)(mtile * nt + ntile) * BM + tid, both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the partials have reached memory (agent scope) ...
-                __syncthreads();
-                unsigned target = 0;
-                if (tid == 0)                                        // ... before this tile counts itself
-                    target = (__hip_atomic_fetch_add(p.ln_cnt + mtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned)nt + 1u) * (unsigned)nt;
-                // (B) h
+                    const __amdgpu_buffer_rsrc_t rsH1 = __builtin_amdgcn_make_buffer_rsrc((SCL_ ? p.hs1 : p.C) + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rsH2 = __builtin_amdgcn_make_buffer_rsrc((SCL_ && p.hs2 ? p.hs2 : p.C) + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
+                    const int rr = lane / LPR, rc = lane % LPR;                  // this lane's row inside an instruction's row group, its 16-byte column
+                    auto half = [&](auto ic, auto c2) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr bool C2 = decltype(c2)::value;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                        for (int j = 0; j < TN; ++j) {
+                            float piv = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                            for (int qd = 0; qd < 4; ++qd) {
+                                f32x4 v;
 #pragma unroll
-                        for (int qd = 0; qd < 4; ++qd) {
-                            const f32x4 v = {acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]};
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4, 0, 0);
+                                for (int c = 0; c < 4; ++c) {
+                                    float t = acc[i][j][4 * qd + c];
+                                    if constexpr (LATE_R) t += rv[i][j][qd][c];
+                                    v[c] = t;
+                                    if constexpr (SCL_) {
+                                        if (qd == 0 && c == 0) piv = t;
+                                        const float dv = t - piv;
+                                        s1 += dv; s2 = __builtin_fmaf(dv, dv, s2);
+                                    }
+                                }
+                                *reinterpret_cast<f32x4*>(tb + l31 * WC + 4 * ((8 * j + 2 * qd + lh) ^ fsw(l31))) = v;
+                            }
+                            if constexpr (SCL_) {
+                                const float mean_l = piv + s1 * (1.0f / 16.0f), m2_l = fmaxf(s2 - s1 * s1 * (1.0f / 16.0f), 0.f);
+                                const float mean_o = __shfl_xor(mean_l, 32), m2_o = __shfl_xor(m2_l, 32), dm = mean_l - mean_o;
+                                const int row = m0 + wm * (32 * TM) + i * 32 + l31, blk = (n0 + wn * (32 * TN) + j * 32) >> 5, nblk = p.N >> 5;
+                                if (lh == 0 && row < p.M) {
+                                    float* d = p.stats_out + ((size_t)row * nblk + blk) * 2;
+                                    d[0] = 0.5f * (mean_l + mean_o);
+                                    d[1] = m2_l + m2_o + 8.0f * dm * dm;          // n0 n1 / (n0 + n1) = 16 * 16 / 32
+                                }
+                            }
                         }
-                // (C)
-                if (tid == 0) {
-                    int it = 0;
-                    while ((int)(__hip_atomic_load(p.ln_cnt + mtile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++it > (1 << 23)) { *p.ln_err = 1; break; }          // ~1 s: bounded, so that a protocol error cannot hang the device
-                    }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int k = 0; k < 32 / RPI; ++k) {
+                            const int r = k * RPI + rr;                          // row of the half tile
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(tb + r * WC + 4 * (rc ^ fsw(r)));
+                            const int off = (wm * (32 * TM) + i * 32 + r) * ldc4 + (n0 + wn * WC + 4 * rc) * 4;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, off, 0, MMDM_ST_AUX);
+                            if constexpr (SCL_) {
+                                const float* sp = strip + (wm * (32 * TM) + i * 32 + r < scl_rb ? 0 : WC) + 4 * rc;
+                                const f32x4 sa = *reinterpret_cast<const f32x4*>(sp);
+                                f32x4 w1;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) w1[c] = v[c] * (1.0f + sa[c]);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w1), rsH1, off, 0, MMDM_ST_AUX);
+                                if constexpr (C2) {
+                                    const f32x4 sb = *reinterpret_cast<const f32x4*>(sp + 2 * WC);
+                                    f32x4 w2;
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) w2[c] = v[c] * (1.0f + sb[c]);
+                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w2), rsH2, off, 0, MMDM_ST_AUX);
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    };
+                    auto both = [&](auto c2) {
+                        half(std::integral_constant<int, 0>{}, c2);
+                        if constexpr (TM > 1) half(std::integral_constant<int, 1>{}, c2);
+                        static_assert(TM <= 2, "two 32-row halves per wave at most");
+                    };
+                    if (SCL_ && p.hs2) both(std::true_type{});
+                    else both(std::false_type{});
+                    return;
                 }
-                __syncthreads();
-                // (D) equal counts BN per partial: mean = average of the means, M2 = sum M2 + BN sum (mean_t - mean)^2 (pivoted)
-                if (tid < BM) {
-                    const u64* pr = reinterpret_cast<const u64*>(p.ln_part) + (size_t)mtile * nt * BM + tid;
-                    const float piv = __builtin_bit_cast(float, (unsigned)__hip_atomic_load(pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    float sm = 0.f, sq = 0.f, m2 = 0.f;
-                    for (int t0 = 0; t0 < nt; t0 += 8) {             // eight loads in flight per round trip (the register budget is the K loop's)
-                        u64 raw[8];
+            }
+            if constexpr (SCL_ && ACT == MMDM_EPI_BIAS) {
+                // ---- AdaLN by linearity, producer side: the new rows of the residual stream, their partial LayerNorm statistics (deviations from
+                // the lane's first value, then Chan's combination of the two lanes' halves), and the scaled copies h (1 + s) the next GEMMs read.
+                // One pass per 16-byte quad: nothing is kept beyond the quad, so the kernel's registers stay the K loop's.
+                constexpr int WC = 32 * TN;
+                float* strip = smem + (nkt % NBUF) * C_::A_FLOATS + wave * (4 * WC);      // [copy][sequence][WC]; stage nkt % NBUF is idle (see LIN_)
+                if (lane < 4 * (WC / 4)) *reinterpret_cast<f32x4*>(strip + 4 * lane) = scl_q;
+                __builtin_amdgcn_wave_barrier();
+                const __amdgpu_buffer_rsrc_t rsH1 = __builtin_amdgcn_make_buffer_rsrc(p.hs1 + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsH2 = __builtin_amdgcn_make_buffer_rsrc((p.hs2 ? p.hs2 : p.C) + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
+                auto body = [&](auto c1, auto c2) {
+                    constexpr bool C1 = decltype(c1)::value, C2 = decltype(c2)::value;
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) raw[t] = __hip_atomic_load(pr + (size_t)min(t0 + t, nt - 1) * BM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int i = 0; i < TM; ++i) {
+                        const float* srow = strip + (wm * (32 * TM) + i * 32 + l31 < scl_rb ? 0 : WC) + 4 * lh;
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            const float wgt = t0 + t < nt ? 1.0f : 0.0f;
-                            const float dv = __builtin_bit_cast(float, (unsigned)raw[t]) - piv;
-                            sm += wgt * dv; sq += wgt * dv * dv; m2 += wgt * __builtin_bit_cast(float, (unsigned)(raw[t] >> 32));
+                        for (int j = 0; j < TN; ++j) {
+                            float piv = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                            for (int qd = 0; qd < 4; ++qd) {
+                                const int off = voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4;
+                                f32x4 v, w1, w2, sa, sb;
+                                if constexpr (C1) sa = *reinterpret_cast<const f32x4*>(srow + j * 32 + 8 * qd);
+                                if constexpr (C2) sb = *reinterpret_cast<const f32x4*>(srow + 2 * WC + j * 32 + 8 * qd);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    float t = acc[i][j][4 * qd + c];
+                                    if constexpr (LATE_R) t += rv[i][j][qd][c];
+                                    v[c] = t;
+                                    if (qd == 0 && c == 0) piv = t;
+                                    const float dv = t - piv;
+                                    s1 += dv; s2 = __builtin_fmaf(dv, dv, s2);
+                                    if constexpr (C1) w1[c] = t * (1.0f + sa[c]);
+                                    if constexpr (C2) w2[c] = t * (1.0f + sb[c]);
+                                }
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, off, 0, MMDM_ST_AUX);
+                                if constexpr (C1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w1), rsH1, off, 0, MMDM_ST_AUX);
+                                if constexpr (C2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w2), rsH2, off, 0, MMDM_ST_AUX);
+                            }
+                            const float mean_l = piv + s1 * (1.0f / 16.0f), m2_l = fmaxf(s2 - s1 * s1 * (1.0f / 16.0f), 0.f);
+                            const float mean_o = __shfl_xor(mean_l, 32), m2_o = __shfl_xor(m2_l, 32), dm = mean_l - mean_o;
+                            const int row = m0 + wm * (32 * TM) + i * 32 + l31, blk = (n0 + wn * (32 * TN) + j * 32) >> 5, nblk = p.N >> 5;
+                            if (lh == 0 && row < p.M) {
+                                float* d = p.stats_out + ((size_t)row * nblk + blk) * 2;
+                                d[0] = 0.5f * (mean_l + mean_o);
+                                d[1] = m2_l + m2_o + 8.0f * dm * dm;          // n0 n1 / (n0 + n1) = 16 * 16 / 32
+                            }
                         }
                     }
-                    const float inv_nt = 1.0f / (float)nt;
-                    const float mean = piv + sm * inv_nt;
-                    const float var = (m2 + (float)BN * fmaxf(sq - sm * sm * inv_nt, 0.f)) / (float)p.N;
-                    const float rstd = 1.0f / sqrtf(var + 1e-6f);
-                    xs[tid * 2] = rstd; xs[tid * 2 + 1] = -mean * rstd;
-                }
-                __syncthreads();
-                // (E)
-                const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(p.ln_out + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int rr = wm * (32 * TM) + i * 32 + l31;
-                    const float rstd = xs[rr * 2], nb = xs[rr * 2 + 1];
-                    const int row = min(m0 + rr, p.M - 1);
-                    const float* ssr = p.nss + (size_t)((row / p.nT) % p.nss_rows) * p.nss_ld + col0;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int qd = 0; qd < 4; ++qd) {
-                            const f32x4 sc = *reinterpret_cast<const f32x4*>(ssr + j * 32 + 8 * qd);
-                            const f32x4 sh = *reinterpret_cast<const f32x4*>(ssr + p.N + j * 32 + 8 * qd);
-                            f32x4 v;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                v[c] = __builtin_fmaf(__builtin_fmaf(acc[i][j][4 * qd + c], rstd, nb), 1.0f + sc[c], sh[c]);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsX, voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4, 0, 0);
-                            if (qd == 3) __builtin_amdgcn_sched_barrier(0);       // at most eight table loads in flight: the kernel's register budget is the K loop's
-                        }
-                }
+                };
+                if (p.hs2) body(std::true_type{}, std::true_type{});
+                else body(std::true_type{}, std::false_type{});
                 return;
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    float piv = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         f32x4 v;
@@ -873,27 +890,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                             float t = acc[i][j][4 * qd + c];
                             if constexpr (LATE_R) t += rv[i][j][qd][c];
                             v[c] = act(t);
-                            if constexpr (ACT == MMDM_EPI_BIAS) {
-                                if (qd == 0 && c == 0) piv = t;
-                                const float dv = t - piv;
-                                s1 += dv; s2 = __builtin_fmaf(dv, dv, s2);
-                            }
                         }
                         // the row step is part of the VECTOR offset: only that (plus the immediate) takes part in the range check
                         if (FULLN || col0 + j * 32 + 8 * qd < p.N)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4, 0, 0);
-                    }
-                    if constexpr (ACT == MMDM_EPI_BIAS) {
-                        if (want_stats) {
-                            const float mean_l = piv + s1 * (1.0f / 16.0f), m2_l = fmaxf(s2 - s1 * s1 * (1.0f / 16.0f), 0.f);
-                            const float mean_o = __shfl_xor(mean_l, 32), m2_o = __shfl_xor(m2_l, 32), dm = mean_l - mean_o;
-                            const int row = m0 + wm * (32 * TM) + i * 32 + l31, blk = (n0 + wn * (32 * TN) + j * 32) >> 5, nblk = p.N >> 5;
-                            if (lh == 0 && row < p.M && blk < nblk) {
-                                float* d = p.stats_out + ((size_t)row * nblk + blk) * 2;
-                                d[0] = 0.5f * (mean_l + mean_o);
-                                d[1] = m2_l + m2_o + 8.0f * dm * dm;          // n0 n1 / (n0 + n1) = 16 * 16 / 32
-                            }
-                        }
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4, 0, MMDM_ST_AUX);
                     }
                 }
         } else {
@@ -905,9 +905,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                 for (int j = 0; j < TN; ++j) {
                     if (!FULLN && col0 + j * 32 >= p.N) continue;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, act(acc[i][j][e])), rsC,
-                                                              voff + (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc4 + j * 128, 0, 0);
+                    for (int e = 0; e < 16; ++e) {
+                        float t = acc[i][j][e];
+                        if constexpr (LIN_) t *= lin_rs[i][e >> 2][e & 3];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, act(t)), rsC,
+                                                              voff + (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc4 + j * 128, 0, MMDM_ST_AUX);
+                    }
                 }
         }
     };
@@ -915,6 +918,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
         if (n0 + BN <= p.N) finish(act_c, std::true_type{});
         else finish(act_c, std::false_type{});
     };
+    if constexpr (VEPI) {        // the 16-byte form is only launched for the residual / PE epilogues (launch_glds): identity activation
+        finish_n(std::integral_constant<int, MMDM_EPI_BIAS>{});
+        return;
+    }
     switch (p.epilogue) {
         case MMDM_EPI_BIAS_GELU: finish_n(std::integral_constant<int, MMDM_EPI_BIAS_GELU>{}); break;
         case MMDM_EPI_BIAS_SILU: finish_n(std::integral_constant<int, MMDM_EPI_BIAS_SILU>{}); break;
@@ -925,27 +932,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
 }
 #endif
 
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0, bool DIAG_ = false, bool NORM_ = false, bool LNP_ = false>
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0, bool DIAG_ = false, bool LIN_ = false, bool SCL_ = false, bool TST_ = false>
 __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void gemm_glds_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nwg = p.mt * p.nt;
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    if constexpr (LNP_) {
-        // WHOLE row blocks per XCD (the grid is 8 x the largest share; surplus workgroups leave): the nt tiles of a row block are consecutive
-        // workgroups of one XCD's in-order dispatch, so a tile that waits for its row block waits for workgroups that are already resident
-        // or next in line -- never for the end of another XCD's list.
-        const int qm = p.mt >> 3, rm = p.mt & 7;
-        const int rows_x = qm + (xcd < rm ? 1 : 0), row0_x = xcd * qm + min(xcd, rm), j = bid >> 3;
-        if (j >= rows_x * p.nt) return;
-        swz = row0_x * p.nt + j;
-    }
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     unsigned long long* const stamps = DIAG_ ? p.stamps : nullptr;
     const unsigned long long t_entry = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     if (stamps && threadIdx.x == 0) stamps[8 * (size_t)bid + 5] = t_entry;
-    gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_, DIAG_, NORM_, LNP_>(p, smem, swz, bid);
+    gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_, DIAG_, LIN_, SCL_, TST_>(p, smem, swz, bid);
     if (stamps) {
         if (threadIdx.x == 0) stamps[8 * (size_t)bid + 7] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -961,6 +959,12 @@ inline bool vepi_ok(const GemmArgs& a) {
            (!ext || ((a.ld_extra & 3) == 0 && (reinterpret_cast<uintptr_t>(a.extra) & 15) == 0));
 }
 
+// the tile shapes the production dispatch picks: only these exist in the AdaLN-by-linearity forms
+template <int TM_, int TN_, int BK_, int NBUF_, int PIPE_>
+constexpr bool lin_cfg = PIPE_ == 1 && BK_ == 16 && ((TM_ == 22 && TN_ == 22 && NBUF_ == 5) || (TM_ == 22 && TN_ == 21 && NBUF_ == 4) || (TM_ == 21 && TN_ == 21 && NBUF_ == 4));
+template <int TM_, int TN_>
+constexpr int scl_minw = (TM_ % 10) * (TN_ % 10) >= 4 ? 2 : 1;     // 128 x 128: keep the allocation at two waves per SIMD (what its 80 KB of LDS admit anyway)
+
 template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2, int MINW_ = 1, int PIPE_ = 0>
 int launch_glds(GemmArgs a, hipStream_t st) {
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
@@ -970,8 +974,29 @@ int launch_glds(GemmArgs a, hipStream_t st) {
     // the K = 1024 residual GEMMs) and is neutral-to-slightly-negative for bias/GELU-only epilogues
     const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
     const bool vepi = ext && vepi_ok(a) && !(a.ablate & 16);
-    mmdm_note_gemm("%s<%d,%d,%d,%d,%s>", PIPE_ ? "gemm_pipe" : "gemm_glds", TM_, TN_, BK_, NBUF_, vepi ? "vepi" : "scalar");
     const dim3 grid(a.mt * a.nt), block(C_::THREADS);
+    if constexpr (lin_cfg<TM_, TN_, BK_, NBUF_, PIPE_>) {
+        // the two halves of AdaLN by linearity: instantiations of their own (the caller has checked the shapes: mmdm_linear_f32_fused)
+        if (a.nstats) {
+            mmdm_note_gemm("gemm_pipe_lin<%d,%d,%d,%d,scalar>", TM_, TN_, BK_, NBUF_);
+            hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, 1, false, true, false>), grid, block, C_::SMEM_BYTES, st, a);
+            return mmdm_check_launch("gemm_pipe_lin");
+        }
+        if (a.stats_out) {
+            mmdm_note_gemm("gemm_pipe_scl<%d,%d,%d,%d,%s>", TM_, TN_, BK_, NBUF_, g_gemm_tst ? "vepi-t" : "vepi");
+            if (g_gemm_tst) hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, scl_minw<TM_, TN_>, 1, false, false, true, true>), grid, block, C_::SMEM_BYTES, st, a);
+            else hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, scl_minw<TM_, TN_>, 1, false, false, true, false>), grid, block, C_::SMEM_BYTES, st, a);
+            return mmdm_check_launch("gemm_pipe_scl");
+        }
+        if (vepi && g_gemm_tst && !(a.ablate & ~16) && !a.stamps) {       // plain residual / PE GEMM with transposed stores
+            mmdm_note_gemm("gemm_pipe<%d,%d,%d,%d,vepi-t>", TM_, TN_, BK_, NBUF_);
+            hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, 1, false, false, false, true>), grid, block, C_::SMEM_BYTES, st, a);
+            return mmdm_check_launch("gemm_pipe");
+        }
+    } else if (a.nstats || a.stats_out) {
+        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: this tile configuration has no AdaLN-by-linearity form");
+    }
+    mmdm_note_gemm("%s<%d,%d,%d,%d,%s>", PIPE_ ? "gemm_pipe" : "gemm_glds", TM_, TN_, BK_, NBUF_, vepi ? "vepi" : "scalar");
     if ((a.ablate & ~16) || a.stamps) {              // a tool asked for ablation bits / stamps: the diagnostic instantiation
         if (vepi) hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_, true>), grid, block, C_::SMEM_BYTES, st, a);
         else hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_, true>), grid, block, C_::SMEM_BYTES, st, a);
@@ -980,39 +1005,6 @@ int launch_glds(GemmArgs a, hipStream_t st) {
     else
         hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, PIPE_, false>), grid, block, C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_glds");
-}
-
-// The AdaLN-consuming GEMM (NORM_): 128 x 128 tiles, FOUR stages (64 KB) + the conditioning table of the tile's two sequences (16 KB at
-// K = 1024) = 80 KB: two workgroups per CU, like the five-stage kernel it replaces (four stages measured equal: LAB_NOTES.md).
-inline int norm_smem(int) { return GCfg<22, 22, 16, 4>::SMEM_BYTES + 4 * NORM_MAX_K * (int)sizeof(float); }
-int launch_norm(GemmArgs a, hipStream_t st) {
-    using C_ = GCfg<22, 22, 16, 4>;
-    a.mt = (a.M + C_::BM - 1) / C_::BM;
-    a.nt = (a.N + C_::BN - 1) / C_::BN;
-    mmdm_note_gemm("gemm_pipe_adaln<22,22,16,4,scalar>");
-    hipLaunchKernelGGL((gemm_glds_kernel<22, 22, 16, 4, false, 1, 1, false, true>), dim3(a.mt * a.nt), dim3(C_::THREADS), norm_smem(a.K), st, a);
-    return mmdm_check_launch("gemm_pipe_adaln");
-}
-
-// The AdaLN-producing GEMM (LNP_): the production residual kernels with the row-block rendezvous in the epilogue; grid = 8 x the largest
-// per-XCD share of whole row blocks.
-constexpr int LN_HDR_BYTES = 64 * 1024;          // ln_work: [counters: one unsigned per row block | error flag at the end of the header][partials]
-template <int TM_, int TN_, int NBUF_>
-int launch_lnp(GemmArgs a, hipStream_t st) {
-    using C_ = GCfg<TM_, TN_, 16, NBUF_>;
-    a.mt = (a.M + C_::BM - 1) / C_::BM;
-    a.nt = a.N / C_::BN;
-    const int share = ((a.mt + 7) / 8) * a.nt;
-    mmdm_note_gemm("gemm_pipe_ln<%d,%d,16,%d,vepi>", TM_, TN_, NBUF_);
-    hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, 16, NBUF_, true, 2, 1, false, false, true>), dim3(8 * share), dim3(C_::THREADS), C_::SMEM_BYTES, st, a);
-    return mmdm_check_launch("gemm_pipe_ln");
-}
-template <int TM_, int TN_, int NBUF_>
-int set_attr_lnp() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, 16, NBUF_, true, 2, 1, false, false, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<TM_, TN_, 16, NBUF_>::SMEM_BYTES);
-    if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_pipe_ln): %s", hipGetErrorString(e));
-    return MMDM_OK;
 }
 
 template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2, int MINW_ = 1, int PIPE_ = 0>
@@ -1025,6 +1017,16 @@ int set_attr_glds() {
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_glds): %s", hipGetErrorString(e));
+    }
+    if constexpr (lin_cfg<TM_, TN_, BK_, NBUF_, PIPE_>) {
+        const void* fl[4] = {reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, 1, false, true, false>),
+                             reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, scl_minw<TM_, TN_>, 1, false, false, true, false>),
+                             reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, scl_minw<TM_, TN_>, 1, false, false, true, true>),
+                             reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, 1, false, false, false, true>)};
+        for (const void* f : fl) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_pipe_lin / _scl): %s", hipGetErrorString(e));
+        }
     }
     return MMDM_OK;
 }
@@ -1075,20 +1077,16 @@ inline bool vec_ok(const float* p, int ld, int K) {
 
 }  // namespace
 
-// producer-side AdaLN: the tile the dispatch would pick for (N, K) must divide N; the row-block counters must fit the header
-static bool ln_narrow(int N, int K) { return N <= 512 || K <= 512; }
-bool mmdm_gemm_ln_ok(int M, int N, int K) {
-    const int bn = ln_narrow(N, K) ? 64 : 128;
-    return M > 0 && K >= 96 && (K & 15) == 0 && N % bn == 0 && (M + 127) / 128 <= (LN_HDR_BYTES - 64) / 4;
-}
-size_t mmdm_gemm_ln_work_bytes(int M, int N) { return LN_HDR_BYTES + (size_t)((M + 127) / 128) * 128 * (N / 64) * 2 * sizeof(float); }
-bool mmdm_gemm_fuse_ok(int K, int T) { return K >= 128 && K <= NORM_MAX_K && (K & 127) == 0 && T >= 128; }
+// AdaLN by linearity: shapes both halves cover.  K = width of the residual stream (the consumers' K, the producers' N): whole 128-column
+// groups of statistics, at most LIN_MAX_K; T >= 128 so that a tile of at most 128 rows spans at most two sequences.
+bool mmdm_gemm_fuse_ok(int K, int T) { return K >= 128 && K <= LIN_MAX_K && (K & 127) == 0 && T >= 128; }
 
 int g_gemm_cfg = -1;
 int g_gemm_tail = -1;       // row split of the fractional last round: t > 0: split when the fractional round holds <= t/10 of the resident slots; 0 off;
                             // -1 (default): what the caller's handle asked for through mmdm_gemm_set_tail (one-stream samplers: 10, two-stream: 0)
 static thread_local int t_gemm_tail = 0;
 void mmdm_gemm_set_tail(int t) { t_gemm_tail = t; }
+int mmdm_gemm_get_tail(void) { return t_gemm_tail; }
 int g_gemm_ablate = 0;
 unsigned long long* g_gemm_stamps = nullptr;
 
@@ -1112,24 +1110,20 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_glds<21, 21, 16, 4, 1, 1>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 2>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 3>())) return rc;
-    if ((rc = set_attr_lnp<22, 22, 5>())) return rc;
-    if ((rc = set_attr_lnp<22, 21, 4>())) return rc;
-    {
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<22, 22, 16, 4, false, 1, 1, false, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, norm_smem(NORM_MAX_K));
-        if (e2 != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_pipe_adaln): %s", hipGetErrorString(e2));
-    }
-    const char* e = getenv("MMDM_GEMM_CFG");
-    g_gemm_cfg = e ? atoi(e) : -1;
-    if (const char* t = getenv("MMDM_GEMM_TAIL")) g_gemm_tail = atoi(t);       // forces the rule for every caller (tools)
     return MMDM_OK;
 }
 
-// tuning hook for tools/gemm_bench.py (not part of the public ABI): force a tile configuration, -1 = automatic
-extern "C" void mmdmx_set_gemm_cfg(int cfg) { g_gemm_cfg = cfg; }
-extern "C" void mmdmx_set_gemm_ablate(int a) { g_gemm_ablate = a; }
-extern "C" void mmdmx_set_gemm_tail(int t) { g_gemm_tail = t; }
-extern "C" void mmdmx_set_gemm_stamps(void* p) { g_gemm_stamps = static_cast<unsigned long long*>(p); }
+// diagnostics of this translation unit (mmdm_diag_set, include/mmdm.h section 4): tile configuration override (-1 = automatic), timing
+// ablation bits, row-split rule override, in-kernel stamp buffer.  Process-global, for tools/ only.
+bool mmdm_diag_gemm_f32(const char* key, long long v) {
+    if (!strcmp(key, "gemm_cfg")) g_gemm_cfg = (int)v;
+    else if (!strcmp(key, "gemm_ablate")) g_gemm_ablate = (int)v;
+    else if (!strcmp(key, "gemm_tail")) g_gemm_tail = (int)v;
+    else if (!strcmp(key, "gemm_tst")) g_gemm_tst = (int)v;
+    else if (!strcmp(key, "gemm_stamps")) g_gemm_stamps = reinterpret_cast<unsigned long long*>((uintptr_t)v);
+    else return false;
+    return true;
+}
 
 extern "C" int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                                int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
@@ -1143,9 +1137,9 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
     return mmdm_linear_f32_fused(A, lda, W, ldw, Kw, bias, C, ldc, M, N, K, epilogue, extra, ld_extra, period, nullptr, stream);
 }
 
-// `fuse` (kernels.h): stats_out -- the 16-byte-epilogue kernel also writes the rows' partial LayerNorm statistics; norm_stats / norm_ss --
-// A is the un-normalised residual stream and AdaLN is applied to its fragments inside the GEMM.  Both need the shapes the pipelined
-// kernel covers; a request it cannot honour is an error (the caller decides up front: mmdm_gemm_fuse_ok).
+// `fuse` (kernels.h): the two halves of AdaLN by linearity.  Producer (stats_out [+ hs1 / hs2]): the residual / PE GEMM also writes the rows'
+// partial LayerNorm statistics and scaled copies h (1 + s); consumer (nstats + uc): A is such a copy and the GEMM returns AdaLN(h) W^T + b.
+// Both need the shapes the pipelined kernel covers; a request it cannot honour is an error (the caller decides up front: mmdm_gemm_fuse_ok).
 int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                           int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, const mmdm_gemm_fuse* fuse, void* stream) {
     mmdm_note_gemm_reset();
@@ -1167,35 +1161,28 @@ int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int 
     a.ablate = g_gemm_ablate;
     a.stamps = g_gemm_stamps;
     a.stats_out = fuse ? fuse->stats_out : nullptr;
-    a.nstats = fuse ? fuse->norm_stats : nullptr; a.nss = fuse ? fuse->norm_ss : nullptr;
-    a.nss_ld = fuse ? fuse->ss_ld : 0; a.nss_rows = fuse ? fuse->ss_rows : 1; a.nT = fuse ? fuse->T : 1;
-    a.ln_out = fuse ? fuse->ln_out : nullptr;
-    a.ln_cnt = fuse ? static_cast<unsigned*>(fuse->ln_work) : nullptr;
-    a.ln_err = fuse && fuse->ln_work ? reinterpret_cast<int*>(static_cast<char*>(fuse->ln_work) + LN_HDR_BYTES - 64) : nullptr;
-    a.ln_part = fuse && fuse->ln_work ? reinterpret_cast<float*>(static_cast<char*>(fuse->ln_work) + LN_HDR_BYTES) : nullptr;
+    a.hs1 = fuse ? fuse->hs1 : nullptr; a.sc1 = fuse ? fuse->sc1 : nullptr; a.sc1_rows = fuse ? fuse->sc1_rows : 1;
+    a.hs2 = fuse ? fuse->hs2 : nullptr; a.sc2 = fuse ? fuse->sc2 : nullptr; a.sc2_rows = fuse ? fuse->sc2_rows : 1;
+    a.nstats = fuse ? fuse->nstats : nullptr; a.uc = fuse ? fuse->uc : nullptr; a.uc_rows = fuse ? fuse->uc_rows : 1;
+    a.nss_ld = fuse ? fuse->ss_ld : 0; a.nT = fuse ? fuse->T : 1; a.row0 = fuse ? fuse->row0 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool av = vec_ok(A, lda, K), wv = vec_ok(W, ldw, Kw);
     const bool glds_ok = av && wv && (K % 16 == 0) && Kw == K;
-    if (a.stats_out) {              // producer: needs the pipelined kernel's 16-byte epilogue and whole 32-column blocks
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (a.stats_out) {              // producer: the pipelined kernel's 16-byte epilogue, whole column tiles, N = the width the consumers will read
         const bool ext = epilogue == MMDM_EPI_BIAS_RESID || epilogue == MMDM_EPI_BIAS_PE;
-        if (!(glds_ok && K >= 96 && ext && vepi_ok(a) && (N & 31) == 0 && g_gemm_cfg == -1))
-            return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: row statistics need the pipelined residual / PE GEMM (K >= 96, K %% 16, N %% 32, 16-byte aligned rows)");
-    }
-    if (a.ln_out) {                 // producer of the next block's AdaLN
-        const bool ext = epilogue == MMDM_EPI_BIAS_RESID || epilogue == MMDM_EPI_BIAS_PE;
-        if (!(glds_ok && ext && vepi_ok(a) && mmdm_gemm_ln_ok(M, N, K) && fuse->ln_work && a.nss && a.nss_rows > 0 && a.nT > 0 && a.nss_ld >= 2 * N &&
-              (a.nss_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.nss) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.ln_out) & 15) == 0 && !a.stats_out &&
-              !a.nstats && g_gemm_cfg == -1))
-            return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: producer-side AdaLN needs the pipelined residual / PE GEMM with N a multiple of its tile width, "
-                                  "16-byte aligned rows and tables and a work buffer (M=%d N=%d K=%d)", M, N, K);
-        return ln_narrow(N, K) ? launch_lnp<22, 21, 4>(a, st) : launch_lnp<22, 22, 5>(a, st);
+        // (the kernel always requests the first copy's conditioning rows -- its counted waits include that load -- so hs1 is mandatory)
+        const bool copies = a.hs1 && a.sc1 && a.sc1_rows > 0 && al16(a.hs1) && al16(a.sc1) && (!a.hs2 || (a.sc2 && a.sc2_rows > 0 && al16(a.hs2) && al16(a.sc2))) &&
+                            a.nT >= 128 && a.nss_ld >= N && (a.nss_ld & 3) == 0 && a.row0 >= 0;
+        if (!(glds_ok && K >= 96 && ext && vepi_ok(a) && (N & 127) == 0 && g_gemm_cfg == -1 && !a.nstats && copies))
+            return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: row statistics / scaled copies need the pipelined residual / PE GEMM (K >= 96, K %% 16, N %% 128, "
+                                  "16-byte aligned rows and tables, T >= 128; M=%d N=%d K=%d T=%d)", M, N, K, a.nT);
     }
     if (a.nstats) {                 // consumer
-        if (!(glds_ok && mmdm_gemm_fuse_ok(K, a.nT) && a.nss && a.nss_rows > 0 && a.nss_ld >= 2 * K && (a.nss_ld & 3) == 0 &&
-              (reinterpret_cast<uintptr_t>(a.nss) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.nstats) & 15) == 0 &&
-              (epilogue == MMDM_EPI_BIAS || epilogue == MMDM_EPI_BIAS_GELU) && !a.stats_out))
-            return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: fused AdaLN needs K %% 128 == 0, 128 <= K <= %d, T >= 128, a bias / GELU epilogue and 16-byte aligned tables (K=%d T=%d)", NORM_MAX_K, K, a.nT);
-        return launch_norm(a, st);
+        if (!(glds_ok && mmdm_gemm_fuse_ok(K, a.nT) && a.uc && a.uc_rows > 0 && a.nss_ld >= 2 * N && al16(a.nstats) && a.row0 >= 0 && g_gemm_cfg == -1 &&
+              (epilogue == MMDM_EPI_BIAS || epilogue == MMDM_EPI_BIAS_GELU)))
+            return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: the AdaLN-consuming GEMM needs K %% 128 == 0, 128 <= K <= %d, T >= 128, a bias / GELU epilogue, "
+                                  "a (u | c) table and 16-byte aligned statistics (K=%d T=%d)", LIN_MAX_K, K, a.nT);
     }
     // production choice: LDS-DMA kernel, 128x128 tile / 4 waves (5 workgroups per CU) whenever the operands allow it
     const int tail = g_gemm_tail >= 0 ? g_gemm_tail : t_gemm_tail;
@@ -1224,6 +1211,10 @@ int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int 
                     b.C = C + (size_t)M1 * ldc;
                     if (extra) b.extra = extra + (size_t)M1 * ld_extra;
                     if (a.stats_out) b.stats_out = a.stats_out + (size_t)M1 * (N >> 5) * 2;
+                    if (a.hs1) b.hs1 = a.hs1 + (size_t)M1 * ldc;
+                    if (a.hs2) b.hs2 = a.hs2 + (size_t)M1 * ldc;
+                    if (a.nstats) b.nstats = a.nstats + (size_t)M1 * (K >> 5) * 2;
+                    b.row0 = a.row0 + M1;
                     int rc = narrow ? launch_glds<22, 21, 16, 4, 1, 1>(a, st) : launch_glds<22, 22, 16, 5, 1, 1>(a, st);
                     if (rc) return rc;
                     // remainder: the largest tile that still gives every CU a workgroup
@@ -1272,28 +1263,20 @@ int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int 
     }
 }
 
-extern "C" int mmdm_linear_f32_stats(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
-                                     int epilogue, const float* extra, int ld_extra, int period, float* stats, void* stream) {
-    if (!stats) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32_stats: null stats");
+// Stateless entry points of the two halves (include/mmdm.h section 1): what the sampler's stacks use, exposed for tests, tools and bindings.
+extern "C" int mmdm_linear_f32_scaled(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
+                                      int epilogue, const float* extra, int ld_extra, int period, float* stats, float* hs1, const float* scale1, int scale1_rows,
+                                      float* hs2, const float* scale2, int scale2_rows, int ss_ld, int T, void* stream) {
+    if (!stats) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32_scaled: null stats");
     mmdm_gemm_fuse f;
-    f.stats_out = stats;
+    f.stats_out = stats; f.hs1 = hs1; f.sc1 = scale1; f.sc1_rows = scale1_rows; f.hs2 = hs2; f.sc2 = scale2; f.sc2_rows = scale2_rows; f.ss_ld = ss_ld; f.T = T;
     return mmdm_linear_f32_fused(A, lda, W, ldw, K, bias, C, ldc, M, N, K, epilogue, extra, ld_extra, period, &f, stream);
 }
 
-extern "C" size_t mmdm_linear_f32_ln_work_bytes(int M, int N) { return mmdm_gemm_ln_work_bytes(M, N); }
-extern "C" int mmdm_linear_f32_ln(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
-                                  int epilogue, const float* extra, int ld_extra, int period, const float* ss, int ss_ld, int ss_rows, int T,
-                                  float* ln_out, void* work, void* stream) {
-    if (!ss || !ln_out || !work || T <= 0 || ss_rows <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32_ln: bad arguments");
+extern "C" int mmdm_linear_f32_lnfold(const float* HS, int lda, const float* stats, const float* uc, int uc_rows, int ss_ld, int T,
+                                      const float* W, int ldw, float* C, int ldc, int M, int N, int K, int epilogue, void* stream) {
+    if (!stats || !uc || T <= 0 || uc_rows <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32_lnfold: bad arguments");
     mmdm_gemm_fuse f;
-    f.norm_ss = ss; f.ss_ld = ss_ld; f.ss_rows = ss_rows; f.T = T; f.ln_out = ln_out; f.ln_work = work;
-    return mmdm_linear_f32_fused(A, lda, W, ldw, K, bias, C, ldc, M, N, K, epilogue, extra, ld_extra, period, &f, stream);
-}
-
-extern "C" int mmdm_linear_adaln_f32(const float* H, int ldh, const float* stats, const float* ss, int ss_ld, int ss_rows, int T,
-                                     const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K, int epilogue, void* stream) {
-    if (!stats || !ss || T <= 0 || ss_rows <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_adaln_f32: bad arguments");
-    mmdm_gemm_fuse f;
-    f.norm_stats = stats; f.norm_ss = ss; f.ss_ld = ss_ld; f.ss_rows = ss_rows; f.T = T;
-    return mmdm_linear_f32_fused(H, ldh, W, ldw, K, bias, C, ldc, M, N, K, epilogue, nullptr, 0, 0, &f, stream);
+    f.nstats = stats; f.uc = uc; f.uc_rows = uc_rows; f.ss_ld = ss_ld; f.T = T;
+    return mmdm_linear_f32_fused(HS, lda, W, ldw, K, nullptr, C, ldc, M, N, K, epilogue, nullptr, 0, 0, &f, stream);
 }

@@ -13,6 +13,7 @@
 // activations by the kernels that produce them (AdaLN, attention, the GELU epilogue here).  Structure = gemm_bf16_kernel with
 // three planes per operand tile: LDS-DMA staged, XOR-swizzled 64-byte rows, swapped operands (row on the lane), 16-byte epilogue.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdlib.h>
 #include <type_traits>
 #include "kernels.h"
@@ -625,14 +626,17 @@ int mmdm_gemm_split_init(void) {
     if ((rc = set_attr_w<22, 21>())) return rc;
     if ((rc = set_attr_w<12, 41>())) return rc;
     if ((rc = set_attr_w<14, 41>())) return rc;
-    const char* e = getenv("MMDM_SPLIT_CFG");
-    g_split_cfg = e ? atoi(e) : -1;
     return MMDM_OK;
 }
 
-extern "C" void mmdmx_set_split_cfg(int c) { g_split_cfg = c; }
-extern "C" void mmdmx_set_split_ablate(int c) { g_split_ablate = c; }
-extern "C" void mmdmx_set_split_timeline(void* buf) { g_split_tl = static_cast<unsigned long long*>(buf); }   // 8 u64 per wave of the next packed launches
+// diagnostics of this translation unit (mmdm_diag_set): tile override, ablation bits, timeline buffer (8 u64 per wave of the next packed launches)
+bool mmdm_diag_gemm_split(const char* key, long long v) {
+    if (!strcmp(key, "split_cfg")) g_split_cfg = (int)v;
+    else if (!strcmp(key, "split_ablate")) g_split_ablate = (int)v;
+    else if (!strcmp(key, "split_timeline")) g_split_tl = reinterpret_cast<unsigned long long*>((uintptr_t)v);
+    else return false;
+    return true;
+}
 
 extern "C" int mmdm_f32_split3(const float* in, void* out, int64_t n, int64_t plane_stride, void* stream) {
     if (n <= 0) return MMDM_OK;

@@ -19,8 +19,14 @@ int mmdm_gemm_init(void);
 // Row split of a GEMM's fractional last round of tiles (gemm_f32.hip): t/10 = the largest fraction of a round that is split off; 0 = never.
 // Thread-local; the sampler sets it per handle before it launches a step (one-stream samplers benefit, the two-stream step does not).
 void mmdm_gemm_set_tail(int t);
+int mmdm_gemm_get_tail(void);
 int mmdm_gemm_bf16_init(void);
 int mmdm_gemm_split_init(void);
+// per-translation-unit halves of mmdm_diag_set (include/mmdm.h section 4): true if `key` belongs to the unit
+bool mmdm_diag_gemm_f32(const char* key, long long v);
+bool mmdm_diag_gemm_bf16(const char* key, long long v);
+bool mmdm_diag_gemm_split(const char* key, long long v);
+bool mmdm_diag_attn(const char* key, long long v);
 
 // Activations of the GEMM epilogues, one definition for every kernel.  Each is a FIXED sequence of operations (explicit fma, no
 // expression the compiler may or may not contract), so two instantiations of an epilogue -- fp32 rows vs bf16 planes, one tile shape vs
@@ -79,26 +85,27 @@ int mmdm_blend_cfg_dyn(const float* out1, const float* out2, const float* w, int
                        float* model_out, const mmdm_hist_desc* hd, const int* loop_pos, int B, int T, hipStream_t st);
 int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
-// AdaLN fused around the fp32 GEMM (gemm_f32.hip).  A residual / PE GEMM that produces rows of the residual stream also writes their
-// partial LayerNorm statistics (stats_out [M][N/32][2]: mean and sum of squared deviations per 32-column block); the GEMM that consumes
-// AdaLN(h) takes h itself plus those statistics (norm_stats, over its K) and the conditioning rows (norm_ss: scale | shift of row
-// (m / T) % ss_rows, row stride ss_ld) and modulates its A fragments in registers -- no stand-alone AdaLN pass, no normalised copy.
+// AdaLN folded around the fp32 GEMMs by linearity (gemm_f32.hip; reference: AdaLN.forward src/models/utils/layers.py:13-24):
+//   AdaLN(h) W^T + b = rstd_m ([h (1 + s)] W^T - mean_m u) + c,    u = (1 + s) W^T,  c = t W^T + b    (s | t = the conditioning row of the row's sequence).
+// Producer -- a residual / PE GEMM that writes rows of the residual stream h -- also writes, per row and 32-column block, (mean, M2) ->
+//   stats_out [M][N/32][2], and up to two scaled copies hs_k[m][n] = h[m][n] (1 + sc_k[cond_k(m)][n]) (row stride ldc): the A operands of the
+//   GEMMs that consume AdaLN_k(h).  cond_k(m) = ((row0 + m) / T) % sc_k_rows; table rows have stride ss_ld.
+// Consumer -- a bias / GELU GEMM on A = hs_k -- combines the row's partial statistics (nstats [M][K/32][2]) in its prologue, adds the
+//   rank-2 term -mean_m u_n + sigma_m c_n with one extra 32x32x2 MFMA per (sequence of the tile, MFMA tile) and multiplies by rstd_m in
+//   its epilogue; the table row ((row0 + m) / T) % uc_rows of `uc` holds u [N] | c [N] (stride ss_ld).  `bias` is not read (it is part of c).
+// Both need T >= 128 (a tile of at most 128 rows then spans at most two sequences); no VALU work in the K loop, no rendezvous.
 struct mmdm_gemm_fuse {
     float* stats_out = nullptr;
-    const float* norm_stats = nullptr;
-    const float* norm_ss = nullptr;
-    int ss_ld = 0, ss_rows = 1, T = 1;
-    // Producer-side AdaLN: the residual / PE GEMM also writes ln_out [M][ldc] = AdaLN(C rows; norm_ss, ss_ld, ss_rows, T) -- the operand of
-    // the next block's first GEMM -- through a row-block rendezvous of its column tiles (gemm_f32.hip, LNP_).  ln_work: mmdm_gemm_ln_work_bytes
-    // bytes, zeroed ONCE by the caller (counters are monotonic across launches); at most one such GEMM per ln_work in flight at a time.
-    float* ln_out = nullptr;
-    void* ln_work = nullptr;
+    float* hs1 = nullptr; const float* sc1 = nullptr; int sc1_rows = 1;
+    float* hs2 = nullptr; const float* sc2 = nullptr; int sc2_rows = 1;
+    const float* nstats = nullptr; const float* uc = nullptr; int uc_rows = 1;
+    int ss_ld = 0, T = 1, row0 = 0;
 };
-size_t mmdm_gemm_ln_work_bytes(int M, int N);
-bool mmdm_gemm_ln_ok(int M, int N, int K);   // shapes the producer-side AdaLN covers (N % 128 == 0 or N % 64 == 0 per the tile the dispatch picks)
-bool mmdm_gemm_fuse_ok(int K, int T);      // shapes the fused consumer covers: K % 128 == 0, 128 <= K <= 1024, T >= 128
+bool mmdm_gemm_fuse_ok(int K, int T);      // shapes both halves cover: K % 128 == 0, 128 <= K <= 1024, T >= 128
 int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                           int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, const mmdm_gemm_fuse* fuse, void* stream);
+int mmdm_transpose(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t st);   // dst [cols][ld_dst] = src [rows][ld_src]^T
+int mmdm_add_const(const float* src, float* dst, float v, int n, hipStream_t st);
 int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
                   int nseq, int T, int D, hipStream_t st);
 int mmdm_mdm_unpack(const float* src, float* dst, int nseq, int T, int D, hipStream_t st);

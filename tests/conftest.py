@@ -30,8 +30,18 @@ def pytest_sessionfinish(session, exitstatus):
         import parity_tol
         if parity_tol.REPORT:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            from mixermdm_amd.build import sources_sha
+            head = None
+            try:                                    # the GPU box gets a snapshot without .git: the stamp file tools/_head.txt travels instead
+                import subprocess
+                head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or None
+            except Exception:
+                pass
+            if not head and os.path.exists(os.path.join(ROOT, "tools", "_head.txt")):
+                head = open(os.path.join(ROOT, "tools", "_head.txt")).read().strip()
             with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
-                json.dump({"exitstatus": int(exitstatus), "entries": parity_tol.REPORT}, f, indent=1)
+                json.dump({"exitstatus": int(exitstatus), "git_head": head, "kernel_sources_sha": {m: sources_sha(m) for m in ("fp32", "fp32_split", "bf16_fp8")},
+                           "tests_selected": len(session.items), "entries": parity_tol.REPORT}, f, indent=1)
     except Exception as e:      # the report must never turn a green run red
         print("parity report not written:", e)
 

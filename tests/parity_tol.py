@@ -134,8 +134,12 @@ def compare_step(out, ref32, ref64, what, tol=STEP_TOL):
 
 
 def yardstick(out, ref32, ref64, what, factor=YARD_FACTOR, factor_posvel=YARD_FACTOR_POSVEL, floor=YARD_FLOOR):
-    """Statement 2 for one step: |HIP - f64| <= factor x |fp32 oracle - f64| + floor at p50 / p99 / p99.9 of every channel class (the
-    maximum -- one element -- is recorded; it is asserted through yardstick_sequence).  Returns the figures (also appended to REPORT)."""
+    """Statement 2 for one step: |HIP - f64| <= factor x |fp32 oracle - f64| + floor at p50 / p99 / p99.9 of every channel class.
+    The per-step MAXIMUM ratio is recorded and deliberately NOT bounded here: it is the ratio of two single elements -- in the position /
+    velocity channels of two random rotation-angle errors, one per person and step -- and is heavy-tailed (45.9 x observed in one of 104
+    steps, median 2.2).  What stands behind it: compare_step's element-wise hard bound of the same step (5e-2, never exceeded outside
+    the rot6d outlier allowance) and yardstick_sequence, which bounds the MEDIAN over a sequence of every quantile including the
+    maximum.  Returns the figures (also appended to REPORT)."""
     entry = {"what": what, "kind": "yardstick", "factor": factor, "factor_posvel": factor_posvel, "floor": floor, "tensors": {}}
     fails = []
     for nm, r64 in ref64.items():

@@ -21,6 +21,18 @@ def test_library_exports_every_declared_symbol():
     assert lib.mmdm_version().startswith(b"gfx950;")
 
 
+def test_library_exports_nothing_but_the_declared_abi():
+    """`nm -D`: the dynamic symbol table of libmmdm_hip.so holds exactly the functions include/mmdm.h declares -- no mmdmx_* hooks, no
+    internal cross-translation-unit helpers, no C++ template instantiations (hidden visibility + the linker map csrc/libmmdm.map)."""
+    import subprocess
+    from mixermdm_amd._lib import lib_path
+    hdr = open(os.path.join(ROOT, "include", "mmdm.h")).read()
+    declared = set(re.findall(r"\b(mmdm_[a-z0-9_]+)\s*\(", hdr)) - {"mmdm_handle_s"}
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()}
+    assert exported == declared, sorted(exported ^ declared)
+
+
 def test_config_struct_matches_header_field_order():
     from mixermdm_amd._lib import Config, EncoderLayerWeights
     hdr = open(os.path.join(ROOT, "include", "mmdm.h")).read()

@@ -129,7 +129,9 @@ def test_bf16_and_fp8_modes_vs_oracle_at_full_dims_T300():
         ref = {999: MX.mixer_ddim_step(W, spec, stats, sch, 3.5, 999, xT, xT, cond), 500: MX.mixer_ddim_step(W, spec, stats, sch, 3.5, 500, xT, x2, cond)}
         fwd = MX.mixer_forward(W, spec, stats, fx1, torch.full((n,), 640, dtype=torch.long), fc, fx2)
     torch.set_num_threads(nthr)
-    lim = {"bf16": {"fwd": 2e-2, "out": 3e-2, 999: 1e-3, 500: 1e-3}, "bf16_fp8": {"fwd": 1.5e-1, "out": 1.0, 999: 3e-3, 500: 5e-3}}
+    # stated accuracy, not parity: every bound is ~1.5 x what the mode measures (bf16_fp8 guided output: 0.32-0.54 -- CFG 3.5 multiplies the
+    # uncorrelated evaluation noise of the cond / uncond rows by 4.3)
+    lim = {"bf16": {"fwd": 2e-2, "out": 3e-2, 999: 1e-3, 500: 1e-3}, "bf16_fp8": {"fwd": 1.5e-1, "out": 0.8, 999: 3e-3, 500: 5e-3}}
     seen = {}
     for mode in ("bf16", "bf16_fp8"):
         s = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, precision=mode, **FULL_DIMS)
@@ -227,12 +229,12 @@ def test_packed_bf16_and_fp8_linear_are_bitwise_the_plane_kernels(M, N, K):
             it = {torch.float32: torch.int32, torch.bfloat16: torch.int16, torch.float8_e4m3fn: torch.int8}[od]
             assert torch.equal(got.view(it), want.view(it)), (epi, od)
             if N % 256 == 0:            # the 128 x 256 form the large shards take (W fragments requested half a step ahead): same bits
-                lib.mmdmx_set_bf16_cfg(12)
+                lib.mmdm_diag_set(b"bf16_cfg", 12)
                 try:
                     wide = ops.linear_fp8(xq, xs, wqp, ws, b.to(d), epi, extra, out_dtype=od, packed=True)
                     assert lib.mmdm_last_gemm_kernel().decode() == "gemm_fp8w<14,42>"
                 finally:
-                    lib.mmdmx_set_bf16_cfg(-1)
+                    lib.mmdm_diag_set(b"bf16_cfg", -1)
                 assert torch.equal(wide.view(it), want.view(it)), (epi, od, "128x256")
     with pytest.raises(Exception):
         ops.linear_bf16(xb, ops.pack_weight_frag(wb[:96].contiguous()), packed=True)       # N % 128

@@ -178,33 +178,34 @@ def test_full_dims_T300_B2_step_vs_oracle(samplers, oracle_t300_b2, mode):
     _check_step(s, xT, x2, 500, dict(zip(names, mid)), f"T=300 B=2 i=500 [{mode}]", f64b)      # chains that differ, mid-schedule coefficients
 
 
-@pytest.mark.parametrize("which", ["consumer", "producer"])
-def test_full_dims_step_with_adaln_inside_the_gemm(samplers, oracle_t300_b2, which):
-    """The two fused forms of AdaLN, both off by default because they measured slower (LAB_NOTES.md).  consumer (MMDM_FUSE_ADALN): applied to
-    the A fragments of the GEMM that reads it, from the producer's partial row statistics; producer (MMDM_LN_PRODUCER): written by the
-    residual GEMM that produces the rows, through a row-block rendezvous of its column tiles.  Same parity bar as the default path; not
-    bit-identical to it (proof that the path ran)."""
-    from mixermdm_amd._lib import load_library
+def test_full_dims_step_adaln_by_linearity_vs_the_stand_alone_pass(case, samplers, oracle_t300_b2, monkeypatch):
+    """The fp32 stacks fold AdaLN around their GEMMs by linearity (gemm_f32.hip LIN_ / SCL_: no stand-alone pass).  A second handle created
+    with MMDM_NO_LIN_ADALN=1 keeps the pass: both meet the same parity bar against the oracle and the float64 yardstick, they differ (proof
+    that each path ran) and they agree with each other to rounding."""
+    from mixermdm_amd.sampler import Sampler
+    from mixermdm_amd.synthetic import FULL_DIMS
+    _, sd, _, stats, _ = case
     cond, xT, x2, _, (mid, f64b) = oracle_t300_b2
-    s = samplers["fp32"]
-    s.set_schedule("ddim1000")
-    s.begin(cond, xT)
-    lib = load_library()
-    hook = lib.mmdmx_set_fuse_adaln if which == "consumer" else lib.mmdmx_set_ln_producer
+    monkeypatch.setenv("MMDM_NO_LIN_ADALN", "1")
+    s0 = Sampler(d_heads=8, m_heads=8, max_batch=2, max_frames=300, precision="fp32", **FULL_DIMS)
+    monkeypatch.delenv("MMDM_NO_LIN_ADALN")
+    s0.load_state_dict(sd)
+    s0.set_norm_stats(*[t.numpy() for t in stats])
+    s0.prepare()
     outs = {}
-    try:
-        for on in (0, 1):
-            hook(on)
-            _force(s, xT, x2, 500)
-            s.run(1, use_graph=False)                   # eager: a captured step graph would replay the kernels it was captured with
-            outs[on] = {k: v.clone() for k, v in s.state().items() if k in NAMES}
-    finally:
-        hook(-1)
+    for tag, s in (("pass", s0), ("lin", samplers["fp32"])):
+        s.set_schedule("ddim1000")
+        s.begin(cond, xT)
+        _force(s, xT, x2, 500)
+        s.run(1, use_graph=False)
+        outs[tag] = {k: v.clone() for k, v in s.state().items() if k in NAMES}
+    s0.close()
     refs = dict(zip(NAMES, mid))
-    compare_step(outs[1], refs, f64b, f"T=300 B=2 i=500 [fp32, AdaLN in the GEMM: {which}]")
-    yardstick(outs[1], refs, f64b, f"T=300 B=2 i=500 [fp32, AdaLN in the GEMM: {which}]")
-    assert not torch.equal(outs[0]["pred_xstart2"], outs[1]["pred_xstart2"])
-    assert_close(outs[1]["pred_xstart2"], outs[0]["pred_xstart2"], atol=2e-3, rtol=2e-3, frac=1e-3, what="AdaLN in the GEMM vs the stand-alone pass")
+    for tag in ("pass", "lin"):
+        compare_step(outs[tag], refs, f64b, f"T=300 B=2 i=500 [fp32, AdaLN: {tag}]")
+        yardstick(outs[tag], refs, f64b, f"T=300 B=2 i=500 [fp32, AdaLN: {tag}]")
+    assert not torch.equal(outs["pass"]["pred_xstart2"], outs["lin"]["pred_xstart2"])
+    assert_close(outs["lin"]["pred_xstart2"], outs["pass"]["pred_xstart2"], atol=2e-3, rtol=2e-3, frac=1e-3, what="AdaLN by linearity vs the stand-alone pass")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -339,27 +340,10 @@ def test_production_split_gemm_tiles_vs_float64(gemm_operands, N, K, epi):
         assert torch.equal(ops.linear_split(xs, wp, b.to(d), epi, split_out=True, packed=True), g3)
 
 
-@pytest.mark.parametrize("N,K,epi", SHAPES[:4])
-def test_production_bf16_gemm_tiles_vs_float64_of_rounded_operands(N, K, epi):
-    from mixermdm_amd import ops
-    from mixermdm_amd._lib import load_library
-    d = dev()
-    x, w, b = rnd(301, M_FULL, K), rnd(302, N, K, scale=1 / math.sqrt(K)), rnd(303, N)
-    r = rnd(304, M_FULL, N) if epi == "resid" else None
-    xb, wb = ops.to_bf16(x.to(d)), ops.to_bf16(w.to(d))
-    with _Threads():
-        ref = _f64_ref(xb.float().cpu(), wb.float().cpu(), b, epi, r)
-    got = ops.linear_bf16(xb, wb, b.to(d), epi, r.to(d) if r is not None else None)
-    kern = load_library().mmdm_last_gemm_kernel().decode()
-    assert kern in PRODUCTION_BF16, kern
-    assert_close(got, ref.float(), atol=2e-5 * math.sqrt(K / 1024), rtol=1e-5, what=f"linear_bf16 19200x{N}x{K} {epi} on {kern}")
-
-
 # instantiations the dispatch rules pick at M = 19 200 (update together with the rules in gemm_f32.hip / gemm_split.hip / gemm_bf16.hip)
 PRODUCTION_F32 = {"gemm_pipe<22,22,16,5,vepi>", "gemm_pipe<22,22,16,5,scalar>", "gemm_pipe<22,21,16,4,vepi>", "gemm_pipe<22,21,16,4,scalar>"}
 PRODUCTION_SPLIT = {"gemm_split<42,22>", "gemm_split<22,21>"}
 PRODUCTION_SPLIT_PACKED = {"gemm_splitw<14,41>", "gemm_splitw<12,41>"}
-PRODUCTION_BF16 = {"gemm_bf16<42,22>"}
 
 
 def test_dispatch_puts_the_layer_gemms_on_the_large_tiles():

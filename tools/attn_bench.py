@@ -1,12 +1,12 @@
 """Stand-alone timing of the fp32 attention kernel at the step's shapes (GPU box), after a clock warm-up (the first ~30 launches after an idle
-period run at lower clocks: without it this script read 246 us where the kernel takes 208).  ABL= ablation bits (mmdmx_set_attn_ablate,
+period run at lower clocks: without it this script read 246 us where the kernel takes 208).  ABL= ablation bits (mmdm_diag_set "attn_ablate",
 diagnostic instantiation)."""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, statistics
 from mixermdm_amd import ops, load_library
 lib = load_library()
 ops.attention(torch.zeros(1,16,64,device="cuda:0"),torch.zeros(1,16,64,device="cuda:0"),torch.zeros(1,16,64,device="cuda:0"),1)
-lib.mmdmx_set_attn_ablate(int(os.environ.get("ABL","0")))
+lib.mmdm_diag_set(b"attn_ablate", int(os.environ.get("ABL","0")))
 d = torch.device("cuda:0")
 _w = torch.randn(4096, 4096, device=d)
 for _ in range(40): ops.linear(_w, _w)          # clock ramp

@@ -1,5 +1,5 @@
 """Per-workgroup timeline of one fp32 attention launch (GPU box): entry, loop start, loop end, kernel end, CU placement, and wave 0's time in the
-three phases of a chunk (Q K^T, softmax, P V).  Uses the diagnostic stamps of attn_mfma_kernel (mmdmx_set_attn_stamps)."""
+three phases of a chunk (Q K^T, softmax, P V).  Uses the diagnostic stamps of attn_mfma_kernel (mmdm_diag_set "attn_stamps")."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
@@ -7,17 +7,17 @@ from mixermdm_amd import ops, load_library
 lib = load_library()
 d = torch.device("cuda:0")
 ops.attention(torch.zeros(1,16,64,device=d),torch.zeros(1,16,64,device=d),torch.zeros(1,16,64,device=d),1)
-lib.mmdmx_set_attn_ablate(int(os.environ.get("ABL","0")))
+lib.mmdm_diag_set(b"attn_ablate", int(os.environ.get("ABL","0")))
 for nseq, T, H, dh in [(64, 300, 8, 128), (64, 300, 8, 64)]:
     D = H * dh
     qkv = torch.randn(nseq, T, 3 * D, device=d)
     for _ in range(3):
         ops.attention(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], H)
     stamps = torch.zeros(4096 * 8, dtype=torch.int64, device=d)
-    lib.mmdmx_set_attn_stamps(C.c_void_p(stamps.data_ptr()))
+    lib.mmdm_diag_set(b"attn_stamps", stamps.data_ptr())
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); ops.attention(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], H); e1.record(); torch.cuda.synchronize()
-    lib.mmdmx_set_attn_stamps(C.c_void_p(0))
+    lib.mmdm_diag_set(b"attn_stamps", 0)
     s = stamps.cpu().numpy().reshape(-1, 8)
     s = s[s[:, 0] != 0]
     t0 = s[:, 0].min()

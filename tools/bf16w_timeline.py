@@ -1,11 +1,10 @@
 """Packed bf16 GEMM (gemm_bf16w_kernel): how much of a workgroup's life is its K loop, and the shader clock inside it
-(s_memtime / s_memrealtime; mmdmx_set_bf16_timeline).  the matrix pipe never idles at 32 (128 x 256 tile) or 16 (128 x 128) MFMAs x 32 cycles per wave and step, two waves per SIMD."""
+(s_memtime / s_memrealtime; mmdm_diag_set "bf16_timeline").  the matrix pipe never idles at 32 (128 x 256 tile) or 16 (128 x 128) MFMAs x 32 cycles per wave and step, two waves per SIMD."""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, math, ctypes as C
 from mixermdm_amd import ops, load_library
 lib = load_library(); d = torch.device("cuda:0")
 vp = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
-lib.mmdmx_set_bf16_timeline.argtypes = [C.c_void_p]
 for M, N, K, epi in [(19200, 3072, 1024, "bias"), (19200, 1024, 1024, "resid"), (19200, 1024, 2048, "resid"), (8192, 8192, 8192, "bias")]:
     x = torch.randn(M, K, device=d); w = torch.randn(N, K, device=d) / math.sqrt(K); b = torch.randn(N, device=d)
     xb, wb = ops.to_bf16(x), ops.to_bf16(w); wp = ops.pack_weight_frag(wb)
@@ -16,7 +15,7 @@ for M, N, K, epi in [(19200, 3072, 1024, "bias"), (19200, 1024, 1024, "resid"), 
     bn = 256 if kern.endswith("42>") else 128
     nwg = ((M + 127) // 128) * (N // bn)
     tl = torch.zeros(nwg * 4, device=d, dtype=torch.int64)
-    lib.mmdmx_set_bf16_timeline(vp(tl)); call(); torch.cuda.synchronize(); lib.mmdmx_set_bf16_timeline(None)
+    lib.mmdm_diag_set(b"bf16_timeline", tl.data_ptr()); call(); torch.cuda.synchronize(); lib.mmdm_diag_set(b"bf16_timeline", 0)
     t = tl.view(nwg, 4).double().cpu()
     mhz = (100.0 * t[:, 0] / t[:, 1].clamp(min=1)).median().item()
     nkt = t[0, 3].item()

@@ -5,13 +5,13 @@ lib = load_library()
 d = torch.device("cuda:0")
 shapes = [(19200,3072,1024,"qkv"),(19200,1024,1024,"out"),(19200,2048,1024,"ffn1"),(19200,1024,2048,"ffn2"),
           (19200,1536,512,"m.qkv"),(19200,512,512,"m.out"),(19200,1024,512,"m.ffn1"),(19200,512,1024,"m.ffn2"),(4096,4096,4096,"sq4k")]
-# CFGS: comma-separated tile configurations (mmdmx_set_gemm_cfg; -1 = the production dispatch), each optionally ":t" = row split of the
-# fractional last round when it holds <= t/10 of the resident slots (mmdmx_set_gemm_tail), e.g. CFGS=-1,-1:6,-1:10
+# CFGS: comma-separated tile configurations (mmdm_diag_set "gemm_cfg"; -1 = the production dispatch), each optionally ":t" = row split of the
+# fractional last round when it holds <= t/10 of the resident slots (mmdm_diag_set "gemm_tail"), e.g. CFGS=-1,-1:6,-1:10
 cfgs = [c for c in os.environ.get("CFGS","0,1,4").split(",")]
 def set_cfg(c):
     cfg, _, tail = c.partition(":")
-    lib.mmdmx_set_gemm_cfg(int(cfg)); lib.mmdmx_set_gemm_tail(int(tail or 0))
-lib.mmdmx_set_gemm_ablate(int(os.environ.get('ABL','0')))
+    lib.mmdm_diag_set(b"gemm_cfg", int(cfg)); lib.mmdm_diag_set(b"gemm_tail", int(tail or 0))
+lib.mmdm_diag_set(b"gemm_ablate", int(os.environ.get('ABL','0')))
 only = sys.argv[1:]
 rounds, reps = 7, 4
 # clock ramp: after an idle period the first ~30 launches run at lower clocks (a 1 ms GEMM went 1133 -> 900 us over 40 back-to-back calls);

@@ -14,7 +14,7 @@ for M,N,K,name,epi in shapes:
     if epi=="resid": ref = ref + extra
     line=f"{name:6s} {M}x{N}x{K} {epi:5s}"
     for c in cfgs:
-        lib.mmdmx_set_bf16_cfg(c)
+        lib.mmdm_diag_set(b"bf16_cfg", c)
         out = ops.linear_bf16(xb,wb,b,epi,extra)
         err=(out-ref).abs().max().item()
         res=[]
@@ -35,10 +35,10 @@ for M,N,K,name,epi in shapes:
         call = lambda: lib.mmdm_linear_bf16_packed(vp(xb), K, vp(wp), vp(b), vp(outp), N, 0, M, N, K, ops.EPI[epi], vp(ex), N if ex is not None else 0, 0, st)
         assert call() == 0, lib.mmdm_last_error()
         torch.cuda.synchronize()
-        lib.mmdmx_set_bf16_cfg(-1)
+        lib.mmdm_diag_set(b"bf16_cfg", -1)
         ref2 = ops.linear_bf16(xb, wb, b, epi, extra)
-        for pc, tag in ((12, "128x256"), (11, "128x128")):          # forced packed tile shapes (mmdmx_set_bf16_cfg 12 / 11)
-            lib.mmdmx_set_bf16_cfg(pc)
+        for pc, tag in ((12, "128x256"), (11, "128x128")):          # forced packed tile shapes (mmdm_diag_set "bf16_cfg" 12 / 11)
+            lib.mmdm_diag_set(b"bf16_cfg", pc)
             assert call() == 0, lib.mmdm_last_error()
             torch.cuda.synchronize()
             same = torch.equal(outp, ref2)
@@ -48,5 +48,5 @@ for M,N,K,name,epi in shapes:
                 for _ in range(4): call()
                 e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
             ms=statistics.median(res); line+=f" | packed {tag}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:7.1f}TF {'==' if same else '!='}"
-        lib.mmdmx_set_bf16_cfg(-1)
+        lib.mmdm_diag_set(b"bf16_cfg", -1)
     print(line, flush=True)

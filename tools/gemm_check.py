@@ -9,7 +9,7 @@ ops.linear(torch.zeros(8, 64, device=d), torch.zeros(8, 64, device=d))     # run
 cfgs = [int(c) for c in os.environ.get("CFGS", "30").split(",")]
 g = torch.Generator().manual_seed(0)
 for cfg in cfgs:
-    lib.mmdmx_set_gemm_cfg(cfg)
+    lib.mmdm_diag_set(b"gemm_cfg", cfg)
     worst = 0.0
     for M, N, K, epi in [(19200, 1024, 1024, "resid"), (1200, 3072, 1024, "bias"), (300, 2048, 1024, "gelu"), (777, 512, 2048, "resid"), (130, 136, 64, "bias"),
                          (19200, 512, 512, "resid"), (257, 1024, 48, "bias"), (64, 64, 80, "pe")]:
@@ -27,4 +27,4 @@ for cfg in cfgs:
     a = ops.linear(x.to(d), w.to(d), b.to(d)); bb = ops.linear(x.to(d), w.to(d), b.to(d))
     assert torch.equal(a, bb)
     print(f"cfg {cfg}: worst scaled error {worst:.2e} {'OK' if worst < 3e-5 else 'FAIL'}")
-lib.mmdmx_set_gemm_cfg(-1)
+lib.mmdm_diag_set(b"gemm_cfg", -1)

@@ -2,8 +2,7 @@ import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspa
 import torch, math, statistics, ctypes as C
 from mixermdm_amd import ops, load_library
 lib = load_library()
-lib.mmdmx_set_split_cfg.argtypes = [C.c_int]
-lib.mmdmx_set_split_ablate(int(os.environ.get('ABL','0')))
+lib.mmdm_diag_set(b"split_ablate", int(os.environ.get('ABL','0')))
 d = torch.device("cuda:0")
 vp = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -45,15 +44,15 @@ for M,N,K,name,epi in shapes:
         assert rc == 0, lib.mmdm_last_error()
     if epi != "resid":
         o1 = torch.empty(M, N, device=d); o2 = torch.empty(M, N, device=d)
-        lib.mmdmx_set_split_cfg(-1)
+        lib.mmdm_diag_set(b"split_cfg", -1)
         lin_split(xs, ws, b, epi, None, o1, M, N, K); lin_packed(xs, wp, b, epi, None, o2, M, N, K)
         line += " | packed==planes: " + str(torch.equal(o1, o2))
         for c in os.environ.get("PCFGS", "p-1,p5").split(","):
-            lib.mmdmx_set_split_cfg(int(c[1:])); lin_packed(xs, wp, b, epi, None, o2, M, N, K); line += "/" + str(torch.equal(o1, o2))
+            lib.mmdm_diag_set(b"split_cfg", int(c[1:])); lin_packed(xs, wp, b, epi, None, o2, M, N, K); line += "/" + str(torch.equal(o1, o2))
     pk = os.environ.get("PCFGS", "p-1,p5").split(",")
     for c in cfgs + pk:
         if isinstance(c, str):
-            lib.mmdmx_set_split_cfg(int(c[1:]))
+            lib.mmdm_diag_set(b"split_cfg", int(c[1:]))
             ts = []
             for r in range(5):
                 lin_packed(xs, wp, b, epi, extra, out, M, N, K)
@@ -63,7 +62,7 @@ for M,N,K,name,epi in shapes:
                 e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1)/4)
             ms = statistics.median(ts); line += f" | {c}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:6.1f}TF"
             continue
-        lib.mmdmx_set_split_cfg(c)
+        lib.mmdm_diag_set(b"split_cfg", c)
         ts = []
         for r in range(5):
             lin_split(xs, ws, b, epi, extra, out, M, N, K)

@@ -1,5 +1,5 @@
 """Per-workgroup timeline of one fp32 GEMM launch (GPU box): when does each workgroup start, enter its K loop, leave it; how many share a CU.
-Uses the diagnostic stamps of gemm_glds_kernel (mmdmx_set_gemm_stamps); production launches carry a null stamp pointer."""
+Uses the diagnostic stamps of gemm_glds_kernel (mmdm_diag_set "gemm_stamps"); production launches carry a null stamp pointer."""
 import os, sys, math, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
@@ -8,8 +8,8 @@ lib = load_library()
 d = torch.device("cuda:0")
 shapes = {"out": (19200, 1024, 1024, "resid"), "ffn2": (19200, 1024, 2048, "resid"), "qkv": (19200, 3072, 1024, "bias"), "ffn1": (19200, 2048, 1024, "gelu")}
 ops.linear(torch.zeros(8, 64, device=d), torch.zeros(8, 64, device=d))     # lazy init first (it resets the forced configuration)
-lib.mmdmx_set_gemm_cfg(int(os.environ.get("CFG", "-1")))
-lib.mmdmx_set_gemm_ablate(int(os.environ.get("ABL", "0")))
+lib.mmdm_diag_set(b"gemm_cfg", int(os.environ.get("CFG", "-1")))
+lib.mmdm_diag_set(b"gemm_ablate", int(os.environ.get("ABL", "0")))
 for name in (sys.argv[1:] or ["out", "qkv"]):
     M, N, K, epi = shapes[name]
     x = torch.randn(M, K, device=d); w = torch.randn(N, K, device=d) / math.sqrt(K); b = torch.randn(N, device=d)
@@ -18,10 +18,10 @@ for name in (sys.argv[1:] or ["out", "qkv"]):
     for _ in range(3):
         ops.linear(x, w, b, epi, extra, out=out)
     stamps = torch.zeros(8192 * 8, dtype=torch.int64, device=d)
-    lib.mmdmx_set_gemm_stamps(C.c_void_p(stamps.data_ptr()))
+    lib.mmdm_diag_set(b"gemm_stamps", stamps.data_ptr())
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); ops.linear(x, w, b, epi, extra, out=out); e1.record(); torch.cuda.synchronize()
-    lib.mmdmx_set_gemm_stamps(C.c_void_p(0))
+    lib.mmdm_diag_set(b"gemm_stamps", 0)
     kern = lib.mmdm_last_gemm_kernel().decode()
     raw = stamps.cpu().numpy()
     import re

@@ -1,4 +1,4 @@
-"""Where a wave of the packed fp32-split GEMM spends its K step: s_memtime sums per phase (mmdmx_set_split_timeline).
+"""Where a wave of the packed fp32-split GEMM spends its K step: s_memtime sums per phase (mmdm_diag_set "split_timeline").
 Phases of one step: 0 = 24 MFMAs of k-block 0 (+ A fragment reads, next step's B loads); 1 = 12 MFMAs of k-block 1; 2 = counted vmcnt wait;
 3 = barrier; 4 = last 12 MFMAs (+ next stage's A reads and LDS-DMA requests)."""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,14 +8,12 @@ lib = load_library()
 d = torch.device("cuda:0")
 vp = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-lib.mmdmx_set_split_timeline.argtypes = [C.c_void_p]
 def split(x):
     out = torch.empty(3, *x.shape, device=d, dtype=torch.bfloat16); n = x.numel()
     assert lib.mmdm_f32_split3(vp(x), vp(out), n, n, st()) == 0
     return out
-lib.mmdmx_set_split_cfg.argtypes = [C.c_int]
 for cfg in [int(c) for c in os.environ.get("CFGS", "-1,5").split(",")]:
-  lib.mmdmx_set_split_cfg(cfg)
+  lib.mmdm_diag_set(b"split_cfg", cfg)
   print("split cfg", cfg)
   for M, N, K in [(19200, 3072, 1024), (4096, 4096, 4096)]:
       x = torch.randn(M, K, device=d); w = torch.randn(N, K, device=d) / math.sqrt(K); b = torch.randn(N, device=d)
@@ -27,7 +25,7 @@ for cfg in [int(c) for c in os.environ.get("CFGS", "-1,5").split(",")]:
       for _ in range(int(os.environ.get("WARM", "30"))): call()
       nwg = ((M + 127) // 128) * (N // 128)
       tl = torch.zeros(nwg * 4 * 8, device=d, dtype=torch.int64)
-      lib.mmdmx_set_split_timeline(vp(tl)); assert call() == 0; torch.cuda.synchronize(); lib.mmdmx_set_split_timeline(None)
+      lib.mmdm_diag_set(b"split_timeline", tl.data_ptr()); assert call() == 0; torch.cuda.synchronize(); lib.mmdm_diag_set(b"split_timeline", 0)
       t = tl.view(nwg, 4, 8).double().cpu()
       nkt = t[0, 0, 5].item()
       per = t[:, :, :5] / nkt                     # cycles per step and phase
