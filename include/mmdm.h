@@ -21,8 +21,6 @@
  *   MMDM_NO_PACK=1       keep the low-precision weight twins of precision 1-3 in row-major planes instead of MFMA fragment order (the
  *                        packed and the plane kernels are bit-identical; tests/test_gpu_packed_modes.py compares them).
  *   MMDM_QKP / MMDM_NO_QKP / MMDM_NO_BF16_PV   precision >= 1: force / forbid the bf16-plane Q K^T and the bf16 P V forms of the attention.
- *   MMDM_NO_LIN_ADALN=1  precision 0: keep the stand-alone AdaLN pass instead of folding AdaLN around the GEMMs by linearity
- *                        (mmdm_linear_f32_scaled / _lnfold below); results agree to fp32 rounding (A/B measurements, tests).
  * All of them are read ONCE, by mmdm_create, into the handle: a handle's behaviour never changes after it exists, and the stateless kernels
  * of section 1 read no environment at all.  The library exports exactly the symbols this header declares (hidden visibility otherwise);
  * section 4 is the one diagnostic entry point the scripts under tools/ use.
@@ -128,27 +126,6 @@ int mmdm_f32_split3(const float* in, void* out, int64_t n, int64_t plane_stride,
  * row(s) = s % ss_rows.  ss is the output of Linear(SiLU(emb)) (scale first, shift second), row stride ss_ld.
  * Replaces AdaLN.forward  src/models/utils/layers.py:15-25. */
 int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss_rows, float* out, int nseq, int T, int D, void* stream);
-
-/* AdaLN folded around the fp32 GEMMs by linearity: no stand-alone AdaLN pass over the residual stream, no VALU work in a K loop, no
- * rendezvous between tiles.  Reference: AdaLN.forward feeding nn.Linear / MultiheadAttention.in_proj -- src/models/utils/layers.py:13-24,
- * 36-44, 77-87, 99-104.  With (s | t) the conditioning row of a row's sequence, mean_m / rstd_m its LayerNorm statistics (eps 1e-6):
- *     AdaLN(h) W^T + b  =  rstd_m ( [h (1 + s)] W^T  -  mean_m u )  +  c,        u = (1 + s) W^T,   c = t W^T + b.
- *
- * mmdm_linear_f32_scaled (producer): mmdm_linear_f32 with a residual (MMDM_EPI_BIAS_RESID) or positional (MMDM_EPI_BIAS_PE) epilogue that
- *   ALSO writes, for every output row and 32-column block, (mean, sum of squared deviations) of the stored values -- stats [M][N/32][2] --
- *   and the scaled copy hs1[m][n] = C[m][n] (1 + scale1[((m / T) % scale1_rows) * ss_ld + n]) (row stride ldc), optionally a second copy
- *   hs2 with its own table (scale2 may be NULL).  Needs N % 128 == 0, K % 16 == 0, K >= 96, T >= 128, 16-byte aligned rows / tables.
- * mmdm_linear_f32_lnfold (consumer): C = epilogue( AdaLN(h) W^T + b ), epilogue MMDM_EPI_BIAS or MMDM_EPI_BIAS_GELU, from HS = the scaled
- *   copy of h, stats = what the producer wrote for it ([M][K/32][2]) and uc = the table whose row (m / T) % uc_rows holds u [N] | c [N]
- *   (row stride ss_ld >= 2N; the bias is part of c).  One extra 32x32x2 MFMA per (sequence of a tile, MFMA tile) adds -mean_m u_n +
- *   sigma_m c_n to the accumulators, the epilogue multiplies by rstd_m.  Needs K % 128 == 0, 128 <= K <= 1024, T >= 128.
- * The sampler's fp32 stacks run on these two (u | c come out of the per-step conditioning GEMM as extra columns: W W_s and W W_t are
- * formed once at mmdm_prepare); MMDM_NO_LIN_ADALN=1 in the environment of mmdm_create's process keeps the stand-alone pass. */
-int mmdm_linear_f32_scaled(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
-                           int epilogue, const float* extra, int ld_extra, int period, float* stats, float* hs1, const float* scale1, int scale1_rows,
-                           float* hs2, const float* scale2, int scale2_rows, int ss_ld, int T, void* stream);
-int mmdm_linear_f32_lnfold(const float* HS, int lda, const float* stats, const float* uc, int uc_rows, int ss_ld, int T,
-                           const float* W, int ldw, float* C, int ldc, int M, int N, int K, int epilogue, void* stream);
 
 /* Same with a selectable output type: out_bf16 != 0 writes `out` as bf16 (operand of the next bf16 GEMM). */
 int mmdm_adaln_ex(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, int nseq, int T, int D, void* stream);
@@ -399,6 +376,8 @@ int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launc
 /* Sets one PROCESS-GLOBAL diagnostic switch; not thread-safe, never needed to use the library.  Timing ablations and in-kernel stamps live
  * in separate DIAGNOSTIC kernel instantiations that are only launched while a switch asks for them: the kernels a handle launches by
  * default contain no diagnostic code.  Keys (value -1 / 0 = back to normal):
+ *   "bf16_tst"                                   0 = the bf16 / fp8 GEMMs store their results directly (row-per-lane) instead of through the
+ *                                                workgroup's LDS transposition (bit-identical results; A/B timing)
  *   "gemm_cfg" / "split_cfg" / "bf16_cfg"       force a tile configuration of the fp32 / fp32-split / bf16-fp8 GEMM dispatch (-1 = automatic)
  *   "gemm_tail"                                  force the row-split rule of the fp32 dispatch (t/10 of a round; -1 = the caller's handle decides)
  *   "gemm_ablate" / "split_ablate" / "attn_ablate"   timing-ablation bits (wrong results)

@@ -37,8 +37,6 @@ SYMBOLS = {
     "mmdm_last_error": (C.c_char_p, []),
     "mmdm_version": (C.c_char_p, []),
     "mmdm_linear_f32": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
-    "mmdm_linear_f32_scaled": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _I, _I, _I, _VP]),
-    "mmdm_linear_f32_lnfold": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _I, _VP, _I, _I, _I, _I, _I, _VP]),
     "mmdm_linear_bf16": (_I, [_VP, _I, _VP, _I, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
     "mmdm_f32_to_bf16": (_I, [_VP, _VP, C.c_int64, _VP]),
     "mmdm_linear_split": (_I, [_VP, _I, C.c_int64, _VP, _I, C.c_int64, _VP, _VP, _I, C.c_int64, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),

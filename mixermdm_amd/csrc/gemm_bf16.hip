@@ -37,6 +37,7 @@ struct BArgs {
     float a_const, out_scale;                     // fp8: de-quantisation factor of A when a_scale is null; fp8 output is e4m3(value * out_scale)
     unsigned long long* tl;               // diagnostic (tools/bf16w_timeline.py): per-workgroup {loop shader clocks, loop 100 MHz ticks, whole-kernel ticks, K steps}; null in production
     __bf16* P2; int p2_cols, ld2;         // optional second output: columns [0, p2_cols) also as bf16 (attention Q/K operands)
+    int tst;                              // results leave through the workgroup's LDS transposition (bf16_finish_t)
 };
 
 
@@ -62,7 +63,136 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
     return (unsigned)w;
 }
 
+// Cache policy of the transposed epilogue's stores (aux immediate of buffer_store: 0 = write-back through L2, 2 = nt): whole lines that the
+// next kernel streams once.
+#ifndef MMDM_BT_AUX
+#define MMDM_BT_AUX 2
+#endif
+#ifndef MMDM_BF16_TST_DEFAULT
+#define MMDM_BF16_TST_DEFAULT 1
+#endif
+int g_bf16_tst = MMDM_BF16_TST_DEFAULT;        // mmdm_diag_set "bf16_tst": 0 = the direct (row-per-lane) epilogue
+
 #if defined(__HIP_DEVICE_COMPILE__)
+// Transposed epilogue.  In the D^T map a lane owns an output ROW: the direct form below writes bf16 results as 8-byte pieces (fp8: 4-byte) of
+// 32 different rows per instruction -- every 128-byte line of C is assembled from 8-16 partial writes of two waves -- and at K = 1024 a tile's
+// K loop (8-16 steps) is shorter than that epilogue.  Here the workgroup's tile goes, a few 32-row tiles at a time, through an XOR-swizzled
+// image [rows][BN columns] in the (now idle) operand stages, and leaves as whole rows: one instruction stores 64 x 16 contiguous bytes per
+// row group.  Values and arithmetic are those of bf16_finish: bit-identical results.  Returns false (nothing done) for the cases it does not
+// cover: a second plane output, a ragged last column tile.
+// The residual / PE rows of an fp32-output tile that takes the transposed epilogue are added THERE -- (b + sum_k a_k w_k) + r, the order of the
+// reference's `x + linear(...)`, read as whole lines -- instead of starting the accumulators: a tile's first MFMA no longer waits for 64 KB
+// of residual (plus a vmcnt(0) in front of the operand pipeline).  Same predicate at kernel start and in the epilogue.
+__device__ __forceinline__ bool bf16_late_ext(const BArgs& p, int n0, int BN) {
+    return p.tst && !p.P2 && n0 + BN <= p.N && p.out_bf16 == 0 && (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE);
+}
+
+template <int TM, int TN, int ET, int BM, int BN, int NWAVES>
+__device__ __forceinline__ bool bf16_finish_t(const BArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, float* smem) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    if (p.P2 || n0 + BN > p.N) return false;
+    const int l31 = lane & 31, lh = lane >> 5, wave = threadIdx.x >> 6;
+    __builtin_amdgcn_s_barrier();                             // every wave has left the K loop: the operand stages are free
+    auto finish = [&](auto act_c, auto out_c) {
+        constexpr int ACT = decltype(act_c)::value, OUT = decltype(out_c)::value;
+        constexpr int EBO = OUT == 0 ? 4 : (OUT == 1 ? 2 : 1);                 // bytes per output element
+        constexpr int RB = BN * EBO, CPR = RB / 16;                            // bytes / 16-byte chunks per image row
+        constexpr int NRT = BM / 32;                                           // 32-row tiles of the workgroup tile
+        constexpr int FIT = (48 * 1024) / (32 * RB);                           // row tiles the 48 KB of operand stages hold
+        constexpr int RPP = FIT >= NRT ? NRT : (FIT >= 4 ? 4 : (FIT >= 2 ? 2 : 1));      // row tiles per phase (a power of two that divides NRT)
+        static_assert(FIT >= 1 && NRT % RPP == 0, "image does not fit the operand stages");
+        static_assert(CPR <= 64, "a row of the image is at most one store instruction");
+        constexpr int LPR = CPR, RPI = 64 / LPR;                               // lanes per row, rows per store instruction
+        constexpr int ROWS = 32 * RPP, RPW = ROWS / NWAVES;                    // rows per phase, rows each wave stores per phase
+        static_assert(ROWS % NWAVES == 0 && RPW % RPI == 0, "rows of a phase must divide over the waves' store instructions");
+        constexpr int SWM = CPR - 1 < 15 ? CPR - 1 : 15;                       // chunk swizzle mask
+        const bool late = OUT == 0 && bf16_late_ext(p, n0, BN);                // residual / PE rows added in phase (2), coalesced
+        const bool ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && !late;
+        const int rows_here = min(p.M - m0, BM);
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(p.C) + (size_t)m0 * p.ldc * EBO, 0, rows_here * p.ldc * EBO, 0x00020000);
+        char* img = reinterpret_cast<char*>(smem);
+        const int rr = lane / LPR, rc = lane % LPR;                            // phase (2): this lane's row inside a store instruction's row group, its 16-byte column
+#pragma unroll
+        for (int ph = 0; ph < NRT / RPP; ++ph) {
+            // (0) the residual / PE quads this lane adds in phase (2): requested first, they land behind the image write and the barrier
+            f32x4 rq[OUT == 0 ? RPW / RPI : 1];
+            if constexpr (OUT == 0) {
+                if (late) {
+#pragma unroll
+                    for (int k = 0; k < RPW / RPI; ++k) {
+                        const int ir = wave * RPW + k * RPI + rr;
+                        const int rowc = min(m0 + (ph * RPP + ir / 32) * 32 + (ir & 31), p.M - 1);
+                        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? rowc % p.period : rowc;
+                        rq[k] = *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + n0 + rc * 4);
+                    }
+                }
+            }
+            // (1) this wave's row tiles of the phase -> image (values exactly as the direct epilogue forms them)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rt = wm * TM + i;                                    // row tile of the workgroup tile (wave-uniform)
+                if (rt / RPP != ph) continue;
+                const int ir = (rt % RPP) * 32 + l31;                          // image row
+                const int row = m0 + rt * 32 + l31, rowc = min(row, p.M - 1);
+                float sa = 1.f;
+                if constexpr (ET == 1) sa = p.a_scale ? p.a_scale[rowc] : p.a_const;
+                const int er = p.epilogue == MMDM_EPI_BIAS_PE ? rowc % p.period : rowc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int lc = wn * (32 * TN) + j * 32 + 8 * qd + 4 * lh;           // column inside the tile
+                        const int col = n0 + lc;
+                        f32x4 v, add = {0.f, 0.f, 0.f, 0.f}, sw4 = {1.f, 1.f, 1.f, 1.f};
+                        if constexpr (ET == 1) {
+                            if (p.w_scale) sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + col);
+                            if (p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + col);
+                            if (ext) add += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float t = acc[i][j][4 * qd + c];
+                            if constexpr (ET == 1) t = t * (sa * sw4[c]) + add[c];
+                            if constexpr (ACT == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
+                            else if constexpr (ACT == MMDM_EPI_BIAS_SILU) t = silu(t);
+                            v[c] = t;
+                        }
+                        const int cb = lc * EBO;                                            // byte column inside the image row
+                        char* dst = img + ir * RB + (((cb >> 4) ^ (ir & SWM)) << 4) + (cb & 15);
+                        if constexpr (OUT == 1) { const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; *reinterpret_cast<bf16x4*>(dst) = o; }
+                        else if constexpr (OUT == 2) *reinterpret_cast<unsigned*>(dst) = pack_fp8x4(v * p.out_scale);
+                        else *reinterpret_cast<f32x4*>(dst) = v;
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // (2) image -> C, whole rows
+#pragma unroll
+            for (int k = 0; k < RPW / RPI; ++k) {
+                const int ir = wave * RPW + k * RPI + rr;
+                f32x4 v = *reinterpret_cast<const f32x4*>(img + ir * RB + ((rc ^ (ir & SWM)) << 4));
+                if constexpr (OUT == 0) { if (late) v += rq[k]; }
+                const int trow = (ph * RPP + ir / 32) * 32 + (ir & 31);                     // row inside the workgroup tile
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, trow * p.ldc * EBO + n0 * EBO + rc * 16, 0, MMDM_BT_AUX);
+            }
+            if (ph + 1 < NRT / RPP) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                                                // the image is rewritten by the next phase
+            }
+        }
+    };
+    auto finish_out = [&](auto act_c) {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        if (p.out_bf16 == 1) finish(act_c, I1{});
+        else if (p.out_bf16 == 2) finish(act_c, I2{});
+        else finish(act_c, I0{});
+    };
+    if (p.epilogue == MMDM_EPI_BIAS_GELU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_GELU>{});
+    else if (p.epilogue == MMDM_EPI_BIAS_SILU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_SILU>{});
+    else finish_out(std::integral_constant<int, MMDM_EPI_BIAS>{});
+    return true;
+}
+
 template <int TM, int TN, int ET, int BM>
 __device__ __forceinline__ void bf16_finish(const BArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int l31, int lh) {
     // Activation, output form (fp32 / bf16 / fp8) and the optional bf16 copy are chosen ONCE per tile, outside the element loops (see
@@ -209,7 +339,7 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS), (BCfg<TM_, TN_>::THREADS
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     } else {
         const bool has_bias = p.bias != nullptr;
-        const bool has_ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
+        const bool has_ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && !bf16_late_ext(p, n0, BN);
         f32x4 bv[TN][4], ev[TM][TN][4];
         int colc[TN][4];
 #pragma unroll
@@ -317,7 +447,8 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS), (BCfg<TM_, TN_>::THREADS
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
 
-    bf16_finish<TM, TN, ET, BM>(p, acc, m0, n0, wm, wn, l31, lh);
+    if (!(p.tst && bf16_finish_t<TM, TN, ET, BM, BN, C_::NWAVES>(p, acc, m0, n0, wm, wn, lane, smem)))
+        bf16_finish<TM, TN, ET, BM>(p, acc, m0, n0, wm, wn, l31, lh);
 #endif
 }
 
@@ -427,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     } else {
         const bool has_bias = p.bias != nullptr;
-        const bool has_ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
+        const bool has_ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && !bf16_late_ext(p, n0, BN);
         int colc[TN][4];
         f32x4 bv[TN][4];
 #pragma unroll
@@ -621,7 +752,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
     if constexpr (TL) { t_r1 = __builtin_amdgcn_s_memrealtime(); t_c1 = __builtin_readcyclecounter(); }
-    bf16_finish<TM, TN, ET, BM>(p, acc, m0, n0, wm, wn, l31, lh);
+    if (!(p.tst && bf16_finish_t<TM, TN, ET, BM, BN, NW>(p, acc, m0, n0, wm, wn, lane, smem)))
+        bf16_finish<TM, TN, ET, BM>(p, acc, m0, n0, wm, wn, l31, lh);
     if constexpr (TL) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (p.tl && tid == 0) {
@@ -707,6 +839,7 @@ int mmdm_gemm_bf16_init(void) {
 // diagnostics of this translation unit (mmdm_diag_set): tile override; timeline buffer (4 u64 per workgroup of the next packed launches)
 bool mmdm_diag_gemm_bf16(const char* key, long long v) {
     if (!strcmp(key, "bf16_cfg")) g_bf16_cfg = (int)v;
+    else if (!strcmp(key, "bf16_tst")) g_bf16_tst = (int)v;
     else if (!strcmp(key, "bf16_timeline")) g_bf16_tl = reinterpret_cast<unsigned long long*>((uintptr_t)v);
     else return false;
     return true;
@@ -773,6 +906,7 @@ int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const fl
     a.mt = a.nt = 0;
     a.a_scale = a.w_scale = nullptr; a.a_const = a.out_scale = 1.f; a.tl = packed ? g_bf16_tl : nullptr;
     a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
+    a.tst = g_bf16_tst;
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_bf16: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (packed) {
@@ -843,6 +977,7 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
     a.a_scale = a_scale; a.w_scale = w_scale;
     a.a_const = a_const; a.out_scale = out_scale; a.tl = packed ? g_bf16_tl : nullptr;
     a.P2 = static_cast<__bf16*>(bf16_copy); a.p2_cols = copy_cols; a.ld2 = ld2;
+    a.tst = g_bf16_tst;
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (packed) {

@@ -17,14 +17,7 @@
 #include <type_traits>
 #include "kernels.h"
 
-// cache policy of the epilogues' result stores (aux immediate of buffer_store: 0 = default write-back through L2; 2 = nt).
-#ifndef MMDM_ST_AUX
-#define MMDM_ST_AUX 0
-#endif
-
 namespace {
-
-int g_gemm_tst = 1;        // 16-byte epilogues of the pipelined kernel leave through the LDS transposition (mmdm_diag_set "gemm_tst" 0 = direct stores)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -35,18 +28,6 @@ struct GemmArgs {
     int lda, ldw, ldc, ld_extra;
     int M, N, K, Kw, epilogue, period;   // Kw >= K: readable columns of W (zero beyond K)
     int mt, nt;
-    // AdaLN folded around the GEMMs by linearity (mmdm_gemm_fuse, kernels.h; reference: AdaLN.forward src/models/utils/layers.py:13-24):
-    //   AdaLN(h) W^T + b = rstd_m ([h (1 + s)] W^T - mean_m u) + c,  u = (1 + s) W^T,  c = t W^T + b.
-    // Producer side (SCL_ instantiation: the 16-byte epilogue of a residual / PE GEMM that writes rows of the residual stream h): per output
-    // row and 32-column block the pair (mean, M2 = sum of squared deviations) of the values just stored -> stats_out [M][N/32][2], and up
-    // to two scaled copies hs_k[m][n] = h[m][n] (1 + sc_k[((row0 + m) / nT) % sc_rows_k][n]) (row stride ldc, table row stride nss_ld).
-    // Consumer side (LIN_ instantiation, scalar epilogue, A = a scaled copy): the prologue combines the rows' statistics from nstats
-    // [M][K/32][2]; one extra 32x32x2 MFMA per (sequence of the tile, MFMA tile) adds -mean_m u_n + sigma_m c_n to the zero-initialised
-    // accumulators (u | c = uc + (((row0 + m) / nT) % uc_rows) * nss_ld, u at [0, N), c at [N, 2N)); the epilogue multiplies by rstd_m.
-    float* stats_out;
-    float* hs1; const float* sc1; float* hs2; const float* sc2;
-    const float* nstats; const float* uc;
-    int sc1_rows, sc2_rows, uc_rows, nss_ld, nT, row0;
     int ablate;                          // timing experiments only (tools/gemm_bench.py); 0 in production
     unsigned long long* stamps;          // diagnostic builds of a launch only (tools/gemm_timeline.py): per-workgroup {start, loop start, loop end, placement, kernel end, kernel entry, residual landed, stores issued}, then {s_memtime at loop start, loop end} per workgroup
                                          // in 100 MHz s_memrealtime ticks; nullptr in production (one never-taken scalar branch per workgroup)
@@ -225,7 +206,6 @@ __global__ __launch_bounds__((Cfg<TM_, TN_, BK_>::THREADS)) void gemm_f32_kernel
 // read (16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3)): a 16-lane read group then covers 16 distinct
 // 16-byte bank slots.  Rows past M / N are clamped on load (their results are never stored).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int LIN_MAX_K = 1024;       // AdaLN by linearity, consumer: the prologue loads LIN_MAX_K / 128 statistics quads per row and lane half
 template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2>
 struct GCfg {
     static constexpr int WGM = TM_ / 10, WGN = TN_ / 10, TM = TM_ % 10, TN = TN_ % 10;
@@ -275,15 +255,8 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // DIAG_: the timing ablations (GemmArgs::ablate) and in-kernel stamps (GemmArgs::stamps) exist in a second instantiation only, launched
 // when a tool has set one of them (tools/gemm_bench.py ABL=, tools/gemm_timeline.py, bench.py's loop clock); the production instantiation
 // sees compile-time zeros -- no diagnostic branch, load or register in the shipped kernels.
-// LIN_ / SCL_: the consumer / producer halves of AdaLN by linearity (GemmArgs) -- instantiations of their own, so the plain kernels carry
-// none of their code or registers.
-// TST_ (16-byte epilogue of the pipelined kernel): results leave through a wave-private LDS transposition, so that one store instruction
-// covers whole 128-byte lines of a few rows instead of 16 bytes of each of 32 rows (see the epilogue).
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_, bool DIAG_, bool LIN_ = false, bool SCL_ = false, bool TST_ = false>
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int PIPE_, bool DIAG_>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int swz, int bid) {
-    static_assert(!TST_ || (PIPE_ == 1 && VEPI), "transposed stores exist in the pipelined kernel's 16-byte epilogue");
-    static_assert(!LIN_ || (PIPE_ == 1 && !VEPI && !SCL_), "the AdaLN-consuming form exists in the pipelined kernel with the scalar epilogue (bias / GELU consumers)");
-    static_assert(!SCL_ || (PIPE_ == 1 && VEPI), "the AdaLN-producing form exists in the pipelined kernel with the 16-byte epilogue (residual / PE producers)");
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
     const GemmArgs& p = pp;
     unsigned long long* const p_stamps = DIAG_ ? pp.stamps : nullptr;
@@ -383,11 +356,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * (32 * TN) + j * 32 + l31;
             const bool cok = col < p.N;
-            const float bv = (!LIN_ && p.bias && cok) ? p.bias[col] : 0.f;        // LIN_: the bias is part of c (rank-2 term below)
+            const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = bv;
-                if (!LIN_ && (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE)) {
+                if (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) {
                     const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     if (cok && row < p.M) {
                         const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
@@ -399,91 +372,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
         }
     }
 
-    // ---- AdaLN by linearity, consumer side (LIN_): row statistics and the (u | c) rows of this tile ---------------------------------
-    // The prologue's global loads are ISSUED here, before the operand ring's first requests, and CONSUMED behind them (in-order retirement:
-    // waiting for these loads never waits for a ring tile), so the ring's latency covers the prologue's.  A tile of BM <= 128 rows spans
-    // at most two sequences (host: nT >= 128): rows below the tile-relative boundary `lin_rb` belong to sequence q0, the others to q0 + 1.
-    float ln_rstd[LIN_ ? TM : 1];                                // per row tile of this lane (row = lane & 31): 1 / sqrt(var + eps)
-    float lin_b0[LIN_ ? TN : 1], lin_b1[LIN_ ? TN : 1];          // weight-side operand of the rank-2 MFMA: lane half 0: u_n, half 1: c_n; sequence q0 / q0 + 1
-    constexpr int NLD = LIN_MAX_K / 128;                         // 16-byte statistics loads per row and lane half at the largest K (two partials each)
-    f32x4 pv[LIN_ ? TM : 1][LIN_ ? NLD : 1];
-    int lin_rb = BM;
-    if constexpr (LIN_) {
-        const int K = p.K, nblk = K >> 5, nh = nblk >> 1;        // nh partials per lane half (host: K % 128 == 0 -> nh even)
-        // (a) statistics: lane half lh combines half of the row's 32-column partials, the partner lane (lane ^ 32) the other half;
-        //     compile-time load count, addresses clamped into the half (one wait for the lot, not one per load)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = min(m0 + wm * (32 * TM) + i * 32 + l31, p.M - 1);
-            const float* sp = p.nstats + ((size_t)row * nblk + (size_t)lh * nh) * 2;
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) pv[i][u] = *reinterpret_cast<const f32x4*>(sp + 4 * min(u, (nh >> 1) - 1));
-        }
-        // (b) u_n | c_n of the tile's two sequences for this lane's output columns
-        const int g0 = p.row0 + m0, q0 = g0 / p.nT;
-        lin_rb = (q0 + 1) * p.nT - g0;
-        const float* uc0 = p.uc + (size_t)(q0 % p.uc_rows) * p.nss_ld + (lh ? p.N : 0);
-        const float* uc1 = p.uc + (size_t)((q0 + 1) % p.uc_rows) * p.nss_ld + (lh ? p.N : 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = min(n0 + wn * (32 * TN) + j * 32 + l31, p.N - 1);      // columns past N repeat the last one (never stored)
-            lin_b0[j] = uc0[col];
-            lin_b1[j] = uc1[col];
-            // issue BOTH loads here: left alone, the compiler sinks the second sequence's load into the (wave-uniform) branch that uses it, where it
-            // is followed by s_waitcnt vmcnt(0) -- one memory latency plus the drain of the whole operand ring in 43 % of the tiles
-            asm volatile("" : "+v"(lin_b0[j]), "+v"(lin_b1[j]));
-        }
-    }
-    auto lin_consume = [&]() {
-        if constexpr (LIN_) {
-            const int K = p.K, nblk = K >> 5, nh = nblk >> 1;
-            float a0[TM], a1[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                // within this half: block means relative to the half's first block mean (pivot: no cancellation in the squares), Chan's
-                // combination over equal blocks of 32: M2_half = sum M2_b + 32 (S2 - S1^2 / nh); then the two halves (nh * 32 elements each)
-                const float piv = pv[i][0][0];
-                float s1 = 0.f, s2 = 0.f, m2 = 0.f;
-#pragma unroll
-                for (int u = 0; u < NLD; ++u) {
-                    const f32x4 v = pv[i][u];                        // (mean, M2) of two blocks
-                    const float wgt = 2 * u < nh ? 1.0f : 0.0f;     // loads past the half repeat its last pair: weight 0
-                    const float d0 = v[0] - piv, d1 = v[2] - piv;
-                    s1 += wgt * (d0 + d1); s2 += wgt * (d0 * d0 + d1 * d1); m2 += wgt * (v[1] + v[3]);
-                }
-                const float mean_h = piv + s1 / (float)nh;
-                const float m2_h = m2 + 32.0f * fmaxf(s2 - s1 * s1 / (float)nh, 0.f);
-                const float mean_o = __shfl_xor(mean_h, 32), m2_o = __shfl_xor(m2_h, 32);
-                const float mean = 0.5f * (mean_h + mean_o), dm = mean_h - mean_o;
-                const float var = (m2_h + m2_o + 0.25f * (float)K * dm * dm) / (float)K;      // n0 n1 / (n0 + n1) = K / 4
-                const float sigma = sqrtf(var + 1e-6f);
-                ln_rstd[i] = 1.0f / sigma;
-                // activation-side operand of the rank-2 MFMA (k = lane half): -mean_m | sigma_m, zero for the rows of the other sequence
-                const float v = lh ? sigma : -mean;
-                const bool first = wm * (32 * TM) + i * 32 + l31 < lin_rb;
-                a0[i] = first ? v : 0.f;
-                a1[i] = first ? 0.f : v;
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], lin_b0[j], acc[i][j], 0, 0, 0);
-            if (lin_rb < BM) {                                       // the tile spans a second sequence (wave-uniform)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], lin_b1[j], acc[i][j], 0, 0, 0);
-            }
-        }
-    };
-
     if constexpr (PIPE_ != 0) {
         // The first NBUF-1 operand tiles are requested behind the accumulator-initialisation loads; vmcnt retires in order, so
         // "at most the NBUF-2 newest tiles outstanding" means the initialisation values and tile 0 have landed: the loop starts on
         // tile 0 while the others are still on their way (the host side guarantees nkt >= NBUF).
 #pragma unroll
         for (int t = 0; t < NBUF - 1; ++t) stage(t);
-        lin_consume();
         wait_vm<(NBUF - 2) * C_::NI>();
     } else {
         // the accumulator-init loads above must not be counted by the pipeline's vmcnt arithmetic
@@ -499,11 +393,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
     const int b_row = (wn * (32 * TN) + l31) * BK;
 
     f32x4 rv[LATE_R ? TM : 1][LATE_R ? TN : 1][4];               // the late residual tile (LATE_R only)
-    // SCL_: the conditioning rows (scale part) of the tile's two sequences for both copies, restricted to this wave's 32 TN columns:
-    // [copy][sequence][32 TN] floats = ONE 16-byte load per lane, requested with the residual tile and parked in a wave-private LDS strip
-    // after the loop -- no long-lived registers, no global round trip in the epilogue.
-    f32x4 scl_q = {0.f, 0.f, 0.f, 0.f};
-    int scl_rb = BM;
     if constexpr (PIPE_ != 0) {
         static_assert((C_::G == 2 || C_::G == 4) && NBUF >= 3 && NBUF <= 6, "pipelined loop: K step 16 or 32 (two / four k-groups), 3 to 6 stages");
         static_assert((C_::NI + 1) / 2 <= 4 * TM * TN - 1, "LDS-DMA pieces of a tile must fit behind the MFMAs of two k-groups");
@@ -530,7 +419,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
         };
         auto mm = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) { mm_s(af, bf, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); };
         // `left` = tiles that may stay in flight behind the one being waited for (+ the NR residual loads issued at the start of the drain)
-        constexpr int NR = LATE_R ? TM * TN * 4 + (SCL_ ? 1 : 0) : 0;      // SCL_: + this lane's quad of the (1 + s) rows
+        constexpr int NR = LATE_R ? TM * TN * 4 : 0;
         auto wait_left = [&](int left) {
             if (left >= 4) wait_vm<4 * NI + NR>();
             else if (left == 3) wait_vm<3 * NI + NR>();
@@ -602,16 +491,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
             for (int i = 0; i < TM; ++i) {
                 const int row = m0 + wm * (32 * TM) + i * 32 + l31;
                 const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
-                if constexpr (SCL_) {
-                    // whole column tiles (host: N % 128 == 0): one address per row tile, the column steps are immediates -- the 15 other
-                    // 64-bit addresses (and their clamps) of the general form below would not fit beside this kernel's epilogue
-                    const float* rp = p.extra + (size_t)(row < p.M ? er : 0) * p.ld_extra + n0 + wn * (32 * TN) + 4 * lh;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int qd = 0; qd < 4; ++qd) rv[i][j][qd] = *reinterpret_cast<const f32x4*>(rp + j * 32 + 8 * qd);
-                    continue;
-                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -622,18 +501,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                         rv[i][j][qd] = *reinterpret_cast<const f32x4*>(p.extra + (size_t)rr * p.ld_extra + cc);
                     }
             }
-        }
-        if constexpr (SCL_) {
-            constexpr int Q = 8 * TN;                                    // quads per table row of this wave's columns
-            const int g0 = p.row0 + m0, q0 = g0 / p.nT;
-            scl_rb = (q0 + 1) * p.nT - g0;                               // tile-relative row where sequence q0 + 1 begins
-            const int qq = lane % Q, x = (lane / Q) & 1, k = (lane / (2 * Q)) & 1;
-            const bool two = k && p.sc2 != nullptr;
-            const float* tab = two ? p.sc2 : p.sc1;
-            // conditioning rows of the two sequences, per copy: four scalar remainders, selected per lane
-            const int r10 = q0 % p.sc1_rows, r11 = (q0 + 1) % p.sc1_rows, r20 = p.sc2 ? q0 % p.sc2_rows : 0, r21 = p.sc2 ? (q0 + 1) % p.sc2_rows : 0;
-            const int r = two ? (x ? r21 : r20) : (x ? r11 : r10);
-            scl_q = *reinterpret_cast<const f32x4*>(tab + (size_t)r * p.nss_ld + n0 + wn * (32 * TN) + 4 * qq);
         }
         for (int kt = n_main < 0 ? 0 : n_main; kt < nkt; ++kt)           // drain: no new tile
             step(std::false_type{}, nkt - kt - 2, kt + 1 < nkt);
@@ -704,23 +571,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
     const int rows_here = min(p.M - m0, BM);
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
     const int ldc4 = p.ldc * 4;
-    // LIN_: the accumulators hold sum_k [h (1 + s)] w - mean_m u_n + sigma_m c_n; the result is rstd_m times that.  In this (scalar) map a
-    // lane's registers are 16 ROWS per MFMA tile while the prologue left rstd on the lane that owns the row: transposed through a wave-private
-    // strip of a ring stage that nobody reads any more -- stage nkt % NBUF: every wave has passed the last barrier of the loop, behind which
-    // only the last tile's stage ((nkt - 1) % NBUF) is read, and no LDS-DMA is in flight -- so no workgroup barrier is needed.
-    f32x4 lin_rs[LIN_ ? TM : 1][4];
-    if constexpr (LIN_) {
-        float* scr = smem + (nkt % NBUF) * C_::A_FLOATS + wave * (32 * TM);
-        if (lh == 0) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) scr[i * 32 + l31] = ln_rstd[i];
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lin_rs[i][q] = *reinterpret_cast<const f32x4*>(scr + i * 32 + 8 * q + 4 * lh);
-    }
     auto finish = [&](auto act_c, auto fulln_c) {
         constexpr int ACT = decltype(act_c)::value;
         constexpr bool FULLN = decltype(fulln_c)::value;
@@ -735,149 +585,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
             // D^T map: lane&31 = output row inside the 32-row tile, register 4*qd + c = output column 8*qd + 4*(lane>>5) + c
             const int col0 = n0 + wn * (32 * TN) + 4 * lh;
             const int voff = (wm * (32 * TM) + l31) * ldc4 + col0 * 4;
-            if constexpr (TST_ && ACT == MMDM_EPI_BIAS) {
-                if (FULLN) {
-                    // ---- LDS-transposed stores.  In the D^T map a lane owns a ROW: a 16-byte store instruction touches 32 rows x 32 bytes (32 cache
-                    // lines, a quarter of each) -- beside a co-resident workgroup in its K loop 16 of them take ~8 us (tools/loop_bench4.hip), and the
-                    // scaled copies of SCL_ triple the count.  Here each 32-row half of the wave's tile goes through a wave-private, XOR-swizzled
-                    // [32 rows][32 TN columns] image in an idle ring stage (stage (nkt + k) % NBUF, k < NBUF - 1: see LIN_) and leaves as whole
-                    // rows: one instruction = 64 / (8 TN) rows x 128 TN bytes.  Same values, same arithmetic: bit-identical to the direct form.
-                    constexpr int WC = 32 * TN, HBF = 32 * WC, LPR = WC / 4, RPI = 64 / LPR, KA = C_::A_FLOATS / HBF;
-                    static_assert(C_::A_FLOATS % HBF == 0 && C_::B_FLOATS >= HBF && C_::B_FLOATS >= 16 * WC, "ring chunks must hold the transposition images");
-                    static_assert((C_::NWAVES + KA - 1) / KA <= 2 * (NBUF - 1) - 1, "not enough idle ring chunks for the waves' images and the scale strip");
-                    auto fst = [&](int k) { const int s0 = nkt % NBUF + k; return s0 >= NBUF ? s0 - NBUF : s0; };      // k-th idle stage
-                    const int wi = wave / KA;
-                    float* tb = wi < NBUF - 1 ? As + fst(wi) * C_::A_FLOATS + (wave % KA) * HBF : Bs + fst(wi - (NBUF - 1)) * C_::B_FLOATS;
-                    auto fsw = [](int r) { return TN == 2 ? (r & 15) : ((r ^ (r >> 3)) & 7); };                          // chunk swizzle of row r (no bank conflicts on either side)
-                    const float* strip = Bs + fst(NBUF - 2) * C_::B_FLOATS + wave * (4 * WC);                             // SCL_: [copy][sequence][WC] (1 + s is formed below)
-                    if constexpr (SCL_) {
-                        if (lane < 4 * (WC / 4)) *reinterpret_cast<f32x4*>(const_cast<float*>(strip) + 4 * lane) = scl_q;
-                    }
-                    const __amdgpu_buffer_rsrc_t rsH1 = __builtin_amdgcn_make_buffer_rsrc((SCL_ ? p.hs1 : p.C) + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
-                    const __amdgpu_buffer_rsrc_t rsH2 = __builtin_amdgcn_make_buffer_rsrc((SCL_ && p.hs2 ? p.hs2 : p.C) + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
-                    const int rr = lane / LPR, rc = lane % LPR;                  // this lane's row inside an instruction's row group, its 16-byte column
-                    auto half = [&](auto ic, auto c2) {
-                        constexpr int i = decltype(ic)::value;
-                        constexpr bool C2 = decltype(c2)::value;
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            float piv = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                            for (int qd = 0; qd < 4; ++qd) {
-                                f32x4 v;
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) {
-                                    float t = acc[i][j][4 * qd + c];
-                                    if constexpr (LATE_R) t += rv[i][j][qd][c];
-                                    v[c] = t;
-                                    if constexpr (SCL_) {
-                                        if (qd == 0 && c == 0) piv = t;
-                                        const float dv = t - piv;
-                                        s1 += dv; s2 = __builtin_fmaf(dv, dv, s2);
-                                    }
-                                }
-                                *reinterpret_cast<f32x4*>(tb + l31 * WC + 4 * ((8 * j + 2 * qd + lh) ^ fsw(l31))) = v;
-                            }
-                            if constexpr (SCL_) {
-                                const float mean_l = piv + s1 * (1.0f / 16.0f), m2_l = fmaxf(s2 - s1 * s1 * (1.0f / 16.0f), 0.f);
-                                const float mean_o = __shfl_xor(mean_l, 32), m2_o = __shfl_xor(m2_l, 32), dm = mean_l - mean_o;
-                                const int row = m0 + wm * (32 * TM) + i * 32 + l31, blk = (n0 + wn * (32 * TN) + j * 32) >> 5, nblk = p.N >> 5;
-                                if (lh == 0 && row < p.M) {
-                                    float* d = p.stats_out + ((size_t)row * nblk + blk) * 2;
-                                    d[0] = 0.5f * (mean_l + mean_o);
-                                    d[1] = m2_l + m2_o + 8.0f * dm * dm;          // n0 n1 / (n0 + n1) = 16 * 16 / 32
-                                }
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int k = 0; k < 32 / RPI; ++k) {
-                            const int r = k * RPI + rr;                          // row of the half tile
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(tb + r * WC + 4 * (rc ^ fsw(r)));
-                            const int off = (wm * (32 * TM) + i * 32 + r) * ldc4 + (n0 + wn * WC + 4 * rc) * 4;
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, off, 0, MMDM_ST_AUX);
-                            if constexpr (SCL_) {
-                                const float* sp = strip + (wm * (32 * TM) + i * 32 + r < scl_rb ? 0 : WC) + 4 * rc;
-                                const f32x4 sa = *reinterpret_cast<const f32x4*>(sp);
-                                f32x4 w1;
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) w1[c] = v[c] * (1.0f + sa[c]);
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w1), rsH1, off, 0, MMDM_ST_AUX);
-                                if constexpr (C2) {
-                                    const f32x4 sb = *reinterpret_cast<const f32x4*>(sp + 2 * WC);
-                                    f32x4 w2;
-#pragma unroll
-                                    for (int c = 0; c < 4; ++c) w2[c] = v[c] * (1.0f + sb[c]);
-                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w2), rsH2, off, 0, MMDM_ST_AUX);
-                                }
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    };
-                    auto both = [&](auto c2) {
-                        half(std::integral_constant<int, 0>{}, c2);
-                        if constexpr (TM > 1) half(std::integral_constant<int, 1>{}, c2);
-                        static_assert(TM <= 2, "two 32-row halves per wave at most");
-                    };
-                    if (SCL_ && p.hs2) both(std::true_type{});
-                    else both(std::false_type{});
-                    return;
-                }
-            }
-            if constexpr (SCL_ && ACT == MMDM_EPI_BIAS) {
-                // ---- AdaLN by linearity, producer side: the new rows of the residual stream, their partial LayerNorm statistics (deviations from
-                // the lane's first value, then Chan's combination of the two lanes' halves), and the scaled copies h (1 + s) the next GEMMs read.
-                // One pass per 16-byte quad: nothing is kept beyond the quad, so the kernel's registers stay the K loop's.
-                constexpr int WC = 32 * TN;
-                float* strip = smem + (nkt % NBUF) * C_::A_FLOATS + wave * (4 * WC);      // [copy][sequence][WC]; stage nkt % NBUF is idle (see LIN_)
-                if (lane < 4 * (WC / 4)) *reinterpret_cast<f32x4*>(strip + 4 * lane) = scl_q;
-                __builtin_amdgcn_wave_barrier();
-                const __amdgpu_buffer_rsrc_t rsH1 = __builtin_amdgcn_make_buffer_rsrc(p.hs1 + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rsH2 = __builtin_amdgcn_make_buffer_rsrc((p.hs2 ? p.hs2 : p.C) + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
-                auto body = [&](auto c1, auto c2) {
-                    constexpr bool C1 = decltype(c1)::value, C2 = decltype(c2)::value;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const float* srow = strip + (wm * (32 * TM) + i * 32 + l31 < scl_rb ? 0 : WC) + 4 * lh;
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            float piv = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                            for (int qd = 0; qd < 4; ++qd) {
-                                const int off = voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4;
-                                f32x4 v, w1, w2, sa, sb;
-                                if constexpr (C1) sa = *reinterpret_cast<const f32x4*>(srow + j * 32 + 8 * qd);
-                                if constexpr (C2) sb = *reinterpret_cast<const f32x4*>(srow + 2 * WC + j * 32 + 8 * qd);
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) {
-                                    float t = acc[i][j][4 * qd + c];
-                                    if constexpr (LATE_R) t += rv[i][j][qd][c];
-                                    v[c] = t;
-                                    if (qd == 0 && c == 0) piv = t;
-                                    const float dv = t - piv;
-                                    s1 += dv; s2 = __builtin_fmaf(dv, dv, s2);
-                                    if constexpr (C1) w1[c] = t * (1.0f + sa[c]);
-                                    if constexpr (C2) w2[c] = t * (1.0f + sb[c]);
-                                }
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, off, 0, MMDM_ST_AUX);
-                                if constexpr (C1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w1), rsH1, off, 0, MMDM_ST_AUX);
-                                if constexpr (C2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w2), rsH2, off, 0, MMDM_ST_AUX);
-                            }
-                            const float mean_l = piv + s1 * (1.0f / 16.0f), m2_l = fmaxf(s2 - s1 * s1 * (1.0f / 16.0f), 0.f);
-                            const float mean_o = __shfl_xor(mean_l, 32), m2_o = __shfl_xor(m2_l, 32), dm = mean_l - mean_o;
-                            const int row = m0 + wm * (32 * TM) + i * 32 + l31, blk = (n0 + wn * (32 * TN) + j * 32) >> 5, nblk = p.N >> 5;
-                            if (lh == 0 && row < p.M) {
-                                float* d = p.stats_out + ((size_t)row * nblk + blk) * 2;
-                                d[0] = 0.5f * (mean_l + mean_o);
-                                d[1] = m2_l + m2_o + 8.0f * dm * dm;          // n0 n1 / (n0 + n1) = 16 * 16 / 32
-                            }
-                        }
-                    }
-                };
-                if (p.hs2) body(std::true_type{}, std::true_type{});
-                else body(std::true_type{}, std::false_type{});
-                return;
-            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -893,7 +600,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
                         }
                         // the row step is part of the VECTOR offset: only that (plus the immediate) takes part in the range check
                         if (FULLN || col0 + j * 32 + 8 * qd < p.N)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4, 0, MMDM_ST_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voff + i * 32 * ldc4 + (j * 32 + 8 * qd) * 4, 0, 0);
                     }
                 }
         } else {
@@ -907,9 +614,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         float t = acc[i][j][e];
-                        if constexpr (LIN_) t *= lin_rs[i][e >> 2][e & 3];
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, act(t)), rsC,
-                                                              voff + (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc4 + j * 128, 0, MMDM_ST_AUX);
+                                                              voff + (i * 32 + (e & 3) + 8 * (e >> 2)) * ldc4 + j * 128, 0, 0);
                     }
                 }
         }
@@ -932,7 +638,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& pp, float* smem, int s
 }
 #endif
 
-template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0, bool DIAG_ = false, bool LIN_ = false, bool SCL_ = false, bool TST_ = false>
+template <int TM_, int TN_, int BK_, int NBUF_, bool VEPI, int MINW_ = 1, int PIPE_ = 0, bool DIAG_ = false>
 __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void gemm_glds_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -943,7 +649,7 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void 
     unsigned long long* const stamps = DIAG_ ? p.stamps : nullptr;
     const unsigned long long t_entry = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     if (stamps && threadIdx.x == 0) stamps[8 * (size_t)bid + 5] = t_entry;
-    gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_, DIAG_, LIN_, SCL_, TST_>(p, smem, swz, bid);
+    gemm_tile<TM_, TN_, BK_, NBUF_, VEPI, PIPE_, DIAG_>(p, smem, swz, bid);
     if (stamps) {
         if (threadIdx.x == 0) stamps[8 * (size_t)bid + 7] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -959,12 +665,6 @@ inline bool vepi_ok(const GemmArgs& a) {
            (!ext || ((a.ld_extra & 3) == 0 && (reinterpret_cast<uintptr_t>(a.extra) & 15) == 0));
 }
 
-// the tile shapes the production dispatch picks: only these exist in the AdaLN-by-linearity forms
-template <int TM_, int TN_, int BK_, int NBUF_, int PIPE_>
-constexpr bool lin_cfg = PIPE_ == 1 && BK_ == 16 && ((TM_ == 22 && TN_ == 22 && NBUF_ == 5) || (TM_ == 22 && TN_ == 21 && NBUF_ == 4) || (TM_ == 21 && TN_ == 21 && NBUF_ == 4));
-template <int TM_, int TN_>
-constexpr int scl_minw = (TM_ % 10) * (TN_ % 10) >= 4 ? 2 : 1;     // 128 x 128: keep the allocation at two waves per SIMD (what its 80 KB of LDS admit anyway)
-
 template <int TM_, int TN_, int BK_ = 16, int NBUF_ = 2, int MINW_ = 1, int PIPE_ = 0>
 int launch_glds(GemmArgs a, hipStream_t st) {
     using C_ = GCfg<TM_, TN_, BK_, NBUF_>;
@@ -975,27 +675,6 @@ int launch_glds(GemmArgs a, hipStream_t st) {
     const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
     const bool vepi = ext && vepi_ok(a) && !(a.ablate & 16);
     const dim3 grid(a.mt * a.nt), block(C_::THREADS);
-    if constexpr (lin_cfg<TM_, TN_, BK_, NBUF_, PIPE_>) {
-        // the two halves of AdaLN by linearity: instantiations of their own (the caller has checked the shapes: mmdm_linear_f32_fused)
-        if (a.nstats) {
-            mmdm_note_gemm("gemm_pipe_lin<%d,%d,%d,%d,scalar>", TM_, TN_, BK_, NBUF_);
-            hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, 1, false, true, false>), grid, block, C_::SMEM_BYTES, st, a);
-            return mmdm_check_launch("gemm_pipe_lin");
-        }
-        if (a.stats_out) {
-            mmdm_note_gemm("gemm_pipe_scl<%d,%d,%d,%d,%s>", TM_, TN_, BK_, NBUF_, g_gemm_tst ? "vepi-t" : "vepi");
-            if (g_gemm_tst) hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, scl_minw<TM_, TN_>, 1, false, false, true, true>), grid, block, C_::SMEM_BYTES, st, a);
-            else hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, scl_minw<TM_, TN_>, 1, false, false, true, false>), grid, block, C_::SMEM_BYTES, st, a);
-            return mmdm_check_launch("gemm_pipe_scl");
-        }
-        if (vepi && g_gemm_tst && !(a.ablate & ~16) && !a.stamps) {       // plain residual / PE GEMM with transposed stores
-            mmdm_note_gemm("gemm_pipe<%d,%d,%d,%d,vepi-t>", TM_, TN_, BK_, NBUF_);
-            hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, 1, false, false, false, true>), grid, block, C_::SMEM_BYTES, st, a);
-            return mmdm_check_launch("gemm_pipe");
-        }
-    } else if (a.nstats || a.stats_out) {
-        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: this tile configuration has no AdaLN-by-linearity form");
-    }
     mmdm_note_gemm("%s<%d,%d,%d,%d,%s>", PIPE_ ? "gemm_pipe" : "gemm_glds", TM_, TN_, BK_, NBUF_, vepi ? "vepi" : "scalar");
     if ((a.ablate & ~16) || a.stamps) {              // a tool asked for ablation bits / stamps: the diagnostic instantiation
         if (vepi) hipLaunchKernelGGL((gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, PIPE_, true>), grid, block, C_::SMEM_BYTES, st, a);
@@ -1017,16 +696,6 @@ int set_attr_glds() {
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_glds): %s", hipGetErrorString(e));
-    }
-    if constexpr (lin_cfg<TM_, TN_, BK_, NBUF_, PIPE_>) {
-        const void* fl[4] = {reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, false, MINW_, 1, false, true, false>),
-                             reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, scl_minw<TM_, TN_>, 1, false, false, true, false>),
-                             reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, scl_minw<TM_, TN_>, 1, false, false, true, true>),
-                             reinterpret_cast<const void*>(&gemm_glds_kernel<TM_, TN_, BK_, NBUF_, true, MINW_, 1, false, false, false, true>)};
-        for (const void* f : fl) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_pipe_lin / _scl): %s", hipGetErrorString(e));
-        }
     }
     return MMDM_OK;
 }
@@ -1077,10 +746,6 @@ inline bool vec_ok(const float* p, int ld, int K) {
 
 }  // namespace
 
-// AdaLN by linearity: shapes both halves cover.  K = width of the residual stream (the consumers' K, the producers' N): whole 128-column
-// groups of statistics, at most LIN_MAX_K; T >= 128 so that a tile of at most 128 rows spans at most two sequences.
-bool mmdm_gemm_fuse_ok(int K, int T) { return K >= 128 && K <= LIN_MAX_K && (K & 127) == 0 && T >= 128; }
-
 int g_gemm_cfg = -1;
 int g_gemm_tail = -1;       // row split of the fractional last round: t > 0: split when the fractional round holds <= t/10 of the resident slots; 0 off;
                             // -1 (default): what the caller's handle asked for through mmdm_gemm_set_tail (one-stream samplers: 10, two-stream: 0)
@@ -1119,7 +784,6 @@ bool mmdm_diag_gemm_f32(const char* key, long long v) {
     if (!strcmp(key, "gemm_cfg")) g_gemm_cfg = (int)v;
     else if (!strcmp(key, "gemm_ablate")) g_gemm_ablate = (int)v;
     else if (!strcmp(key, "gemm_tail")) g_gemm_tail = (int)v;
-    else if (!strcmp(key, "gemm_tst")) g_gemm_tst = (int)v;
     else if (!strcmp(key, "gemm_stamps")) g_gemm_stamps = reinterpret_cast<unsigned long long*>((uintptr_t)v);
     else return false;
     return true;
@@ -1134,14 +798,6 @@ extern "C" int mmdm_linear_f32(const float* A, int lda, const float* W, int ldw,
 // handle stores zero-padded to 264 columns be fetched with 16-byte loads.
 int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream) {
-    return mmdm_linear_f32_fused(A, lda, W, ldw, Kw, bias, C, ldc, M, N, K, epilogue, extra, ld_extra, period, nullptr, stream);
-}
-
-// `fuse` (kernels.h): the two halves of AdaLN by linearity.  Producer (stats_out [+ hs1 / hs2]): the residual / PE GEMM also writes the rows'
-// partial LayerNorm statistics and scaled copies h (1 + s); consumer (nstats + uc): A is such a copy and the GEMM returns AdaLN(h) W^T + b.
-// Both need the shapes the pipelined kernel covers; a request it cannot honour is an error (the caller decides up front: mmdm_gemm_fuse_ok).
-int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
-                          int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, const mmdm_gemm_fuse* fuse, void* stream) {
     mmdm_note_gemm_reset();
     if (M == 0 || N == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
@@ -1160,30 +816,9 @@ int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int 
     a.mt = a.nt = 0;
     a.ablate = g_gemm_ablate;
     a.stamps = g_gemm_stamps;
-    a.stats_out = fuse ? fuse->stats_out : nullptr;
-    a.hs1 = fuse ? fuse->hs1 : nullptr; a.sc1 = fuse ? fuse->sc1 : nullptr; a.sc1_rows = fuse ? fuse->sc1_rows : 1;
-    a.hs2 = fuse ? fuse->hs2 : nullptr; a.sc2 = fuse ? fuse->sc2 : nullptr; a.sc2_rows = fuse ? fuse->sc2_rows : 1;
-    a.nstats = fuse ? fuse->nstats : nullptr; a.uc = fuse ? fuse->uc : nullptr; a.uc_rows = fuse ? fuse->uc_rows : 1;
-    a.nss_ld = fuse ? fuse->ss_ld : 0; a.nT = fuse ? fuse->T : 1; a.row0 = fuse ? fuse->row0 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool av = vec_ok(A, lda, K), wv = vec_ok(W, ldw, Kw);
     const bool glds_ok = av && wv && (K % 16 == 0) && Kw == K;
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (a.stats_out) {              // producer: the pipelined kernel's 16-byte epilogue, whole column tiles, N = the width the consumers will read
-        const bool ext = epilogue == MMDM_EPI_BIAS_RESID || epilogue == MMDM_EPI_BIAS_PE;
-        // (the kernel always requests the first copy's conditioning rows -- its counted waits include that load -- so hs1 is mandatory)
-        const bool copies = a.hs1 && a.sc1 && a.sc1_rows > 0 && al16(a.hs1) && al16(a.sc1) && (!a.hs2 || (a.sc2 && a.sc2_rows > 0 && al16(a.hs2) && al16(a.sc2))) &&
-                            a.nT >= 128 && a.nss_ld >= N && (a.nss_ld & 3) == 0 && a.row0 >= 0;
-        if (!(glds_ok && K >= 96 && ext && vepi_ok(a) && (N & 127) == 0 && g_gemm_cfg == -1 && !a.nstats && copies))
-            return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: row statistics / scaled copies need the pipelined residual / PE GEMM (K >= 96, K %% 16, N %% 128, "
-                                  "16-byte aligned rows and tables, T >= 128; M=%d N=%d K=%d T=%d)", M, N, K, a.nT);
-    }
-    if (a.nstats) {                 // consumer
-        if (!(glds_ok && mmdm_gemm_fuse_ok(K, a.nT) && a.uc && a.uc_rows > 0 && a.nss_ld >= 2 * N && al16(a.nstats) && a.row0 >= 0 && g_gemm_cfg == -1 &&
-              (epilogue == MMDM_EPI_BIAS || epilogue == MMDM_EPI_BIAS_GELU)))
-            return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_f32: the AdaLN-consuming GEMM needs K %% 128 == 0, 128 <= K <= %d, T >= 128, a bias / GELU epilogue, "
-                                  "a (u | c) table and 16-byte aligned statistics (K=%d T=%d)", LIN_MAX_K, K, a.nT);
-    }
     // production choice: LDS-DMA kernel, 128x128 tile / 4 waves (5 workgroups per CU) whenever the operands allow it
     const int tail = g_gemm_tail >= 0 ? g_gemm_tail : t_gemm_tail;
     switch (g_gemm_cfg) {
@@ -1210,11 +845,6 @@ int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int 
                     b.A = A + (size_t)M1 * lda;
                     b.C = C + (size_t)M1 * ldc;
                     if (extra) b.extra = extra + (size_t)M1 * ld_extra;
-                    if (a.stats_out) b.stats_out = a.stats_out + (size_t)M1 * (N >> 5) * 2;
-                    if (a.hs1) b.hs1 = a.hs1 + (size_t)M1 * ldc;
-                    if (a.hs2) b.hs2 = a.hs2 + (size_t)M1 * ldc;
-                    if (a.nstats) b.nstats = a.nstats + (size_t)M1 * (K >> 5) * 2;
-                    b.row0 = a.row0 + M1;
                     int rc = narrow ? launch_glds<22, 21, 16, 4, 1, 1>(a, st) : launch_glds<22, 22, 16, 5, 1, 1>(a, st);
                     if (rc) return rc;
                     // remainder: the largest tile that still gives every CU a workgroup
@@ -1261,22 +891,4 @@ int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int 
         case 4: return launch_cfg<42, 22, 16>(a, av, wv, st);
         default: return launch_cfg<22, 22, 16>(a, av, wv, st);
     }
-}
-
-// Stateless entry points of the two halves (include/mmdm.h section 1): what the sampler's stacks use, exposed for tests, tools and bindings.
-extern "C" int mmdm_linear_f32_scaled(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
-                                      int epilogue, const float* extra, int ld_extra, int period, float* stats, float* hs1, const float* scale1, int scale1_rows,
-                                      float* hs2, const float* scale2, int scale2_rows, int ss_ld, int T, void* stream) {
-    if (!stats) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32_scaled: null stats");
-    mmdm_gemm_fuse f;
-    f.stats_out = stats; f.hs1 = hs1; f.sc1 = scale1; f.sc1_rows = scale1_rows; f.hs2 = hs2; f.sc2 = scale2; f.sc2_rows = scale2_rows; f.ss_ld = ss_ld; f.T = T;
-    return mmdm_linear_f32_fused(A, lda, W, ldw, K, bias, C, ldc, M, N, K, epilogue, extra, ld_extra, period, &f, stream);
-}
-
-extern "C" int mmdm_linear_f32_lnfold(const float* HS, int lda, const float* stats, const float* uc, int uc_rows, int ss_ld, int T,
-                                      const float* W, int ldw, float* C, int ldc, int M, int N, int K, int epilogue, void* stream) {
-    if (!stats || !uc || T <= 0 || uc_rows <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_linear_f32_lnfold: bad arguments");
-    mmdm_gemm_fuse f;
-    f.nstats = stats; f.uc = uc; f.uc_rows = uc_rows; f.ss_ld = ss_ld; f.T = T;
-    return mmdm_linear_f32_fused(HS, lda, W, ldw, K, nullptr, C, ldc, M, N, K, epilogue, nullptr, 0, 0, &f, stream);
 }

@@ -37,6 +37,7 @@ struct SArgs {
     int row0;                             // global index of row 0 (PE epilogue of a row-sliced launch)
     unsigned long long* tl;               // diagnostic: per-wave phase cycle sums (tools/split_timeline.py), null in production
     __bf16* P2; size_t p2_plane; int p2_cols, ld2;   // optional second output: columns [0, p2_cols) also as three bf16 planes (attention Q/K operands)
+    int tst;                              // packed-W kernel: results leave through the workgroup's LDS transposition (split_finish_t)
 };
 
 
@@ -129,6 +130,130 @@ __device__ __forceinline__ void split_finish(const SArgs& p, f32x16 (&acc)[TM][T
     if (p.epilogue == MMDM_EPI_BIAS_GELU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_GELU>{});
     else if (p.epilogue == MMDM_EPI_BIAS_SILU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_SILU>{});
     else finish_out(std::integral_constant<int, MMDM_EPI_BIAS>{});
+}
+#endif
+
+#ifndef MMDM_ST_AUX
+#define MMDM_ST_AUX 2          // cache policy of the transposed epilogue's stores (buffer_store aux: 0 = write-back, 2 = nt): see gemm_f32 / gemm_bf16
+#endif
+#ifndef MMDM_SPLIT_TST_DEFAULT
+#define MMDM_SPLIT_TST_DEFAULT 1
+#endif
+int g_split_tst = MMDM_SPLIT_TST_DEFAULT;      // mmdm_diag_set "split_tst": 0 = the direct (row-per-lane) epilogue
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Transposed epilogue of the packed-W kernel (four waves side by side, each TM x 1 MFMA tiles: BN = 128).  In the D^T map a lane owns an
+// output ROW: the direct form stores 16 bytes (fp32) or three times 8 bytes (the three bf16 planes of FFN-1's output) of 32 different rows per
+// instruction.  Here the workgroup's tile goes through an XOR-swizzled image [rows][128 columns] (per plane) in the idle A stages and leaves
+// as whole rows; the residual / PE rows of the fp32 form are read the same way -- whole lines, requested before the image is written -- and
+// added last, (b + sum_k a_k w_k) + r as in the direct form.  Same values, same arithmetic: bit-identical results (gemm_bf16.hip has the
+// measurement: +50 % on the bf16-output projections).  Returns false (nothing done) for what it does not cover: a second plane output, a
+// ragged last column tile.
+template <int TM, int BM, int NWAVES>
+__device__ __forceinline__ bool split_finish_t(const SArgs& p, f32x16 (&acc)[TM][1], int m0, int n0, int wn, int lane, float* smem, int smem_bytes) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int BN = 32 * NWAVES;
+    static_assert(BN == 128 && BM == 32 * TM, "four waves side by side, each TM x 1 tiles of 32 x 32");
+    if (p.P2 || n0 + BN > p.N || !p.tst || (p.out_split && (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE))) return false;
+    const int l31 = lane & 31, lh = lane >> 5, wave = wn;
+    __builtin_amdgcn_s_barrier();                             // every wave has left the K loop: the A stages are free
+    const bool ext = p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE;
+    const int rows_here = min(p.M - m0, BM);
+    char* img = reinterpret_cast<char*>(smem);
+    auto finish = [&](auto act_c, auto split_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool SPLIT = decltype(split_c)::value;
+        constexpr int EBO = SPLIT ? 2 : 4, NPL = SPLIT ? 3 : 1;
+        constexpr int RB = BN * EBO, CPR = RB / 16;                            // bytes / 16-byte chunks per image row (16 or 32)
+        constexpr int FIT = (3 * 3 * BM * 16 * 4) / (32 * RB * NPL);           // 32-row tiles the three A stages hold
+        constexpr int RPP = FIT >= TM ? TM : (FIT >= 2 ? 2 : 1);               // row tiles per phase
+        static_assert(FIT >= 1 && TM % RPP == 0, "image does not fit the A stages");
+        constexpr int LPR = CPR, RPI = 64 / LPR, ROWS = 32 * RPP, RPW = ROWS / NWAVES;
+        static_assert(RPW % RPI == 0, "rows of a phase must divide over the waves' store instructions");
+        constexpr int PIMG = ROWS * RB;                                        // bytes of one plane's image
+        const int rr = lane / LPR, rc = lane % LPR;
+        const size_t cplane = SPLIT ? p.pc * 2 : 0;                            // byte stride between output planes
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(p.C) + (size_t)m0 * p.ldc * EBO, 0,
+                                                                             SPLIT ? 0xffffffffu : (unsigned)(rows_here * p.ldc * EBO), 0x00020000);
+#pragma unroll
+        for (int ph = 0; ph < TM / RPP; ++ph) {
+            f32x4 rq[SPLIT ? 1 : RPW / RPI];
+            if constexpr (!SPLIT) {
+                if (ext) {
+#pragma unroll
+                    for (int k = 0; k < RPW / RPI; ++k) {
+                        const int ir = wave * RPW + k * RPI + rr;
+                        const int rowc = min(m0 + ph * ROWS + ir, p.M - 1);
+                        const int er = p.epilogue == MMDM_EPI_BIAS_PE ? (rowc + p.row0) % p.period : rowc;
+                        rq[k] = *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + n0 + rc * 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = ph * RPP; i < (ph + 1) * RPP; ++i) {
+                const int ir = (i - ph * RPP) * 32 + l31;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float t = acc[i][0][4 * qd + c];
+                        if constexpr (ACT == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
+                        else if constexpr (ACT == MMDM_EPI_BIAS_SILU) t = silu(t);
+                        v[c] = t;
+                    }
+                    const int cb = (wn * 32 + 8 * qd + 4 * lh) * EBO;           // byte column inside the image row
+                    char* dst = img + ir * RB + (((cb >> 4) ^ (ir & 15)) << 4) + (cb & 15);
+                    if constexpr (SPLIT) {
+                        bf16x4 o1, o2, o3;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            o1[c] = (__bf16)v[c];
+                            const float r1 = v[c] - (float)o1[c];
+                            o2[c] = (__bf16)r1;
+                            o3[c] = (__bf16)(r1 - (float)o2[c]);
+                        }
+                        *reinterpret_cast<bf16x4*>(dst) = o1;
+                        *reinterpret_cast<bf16x4*>(dst + PIMG) = o2;
+                        *reinterpret_cast<bf16x4*>(dst + 2 * PIMG) = o3;
+                    } else {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int k = 0; k < RPW / RPI; ++k) {
+                const int ir = wave * RPW + k * RPI + rr;
+                const int trow = ph * ROWS + ir;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(img + pl * PIMG + ir * RB + ((rc ^ (ir & 15)) << 4));
+                    if constexpr (!SPLIT) { if (ext) v += rq[k]; }
+                    if constexpr (SPLIT) {
+                        if (m0 + trow < p.M)            // (the plane stride defeats the resource's row clipping: explicit, wave-divergent only in the last row tile)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (unsigned)(trow * p.ldc * EBO + n0 * EBO + rc * 16), (unsigned)(pl * cplane), MMDM_ST_AUX);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, trow * p.ldc * EBO + n0 * EBO + rc * 16, 0, MMDM_ST_AUX);
+                    }
+                }
+            }
+            if (ph + 1 < TM / RPP) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    };
+    auto finish_out = [&](auto act_c) {
+        if (p.out_split) finish(act_c, std::true_type{});
+        else finish(act_c, std::false_type{});
+    };
+    if (p.epilogue == MMDM_EPI_BIAS_GELU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_GELU>{});
+    else if (p.epilogue == MMDM_EPI_BIAS_SILU) finish_out(std::integral_constant<int, MMDM_EPI_BIAS_SILU>{});
+    else finish_out(std::integral_constant<int, MMDM_EPI_BIAS>{});
+    (void)smem_bytes;
+    return true;
 }
 #endif
 
@@ -543,6 +668,9 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
 
+    if constexpr (TN == 1 && C_::WGM == 1 && C_::WGN == 4) {
+        if (split_finish_t<TM, BM, C_::NWAVES>(p, acc, m0, n0, wn, lane, smem, 3 * C_::A_FLOATS * 4)) return;
+    }
     if (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -632,6 +760,7 @@ int mmdm_gemm_split_init(void) {
 // diagnostics of this translation unit (mmdm_diag_set): tile override, ablation bits, timeline buffer (8 u64 per wave of the next packed launches)
 bool mmdm_diag_gemm_split(const char* key, long long v) {
     if (!strcmp(key, "split_cfg")) g_split_cfg = (int)v;
+    else if (!strcmp(key, "split_tst")) g_split_tst = (int)v;
     else if (!strcmp(key, "split_ablate")) g_split_ablate = (int)v;
     else if (!strcmp(key, "split_timeline")) g_split_tl = reinterpret_cast<unsigned long long*>((uintptr_t)v);
     else return false;
@@ -697,6 +826,7 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
     a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_split = out_split;
     a.mt = a.nt = 0; a.ablate = g_split_ablate; a.row0 = 0; a.tl = packed ? g_split_tl : nullptr;
     a.P2 = static_cast<__bf16*>(planes2); a.p2_plane = (size_t)plane2_stride; a.p2_cols = planes2_cols; a.ld2 = ld2;
+    a.tst = g_split_tst;
     if (planes2 && ((ld2 & 3) || (plane2_stride & 3) || (planes2_cols & 3) || !al16(planes2)))
         return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split: second output needs 8-byte aligned bf16 rows / planes");
     hipStream_t st = static_cast<hipStream_t>(stream);

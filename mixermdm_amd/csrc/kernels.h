@@ -85,27 +85,6 @@ int mmdm_blend_cfg_dyn(const float* out1, const float* out2, const float* w, int
                        float* model_out, const mmdm_hist_desc* hd, const int* loop_pos, int B, int T, hipStream_t st);
 int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
-// AdaLN folded around the fp32 GEMMs by linearity (gemm_f32.hip; reference: AdaLN.forward src/models/utils/layers.py:13-24):
-//   AdaLN(h) W^T + b = rstd_m ([h (1 + s)] W^T - mean_m u) + c,    u = (1 + s) W^T,  c = t W^T + b    (s | t = the conditioning row of the row's sequence).
-// Producer -- a residual / PE GEMM that writes rows of the residual stream h -- also writes, per row and 32-column block, (mean, M2) ->
-//   stats_out [M][N/32][2], and up to two scaled copies hs_k[m][n] = h[m][n] (1 + sc_k[cond_k(m)][n]) (row stride ldc): the A operands of the
-//   GEMMs that consume AdaLN_k(h).  cond_k(m) = ((row0 + m) / T) % sc_k_rows; table rows have stride ss_ld.
-// Consumer -- a bias / GELU GEMM on A = hs_k -- combines the row's partial statistics (nstats [M][K/32][2]) in its prologue, adds the
-//   rank-2 term -mean_m u_n + sigma_m c_n with one extra 32x32x2 MFMA per (sequence of the tile, MFMA tile) and multiplies by rstd_m in
-//   its epilogue; the table row ((row0 + m) / T) % uc_rows of `uc` holds u [N] | c [N] (stride ss_ld).  `bias` is not read (it is part of c).
-// Both need T >= 128 (a tile of at most 128 rows then spans at most two sequences); no VALU work in the K loop, no rendezvous.
-struct mmdm_gemm_fuse {
-    float* stats_out = nullptr;
-    float* hs1 = nullptr; const float* sc1 = nullptr; int sc1_rows = 1;
-    float* hs2 = nullptr; const float* sc2 = nullptr; int sc2_rows = 1;
-    const float* nstats = nullptr; const float* uc = nullptr; int uc_rows = 1;
-    int ss_ld = 0, T = 1, row0 = 0;
-};
-bool mmdm_gemm_fuse_ok(int K, int T);      // shapes both halves cover: K % 128 == 0, 128 <= K <= 1024, T >= 128
-int mmdm_linear_f32_fused(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
-                          int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, const mmdm_gemm_fuse* fuse, void* stream);
-int mmdm_transpose(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t st);   // dst [cols][ld_dst] = src [rows][ld_src]^T
-int mmdm_add_const(const float* src, float* dst, float v, int n, hipStream_t st);
 int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
                   int nseq, int T, int D, hipStream_t st);
 int mmdm_mdm_unpack(const float* src, float* dst, int nseq, int T, int D, hipStream_t st);

@@ -112,13 +112,7 @@ struct StackW {          // a transformer stack: denoiser blocks or Influence bl
     int D = 0, F = 0, L = 0, H = 0, n_ada = 0;
     bool has_ca = false;
     bool w_packed = false;                      // low-precision weight twins stored in MFMA fragment order (gemm_splitw_kernel / gemm_bf16w_kernel take W straight from global memory)
-    float *ada_w = nullptr, *ada_b = nullptr;   // [L*n_ada*2D (+ L*uc_layer), D], [same rows]  (slots: sa, [ca_q, ca_kv,] ffn; then the (u | c) rows)
-    // AdaLN by linearity (precision 0; gemm_f32.hip LIN_ / SCL_): besides (scale | shift) of every norm, the conditioning GEMM of a step also
-    // yields, for every GEMM that consumes an AdaLN output, u = (1 + scale) W^T and c = shift W^T + b -- as MORE COLUMNS of the same
-    // projection: u = se (W W_s)^T + W (1 + b_s), c = se (W W_t)^T + (W b_t + b), with the products formed once at mmdm_prepare.
-    // Row layout of the table: [L * n_ada * 2D: scale | shift per norm][per layer: for each consumer (QKV, CA q, CA K|V, FFN-1): u [N] | c [N]].
-    int uc0 = 0, uc_layer = 0;                  // first (u | c) column, (u | c) columns per layer; 0 = the stack has no such block
-    int uc_off[4] = {0, 0, 0, 0};               // consumer -> column inside a layer's block (u at +0, c at +N)
+    float *ada_w = nullptr, *ada_b = nullptr;   // [L*n_ada*2D, D], [L*n_ada*2D]  (slots: sa, [ca_q, ca_kv,] ffn)
     std::vector<LayerW> layers;
     std::vector<LayerWB> layers_b;
 };
@@ -144,8 +138,6 @@ struct Scratch {          // transformer-stack work buffers (one set per concurr
     float *xp = nullptr;      // [2][rows][NFP] repacked pose operands of the embedding GEMMs
     void *qk = nullptr, *kvp = nullptr;   // precision >= 1: bf16 plane copies of the attention's Q|K ([planes][R][2D]) and cross-attention K ([planes][R][D])
     float* xs = nullptr;                  // precision == 3: per-row scales of the fp8 AdaLN output in xn
-    float* hstat = nullptr;               // precision == 0: partial LayerNorm statistics of the rows of h, [R][D/32][2] (AdaLN by linearity, gemm_f32.hip)
-    float* xn2 = nullptr;                 // precision == 0: second scaled copy of the residual stream (the other stream's xf_norm in the Jacobi cross attention)
 };
 
 struct Prof {
@@ -220,7 +212,6 @@ struct mmdm_handle_s {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
     bool overlap = true;
     // switches read from the environment ONCE, at mmdm_create (include/mmdm.h lists them): a handle's behaviour never changes afterwards
-    bool lin_on = true;          // AdaLN by linearity (fp32 stacks); false when MMDM_NO_LIN_ADALN=1
     bool force_qkp = false, no_qkp = false, no_pvb = false, no_pack = false;      // MMDM_QKP, MMDM_NO_QKP, MMDM_NO_BF16_PV, MMDM_NO_PACK
 
     Prof prof;
@@ -267,14 +258,8 @@ void add_ignored(mmdm_handle h, const std::string& name) {
 
 int build_stack(mmdm_handle h, StackW& st, const std::string& pfx, int D, int F, int L, int H, bool has_ca, bool ca_keys_ignored) {
     st.D = D; st.F = F; st.L = L; st.H = H; st.has_ca = has_ca; st.n_ada = has_ca ? 4 : 2;
-    if (h->cfg.precision == 0 && mmdm_gemm_fuse_ok(D, 128) && (F & 127) == 0) {
-        st.uc0 = L * st.n_ada * 2 * D;
-        if (has_ca) { st.uc_off[0] = 0; st.uc_off[1] = 6 * D; st.uc_off[2] = 8 * D; st.uc_off[3] = 12 * D; st.uc_layer = 12 * D + 2 * F; }
-        else { st.uc_off[0] = 0; st.uc_off[3] = 6 * D; st.uc_layer = 6 * D + 2 * F; }
-    }
-    const size_t ada_rows = (size_t)L * (st.n_ada * 2 * D + st.uc_layer);
-    RC(dalloc(h, &st.ada_w, ada_rows * D));
-    RC(dalloc(h, &st.ada_b, ada_rows));
+    RC(dalloc(h, &st.ada_w, (size_t)L * st.n_ada * 2 * D * D));
+    RC(dalloc(h, &st.ada_b, (size_t)L * st.n_ada * 2 * D));
     st.layers.resize(L);
     const bool bf = h->cfg.precision >= 1;
     const size_t planes = h->cfg.precision == 2 ? 3 : 1;   // fp32-split: three bf16 planes per weight (gemm_split.hip)
@@ -446,9 +431,9 @@ int prof_end(const Ctx& c, int cls) {
 }
 
 int linear(const Ctx& c, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
-           int epi = MMDM_EPI_BIAS, const float* extra = nullptr, int ld_extra = 0, int period = 0, int Kw = 0, const mmdm_gemm_fuse* fuse = nullptr) {
+           int epi = MMDM_EPI_BIAS, const float* extra = nullptr, int ld_extra = 0, int period = 0, int Kw = 0) {
     RC(prof_begin(c, 0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1))));
-    RC(mmdm_linear_f32_fused(A, lda, W, ldw, Kw ? Kw : K, bias, C, ldc, M, N, K, epi, extra, ld_extra, period, fuse, c.st));
+    RC(mmdm_linear_f32_ex(A, lda, W, ldw, Kw ? Kw : K, bias, C, ldc, M, N, K, epi, extra, ld_extra, period, c.st));
     return prof_end(c, 0);
 }
 
@@ -472,8 +457,6 @@ struct StackRun {
     int ca_mode;            // 0 none; 1 keys/values = the other half of the layer INPUT (in2in.py:439-440); 2 = fixed `kv_src`
     const float* kv_src;
     int l0 = 0;             // first block to run (the "dual_individual" quirk runs only the last block on person b)
-    bool lin = false;       // fp32, AdaLN by linearity: the GEMM that produced hbuf left the rows' statistics in S.hstat and the scaled copies of
-                            // block l0's first norm(s) in S.xn (/ S.xn2); false = stand-alone AdaLN passes
 };
 
 // h [nseq*T, D] is updated in place through the L blocks (TransformerBlockDoubleCond / TransformerBlock / InfluenceBlockCross).
@@ -523,23 +506,11 @@ int attention_b(const Ctx& c, const float* Q, int ldq, const float* K, int ldk, 
     return prof_end(c, 1);
 }
 
-int ss_ld_of(const ModuleW& m) { return m.st.L * (m.st.n_ada * 2 * m.st.D + m.st.uc_layer); }
-
-// AdaLN by linearity on the fp32 path (gemm_f32.hip, LIN_ / SCL_): ON whenever the stack's shapes allow it; MMDM_NO_LIN_ADALN=1 in the
-// environment when the handle is created keeps the stand-alone AdaLN pass for that handle (A/B measurements and tests).  Needs T >= 128 (at most two sequences per 128-row tile), a stack
-// with a (u | c) block (StackW::uc_layer) and the pipelined GEMM's shapes for every producer / consumer of the stack.
-bool lin_adaln(mmdm_handle h, const StackW& w, int T) {
-    return h->lin_on && h->cfg.precision == 0 && h->cfg.single_only != 3 && w.uc_layer > 0 && mmdm_gemm_fuse_ok(w.D, T);
-}
+int ss_ld_of(const ModuleW& m) { return m.st.L * m.st.n_ada * 2 * m.st.D; }
 
 // h [nseq*T, D] is updated in place through the L blocks (TransformerBlockDoubleCond / TransformerBlock / InfluenceBlockCross).
 // precision == 1: the GEMM operands xn / att / f1 are written as bf16 by their producers and the weights come from the bf16 twins;
 // the residual stream h, the Q/K/V projections, softmax and all accumulation stay fp32.
-// StackRun::lin (fp32): no stand-alone AdaLN pass.  The GEMM that writes a new version of the residual stream (PE embedding before the
-// stack, then every out-projection / FFN-2) also leaves the rows' LayerNorm statistics in S.hstat and the copy h (1 + scale) of the NEXT
-// norm in S.xn (plus, for the Jacobi cross attention, the copy of the other stream's xf_norm in S.xn2); the GEMM that consumes the norm
-// reads that copy and finishes AdaLN in its prologue / epilogue (gemm_f32.hip).  Only a norm of something that is not the residual
-// stream (the fixed Influence CA source) keeps its pass.
 int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     const Scratch& S = *c.s;
     const int D = w.D, F = w.F, R = r.nseq * r.T, dh = D / w.H;
@@ -547,34 +518,12 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     const bool bf = prec >= 1, f8 = prec == 3;
     const int ob = f8 ? 1 : prec;           // output mode of the attention (operand of the out-projection): 0 fp32, 1 bf16, 2 three bf16 planes
     auto bw = [](const void* base, size_t elems) { return static_cast<const void*>(static_cast<const uint16_t*>(base) + elems); };
-    const bool lin = r.lin && prec == 0;
-    // which norm's scale the copies in S.xn / S.xn2 currently carry (the pointer of its scale | shift slot identifies the norm)
-    const float *cur1 = lin ? r.ss + (size_t)r.sa_row0 * r.ss_ld + ((size_t)r.l0 * w.n_ada) * 2 * D : nullptr;
-    const float *cur2 = lin && r.ca_mode == 1 ? r.ss + (size_t)r.ca_row0 * r.ss_ld + ((size_t)r.l0 * w.n_ada + 2) * 2 * D : nullptr;
-    // a norm the next GEMM completes: the copy to read and the consumer's (u | c) rows
-    struct Pend { const float* A = nullptr; const float* uc = nullptr; int rows = 0; } pend;
     // one GEMM of the stack: fp32 (A fp32, W fp32), bf16 (A bf16 from the producer, W twin) or fp32-split (three planes each).
     // wtot = elements of the whole weight matrix the twin was made from (its plane stride); the A plane stride is R*K.
-    // next_ss / next2_ss (lin, residual GEMMs): the norms that read the rows this GEMM writes
     auto gemm = [&](const float* A, int lda, const float* Wf, const void* Wb, size_t woff, size_t wtot, const float* bias, float* C, int ldc, int out_b,
-                    int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second(), const float* next_ss = nullptr, int next_rows = 0,
-                    const float* next2_ss = nullptr, int next2_rows = 0) -> int {
+                    int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) -> int {
         if (prec == 2) return linear_s(c, A, lda, (size_t)R * K, bw(Wb, woff), w.w_packed ? 0 : K, wtot, bias, C, ldc, (size_t)R * N, out_b == 2, R, N, K, epi, extra, ld_extra, s2);
         if (bf) return linear_b(c, A, lda, bw(Wb, woff), w.w_packed ? 0 : K, bias, C, ldc, out_b, R, N, K, epi, extra, ld_extra, s2);
-        if (lin && A == S.xn && pend.A) {               // the operand is AdaLN(h): read the scaled copy, finish the norm inside the GEMM
-            mmdm_gemm_fuse f;
-            f.nstats = S.hstat; f.uc = pend.uc; f.uc_rows = pend.rows; f.ss_ld = r.ss_ld; f.T = r.T;
-            const float* Ah = pend.A;
-            pend = Pend();
-            return linear(c, Ah, D, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra, 0, 0, &f);
-        }
-        if (lin && C == hbuf && epi == MMDM_EPI_BIAS_RESID && next_ss) {      // a new version of the residual stream
-            mmdm_gemm_fuse f;
-            f.stats_out = S.hstat; f.hs1 = S.xn; f.sc1 = next_ss; f.sc1_rows = next_rows; f.ss_ld = r.ss_ld; f.T = r.T;
-            if (next2_ss) { f.hs2 = S.xn2; f.sc2 = next2_ss; f.sc2_rows = next2_rows; }
-            cur1 = next_ss; cur2 = next2_ss;
-            return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra, 0, 0, &f);
-        }
         return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra);
     };
     // bf16 path with a head size the plane kernel covers: the projection GEMMs also emit a bf16 copy of Q and K and the scores come from
@@ -590,18 +539,8 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         return linear_8(c, A, K, unit_a ? nullptr : S.xs, static_cast<const uint8_t*>(W8) + row0 * K, w_frag ? 0 : K, Ws + row0, bias, C, ldc, out_mode, R, N, K, epi, extra, ld_extra, s2,
                         unit_a ? 1.0f / GSCALE : 1.0f, out_mode == 2 ? GSCALE : 1.0f);
     };
-    // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / three planes, or fp8 + per-row scales.  lin: a norm of the residual stream
-    // only selects the copy its consumer reads (`cons`: 0 QKV, 1 CA q, 2 CA K|V, 3 FFN-1; row0 / rows: the norm's conditioning rows)
-    int cur_layer = r.l0;
-    auto norm = [&](const float* src, const float* ssp, int row0, int rows, int cons) -> int {
-        if (lin && src == hbuf) {
-            pend.A = ssp == cur1 ? S.xn : ssp == cur2 ? S.xn2 : nullptr;
-            if (!pend.A) return mmdm_set_error(MMDM_ERR_STATE, "run_stack: no scaled copy of the residual stream was prepared for this norm (layer %d, consumer %d)", cur_layer, cons);
-            pend.uc = r.ss + (size_t)row0 * r.ss_ld + w.uc0 + (size_t)cur_layer * w.uc_layer + w.uc_off[cons];
-            pend.rows = rows;
-            return MMDM_OK;
-        }
-        pend = Pend();
+    // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / three planes, or fp8 + per-row scales
+    auto norm = [&](const float* src, const float* ssp, int rows) -> int {
         if (f8) return mmdm_adaln_any(src, ssp, r.ss_ld, rows, S.xn, 3, S.xs, r.nseq, r.T, D, c.st);
         return mmdm_adaln_ex(src, ssp, r.ss_ld, rows, S.xn, ob, r.nseq, r.T, D, c.st);
     };
@@ -609,12 +548,11 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     // one-plane (bf16 / fp8) modes: the projection GEMMs' bf16 copy also covers V, and P.V runs on the bf16 matrix cores (attn_qkp_kernel<DH, 1, true>)
     const bool pvb = qkp && np == 1 && !c.h->no_pvb;
     for (int l = r.l0; l < w.L; ++l) {
-        cur_layer = l;
         const LayerW& lw = w.layers[l];
         const LayerWB lb = bf ? w.layers_b[l] : LayerWB();
         auto ss_at = [&](int slot, int row0) { return r.ss + (size_t)row0 * r.ss_ld + ((size_t)l * w.n_ada + slot) * 2 * D; };
         // --- self attention (layers.py:36-45)
-        RC(norm(hbuf, ss_at(0, r.sa_row0), r.sa_row0, r.sa_rows, 0));
+        RC(norm(hbuf, ss_at(0, r.sa_row0), r.sa_rows));
         const int qkld = pvb ? 3 * D : 2 * D;           // row stride of the bf16 copy of the packed projection: Q|K or Q|K|V
         // all-bf16 attention: nothing reads the fp32 projection, so the GEMM writes bf16 only (a third of the bytes: the fp8 QKV GEMM is output-bound)
         if (pvb) {
@@ -629,7 +567,7 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
             // keys/values of the cross attention come from the layer INPUT of the other stream (or a fixed source):
             // project them before the residual below overwrites h.
             const float* src = r.ca_mode == 1 ? hbuf : r.kv_src;
-            RC(norm(src, ss_at(2, r.ca_row0), r.ca_row0, r.ca_rows, 2));
+            RC(norm(src, ss_at(2, r.ca_row0), r.ca_rows));
             const int kvld = pvb ? 2 * D : D;             // bf16 copy of the cross-attention projection: K or K|V
             if (pvb) {
                 if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kvp, 2 * D, 1, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, Second(), w.w_packed));
@@ -638,11 +576,11 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
             else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld)));
         }
         const int ffn_slot = w.has_ca ? 3 : 1;
-        if (r.ca_mode) RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), ss_at(1, r.ca_row0), r.ca_rows));
-        else RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), ss_at(ffn_slot, r.ffn_row0), r.ffn_rows));
+        if (r.ca_mode) RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
+        else RC(gemm(S.att, D, lw.sa_out_w, lb.sa_out_w, 0, (size_t)D * D, lw.sa_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         // --- cross attention (layers.py:77-88)
         if (r.ca_mode) {
-            RC(norm(hbuf, ss_at(1, r.ca_row0), r.ca_row0, r.ca_rows, 1));
+            RC(norm(hbuf, ss_at(1, r.ca_row0), r.ca_rows));
             if (pvb) {
                 if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qk, D, 1, D, D, MMDM_EPI_BIAS, nullptr, 0, Second(), w.w_packed));
                 else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, static_cast<float*>(S.qk), D, 1, D, D, MMDM_EPI_BIAS, nullptr, 0));
@@ -651,46 +589,39 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
             if (qkp) RC(attention_p(c, S.qk, D, (size_t)R * D, S.kvp, pvb ? 2 * D : D, (size_t)R * (pvb ? 2 * D : D), np, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
                                     r.ca_mode == 1 ? r.nseq / 2 : 0, pvb ? static_cast<const uint16_t*>(S.kvp) + D : nullptr, 2 * D));
             else RC(attention_b(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
-            RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, (size_t)D * D, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), ss_at(ffn_slot, r.ffn_row0), r.ffn_rows));
+            RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, (size_t)D * D, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));
         }
         // --- FFN (layers.py:99-106)
-        RC(norm(hbuf, ss_at(ffn_slot, r.ffn_row0), r.ffn_row0, r.ffn_rows, 3));
+        RC(norm(hbuf, ss_at(ffn_slot, r.ffn_row0), r.ffn_rows));
         if (f8) {               // FFN on fp8 operands: the GELU output is written as e4m3 at unit scale and read back as the down-projection's A
             RC(gemm8(S.xn, false, lb.f1_8, lb.f1_s, 0, lw.f1_b, S.f1, F, 2, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
             RC(gemm8(S.f1, true, lb.f2_8, lb.f2_s, 0, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), w.w_packed && F >= 2048));
         } else {
             RC(gemm(S.xn, D, lw.f1_w, lb.f1_w, 0, (size_t)F * D, lw.f1_b, S.f1, F, ob, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
-            // the next block starts with sa_block.norm of these rows (and, Jacobi cross attention, with the other stream's xf_norm of them)
-            const bool more = l + 1 < w.L;
-            const float* nx = more ? r.ss + (size_t)r.sa_row0 * r.ss_ld + ((size_t)(l + 1) * w.n_ada) * 2 * D : nullptr;
-            const float* nx2 = more && r.ca_mode == 1 ? r.ss + (size_t)r.ca_row0 * r.ss_ld + ((size_t)(l + 1) * w.n_ada + 2) * 2 * D : nullptr;
-            RC(gemm(S.f1, F, lw.f2_w, lb.f2_w, 0, (size_t)D * F, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), nx, r.sa_rows, nx2, r.ca_rows));
+            RC(gemm(S.f1, F, lw.f2_w, lb.f2_w, 0, (size_t)D * F, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D));
         }
     }
     return MMDM_OK;
 }
 
 // emb rows -> silu -> all AdaLN projections of a module.  se = silu(time_tab[step] + txt), ss = se W_ada^T + b_ada.
-// T: frames of the call -- when the stack runs AdaLN by linearity (lin_adaln) the projection also yields the consumers' (u | c) columns.
-int cond_vectors(const Ctx& c, const ModuleW& m, const float* txt, float* se, float* ss, int rows, int T) {
+int cond_vectors(const Ctx& c, const ModuleW& m, const float* txt, float* se, float* ss, int rows) {
     const StackW& w = m.st;
     RC(mmdm_cond_silu_f32(m.time_tab, c.h->d_step, txt, se, rows, w.D, c.st));
-    const int ld = ss_ld_of(m), N = lin_adaln(c.h, w, T) ? ld : w.L * w.n_ada * 2 * w.D;
-    return linear(c, se, w.D, w.ada_w, w.D, w.ada_b, ss, ld, rows, N, w.D);
+    const int N = ss_ld_of(m);
+    return linear(c, se, w.D, w.ada_w, w.D, w.ada_b, ss, N, rows, N, w.D);
 }
 
 // motion_embed + positional encoding of one person slice (in2in.py:426-431): x [nb*T rows, ld 524 or 262] -> h rows
-// xpad: one person's repacked rows [nb*T, NFP] (mmdm_repack_pose); pe_row0 = 1 for MDMDenoiser (token 0 is the conditioning token).
-// fuse (AdaLN by linearity): the rows' statistics and the scaled copies for the stack's first norm(s) (kernels.h: mmdm_gemm_fuse, producer half).
-int embed(const Ctx& c, const ModuleW& m, const float* xpad, float* hdst, int nb, int T, int pe_row0 = 0, const mmdm_gemm_fuse* fuse = nullptr) {
-    return linear(c, xpad, NFP, m.me_w, NFP, m.me_b, hdst, m.st.D, nb * T, m.st.D, NFP, MMDM_EPI_BIAS_PE, m.pe + (size_t)pe_row0 * m.st.D, m.st.D, T, NFP, fuse);
+// xpad: one person's repacked rows [nb*T, NFP] (mmdm_repack_pose); pe_row0 = 1 for MDMDenoiser (token 0 is the conditioning token)
+int embed(const Ctx& c, const ModuleW& m, const float* xpad, float* hdst, int nb, int T, int pe_row0 = 0) {
+    return linear(c, xpad, NFP, m.me_w, NFP, m.me_b, hdst, m.st.D, nb * T, m.st.D, NFP, MMDM_EPI_BIAS_PE, m.pe + (size_t)pe_row0 * m.st.D, m.st.D, T, NFP);
 }
 
 // denoiser1 on the CFG-doubled batch n; xa [B or n rows...]: source rows are taken from `x` with `xrows` samples, repeated to n.
 // Sequence order in h: person-major: seq = p*n + b.
 int run_denoiser(const Ctx& c, const ModuleW& m, bool interaction, const float* x, int xb, int npers, int ldx, int n, int T,
                  const float* ss, int ss_ld, float* out, int ldo) {
-    mmdm_handle H = c.h;
     const int D = m.st.D;
     StackRun r;
     r.nseq = npers * n; r.T = T; r.ss = ss; r.ss_ld = ss_ld;
@@ -699,20 +630,12 @@ int run_denoiser(const Ctx& c, const ModuleW& m, bool interaction, const float* 
     r.ca_row0 = 2 * n; r.ca_rows = n;
     r.ca_mode = interaction ? 1 : 0;
     r.kv_src = nullptr;
-    r.lin = lin_adaln(H, m.st, T) && c.s->hstat && c.s->xn2;
     // embed: `x` holds xb samples (xb == n, or xb == n/2 when cond/uncond halves share the same x: cfg_sampler.py:41-42)
     RC(mmdm_repack_pose(x, ldx, c.s->xp, npers, xb * T, NFP, c.st));
     for (int p = 0; p < npers; ++p)
         for (int rep = 0; rep < n / xb; ++rep) {
             const size_t row0 = ((size_t)p * n + (size_t)rep * xb) * T;
-            mmdm_gemm_fuse f;
-            if (r.lin) {             // block 0's sa_block.norm (and the other stream's xf_norm) read these rows
-                f.stats_out = c.s->hstat + row0 * (D / 32) * 2;
-                f.hs1 = c.s->xn + row0 * D; f.sc1 = ss + (size_t)r.sa_row0 * ss_ld; f.sc1_rows = r.sa_rows;
-                if (interaction) { f.hs2 = c.s->xn2 + row0 * D; f.sc2 = ss + (size_t)r.ca_row0 * ss_ld + (size_t)2 * 2 * D; f.sc2_rows = r.ca_rows; }
-                f.ss_ld = ss_ld; f.T = T; f.row0 = (int)row0;
-            }
-            RC(embed(c, m, c.s->xp + (size_t)p * xb * T * NFP, c.s->h + row0 * D, xb, T, 0, r.lin ? &f : nullptr));
+            RC(embed(c, m, c.s->xp + (size_t)p * xb * T * NFP, c.s->h + row0 * D, xb, T));
         }
     RC(run_stack(c, m.st, c.s->h, r));
     for (int p = 0; p < npers; ++p)   // FinalLayer (layers.py:109-116), per person, concatenated on the channel axis (in2in.py:455-461)
@@ -809,17 +732,8 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     r.ffn_row0 = 2 * n; r.ffn_rows = n;        // FFN is conditioned on cond_I (influence.py:46)
     r.ca_mode = 2; r.kv_src = H->mI;
     const bool split = H->overlap && !H->prof.on && c.s == &H->sa && H->sb.h;      // the two Influence calls on two streams, each with its own scratch
-    r.lin = lin_adaln(H, H->mx.st, T) && H->sa.hstat && (!split || H->sb.hstat);
     for (int p = 0; p < 2; ++p) {
-        mmdm_gemm_fuse f;
-        if (r.lin) {                           // block 0's sa_block.norm reads these rows: statistics + the scaled copy, in the scratch of the stack that runs them
-            const Scratch& dst = split && p == 1 ? H->sb : H->sa;
-            const size_t off = split ? 0 : (size_t)p * n * T;
-            f.stats_out = dst.hstat + off * (Dm / 32) * 2;
-            f.hs1 = dst.xn + off * Dm; f.sc1 = H->ss_mx + (split ? (size_t)p * n : 0) * r.ss_ld; f.sc1_rows = split ? n : 2 * n;
-            f.ss_ld = r.ss_ld; f.T = T; f.row0 = (int)off;
-        }
-        RC(embed(c, H->mx, H->sa.xp + (size_t)p * n * T * NFP, c.s->h + (size_t)p * n * T * Dm, n, T, 0, r.lin ? &f : nullptr));
+        RC(embed(c, H->mx, H->sa.xp + (size_t)p * n * T * NFP, c.s->h + (size_t)p * n * T * Dm, n, T));
         RC(embed(c, H->mx, H->sb.xp + (size_t)p * n * T * NFP, H->mI + (size_t)p * n * T * Dm, n, T));
     }
     if (split) {
@@ -869,7 +783,7 @@ int run_step(const Ctx& c) {
         if (H->d1.kind == 1) {
             RC(run_denoiser_mdm(c, H->d1, H->x, B, 1, NF, n, T, H->cond_cat, H->td1, H->o1, NF));
         } else {
-            RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, n, T));
+            RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, n));
             RC(run_denoiser(c, H->d1, false, H->x, B, 1, NF, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF));
         }
         RC(mmdm_cfg_ddim_f32(H->o1, H->d_coef, H->S, H->d_step, H->cfg.cfg_scale, H->x, H->px1, B, T, NF, c.st));
@@ -877,7 +791,7 @@ int run_step(const Ctx& c) {
     }
     if (H->cfg.single_only == 2) {   // stand-alone interaction denoiser, 4 CFG copies of x (cfg_sampler.py:70-71)
         const int n4 = 4 * B;
-        RC(cond_vectors(c, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n4, T));
+        RC(cond_vectors(c, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n4));
         RC(run_denoiser(c, H->d2, true, H->x, B, 2, NF2, n4, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
         RC(mmdm_cfg4_ddim_f32(H->o2, H->d_coef, H->S, H->d_step, H->cfg.cfg_scale, H->cfg.cfg_scale_interaction, H->cfg.cfg_scale_individual,
                               H->x, H->px1, B, T, NF2, c.st));
@@ -897,17 +811,17 @@ int run_step(const Ctx& c) {
         Ctx c2{H, H->st2, &H->sb};
         HIPCHK(hipEventRecord(H->ev_fork, c.st));
         HIPCHK(hipStreamWaitEvent(H->st2, H->ev_fork, 0));
-        RC(cond_vectors(c2, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n, T));
+        RC(cond_vectors(c2, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n));
         RC(run_denoiser(c2, H->d2, true, xin2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
-        if (H->d1.kind == 0) RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n, T));
+        if (H->d1.kind == 0) RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n));
         RC(model1(c));
-        if (!dual) RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n, T));
+        if (!dual) RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n));
         HIPCHK(hipEventRecord(H->ev_join, H->st2));
         HIPCHK(hipStreamWaitEvent(c.st, H->ev_join, 0));
     } else {
-        if (H->d1.kind == 0) RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n, T));
-        RC(cond_vectors(c, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n, T));
-        if (!dual) RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n, T));
+        if (H->d1.kind == 0) RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, 2 * n));
+        RC(cond_vectors(c, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n));
+        if (!dual) RC(cond_vectors(c, H->mx, H->txt_mx, H->se_mx, H->ss_mx, 3 * n));
         RC(model1(c));
         RC(run_denoiser(c, H->d2, true, xin2, B, 2, NF2, n, T, H->ss_d2, ss_ld_of(H->d2), H->o2, NF2));
     }
@@ -1038,9 +952,6 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
             (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f * opx / 2)) ||
             (rc = dalloc(h, &sc->xp, (size_t)2 * n * T * NFP)))
             return fail(rc);
-        // AdaLN by linearity (fp32 handles whose stacks have a (u | c) block): row statistics and the second scaled copy of the residual stream
-        const bool any_uc = h->d1.st.uc_layer || h->d2.st.uc_layer || h->mx.st.uc_layer;
-        if (c.precision == 0 && any_uc && ((rc = dalloc(h, &sc->hstat, R * (d / 32 + 1) * 2)) || (rc = dalloc(h, &sc->xn2, R * d)))) return fail(rc);
         if (c.precision >= 1) {
             const size_t npl = c.precision == 2 ? 3 : 1;
             float *q1 = nullptr, *q2 = nullptr;
@@ -1057,7 +968,6 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
         return fail(mmdm_set_error(MMDM_ERR_HIP, "mmdm_create: stream/event creation failed"));
     h->overlap = getenv("MMDM_NO_OVERLAP") == nullptr;
     auto env_on = [](const char* k) { const char* v = getenv(k); return v != nullptr && strcmp(v, "0") != 0; };
-    h->lin_on = !env_on("MMDM_NO_LIN_ADALN");
     h->force_qkp = env_on("MMDM_QKP"); h->no_qkp = env_on("MMDM_NO_QKP"); h->no_pvb = env_on("MMDM_NO_BF16_PV");
     h->no_pack = env_on("MMDM_NO_PACK") || env_on("MMDM_SPLIT_NO_PACK");
     const size_t PT = (size_t)n * T * (so == 1 ? NF : NF2);
@@ -1223,48 +1133,6 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
             }
         }
         HIPCHK(hipDeviceSynchronize());
-    }
-    if (h->cfg.precision == 0) {
-        // AdaLN by linearity: the (u | c) rows of every stack's conditioning projection (StackW::uc_layer).  For a GEMM with weight W [N, D]
-        // and bias b that consumes the norm with projection (W_s | W_t) [2D, D], (b_s | b_t):
-        //   u = (1 + s) W^T = se (W W_s)^T + W (1 + b_s),     c = t W^T + b = se (W W_t)^T + (W b_t + b)
-        // -- the products are formed here, once, with the library's own fp32 GEMM, and stored as rows of ada_w / ada_b.
-        size_t maxD = 0;
-        for (ModuleW* m : {&h->d1, &h->d2, &h->mx})
-            if (m->st.uc_layer) maxD = std::max(maxD, (size_t)m->st.D);
-        if (maxD) {
-            float *tr = nullptr, *vec = nullptr;                    // [D][2D]: transposed (W_s | W_t) of one norm; [D]: 1 + b_s
-            HIPCHK(hipMalloc(&tr, maxD * 2 * maxD * sizeof(float)));
-            struct Free { float* p; ~Free() { if (p) (void)hipFree(p); } } f1{tr};
-            HIPCHK(hipMalloc(&vec, maxD * sizeof(float)));
-            Free f2{vec};
-            for (ModuleW* m : {&h->d1, &h->d2, &h->mx}) {
-                StackW& st = m->st;
-                if (!st.uc_layer) continue;
-                const int D = st.D, F = st.F;
-                for (int l = 0; l < st.L; ++l) {
-                    const LayerW& lw = st.layers[l];
-                    struct Cons { int id; const float* W; const float* b; int N; int slot; };
-                    std::vector<Cons> cons = {{0, lw.sa_in_w, lw.sa_in_b, 3 * D, 0}, {3, lw.f1_w, lw.f1_b, F, st.has_ca ? 3 : 1}};
-                    if (st.has_ca) { cons.push_back({1, lw.ca_in_w, lw.ca_in_b, D, 1}); cons.push_back({2, lw.ca_in_w + (size_t)D * D, lw.ca_in_b + D, 2 * D, 2}); }
-                    for (const Cons& q : cons) {
-                        const float* Wst = st.ada_w + ((size_t)l * st.n_ada + q.slot) * 2 * D * D;       // rows [0, D): scale, [D, 2D): shift (layers.py:23)
-                        const float* bst = st.ada_b + ((size_t)l * st.n_ada + q.slot) * 2 * D;
-                        const size_t row = (size_t)st.uc0 + (size_t)l * st.uc_layer + st.uc_off[q.id];
-                        float* dW = st.ada_w + row * D;
-                        float* dB = st.ada_b + row;
-                        int rc = mmdm_transpose(Wst, D, tr, 2 * D, 2 * D, D, nullptr);
-                        if (!rc) rc = mmdm_linear_f32(q.W, D, tr, 2 * D, nullptr, dW, D, q.N, D, D, MMDM_EPI_BIAS, nullptr, 0, 0, nullptr);
-                        if (!rc) rc = mmdm_linear_f32(q.W, D, tr + D, 2 * D, nullptr, dW + (size_t)q.N * D, D, q.N, D, D, MMDM_EPI_BIAS, nullptr, 0, 0, nullptr);
-                        if (!rc) rc = mmdm_add_const(bst, vec, 1.0f, D, nullptr);
-                        if (!rc) rc = mmdm_linear_f32(q.W, D, vec, D, nullptr, dB, 1, q.N, 1, D, MMDM_EPI_BIAS, nullptr, 0, 0, nullptr);
-                        if (!rc) rc = mmdm_linear_f32(q.W, D, bst + D, D, nullptr, dB + q.N, 1, q.N, 1, D, MMDM_EPI_BIAS_RESID, q.b, 1, 0, nullptr);
-                        if (rc) return herr(h, rc);
-                    }
-                }
-            }
-            HIPCHK(hipDeviceSynchronize());
-        }
     }
     h->prepared = true;
     return MMDM_OK;
@@ -1496,7 +1364,7 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
         if ((rc = build_time_tab(c, h->d1))) return done(rc);
         if ((rc = text_rows(c, h->d1, cond, 5 * td, 3 * td, h->txt_d1, 0, n))) return done(rc);
         if ((rc = text_rows(c, h->d1, cond, 5 * td, 4 * td, h->txt_d1, n, n))) return done(rc);
-        if ((rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, 2 * n, T))) return done(rc);
+        if ((rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, 2 * n))) return done(rc);
         rc = run_dual_individual(c, h->d1, x, n, n, T, h->ss_d1, ss_ld_of(h->d1), out);
         return done(rc);
     }
@@ -1508,7 +1376,7 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
     if (which == 0) {
         if ((rc = build_time_tab(c, h->d1))) return done(rc);
         if ((rc = linear(c, cond, td, h->d1.te_w, td, h->d1.te_b, h->txt_d1, h->d1.st.D, n, h->d1.st.D, td))) return done(rc);
-        if ((rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, n, T))) return done(rc);
+        if ((rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, n))) return done(rc);
         rc = run_denoiser(c, h->d1, false, x, n, 1, NF, n, T, h->ss_d1, ss_ld_of(h->d1), out, NF);
         return done(rc);
     }
@@ -1519,7 +1387,7 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
         if ((rc = text_rows(c, h->d2, cond, ldc, ig ? 0 : td, h->txt_d2, 0, n))) return done(rc);
         if ((rc = text_rows(c, h->d2, cond, ldc, ig ? 0 : 2 * td, h->txt_d2, n, n))) return done(rc);
         if ((rc = text_rows(c, h->d2, cond, ldc, 0, h->txt_d2, 2 * n, n))) return done(rc);
-        if ((rc = cond_vectors(c, h->d2, h->txt_d2, h->se_d2, h->ss_d2, 3 * n, T))) return done(rc);
+        if ((rc = cond_vectors(c, h->d2, h->txt_d2, h->se_d2, h->ss_d2, 3 * n))) return done(rc);
         rc = run_denoiser(c, h->d2, true, x, n, 2, NF2, n, T, h->ss_d2, ss_ld_of(h->d2), out, NF2);
         return done(rc);
     }
@@ -1538,9 +1406,9 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
         cnd = h->cond_cat;
     }
     if ((rc = text_all(c, cnd, nn))) return done(rc);
-    if (h->d1.kind == 0 && (rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, 2 * nn, T))) return done(rc);
-    if ((rc = cond_vectors(c, h->d2, h->txt_d2, h->se_d2, h->ss_d2, 3 * nn, T))) return done(rc);
-    if ((rc = cond_vectors(c, h->mx, h->txt_mx, h->se_mx, h->ss_mx, 3 * nn, T))) return done(rc);
+    if (h->d1.kind == 0 && (rc = cond_vectors(c, h->d1, h->txt_d1, h->se_d1, h->ss_d1, 2 * nn))) return done(rc);
+    if ((rc = cond_vectors(c, h->d2, h->txt_d2, h->se_d2, h->ss_d2, 3 * nn))) return done(rc);
+    if ((rc = cond_vectors(c, h->mx, h->txt_mx, h->se_mx, h->ss_mx, 3 * nn))) return done(rc);
     rc = h->d1.kind == 1 ? run_denoiser_mdm(c, h->d1, x, xb, 2, NF2, nn, T, cnd + 3 * td, h->cond_w, h->o1, NF2)
                          : run_denoiser(c, h->d1, false, x, xb, 2, NF2, nn, T, h->ss_d1, ss_ld_of(h->d1), h->o1, NF2);
     if (rc) return done(rc);

@@ -357,34 +357,3 @@ extern "C" int mmdm_influence_head_f32(const float* h, const float* Wout, const 
     hipLaunchKernelGGL(influence_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), h, Wout, bout, w, rows, D, nw);
     return mmdm_check_launch("influence_head");
 }
-
-// ---- prepare-time helpers of the AdaLN-by-linearity tables (mmdm.hip: mmdm_prepare) ------------------------------------------------------
-namespace {
-// dst [cols][ldd] = transpose of src [rows][lds] (32 x 32 tiles through LDS; prepare-time only)
-__global__ void transpose_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int rows, int cols) {
-    __shared__ float t[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    for (int k = threadIdx.y; k < 32; k += 8) {
-        const int r = r0 + k, c = c0 + threadIdx.x;
-        t[k][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * lds_ + c] : 0.f;
-    }
-    __syncthreads();
-    for (int k = threadIdx.y; k < 32; k += 8) {
-        const int c = c0 + k, r = r0 + threadIdx.x;
-        if (c < cols && r < rows) dst[(size_t)c * ldd + r] = t[threadIdx.x][k];
-    }
-}
-__global__ void add_const_kernel(const float* __restrict__ src, float* __restrict__ dst, float v, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[i] + v;
-}
-}  // namespace
-
-int mmdm_transpose(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t st) {
-    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, src, ld_src, dst, ld_dst, rows, cols);
-    return mmdm_check_launch("transpose");
-}
-int mmdm_add_const(const float* src, float* dst, float v, int n, hipStream_t st) {
-    hipLaunchKernelGGL(add_const_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, dst, v, n);
-    return mmdm_check_launch("add_const");
-}

@@ -46,38 +46,6 @@ def linear(x, weight, bias=None, epilogue="bias", extra=None, period=0, out=None
     return out.reshape(*x.shape[:-1], N) if x.is_contiguous() else out
 
 
-def linear_scaled(x, weight, bias, epilogue, extra, scale1, T, period=0, scale1_rows=None, scale2=None, scale2_rows=None):
-    """linear() with a residual / PE epilogue that also returns the producer half of AdaLN by linearity (mmdm_linear_f32_scaled):
-    (y [M, N], stats [M, N/32, 2], hs1 [M, N] = y * (1 + scale1[(m // T) % rows]), hs2 or None).  scale tables: [rows, >= N], same row stride."""
-    _chk(x, weight, bias, extra, scale1, scale2)
-    K, N = x.shape[-1], weight.shape[0]
-    x2 = x.reshape(-1, K)
-    M = x2.shape[0]
-    out = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    stats = torch.empty(M, N // 32, 2, device=x.device, dtype=torch.float32)
-    hs1 = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    hs2 = torch.empty(M, N, device=x.device, dtype=torch.float32) if scale2 is not None else None
-    if scale2 is not None and scale2.stride(0) != scale1.stride(0):
-        raise ValueError("scale1 and scale2 must share one row stride")
-    check(load_library().mmdm_linear_f32_scaled(_p(x2), x2.stride(0), _p(weight), weight.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, EPI[epilogue],
-                                                _p(extra), extra.stride(0) if extra is not None else 0, period, _p(stats), _p(hs1), _p(scale1),
-                                                scale1_rows or scale1.shape[0], _p(hs2), _p(scale2), (scale2_rows or scale2.shape[0]) if scale2 is not None else 1,
-                                                scale1.stride(0), T, _stream()))
-    return out, stats, hs1, hs2
-
-
-def linear_lnfold(hs, stats, uc, T, weight, epilogue="bias", uc_rows=None):
-    """epilogue(AdaLN(h) @ weight.T + bias) from the scaled copy hs = h * (1 + s), the producer's statistics and the table uc [rows, >= 2N] whose
-    row (m // T) % uc_rows holds u = (1 + s) @ weight.T | c = t @ weight.T + bias (mmdm_linear_f32_lnfold)."""
-    _chk(hs, stats, uc, weight)
-    M, K = hs.shape
-    N = weight.shape[0]
-    out = torch.empty(M, N, device=hs.device, dtype=torch.float32)
-    check(load_library().mmdm_linear_f32_lnfold(_p(hs), hs.stride(0), _p(stats), _p(uc), uc_rows or uc.shape[0], uc.stride(0), T, _p(weight), weight.stride(0),
-                                                _p(out), out.stride(0), M, N, K, EPI[epilogue], _stream()))
-    return out
-
-
 def adaln(h, ss, ss_rows=None):
     """h [nseq, T, D]; ss [rows, 2D] (scale | shift); row(s) = s % ss_rows."""
     _chk(h, ss)

@@ -527,105 +527,3 @@ def test_linear_split_packed_is_bitwise_the_plane_kernel(M, N, K):
         assert torch.equal(out, ops.linear_split(xs, ws, b.to(d))[:, n0:])
     with pytest.raises(Exception):
         ops.linear_split(ops.split3(x[:, :48].contiguous().to(d)), ops.split_pack_weight(ops.split3(w[:, :48].contiguous().to(d))), packed=True)   # K % 64
-
-
-# ---- AdaLN by linearity around the fp32 GEMMs (producer: statistics + scaled copies; consumer: prologue + rank-2 MFMA + rstd epilogue) ----
-def load_library_kernel():
-    from mixermdm_amd._lib import load_library
-    return load_library().mmdm_last_gemm_kernel().decode()
-
-
-def _uc_table(ss, K, w1, b1):
-    """What the sampler's conditioning GEMM yields for one consumer: rows (1 + s) W^T | t W^T + b (float64 on the host, rounded to fp32)."""
-    s64, t64 = ss.double()[:, :K], ss.double()[:, K:2 * K]
-    u = (1 + s64) @ w1.double().T
-    c = t64 @ w1.double().T + b1.double()
-    return torch.cat([u, c], dim=1).float()
-
-
-@pytest.mark.parametrize("nseq,T,K,N,epi,off", [(2, 300, 1024, 3072, "bias", 0.5), (5, 150, 1024, 1024, "gelu", 1.0), (3, 128, 512, 1536, "bias", 0.0), (2, 700, 256, 128, "gelu", 2.0),
-                                                (7, 131, 128, 2048, "bias", 0.5), (64, 300, 1024, 2048, "gelu", 0.3), (1, 1200, 1024, 1024, "bias", 0.3)])
-def test_adaln_by_linearity_matches_adaln_then_linear(nseq, T, K, N, epi, off):
-    """h = resid + x W0^T + b0 (producer: writes h, the partial row statistics and two scaled copies h (1 + s_k)), then
-    epilogue(AdaLN(h) W1^T + b) from a scaled copy inside the consumer GEMM -- against the stand-alone AdaLN pass followed by the plain GEMM
-    and against float64.  Tiles that straddle a sequence boundary (T not a multiple of 128), ragged M, conditioning rows that wrap
-    (rows < sequences), rows of h with a common offset of `off` standard deviations (the linear form's rounding error grows like
-    sqrt(1 + (mean / std)^2): the tolerance follows it; in the networks of this path |mean| / std <= 1)."""
-    from mixermdm_amd import ops
-    M = nseq * T
-    x, w0, b0 = rnd(1, M, 256), rnd(2, K, 256, scale=1 / 16), rnd(3, K)
-    resid = rnd(4, M, K) + off * math.sqrt(2.0)            # h ~ N(off * sqrt 2, 2): mean / std = off
-    w1, b1 = rnd(5, N, K, scale=1 / math.sqrt(K)), rnd(6, N)
-    rows1, rows2 = 3, 2
-    ss1, ss2 = rnd(7, rows1, 2 * K) * 0.5, rnd(8, rows2, 2 * K) * 0.5
-    d = dev()
-    h, stats, hs1, hs2 = ops.linear_scaled(x.to(d), w0.to(d), b0.to(d), "resid", resid.to(d), ss1.to(d), T, scale2=ss2.to(d))
-    assert load_library_kernel().startswith("gemm_pipe_scl<") and load_library_kernel().endswith("vepi-t>")
-    assert torch.equal(h, ops.linear(x.to(d), w0.to(d), b0.to(d), "resid", resid.to(d)))          # statistics and copies are side outputs
-    # the LDS-transposed stores of the 16-byte epilogue change the store pattern, not a bit of the values: direct-store instantiations agree
-    from mixermdm_amd._lib import diag
-    try:
-        diag("gemm_tst", 0)
-        h0, st0, a0, b0_ = ops.linear_scaled(x.to(d), w0.to(d), b0.to(d), "resid", resid.to(d), ss1.to(d), T, scale2=ss2.to(d))
-        assert load_library_kernel().endswith(",vepi>")
-        p0 = ops.linear(x.to(d), w0.to(d), b0.to(d), "resid", resid.to(d))
-        assert load_library_kernel().endswith(",vepi>")
-    finally:
-        diag("gemm_tst", 1)
-    assert torch.equal(h0, h) and torch.equal(st0, stats) and torch.equal(a0, hs1) and torch.equal(b0_, hs2) and torch.equal(p0, h)
-    hb = h.cpu().double().view(M, K // 32, 32)
-    assert_close(stats[..., 0], hb.mean(-1).float(), atol=1e-5, rtol=1e-6, what="block means")
-    assert_close(stats[..., 1], ((hb - hb.mean(-1, keepdim=True)) ** 2).sum(-1).float(), atol=1e-3, rtol=1e-4, what="block M2")
-    sel1, sel2 = (torch.arange(M) // T) % rows1, (torch.arange(M) // T) % rows2
-    assert_close(hs1, h.cpu() * (1 + ss1[sel1, :K]), atol=0, rtol=3e-7, what="scaled copy 1")
-    assert_close(hs2, h.cpu() * (1 + ss2[sel2, :K]), atol=0, rtol=3e-7, what="scaled copy 2")
-    tol = math.sqrt(1 + off * off)
-    for hs, ss, rows, sel in ((hs1, ss1, rows1, sel1), (hs2, ss2, rows2, sel2)):
-        uc = _uc_table(ss, K, w1, b1).to(d)
-        got = ops.linear_lnfold(hs, stats, uc, T, w1.to(d), epi, uc_rows=rows)
-        assert load_library_kernel().startswith("gemm_pipe_lin<")
-        xn = ops.adaln(h.view(nseq, T, K), ss.to(d), rows).view(M, K)
-        want = ops.linear(xn, w1.to(d), b1.to(d), epi)
-        assert_close(got, want, atol=3e-5 * tol, rtol=1e-5 * tol, what="by linearity vs AdaLN pass + GEMM")
-        # float64: LN(eps 1e-6, biased variance) * (1 + scale) + shift with row m -> ss[(m // T) % rows]
-        h64 = h.cpu().double()
-        ln = (h64 - h64.mean(-1, keepdim=True)) / torch.sqrt(h64.var(-1, unbiased=False, keepdim=True) + 1e-6)
-        y = F.linear(ln * (1 + ss.double()[sel, :K]) + ss.double()[sel, K:], w1.double(), b1.double())
-        if epi == "gelu":
-            y = F.gelu(y)
-        assert_close(got, y.float(), atol=5e-5 * tol, rtol=2e-5 * tol, what="by linearity vs float64")
-        # and it is as close to float64 as the two-kernel form is (within the sqrt(1 + off^2) the operand's offset costs)
-        e_lin, e_pass = (got.cpu().double() - y).abs().mean().item(), (want.cpu().double() - y).abs().mean().item()
-        assert e_lin <= 2.0 * tol * e_pass + 1e-9, (e_lin, e_pass)
-
-
-def test_adaln_by_linearity_pe_producer_and_row_offsets():
-    """The PE-embedding producer (K = 272, period T) and a producer / consumer pair that covers a row range of a larger problem (row0 via the
-    sampler's sub-GEMMs is exercised by the sampler tests; here: the stateless entry points on a slice equal the whole-problem result)."""
-    from mixermdm_amd import ops
-    nseq, T, K, N = 3, 140, 512, 1024
-    M = nseq * T
-    d = dev()
-    xp, we, be, pe = rnd(1, M, 272).to(d), rnd(2, K, 272, scale=1 / 16).to(d), rnd(3, K).to(d), rnd(4, T, K).to(d)
-    ss = (rnd(5, nseq, 2 * K) * 0.5)
-    h, stats, hs1, _ = ops.linear_scaled(xp, we, be, "pe", pe, ss.to(d), T, period=T)
-    assert torch.equal(h, ops.linear(xp, we, be, "pe", pe, T))
-    w1, b1 = rnd(6, N, K, scale=1 / math.sqrt(K)), rnd(7, N)
-    got = ops.linear_lnfold(hs1, stats, _uc_table(ss, K, w1, b1).to(d), T, w1.to(d), "bias")
-    want = ops.linear(ops.adaln(h.view(nseq, T, K), ss.to(d), nseq).view(M, K), w1.to(d), b1.to(d), "bias")
-    assert_close(got, want, atol=4e-5, rtol=2e-5, what="PE producer -> consumer")
-
-
-def test_adaln_by_linearity_rejects_what_it_does_not_cover():
-    from mixermdm_amd import ops, MMDMError
-    d = dev()
-    hs, w = torch.zeros(256, 1024, device=d), torch.zeros(64, 1024, device=d)
-    st, uc = torch.zeros(256, 32, 2, device=d), torch.zeros(1, 128, device=d)
-    with pytest.raises(MMDMError, match="T >= 128"):
-        ops.linear_lnfold(hs, st, uc, 64, w)                     # a tile would span more than two sequences
-    with pytest.raises(MMDMError, match="K %% 128|K % 128"):
-        ops.linear_lnfold(torch.zeros(256, 96, device=d), torch.zeros(256, 3, 2, device=d), uc, 128, torch.zeros(64, 96, device=d))
-    with pytest.raises(MMDMError, match="scaled copies need"):
-        ops.linear_scaled(torch.zeros(8, 64, device=d), torch.zeros(40, 64, device=d), None, "resid", torch.zeros(8, 40, device=d), torch.zeros(1, 40, device=d), 128)
-    with pytest.raises(MMDMError, match="scaled copies need"):   # not a residual / PE epilogue
-        ops.linear_scaled(torch.zeros(256, 128, device=d), torch.zeros(128, 128, device=d), None, "gelu", None, torch.zeros(1, 128, device=d), 128)

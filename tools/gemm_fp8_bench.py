@@ -3,7 +3,7 @@ import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspa
 import torch, math, statistics
 from mixermdm_amd import ops, load_library
 lib = load_library(); d = torch.device("cuda:0")
-shapes = [(19200,3072,1024,"qkv","bias",torch.bfloat16),(19200,2048,1024,"ffn1","gelu",torch.float8_e4m3fn),(19200,1024,2048,"ffn2","resid",torch.float32),(8192,8192,8192,"sq8k","bias",torch.bfloat16)]
+shapes = [(19200,3072,1024,"qkv","bias",torch.bfloat16),(19200,1024,1024,"ca q","bias",torch.bfloat16),(19200,2048,1024,"ca kv","bias",torch.bfloat16),(19200,2048,1024,"ffn1","gelu",torch.float8_e4m3fn),(19200,1024,2048,"ffn2","resid",torch.float32),(8192,8192,8192,"sq8k","bias",torch.bfloat16)]
 _w = torch.randn(4096, 4096, device=d)
 for _ in range(60): ops.linear(_w, _w)
 for M,N,K,name,epi,od in shapes:
@@ -11,12 +11,19 @@ for M,N,K,name,epi,od in shapes:
     xq, xs = ops.quantize_rows_fp8(x); wq, ws = ops.quantize_rows_fp8(w); wp = ops.pack_weight_frag(wq)
     extra = torch.randn(M,N,device=d) if epi=="resid" else None
     line = f"{name:5s} {M}x{N}x{K} {epi:5s} -> {str(od)[6:]:14s}"
-    for tag, wgt, pk in (("staged", wq, False), ("packed", wp, True)):
-        f = lambda: ops.linear_fp8(xq, xs, wgt, ws, b, epi, extra, out_dtype=od, packed=pk)
-        f(); res=[]
-        for r in range(5):
-            e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e0.record()
-            for _ in range(4): f()
-            e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
-        ms=statistics.median(res); line+=f" | {tag}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:7.1f}TF"
+    ref = {}
+    for tst in (1, 0):                       # 1: results leave through the workgroup's LDS transposition (whole lines); 0: direct row-per-lane stores
+        lib.mmdm_diag_set(b"bf16_tst", tst)
+        for tag, wgt, pk in (("staged", wq, False), ("packed", wp, True)):
+            f = lambda: ops.linear_fp8(xq, xs, wgt, ws, b, epi, extra, out_dtype=od, packed=pk)
+            o = f(); res=[]
+            key = tag
+            if key in ref: assert torch.equal(o.view(torch.uint8), ref[key].view(torch.uint8)), f"transposed epilogue changed bits: {name} {tag}"
+            else: ref[key] = o
+            for r in range(5):
+                e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e0.record()
+                for _ in range(4): f()
+                e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
+            ms=statistics.median(res); line+=f" | {tag}{'-t' if tst else '-d'}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:7.1f}TF"
+    lib.mmdm_diag_set(b"bf16_tst", 1)
     print(line, flush=True)
