@@ -234,4 +234,24 @@ def test_free_running_ddim50_loop_at_full_dims_vs_oracle():
         yardstick(out, ref32, ref64, f"free-running ddim50 B=1 T=300 [{mode}]", factor=YARD_FACTOR_LOOP, factor_posvel=YARD_FACTOR_LOOP)
         for nm in names:
             assert figures[nm]["mean"] <= 1e-4 and figures[nm]["p99.9"] <= 1e-2, (mode, nm, figures[nm])
+        if mode == "fp32":
+            direct = out_final.clone()
         s.close()
+    # The reference's own entry point for this call shape -- MixerMDM(cfg, ...)(batch) at B = 1, ddim50 (src/scripts/infer/mixermdm.py:73,
+    # 117-124: the infer script; src/evaluation/datasets.py:100-116: forward_test per item) -- through the facade over configs/models/*.yaml:
+    # the same kernels behind the reference API, so the motion is the Sampler's bit for bit and carries the figures asserted above; the
+    # history lists have the reference's lengths and [2B, T, C] shapes.
+    import os
+    from mixermdm_amd.configs import get_config
+    from mixermdm_amd.models import MixerMDM
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = MixerMDM(get_config(os.path.join(root, "configs", "models", "MixerMDM.yaml")), num_frames=300, sampling_strategy="ddim50", config_root=root)
+    m.load_state_dict({"mixing." + k: v for k, v in sd.items()})
+    m.set_norm_stats(*[t.numpy() for t in stats])
+    m = m.to("cuda:0").eval()
+    batch = {"cond": cond.cuda(), "x_T": xT.cuda(), "motion_lens": torch.tensor([[300]])}
+    full = m(batch)
+    assert torch.equal(full["output"], direct), "MixerMDM.forward differs from the Sampler it wraps"
+    assert len(full["influence_i1"]) == 50 and full["influence_i1"][0].shape == (2, 300, 262) and len(full["out_influenced"]) == 50 and full["out1"][0].shape == (2, 300, 524)
+    test = m.forward_test(batch)
+    assert torch.equal(test["output"], direct) and set(test) == {"output", "influence_i1", "influence_i2"}

@@ -1,10 +1,10 @@
 """Copy what tools/bench_round.sh left under gpurun_out/bench_<tag>/ into profiles/<tag>_bench_*.json (tracked) and print the figures.
-usage: python tools/collect_bench.py [round-tag, default r03]"""
+usage: python tools/collect_bench.py [round-tag, default r04]"""
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = os.path.join(ROOT, "gpurun_out", f"bench_{tag}"), os.path.join(ROOT, "profiles")
-for n in ("default", "single", "bf16", "bf16_fp8", "fp8_b64", "b32", "b32_split"):
+for n in ("default", "single", "bf16", "bf16_fp8", "fp8_b64", "b32", "b32_split", "infer_b1", "infer_b15", "configs0"):
     f = os.path.join(src, n + ".json")
     line = next((l for l in open(f) if l.startswith("{")), None) if os.path.exists(f) else None
     if not line:
@@ -19,6 +19,10 @@ for n in ("default", "single", "bf16", "bf16_fp8", "fp8_b64", "b32", "b32_split"
         extra += f"  | full loop {d['full_loop']}"
     if d.get("cpu_baseline"):
         extra += f"  | cpu {d['cpu_baseline'].get('value')} {d['cpu_baseline'].get('unit')}"
+        if d["cpu_baseline"].get("whole_host"):
+            extra += f" (whole host: {d['cpu_baseline']['whole_host'].get('motions_per_s')})"
+    if d.get("facade"):
+        extra += f"  | facade {d['facade']}"
     print(f"{n:10s} {d['ms_per_step']:8.3f} ms/step  {d['value']:.5f} {d['unit']}  roofline {r['achieved']} / {r['peak']} = {r['frac']}  traffic {r['traffic']}  attention {r.get('attention')}{extra}")
 if os.path.exists(os.path.join(src, "full_loops.txt")):
     shutil.copy(os.path.join(src, "full_loops.txt"), os.path.join(dst, f"{tag}_full_loops.txt"))

@@ -1,8 +1,8 @@
 """Copy what tools/profile_round.sh left under gpurun_out/prof_<tag>/ into profiles/ (tracked) and print the figures DESIGN.md quotes.
-usage: python tools/collect_profiles.py [round-tag, default r03]"""
+usage: python tools/collect_profiles.py [round-tag, default r04]"""
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles")
 for n in ("serial", "overlap", "fp32_split_serial", "bf16_serial", "bf16_fp8_serial", "single_serial"):
     st = os.path.join(src, "summary", f"kernel_stats_{n}.csv")
