@@ -182,6 +182,7 @@ def main():
         g_ms, g_n, g_fl, g_by = smp.profile_read(0)
         a_ms, a_n, a_fl, _ = smp.profile_read(1)
         f_ms, f_n, f_fl, f_by = smp.profile_read(2)      # fp8-operand launches (bf16_fp8 only): their own class, their own peak
+        p_ms, p_n, p_fl, _ = smp.profile_read(3)         # fp32 GEMMs of a low-precision handle (embeddings, conditioning, heads): priced against the fp32 roof
         smp.profile(False)
         # fp32_split executes SIX bf16 MFMAs per algorithmic multiply-add block: its roof is the dense bf16 peak / 6.
         # bf16_fp8: two kinds of launches.  The QKV / cross-attention input / FFN GEMMs issue the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4
@@ -190,13 +191,22 @@ def main():
         # `frac_blended` = (time both classes would take at their own peaks) / (time they took).
         peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 6, 1), "bf16_fp8": PEAK_FP8_MFMA_TFLOPS}[args.precision]
         other = None
+        fp32_side = None
+        if p_n:
+            p_ach = p_fl / (p_ms * 1e-3) / 1e12
+            fp32_side = {"achieved": round(p_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(p_ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_per_step": p_n // args.profile_steps,
+                         "avg_launch_us": round(p_ms * 1e3 / p_n, 2), "ms_per_step": round(p_ms / args.profile_steps, 3),
+                         "what": "embedding / conditioning / head GEMMs of this mode: fp32 operands on the fp32 kernel"}
         if args.precision == "bf16_fp8" and f_n:
             b_ach = g_fl / (g_ms * 1e-3) / 1e12
             other = {"achieved": round(b_ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(b_ach / PEAK_BF16_MFMA_TFLOPS, 4), "launches_per_step": g_n // args.profile_steps,
                      "avg_launch_us": round(g_ms * 1e3 / g_n, 2), "ms_per_step": round(g_ms / args.profile_steps, 3)}
             ideal_ms = (f_fl / PEAK_FP8_MFMA_TFLOPS + g_fl / PEAK_BF16_MFMA_TFLOPS) / 1e9
             blended = {"frac_blended": round(ideal_ms / (f_ms + g_ms), 4), "all_gemm_tflops": round((f_fl + g_fl) / ((f_ms + g_ms) * 1e-3) / 1e12, 2),
-                       "all_gemm_frac_of_bf16_peak": round((f_fl + g_fl) / ((f_ms + g_ms) * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+                       "all_gemm_frac_of_bf16_peak": round((f_fl + g_fl) / ((f_ms + g_ms) * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                       # every GEMM launch of the step incl. the fp32 embedding / conditioning / head GEMMs, as round 3 quoted it (0.31 at B = 16, 0.35 at B = 64)
+                       "all_launches_tflops": round((f_fl + g_fl + p_fl) / ((f_ms + g_ms + p_ms) * 1e-3) / 1e12, 2),
+                       "all_launches_frac_of_bf16_peak": round((f_fl + g_fl + p_fl) / ((f_ms + g_ms + p_ms) * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
             g_ms, g_n, g_fl, g_by = f_ms, f_n, f_fl, f_by
         ach = g_fl / (g_ms * 1e-3) / 1e12
         kname = {"fp32": "gemm_glds_kernel<..., PIPE_=1> (v_mfma_f32_32x32x2_f32; software-pipelined LDS-DMA ring: 128x128 tiles x 5 stages, 128x64 x 4 stages when N = 2048 or N, K <= 512; all instantiations of a step averaged)",
@@ -214,6 +224,8 @@ def main():
         if other:
             roof["bf16_launches"] = other
             roof.update(blended)
+        if fp32_side:
+            roof["fp32_launches"] = fp32_side
         try:
             roof["clock"] = None if args.no_clock else loop_clock(args.precision, 4 * B * T if not single else 2 * B * T, peak, ach)
         except Exception as e:          # a diagnostic next to the measurement, never a reason to lose the line
@@ -252,6 +264,7 @@ def main():
             alt_smp.run(min(args.profile_steps, S), use_graph=False)
             g_ms, g_n, g_fl, g_by = alt_smp.profile_read(0)
             a2_ms, a2_n, a2_fl, _ = alt_smp.profile_read(1)
+            q_ms, q_n, q_fl, _ = alt_smp.profile_read(3)
             alt_smp.profile(False)
             pk = round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
             ach2 = g_fl / (g_ms * 1e-3) / 1e12
@@ -260,6 +273,9 @@ def main():
                                "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1), "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
                                "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
                                "attention": {"achieved": round(a2_fl / (a2_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a2_ms / args.profile_steps, 3), "launches_per_step": a2_n // args.profile_steps}}
+            if q_n:
+                alt["roofline"]["fp32_launches"] = {"achieved": round(q_fl / (q_ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "launches_per_step": q_n // args.profile_steps,
+                                                    "ms_per_step": round(q_ms / args.profile_steps, 3)}
             try:
                 alt["roofline"]["clock"] = None if args.no_clock else loop_clock("fp32_split", 4 * B * T, pk, ach2)
             except Exception as e:

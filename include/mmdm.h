@@ -365,8 +365,9 @@ int mmdm_module_forward(mmdm_handle h, int which, const float* x, const float* x
                         float* out, int n, int T, void* stream);
 
 /* Live kernel timing for bench.py: wraps hipEvents on `stream` around every launch of the kernel class `which`
- * (0 = linear/GEMM on fp32 / bf16 / split operands, 1 = attention, 2 = fp8-operand GEMMs of precision 3 -- priced against their own
- * matrix peak) during mmdm_run(use_graph=0) and accumulates. */
+ * (0 = GEMMs in the handle's own operand type: fp32 / bf16 / split planes, 1 = attention, 2 = fp8-operand GEMMs of precision 3, 3 = the fp32
+ * GEMMs of a low-precision handle: embeddings, conditioning, heads -- each class priced against its own matrix peak) during
+ * mmdm_run(use_graph=0) and accumulates. */
 int mmdm_profile_enable(mmdm_handle h, int on);
 int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launches, double* flops, double* algorithmic_bytes);
 

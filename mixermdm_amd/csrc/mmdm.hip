@@ -142,11 +142,12 @@ struct Scratch {          // transformer-stack work buffers (one set per concurr
 
 struct Prof {
     bool on = false;
-    static constexpr int NCLS = 3;               // 0: GEMMs (every operand type but fp8), 1: attention, 2: fp8-operand GEMMs (precision 3)
+    static constexpr int NCLS = 4;               // 0: GEMMs in the handle's own operand type (fp32 / bf16 / split planes), 1: attention, 2: fp8-operand GEMMs
+                                                 // (precision 3), 3: fp32 GEMMs of a low-precision handle (embeddings, conditioning, heads: their roof is the fp32 one)
     std::vector<hipEvent_t> ev[NCLS];            // pairs (start, stop) per launch, per class
-    size_t used[NCLS] = {0, 0, 0};
-    double flops[NCLS] = {0, 0, 0};
-    double bytes[NCLS] = {0, 0, 0};              // algorithmic bytes (operands read once + result written once)
+    size_t used[NCLS] = {0, 0, 0, 0};
+    double flops[NCLS] = {0, 0, 0, 0};
+    double bytes[NCLS] = {0, 0, 0, 0};           // algorithmic bytes (operands read once + result written once)
 };
 
 }  // namespace
@@ -432,9 +433,10 @@ int prof_end(const Ctx& c, int cls) {
 
 int linear(const Ctx& c, const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
            int epi = MMDM_EPI_BIAS, const float* extra = nullptr, int ld_extra = 0, int period = 0, int Kw = 0) {
-    RC(prof_begin(c, 0, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1))));
+    const int cls = c.h && c.h->cfg.precision != 0 ? 3 : 0;
+    RC(prof_begin(c, cls, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1))));
     RC(mmdm_linear_f32_ex(A, lda, W, ldw, Kw ? Kw : K, bias, C, ldc, M, N, K, epi, extra, ld_extra, period, c.st));
-    return prof_end(c, 0);
+    return prof_end(c, cls);
 }
 
 // plain self-attention of nn.TransformerEncoderLayer (no zero key)
