@@ -184,12 +184,12 @@ def main():
         f_ms, f_n, f_fl, f_by = smp.profile_read(2)      # fp8-operand launches (bf16_fp8 only): their own class, their own peak
         p_ms, p_n, p_fl, _ = smp.profile_read(3)         # fp32 GEMMs of a low-precision handle (embeddings, conditioning, heads): priced against the fp32 roof
         smp.profile(False)
-        # fp32_split executes SIX bf16 MFMAs per algorithmic multiply-add block: its roof is the dense bf16 peak / 6.
+        # fp32_split executes THREE fp16 MFMAs per algorithmic multiply-add block: its roof is the dense 16-bit peak / 3.
         # bf16_fp8: two kinds of launches.  The QKV / cross-attention input / FFN GEMMs issue the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4
         # (e4m3 operands, unit E8M0 scales: twice the bf16 rate, 5 PFLOP/s dense) and are the dominant kernel: `achieved` / `peak` / `frac` are
         # theirs.  The attention output projections and embeddings are bf16 launches priced against 2.5 PFLOP/s in `bf16_launches`;
         # `frac_blended` = (time both classes would take at their own peaks) / (time they took).
-        peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 6, 1), "bf16_fp8": PEAK_FP8_MFMA_TFLOPS}[args.precision]
+        peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "bf16_fp8": PEAK_FP8_MFMA_TFLOPS}[args.precision]
         other = None
         fp32_side = None
         if p_n:
@@ -211,7 +211,7 @@ def main():
         ach = g_fl / (g_ms * 1e-3) / 1e12
         kname = {"fp32": "gemm_glds_kernel<..., PIPE_=1> (v_mfma_f32_32x32x2_f32; software-pipelined LDS-DMA ring: 128x128 tiles x 5 stages, 128x64 x 4 stages when N = 2048 or N, K <= 512; all instantiations of a step averaged)",
                  "bf16": "gemm_bf16w_kernel (v_mfma_f32_32x32x16_bf16; weights in MFMA fragment order fetched straight from global memory, A through three LDS-DMA stages, 128x256 tiles, K step 128 bytes)",
-                 "fp32_split": "gemm_splitw_kernel (fp32 result from 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 operand splits; weights in MFMA fragment order fetched straight from global memory, 128x128 tiles, two workgroups per CU; peak = 2500/6 algorithmic TFLOP/s)",
+                 "fp32_split": "gemm_splitw_kernel (fp32 result from 3 x v_mfma_f32_32x32x16_f16 on two-way fp16 operand splits, hi / lo accumulators; weights in MFMA fragment order fetched straight from global memory, 128x128 tiles, two workgroups per CU; peak = 2500/3 algorithmic TFLOP/s)",
                  "bf16_fp8": "gemm_bf16w_kernel<ET=fp8> / gemm_bf16_kernel<ET=fp8> (v_mfma_scale_f32_32x32x64_f8f6f4: e4m3 operands, unit E8M0 block scales, per-row / "
                              "per-output-channel scales in the epilogue, fp32 accumulate; packed weights straight from global memory where the shape allows)"}[args.precision]
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak,
@@ -254,10 +254,10 @@ def main():
         alt_smp.begin(cond, xT); alt_smp.run(2, use_graph)
         xa, xb = smp.state()["x2"], alt_smp.state()["x2"]
         rel = float(((xa - xb).pow(2).mean().sqrt() / xa.pow(2).mean().sqrt()).item())
-        alt = {"mode": "fp32_split (exact 3-way bf16 operand split, six bf16 MFMAs per product, fp32 accumulate)", "ms_per_step": round(a_ms, 3),
+        alt = {"mode": "fp32_split (two-way fp16 operand split, three fp16 MFMAs per product block, fp32 accumulate)", "ms_per_step": round(a_ms, 3),
                "value": round(B / (a_ms * 1e-3 * S), 5), "unit": "motions/s", "rel_rms_vs_fp32_after_2_steps": rel,
                "achieved_tflops_algorithmic": round(algorithmic_flops_per_motion_step(T, single=single) * B / (a_ms * 1e-3) / 1e12, 2)}
-        # its own roofline: live HIP-event pairs around every GEMM launch of an eager pass, against 2500 / 6 algorithmic TFLOP/s
+        # its own roofline: live HIP-event pairs around every GEMM launch of an eager pass, against 2500 / 3 algorithmic TFLOP/s
         if args.profile_steps > 0:
             alt_smp.begin(cond, xT)
             alt_smp.profile(True)
@@ -266,9 +266,9 @@ def main():
             a2_ms, a2_n, a2_fl, _ = alt_smp.profile_read(1)
             q_ms, q_n, q_fl, _ = alt_smp.profile_read(3)
             alt_smp.profile(False)
-            pk = round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
+            pk = round(PEAK_BF16_MFMA_TFLOPS / 3, 1)
             ach2 = g_fl / (g_ms * 1e-3) / 1e12
-            alt["roofline"] = {"bound": "mfma", "kernel": "gemm_splitw_kernel (fp32 result from 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 operand splits; packed weights straight from global memory, 128x128 tiles, two workgroups per CU)",
+            alt["roofline"] = {"bound": "mfma", "kernel": "gemm_splitw_kernel (fp32 result from 3 x v_mfma_f32_32x32x16_f16 on two-way fp16 operand splits; packed weights straight from global memory, 128x128 tiles, two workgroups per CU)",
                                "achieved": round(ach2, 2), "peak": pk, "unit": "TFLOP/s", "frac": round(ach2 / pk, 4), "traffic": measured_traffic(single, "fp32_split", B, T),
                                "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1), "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
                                "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
@@ -328,12 +328,12 @@ def main():
                                              "the reference's own caller shape (src/scripts/infer/mixermdm.py:73,117-124; src/evaluation/datasets.py:58,100-116)" if args.sampler == "ddim50" else "configs[2] shape family")
         wl = ("BASELINE configs[1]: single-person in2IN (individual denoiser, CFG 3.5), T=%d, %s (eta=0), batch %d per GPU, %s, random-init weights" % (T, args.sampler, B, args.precision)) if single else \
              ("BASELINE %s: 2-person MixerMDM (in2IN individual + in2IN interaction + Mixer mode 4, align, CFG 3.5), "
-              "T=%d, %s (eta=0), batch %d per GPU, %s, random-init weights" % (which, T, args.sampler, B, {"fp32": "fp32", "fp32_split": "fp32 via exact 3-way bf16 operand split (six bf16 MFMAs per product)", "bf16": "bf16 GEMM operands / fp32 accumulate (configs[4]-style)", "bf16_fp8": "configs[4]: bf16 path with fp8 e4m3 QKV / FFN GEMM operands, fp32 accumulate"}[args.precision]))
+              "T=%d, %s (eta=0), batch %d per GPU, %s, random-init weights" % (which, T, args.sampler, B, {"fp32": "fp32", "fp32_split": "fp32 via two-way fp16 operand split (three fp16 MFMAs per product block)", "bf16": "bf16 GEMM operands / fp32 accumulate (configs[4]-style)", "bf16_fp8": "configs[4]: bf16 path with fp8 e4m3 QKV / FFN GEMM operands, fp32 accumulate"}[args.precision]))
         line = {
             "metric": "generated motions/sec (1000-step DDPM schedule sampled with DDIM eta=0%s, T=%d, %s)" % ("" if S == 1000 else " on %d respaced steps (%s)" % (S, args.sampler), T, "single-person" if single else "2-person"),
             "value": round(value, 5), "unit": "motions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "ms_per_step_ranks": rank_ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32_split": "f32 (3xbf16 exact operand split, fp32 accumulate)", "bf16": "bf16", "bf16_fp8": "bf16 + fp8 e4m3 QKV/FFN operands"}[args.precision], "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32_split": "f32 (2xfp16 operand split, fp32 accumulate)", "bf16": "bf16", "bf16_fp8": "bf16 + fp8 e4m3 QKV/FFN operands"}[args.precision], "data": "synthetic",
             "config": {"workload": wl,
                        "batch_per_gpu": B, "frames": T, "sampler": args.sampler, "sampler_steps": S, "hipgraph": use_graph, "parallelism": "batch-sharded x%d, no in-loop collective" % world},
             "per_gpu_batch": B,
@@ -385,7 +385,7 @@ def loop_clock(precision, M, peak, achieved):
         st, ck = raw[:8 * n].view(n, 8).double(), raw[8 * n:10 * n].view(n, 2).double()
         mhz = (100.0 * (ck[:, 1] - ck[:, 0]) / (st[:, 2] - st[:, 1]).clamp(min=1)).median().item()
     else:
-        xs, ws = ops.split3(x), ops.split3(w)
+        xs, ws = ops.split_f32(x), ops.split_f32(w)
         wp = ops.split_pack_weight(ws)
         call = lambda: ops.linear_split(xs, wp, b, packed=True)
         for _ in range(300):

@@ -104,23 +104,25 @@ int mmdm_quantize_rows_fp8(const float* in, int ld_in, void* out, int ld_out, fl
 /* AdaLN apply (mmdm_adaln_f32) writing the fp8 GEMM's A operand directly: out [rows, D] e4m3 bytes + row_scale [rows]. */
 int mmdm_adaln_fp8(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, float* row_scale, int nseq, int T, int D, void* stream);
 
-/* fp32 linear layer on the bf16 matrix cores by exact 3-way operand splitting ("fp32-split" precision, mmdm_config.precision = 2):
- * every fp32 x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (3 x 8 significand bits = fp32's 24);
- * a*w is accumulated in fp32 as a1w1 + a1w2 + a2w1 + a1w3 + a3w1 + a2w2 (six v_mfma_f32_32x32x16_bf16; the three dropped terms are
- * < 2^-32 |a||w|), i.e. to fp32 accuracy at 6/16 of the fp32-MFMA cost.  A and W are given as three bf16 planes [3][rows][K]
- * (plane strides in elements, from mmdm_f32_split3 or a split-writing producer); C is fp32 [M,N], or three bf16 planes if out_split.
- * Epilogues / extra / period as mmdm_linear_f32; K % 32 == 0, N % 4 == 0. */
+/* fp32 linear layer on the 16-bit matrix cores from two-way fp16 operand splits ("fp32-split" precision, mmdm_config.precision = 2):
+ * every fp32 x is carried as h = fp16(x), l = fp16((x - h) * 2048), x ~= h + l / 2048 (11 + 11 significand bits: relative error <= 2^-22,
+ * |x| < 65504); a*w is accumulated in fp32 as  hi += ah*wh,  lo += ah*wl + al*wh,  result = hi + lo / 2048  (three
+ * v_mfma_f32_32x32x16_f16; the dropped al*wl is < 2^-22 |a||w|): as accurate against a float64 product as the fp32 MFMA kernel (whose
+ * accumulation rounding over K >= 256 terms is the larger error) at 3/16 of its matrix-core cost.  A and W are given as two fp16 planes
+ * [2][rows][K] (plane strides in elements, from mmdm_f32_split or a split-writing producer); C is fp32 [M,N], or its two fp16 planes if
+ * out_split.  Epilogues / extra / period as mmdm_linear_f32; K % 32 == 0, N % 4 == 0.  (Rounds 1-3 used an exact three-way bf16 split with
+ * six MFMAs per product block; measured no more accurate, twice the matrix-core work: LAB_NOTES.md, round 4.) */
 int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const void* W, int ldw, int64_t w_plane, const float* bias, void* C, int ldc,
                       int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
-/* The same product with W in FRAGMENT ORDER (static weights): mmdm_split_pack_weight permutes the three planes [3][N][K] inside blocks
+/* The same product with W in FRAGMENT ORDER (static weights): mmdm_split_pack_weight permutes the two planes [2][N][K] inside blocks
  * of 32 rows x 16 k so that one wave-wide 16-byte load is one MFMA operand; the kernel then takes W straight from global memory and only
  * A goes through LDS.  Same term order per accumulator: results are bit-identical to mmdm_linear_split.  Needs N % 64 == 0, K % 64 == 0
  * (packing alone: N % 32 == 0, K % 16 == 0); a row slice that starts at a multiple of 32 rows is the same offset as in the plane layout. */
 int mmdm_linear_split_packed(const void* A, int lda, int64_t a_plane, const void* W_packed, int64_t w_plane, const float* bias, void* C, int ldc,
                              int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
 int mmdm_split_pack_weight(const void* W, int ldw, int64_t w_plane, void* out, int64_t out_plane, int N, int K, void* stream);
-/* Exact split of n contiguous fp32 values into three bf16 planes out[0], out[plane_stride], out[2*plane_stride] (elements). */
-int mmdm_f32_split3(const float* in, void* out, int64_t n, int64_t plane_stride, void* stream);
+/* Split of n contiguous fp32 values into the two fp16 planes out[0], out[plane_stride] (elements): in ~= out0 + out1 / 2048. */
+int mmdm_f32_split(const float* in, void* out, int64_t n, int64_t plane_stride, void* stream);
 
 /* AdaLN apply: out[s,t,:] = LN_{eps=1e-6,no affine}(h[s,t,:]) * (1 + ss[row(s), 0:D]) + ss[row(s), D:2D],
  * row(s) = s % ss_rows.  ss is the output of Linear(SiLU(emb)) (scale first, shift second), row stride ss_ld.
@@ -285,9 +287,9 @@ typedef struct {
     int precision;     /* 0: exact fp32 everywhere (the parity path).  1: bf16 operands for the transformer-stack GEMMs (weights
                         *    converted once at mmdm_prepare; AdaLN / attention / GELU outputs written as bf16), fp32 accumulation,
                         *    residual stream, softmax, geometry, DDIM and embeddings (BASELINE configs[4], "bf16 path")
-                        * 2: "fp32-split": fp32 results from the bf16 matrix cores -- the transformer-stack GEMM operands are exact 3-way
-                        *    bf16 splits (weights split at mmdm_prepare, AdaLN / attention / GELU outputs written as three planes) and each
-                        *    product is accumulated as six bf16 MFMAs (mmdm_linear_split); accuracy = fp32 MFMA, everything else as 0
+                        * 2: "fp32-split": fp32 results from the 16-bit matrix cores -- the transformer-stack GEMM operands are two-way
+                        *    fp16 splits (weights split at mmdm_prepare, AdaLN / attention / GELU outputs written as two planes) and each
+                        *    product is accumulated as three fp16 MFMAs (mmdm_linear_split); accuracy = fp32 MFMA, everything else as 0
                         * 3: "bf16_fp8" (BASELINE configs[4]): as 1, with the QKV / cross-attention input projections and both FFN GEMMs on
                         *    fp8 e4m3 operands -- weights quantised per output channel at mmdm_prepare, AdaLN outputs quantised per row by
                         *    the AdaLN kernel, GELU outputs at unit scale -- fp32 accumulation and de-quantisation (mmdm_linear_fp8); the

@@ -42,7 +42,7 @@ SYMBOLS = {
     "mmdm_linear_split": (_I, [_VP, _I, C.c_int64, _VP, _I, C.c_int64, _VP, _VP, _I, C.c_int64, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
     "mmdm_linear_split_packed": (_I, [_VP, _I, C.c_int64, _VP, C.c_int64, _VP, _VP, _I, C.c_int64, _I, _I, _I, _I, _I, _VP, _I, _I, _VP]),
     "mmdm_split_pack_weight": (_I, [_VP, _I, C.c_int64, _VP, C.c_int64, _I, _I, _VP]),
-    "mmdm_f32_split3": (_I, [_VP, _VP, C.c_int64, C.c_int64, _VP]),
+    "mmdm_f32_split": (_I, [_VP, _VP, C.c_int64, C.c_int64, _VP]),
     "mmdm_adaln_f32": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _I, _VP]),
     "mmdm_adaln_ex": (_I, [_VP, _VP, _I, _I, _VP, _I, _I, _I, _I, _VP]),
     "mmdm_attention_ex": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),

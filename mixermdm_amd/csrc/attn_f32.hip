@@ -65,7 +65,7 @@ struct AttnArgs {
     int ldq, ldk, ldv, ldo;
     int nseq, Tq, Tk, H, shift, qtiles, pairs_per_xcd;
     float scale, scale2;
-    int out_bf16;      // 1: O written as bf16 (feeds the bf16 out-projection GEMM); 2: as three bf16 planes (exact split, plane stride nseq*Tq*ldo)
+    int out_bf16;      // 1: O written as bf16 (feeds the bf16 out-projection GEMM); 2: as the two fp16 planes of the fp32-split mode (kernels.h mmdm_split2; plane stride nseq*Tq*ldo)
     unsigned long long* stamps;   // diagnostic launches only (tools/attn_timeline.py): per workgroup {entry, loop start, loop end, kernel end, placement, qk, softmax, pv} in 100 MHz ticks
     int ablate;        // timing experiments only (tools/attn_bench.py, mmdm_diag_set "attn_ablate"); 0 in production
     int flags;         // MMDM_ATTN_NO_ZERO_KEY: plain softmax (nn.MultiheadAttention default); MMDM_ATTN_CAUSAL: key <= query only
@@ -86,7 +86,7 @@ unsigned long long* g_attn_stamps = nullptr;
 typedef __bf16 bf16x4a __attribute__((ext_vector_type(4)));
 
 // Store one query row of the P.V accumulators (element (j, r) of o[] is column NJ*lq + tile-column(j) of row q0 + 4g + r: see load_v_row),
-// scaled by 1/l, as fp32, bf16 or three bf16 planes: 16-byte (fp32) / 8-byte (bf16) accesses.
+// scaled by 1/l, as fp32, bf16 or the two fp16 split planes: 16-byte (fp32) / 8-byte (16-bit) accesses.
 template <int DH, class P>
 __device__ __forceinline__ void store_o_row(const P& p, const f32x4 (&o)[DH / 16], int r, float inv, size_t row_off, int lq) {
     constexpr int NJ = DH / 16;
@@ -97,19 +97,13 @@ __device__ __forceinline__ void store_o_row(const P& p, const f32x4 (&o)[DH / 16
         const f32x4 y = f32x4{o[4 * h][r], o[4 * h + 1][r], o[4 * h + 2][r], o[4 * h + 3][r]} * inv;
         const size_t off = row_off + col;
         if (p.out_bf16 == 2) {
-            bf16x4a b1, b2, b3;
+            mmdm_h4 oh, ol;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                b1[e] = (__bf16)y[e];
-                const float r1 = y[e] - (float)b1[e];
-                b2[e] = (__bf16)r1;
-                b3[e] = (__bf16)(r1 - (float)b2[e]);
-            }
-            __bf16* op = reinterpret_cast<__bf16*>(p.O) + off;
+            for (int e = 0; e < 4; ++e) { const _Float16 t = mmdm_split_hi(y[e]); oh[e] = t; ol[e] = mmdm_split_lo(y[e], t); }
+            _Float16* op = reinterpret_cast<_Float16*>(p.O) + off;
             const size_t plane = (size_t)p.nseq * p.Tq * p.ldo;
-            *reinterpret_cast<bf16x4a*>(op) = b1;
-            *reinterpret_cast<bf16x4a*>(op + plane) = b2;
-            *reinterpret_cast<bf16x4a*>(op + 2 * plane) = b3;
+            *reinterpret_cast<mmdm_h4*>(op) = oh;
+            *reinterpret_cast<mmdm_h4*>(op + plane) = ol;
         } else if (p.out_bf16) {
             const bf16x4a b = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
             *reinterpret_cast<bf16x4a*>(reinterpret_cast<__bf16*>(p.O) + off) = b;
@@ -441,14 +435,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y) {
     if (p.out_bf16 == 2) {
-        __bf16* op = reinterpret_cast<__bf16*>(p.O) + idx;
+        _Float16* op = reinterpret_cast<_Float16*>(p.O) + idx;
         const size_t plane = (size_t)p.nseq * p.Tq * p.ldo;
-        const __bf16 b1 = (__bf16)y;
-        const float r1 = y - (float)b1;
-        const __bf16 b2 = (__bf16)r1;
-        op[0] = b1;
-        op[plane] = b2;
-        op[2 * plane] = (__bf16)(r1 - (float)b2);
+        const _Float16 t = mmdm_split_hi(y);
+        op[0] = t;
+        op[plane] = mmdm_split_lo(y, t);
     } else if (p.out_bf16) {
         reinterpret_cast<__bf16*>(p.O)[idx] = (__bf16)y;
     } else {

@@ -1,17 +1,17 @@
-// fp32 linear layer computed on the bf16 matrix cores by EXACT 3-way operand splitting (gfx950).
+// fp32 linear layer computed on the 16-bit matrix cores from two-way fp16 operand splits (gfx950).
 //
-// Every fp32 value x is the exact sum of three bf16 numbers x1 + x2 + x3 (8 + 8 + 8 significand bits = fp32's 24):
-//   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2).
-// A product a*w then expands into nine bf16 x bf16 terms, each of which the MFMA forms exactly in fp32; the three terms
-// a2*w3, a3*w2, a3*w3 are below 2^-32 of |a||w| and are dropped, the other six are accumulated in fp32:
-//   a*w ~= a1w1 + a1w2 + a2w1 + a1w3 + a3w1 + a2w2          (relative truncation error <= 3 * 2^-32 per product)
-// which is below the rounding error of one fp32 FMA (2^-24).  Measured against a float64 product the result is as accurate as
-// the native v_mfma_f32_32x32x2_f32 kernel (tests/test_gpu_kernels.py::test_linear_split_*) -- and it runs on
-// v_mfma_f32_32x32x16_bf16, whose dense rate is 16x the fp32 MFMA's: six of them cost 6/16 of one fp32 MFMA pass.
+// Every fp32 operand is carried as two fp16 planes (kernels.h, mmdm_split2):  x ~= h + l / 2048,  h = fp16(x),  l = fp16((x - h) * 2048)
+// -- 11 + 11 significand bits, relative representation error <= 2^-22.  A product a*w expands into four fp16 x fp16 terms, each of which the
+// MFMA forms exactly in fp32; al*wl is below 2^-22 |a||w| and is dropped, the other three are accumulated in fp32 in TWO accumulators:
+//   hi += ah*wh,      lo += ah*wl + al*wh,      result = hi + lo / 2048        (one FMA in the epilogue, then the bias / residual order below)
+// The representation error is independent per element and averages over K; the fp32 accumulation chain of ANY fp32 GEMM over K = 1024 terms is
+// ten times larger (tools/split_numerics.py: against a float64 product this form is as accurate as the native v_mfma_f32_32x32x2_f32 kernel and
+// as the six-term bf16 three-way split of rounds 1-3, which it replaces at half the MFMA work and 4 instead of 6 operand bytes per element:
+// tests/test_gpu_kernels.py::test_linear_split_*, tests/test_gpu_headline.py).  Three v_mfma_f32_32x32x16_f16 cost 3/16 of one fp32 MFMA pass.
 //
-// Operands arrive pre-split as three bf16 planes [3][rows][K] (plane stride given): weights are split once at mmdm_prepare,
+// Operands arrive pre-split as two fp16 planes [2][rows][K] (plane stride given): weights are split once at mmdm_prepare,
 // activations by the kernels that produce them (AdaLN, attention, the GELU epilogue here).  Structure = gemm_bf16_kernel with
-// three planes per operand tile: LDS-DMA staged, XOR-swizzled 64-byte rows, swapped operands (row on the lane), 16-byte epilogue.
+// two planes per operand tile: LDS-DMA staged, XOR-swizzled 64-byte rows, swapped operands (row on the lane), 16-byte epilogue.
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <stdlib.h>
@@ -25,18 +25,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+constexpr int NPL = MMDM_SPLIT_NPL;       // operand planes (kernels.h)
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct SArgs {
-    const __bf16* A; const __bf16* W; const float* bias; void* C; const float* extra;
+    const _Float16* A; const _Float16* W; const float* bias; void* C; const float* extra;
     size_t pa, pw, pc;                    // plane strides (elements) of A, W and of a split output
     int lda, ldw, ldc, ld_extra;
     int M, N, K, epilogue, period, out_split;
     int mt, nt, ablate;
     int row0;                             // global index of row 0 (PE epilogue of a row-sliced launch)
     unsigned long long* tl;               // diagnostic: per-wave phase cycle sums (tools/split_timeline.py), null in production
-    __bf16* P2; size_t p2_plane; int p2_cols, ld2;   // optional second output: columns [0, p2_cols) also as three bf16 planes (attention Q/K operands)
+    __bf16* P2; size_t p2_plane; int p2_cols, ld2;   // optional second output: columns [0, p2_cols) also as three exact bf16 planes (Q/K operands of attn_qkp_kernel<DH, 3>)
     int tst;                              // packed-W kernel: results leave through the workgroup's LDS transposition (split_finish_t)
 };
 
@@ -45,17 +48,17 @@ template <int TM_, int TN_>
 struct SCfg {
     static constexpr int WGM = TM_ / 10, WGN = TN_ / 10, TM = TM_ % 10, TN = TN_ % 10;
     static constexpr int NWAVES = WGM * WGN, THREADS = 64 * NWAVES;
-    static constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 32;          // K step in bf16 elements (64 bytes)
+    static constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, BK = 32;          // K step in fp16 elements (64 bytes)
     static constexpr int A_PLANE = BM * 16, B_PLANE = BN * 16;                    // one plane of a tile, 4-byte units
-    static constexpr int A_FLOATS = 3 * A_PLANE, B_FLOATS = 3 * B_PLANE;
+    static constexpr int A_FLOATS = NPL * A_PLANE, B_FLOATS = NPL * B_PLANE;
     static constexpr int SMEM_BYTES = 2 * (A_FLOATS + B_FLOATS) * 4;
     static constexpr int NAP = BM / 16, NBP = BN / 16;                            // 1-KiB pieces per plane
-    static constexpr int NA = 3 * NAP, NB = 3 * NBP;
+    static constexpr int NA = NPL * NAP, NB = NPL * NBP;
     static constexpr int NI = (NA + NB) / NWAVES;
     static_assert((NA + NB) % NWAVES == 0, "pieces must divide evenly over the waves");
 };
 
-// Epilogue shared by the fp32-split kernels: activation, output form (fp32 rows / three bf16 planes) and the optional second plane
+// Epilogue shared by the fp32-split kernels: activation, output form (fp32 rows / the two fp16 operand planes) and the optional second plane
 // output are chosen ONCE per tile, outside the element loops (with the runtime tests inside them every element carried every variant:
 // tens of KB of branchy code that a wave crawls through while a co-resident workgroup owns the matrix pipe; see gemm_f32.hip and
 // tools/gemm_timeline.py).  fp32 rows are stored through a buffer resource over the tile's rows: rows past M are dropped by the hardware.
@@ -86,7 +89,17 @@ __device__ __forceinline__ void split_finish(const SArgs& p, f32x16 (&acc)[TM][T
                         else if constexpr (ACT == MMDM_EPI_BIAS_SILU) t = silu(t);
                         v[c] = t;
                     }
-                    if constexpr (SPLIT || SEC) {
+                    if constexpr (SPLIT) {
+                        h16x4 oh, ol;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { const _Float16 t = mmdm_split_hi(v[c]); oh[c] = t; ol[c] = mmdm_split_lo(v[c], t); }
+                        if (rok && col < p.N) {
+                            _Float16* cp = static_cast<_Float16*>(p.C) + (size_t)row * p.ldc + col;
+                            *reinterpret_cast<h16x4*>(cp) = oh;
+                            *reinterpret_cast<h16x4*>(cp + p.pc) = ol;
+                        }
+                    }
+                    if constexpr (SEC) {
                         bf16x4 o1, o2, o3;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
@@ -96,13 +109,7 @@ __device__ __forceinline__ void split_finish(const SArgs& p, f32x16 (&acc)[TM][T
                             o3[c] = (__bf16)(r1 - (float)o2[c]);
                         }
                         if (rok && col < p.N) {
-                            if constexpr (SPLIT) {
-                                __bf16* cp = static_cast<__bf16*>(p.C) + (size_t)row * p.ldc + col;
-                                *reinterpret_cast<bf16x4*>(cp) = o1;
-                                *reinterpret_cast<bf16x4*>(cp + p.pc) = o2;
-                                *reinterpret_cast<bf16x4*>(cp + 2 * p.pc) = o3;
-                            }
-                            if constexpr (SEC) {
+                            {
                                 if (col < p.p2_cols) {
                                     __bf16* cp = p.P2 + (size_t)(row + p.row0) * p.ld2 + col;
                                     *reinterpret_cast<bf16x4*>(cp) = o1;
@@ -143,7 +150,7 @@ int g_split_tst = MMDM_SPLIT_TST_DEFAULT;      // mmdm_diag_set "split_tst": 0 =
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // Transposed epilogue of the packed-W kernel (four waves side by side, each TM x 1 MFMA tiles: BN = 128).  In the D^T map a lane owns an
-// output ROW: the direct form stores 16 bytes (fp32) or three times 8 bytes (the three bf16 planes of FFN-1's output) of 32 different rows per
+// output ROW: the direct form stores 16 bytes (fp32) or two times 8 bytes (the two fp16 planes of FFN-1's output) of 32 different rows per
 // instruction.  Here the workgroup's tile goes through an XOR-swizzled image [rows][128 columns] (per plane) in the idle A stages and leaves
 // as whole rows; the residual / PE rows of the fp32 form are read the same way -- whole lines, requested before the image is written -- and
 // added last, (b + sum_k a_k w_k) + r as in the direct form.  Same values, same arithmetic: bit-identical results (gemm_bf16.hip has the
@@ -163,9 +170,9 @@ __device__ __forceinline__ bool split_finish_t(const SArgs& p, f32x16 (&acc)[TM]
     auto finish = [&](auto act_c, auto split_c) {
         constexpr int ACT = decltype(act_c)::value;
         constexpr bool SPLIT = decltype(split_c)::value;
-        constexpr int EBO = SPLIT ? 2 : 4, NPL = SPLIT ? 3 : 1;
+        constexpr int EBO = SPLIT ? 2 : 4, NOP = SPLIT ? NPL : 1;               // bytes per element, output planes
         constexpr int RB = BN * EBO, CPR = RB / 16;                            // bytes / 16-byte chunks per image row (16 or 32)
-        constexpr int FIT = (3 * 3 * BM * 16 * 4) / (32 * RB * NPL);           // 32-row tiles the three A stages hold
+        constexpr int FIT = (3 * NPL * BM * 16 * 4) / (32 * RB * NOP);         // 32-row tiles the three A stages hold
         constexpr int RPP = FIT >= TM ? TM : (FIT >= 2 ? 2 : 1);               // row tiles per phase
         static_assert(FIT >= 1 && TM % RPP == 0, "image does not fit the A stages");
         constexpr int LPR = CPR, RPI = 64 / LPR, ROWS = 32 * RPP, RPW = ROWS / NWAVES;
@@ -205,17 +212,11 @@ __device__ __forceinline__ bool split_finish_t(const SArgs& p, f32x16 (&acc)[TM]
                     const int cb = (wn * 32 + 8 * qd + 4 * lh) * EBO;           // byte column inside the image row
                     char* dst = img + ir * RB + (((cb >> 4) ^ (ir & 15)) << 4) + (cb & 15);
                     if constexpr (SPLIT) {
-                        bf16x4 o1, o2, o3;
+                        h16x4 oh, ol;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            o1[c] = (__bf16)v[c];
-                            const float r1 = v[c] - (float)o1[c];
-                            o2[c] = (__bf16)r1;
-                            o3[c] = (__bf16)(r1 - (float)o2[c]);
-                        }
-                        *reinterpret_cast<bf16x4*>(dst) = o1;
-                        *reinterpret_cast<bf16x4*>(dst + PIMG) = o2;
-                        *reinterpret_cast<bf16x4*>(dst + 2 * PIMG) = o3;
+                        for (int c = 0; c < 4; ++c) { const _Float16 t = mmdm_split_hi(v[c]); oh[c] = t; ol[c] = mmdm_split_lo(v[c], t); }
+                        *reinterpret_cast<h16x4*>(dst) = oh;
+                        *reinterpret_cast<h16x4*>(dst + PIMG) = ol;
                     } else {
                         *reinterpret_cast<f32x4*>(dst) = v;
                     }
@@ -228,7 +229,7 @@ __device__ __forceinline__ bool split_finish_t(const SArgs& p, f32x16 (&acc)[TM]
                 const int ir = wave * RPW + k * RPI + rr;
                 const int trow = ph * ROWS + ir;
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
+                for (int pl = 0; pl < NOP; ++pl) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(img + pl * PIMG + ir * RB + ((rc ^ (ir & 15)) << 4));
                     if constexpr (!SPLIT) { if (ext) v += rq[k]; }
                     if constexpr (SPLIT) {
@@ -266,8 +267,8 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
     const int ablate = DIAG ? p.ablate : 0;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                              // [2][3][BM*16]
-    float* Bs = smem + 2 * C_::A_FLOATS;           // [2][3][BN*16]
+    float* As = smem;                              // [2][NPL][BM*16]
+    float* Bs = smem + 2 * C_::A_FLOATS;           // [2][NPL][BN*16]
 
     const int nwg = p.mt * p.nt;
     const int bid = blockIdx.x;
@@ -306,8 +307,8 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
             dst[u] = 2 * C_::A_FLOATS + pl * C_::B_PLANE + 16 * pp * 16;
         }
     }
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.A + (size_t)m0 * p.lda), 0, 0xffffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.W + (size_t)n0 * p.ldw), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A + (size_t)m0 * p.lda), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.W + (size_t)n0 * p.ldw), 0, 0xffffffff, 0x00020000);
     int koff = 0;
     auto stage = [&](int buf) {
 #pragma unroll
@@ -318,9 +319,16 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
         koff += 64;
     };
 
-    // Accumulators start as the bias; the residual / PE tile is added after the loop, (b + sum_k) + r -- the reference's `x + linear(..)`
-    // order and the order of every fp32-split kernel, so a row's bits do not depend on the kernel that produced it.
-    f32x16 acc[TM][TN];
+    // The hi accumulators start as the bias, the lo accumulators at zero; after the loop  (b + sum hi) + (sum lo) / 2048,  then the residual /
+    // PE tile, (..) + r -- the reference's `x + linear(..)` order and the order of every fp32-split kernel, so a row's bits do not depend on
+    // the kernel that produced it.
+    f32x16 acc[TM][TN], accl[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accl[i][j][e] = 0.f;
     {
         f32x4 bv[TN][4];
 #pragma unroll
@@ -350,34 +358,38 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
     //     MFMA of the step (two register sets): no MFMA waits on LDS;
     //   * the step's wait + barrier sits before the last 12 MFMAs: by then every wave has read the whole current stage, so the stage
     //     after next is requested right there, its 9 buffer-addressed DMA pieces placed one by one behind those MFMAs.
-    // The order of the MFMAs on an accumulator (k-block by k-block, six terms smallest first) is unchanged.
-    bf16x8 f0a[3][TM], f0b[3][TN], f1a[3][TM], f1b[3][TN];
-    auto rd = [&](int buf, int kb, bf16x8 (&af)[3][TM], bf16x8 (&bf)[3][TN]) {
+    // The order of the MFMAs on an accumulator is k-block by k-block (lo: ah*wl, then al*wh).
+    h16x8 f0a[NPL][TM], f0b[NPL][TN], f1a[NPL][TM], f1b[NPL][TN];
+    auto rd = [&](int buf, int kb, h16x8 (&af)[NPL][TM], h16x8 (&bf)[NPL][TN]) {
         const float* Ac = As + buf * C_::A_FLOATS + a_row;
         const float* Bc = Bs + buf * C_::B_FLOATS + b_row;
         const int cg = 4 * ((2 * kb + lh) ^ sw);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ac + pl * C_::A_PLANE + i * 32 * 16 + cg));
+            for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(Ac + pl * C_::A_PLANE + i * 32 * 16 + cg));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[pl][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bc + pl * C_::B_PLANE + j * 32 * 16 + cg));
+            for (int j = 0; j < TN; ++j) bf[pl][j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(Bc + pl * C_::B_PLANE + j * 32 * 16 + cg));
         }
     };
-    // six product terms, smallest first; each term walks all TM x TN accumulators so dependent MFMAs are TM*TN apart
-    auto mm = [&](auto t0c, auto t1c, const bf16x8 (&af)[3][TM], const bf16x8 (&bf)[3][TN]) {
+    // three product terms: ah*wl and al*wh into the lo accumulators, ah*wh into the hi ones; each term walks all TM x TN accumulators so
+    // dependent MFMAs are TM*TN apart
+    auto mm = [&](auto t0c, auto t1c, const h16x8 (&af)[NPL][TM], const h16x8 (&bf)[NPL][TN]) {
         constexpr int t0 = decltype(t0c)::value, t1 = decltype(t1c)::value;
-        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+        constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
 #pragma unroll
         for (int t = t0; t < t1; ++t)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if (t < 2) accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[PB[t]][j], af[PA[t]][i], accl[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);
+                }
     };
-    using I0 = std::integral_constant<int, 0>; using I3 = std::integral_constant<int, 3>; using I6 = std::integral_constant<int, 6>;
-    constexpr int NRD = 3 * (TM + TN), NT = TM * TN;          // fragment reads per k-block, MFMAs per term
-    constexpr int NPAIR = C_::NI < 3 * NT - 1 ? C_::NI : 3 * NT - 1;      // DMA pieces that get an MFMA of their own to hide behind
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I3 = std::integral_constant<int, 3>;
+    constexpr int NRD = NPL * (TM + TN), NT = TM * TN;        // fragment reads per k-block, MFMAs per term
+    constexpr int NPAIR = C_::NI < 2 * NT - 1 ? C_::NI : 2 * NT - 1;      // DMA pieces that get an MFMA of their own to hide behind
     stage(0);
     if (nkt > 1) { stage(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C_::NI) : "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -386,12 +398,12 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (!(ablate & 2)) rd(cur, 1, f1a, f1b);
-        mm(I0{}, I6{}, f0a, f0b);
+        mm(I0{}, I3{}, f0a, f0b);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT - 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT - 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        mm(I0{}, I3{}, f1a, f1b);
+        mm(I0{}, I1{}, f1a, f1b);
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nkt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // stage kt+1 landed (stage kt+2 is requested below)
@@ -401,19 +413,23 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_split_kernel(S
             if (!(ablate & 2)) rd(cur ^ 1, 0, f0a, f0b);
             if (kt + 2 < nkt && !(ablate & 1)) stage(cur);           // (ablate bits: timing experiments, tools/gemm_split_bench.py)
         }
-        mm(I3{}, I6{}, f1a, f1b);
+        mm(I1{}, I3{}, f1a, f1b);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
         __builtin_amdgcn_sched_group_barrier(0x100, NRD, 1);
 #pragma unroll
         for (int u = 0; u < NPAIR; ++u) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1); }
         __builtin_amdgcn_sched_group_barrier(0x010, C_::NI - NPAIR, 1);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 1);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
+        for (int j = 0; j < TN; ++j) {
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]), "+v"(accl[i][j]));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_fmaf(accl[i][j][e], MMDM_SPLIT_INV, acc[i][j][e]);
+        }
 
     if (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) {
 #pragma unroll
@@ -465,15 +481,15 @@ int set_attr() {
 // fetches its B fragments with buffer_load_dwordx4 one whole step ahead (two register sets that swap every step), and LDS carries A only.
 // Same six-term order per accumulator: bit-identical to gemm_split_kernel.
 template <int TM_, int TN_, bool TL = false, int NV1_ = 0>
-__global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(SArgs p) {
+__global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS), 2) void gemm_splitw_kernel(SArgs p) {      // two waves per SIMD: 256 registers (two workgroups per CU)
 #if defined(__HIP_DEVICE_COMPILE__)
     using C_ = SCfg<TM_, TN_>;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TM = C_::TM, TN = C_::TN;
     constexpr int NIA = C_::NA / C_::NWAVES;           // LDS-DMA pieces per wave and step (A only)
-    constexpr int NLB = 2 * 3 * TN;                    // B-fragment loads per wave and step
+    constexpr int NLB = 2 * NPL * TN;                  // B-fragment loads per wave and step
     static_assert(C_::NA % C_::NWAVES == 0, "A pieces must divide evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                  // [3 stages][3 planes][BM*16]
+    float* As = smem;                                  // [3 stages][NPL planes][BM*16]
 
     const int nwg = p.mt * p.nt;
     const int bid = blockIdx.x;
@@ -510,8 +526,8 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(
         voff[u] = (int)(((size_t)pl * p.pa + (size_t)rel * p.lda) * 2) + 16 * gch;
         dst[u] = pl * C_::A_PLANE + 16 * pp * 16;
     }
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.A + (size_t)m0 * p.lda), 0, 0xffffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.W), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A + (size_t)m0 * p.lda), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.W), 0, 0xffffffff, 0x00020000);
     auto stage_part = [&](int buf, int kt, auto u0c, auto u1c) {      // kt clamped: the loop stays branch-free, a surplus request re-reads the last tile
         const int koff = min(kt, nkt - 1) * 64;
 #pragma unroll
@@ -520,24 +536,30 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(
     };
     auto stage = [&](int buf, int kt) { stage_part(buf, kt, std::integral_constant<int, 0>{}, std::integral_constant<int, NIA>{}); };
     // packed W: byte offset of block (plane, nb, kb16) = plane*pw*2 + (nb*(K/16) + kb16)*1024; this wave owns nb = n0/32 + wn*TN + j
-    int voffW[3][TN];
+    int voffW[NPL][TN];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int j = 0; j < TN; ++j) voffW[pl][j] = (int)((size_t)pl * p.pw * 2) + ((n0 >> 5) + wn * TN + j) * (p.K >> 4) * 1024 + lane * 16;
-    auto ldb = [&](int kt, bf16x8 (&b0)[3][TN], bf16x8 (&b1)[3][TN]) {
+    auto ldb = [&](int kt, h16x8 (&b0)[NPL][TN], h16x8 (&b1)[NPL][TN]) {
         const int so = min(kt, nkt - 1) * 2048;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b0[pl][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[pl][j], so, 0));
+            for (int j = 0; j < TN; ++j) b0[pl][j] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[pl][j], so, 0));
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b1[pl][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[pl][j] + 1024, so, 0));
+            for (int j = 0; j < TN; ++j) b1[pl][j] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[pl][j] + 1024, so, 0));
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN], accl[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accl[i][j][e] = 0.f;
     {
         f32x4 bv[TN][4];
 #pragma unroll
@@ -559,30 +581,34 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(
 
     const int sw = (l31 >> 2) & 3;
     const int a_row = (wm * (32 * TM) + l31) * 16;
-    bf16x8 f0a[3][TM], f1a[3][TM];
-    bf16x8 bx0[3][TN], bx1[3][TN], by0[3][TN], by1[3][TN];
-    auto rda = [&](int buf, int kb, bf16x8 (&af)[3][TM]) {
+    h16x8 f0a[NPL][TM], f1a[NPL][TM];
+    h16x8 bx0[NPL][TN], bx1[NPL][TN], by0[NPL][TN], by1[NPL][TN];
+    auto rda = [&](int buf, int kb, h16x8 (&af)[NPL][TM]) {
         const float* Ac = As + buf * C_::A_FLOATS + a_row;
         const int cg = 4 * ((2 * kb + lh) ^ sw);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ac + pl * C_::A_PLANE + i * 32 * 16 + cg));
+            for (int i = 0; i < TM; ++i) af[pl][i] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(Ac + pl * C_::A_PLANE + i * 32 * 16 + cg));
     };
-    auto mm = [&](auto t0c, auto t1c, const bf16x8 (&af)[3][TM], const bf16x8 (&bf)[3][TN]) {
+    // three product terms: ah*wl and al*wh into the lo accumulators, ah*wh into the hi ones; each term walks all TM x TN accumulators so
+    // dependent MFMAs are TM*TN apart
+    auto mm = [&](auto t0c, auto t1c, const h16x8 (&af)[NPL][TM], const h16x8 (&bf)[NPL][TN]) {
         constexpr int t0 = decltype(t0c)::value, t1 = decltype(t1c)::value;
-        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+        constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
 #pragma unroll
         for (int t = t0; t < t1; ++t)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if (t < 2) accl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[PB[t]][j], af[PA[t]][i], accl[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[PB[t]][j], af[PA[t]][i], acc[i][j], 0, 0, 0);
+                }
     };
-    using I0 = std::integral_constant<int, 0>; using I3 = std::integral_constant<int, 3>; using I6 = std::integral_constant<int, 6>;
-    constexpr int NRDA = 3 * TM, NT = TM * TN;
-    constexpr int NPB = NLB < 6 * NT - 1 ? NLB : 6 * NT - 1;        // B loads that get an MFMA of their own to hide behind
-    constexpr int NPA = NIA < 3 * NT - 1 ? NIA : 3 * NT - 1;        // same for the A pieces
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I3 = std::integral_constant<int, 3>;
+    constexpr int NRDA = NPL * TM, NT = TM * TN;
+    constexpr int MB = 4 * NT, MA = 2 * NT;                     // MFMAs of a step before / after its barrier: k-block 0 (three terms) + ah*wl of k-block 1 | the other two
     // one K step: B fragments (b0, b1) of this step are in registers (or on their way: the compiler counts them), (n0_, n1_) receive the next step's
     unsigned long long tsum[5] = {0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int slot) {              // s_memtime (shader clock); the read drains lgkmcnt, so stamps sit where that is due anyway
@@ -599,24 +625,24 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(
     // unit at once (16 cycles per 1-KiB instruction); a wave whose request cannot issue cannot issue the MFMAs behind it either -- the 12 MFMAs
     // after the barrier took 125 cycles each instead of 32, and the waves reached the next barrier 900 cycles apart.  With a third stage
     // buffer (kt+2) % 3 is free from the previous step's barrier on, so the step's VMEM instructions -- next step's B fragments and the A pieces of the
-    // stage after next -- are spread one by one over the 9*NT MFMAs before the barrier, NV1 of the A pieces over the 3*NT after it.
+    // stage after next -- are spread one by one over the 4*NT MFMAs before the barrier, NV1 of the A pieces over the 2*NT after it.
     constexpr int NV1 = NV1_ < NIA ? NV1_ : NIA;                 // A pieces requested after the barrier
     constexpr int NV0 = NLB + NIA - NV1;                            // VMEM instructions before it
-    constexpr int SP0 = (9 * NT - 1) / NV0 > 0 ? (9 * NT - 1) / NV0 : 1, NP0 = NV0 * SP0 <= 9 * NT - 1 ? NV0 : (9 * NT - 1) / SP0;
-    constexpr int NP1 = NV1 < 3 * NT - 1 ? NV1 : 3 * NT - 1;
-    auto step = [&](int kt, int cur, int nxt, int nn, bf16x8 (&b0)[3][TN], bf16x8 (&b1)[3][TN], bf16x8 (&n0_)[3][TN], bf16x8 (&n1_)[3][TN]) {
+    constexpr int SP0 = (MB - 1) / NV0 > 0 ? (MB - 1) / NV0 : 1, NP0 = NV0 * SP0 <= MB - 1 ? NV0 : (MB - 1) / SP0;
+    constexpr int NP1 = NV1 < MA - 1 ? NV1 : MA - 1;
+    auto step = [&](int kt, int cur, int nxt, int nn, h16x8 (&b0)[NPL][TN], h16x8 (&b1)[NPL][TN], h16x8 (&n0_)[NPL][TN], h16x8 (&n1_)[NPL][TN]) {
         stamp(kt == 0 ? -1 : 4);
         rda(cur, 1, f1a);
         ldb(kt + 1, n0_, n1_);
         stage_part(nn, kt + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, NIA - NV1>{});
-        mm(I0{}, I6{}, f0a, b0);
-        mm(I0{}, I3{}, f1a, b1);
+        mm(I0{}, I3{}, f0a, b0);
+        mm(I0{}, I1{}, f1a, b1);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NRDA, 0);
 #pragma unroll
         for (int u = 0; u < NP0; ++u) { __builtin_amdgcn_sched_group_barrier(0x008, SP0, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
         __builtin_amdgcn_sched_group_barrier(0x010, NV0 - NP0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 9 * NT - 1 - SP0 * NP0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MB - 1 - SP0 * NP0, 0);
         __builtin_amdgcn_sched_barrier(0);
         stamp(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV0) : "memory");     // A stage kt+1 landed (requested during step kt-1); this step's requests may be in flight
@@ -627,13 +653,13 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(
         stamp(3);
         rda(nxt, 0, f0a);
         stage_part(nn, kt + 2, std::integral_constant<int, NIA - NV1>{}, std::integral_constant<int, NIA>{});
-        mm(I3{}, I6{}, f1a, b1);
+        mm(I1{}, I3{}, f1a, b1);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
         __builtin_amdgcn_sched_group_barrier(0x100, NRDA, 1);
 #pragma unroll
         for (int u = 0; u < NP1; ++u) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x010, 1, 1); }
         __builtin_amdgcn_sched_group_barrier(0x010, NV1 - NP1, 1);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, MA, 1);
         __builtin_amdgcn_sched_barrier(0);
     };
     unsigned long long rt0 = 0, ct0 = 0;
@@ -666,7 +692,11 @@ __global__ __launch_bounds__((SCfg<TM_, TN_>::THREADS)) void gemm_splitw_kernel(
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
+        for (int j = 0; j < TN; ++j) {
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]), "+v"(accl[i][j]));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_fmaf(accl[i][j][e], MMDM_SPLIT_INV, acc[i][j][e]);
+        }
 
     if constexpr (TN == 1 && C_::WGM == 1 && C_::WGN == 4) {
         if (split_finish_t<TM, BM, C_::NWAVES>(p, acc, m0, n0, wn, lane, smem, 3 * C_::A_FLOATS * 4)) return;
@@ -712,10 +742,10 @@ int set_attr_w() {
     return MMDM_OK;
 }
 
-// [3][N][K] planes -> fragment order (see gemm_splitw_kernel); one thread per 16-byte chunk
-__global__ void pack_split_w_kernel(const __bf16* __restrict__ in, int ldw, size_t in_plane, __bf16* __restrict__ out, size_t out_plane, int N, int K) {
+// [NPL][N][K] planes -> fragment order (see gemm_splitw_kernel); one thread per 16-byte chunk
+__global__ void pack_split_w_kernel(const _Float16* __restrict__ in, int ldw, size_t in_plane, _Float16* __restrict__ out, size_t out_plane, int N, int K) {
     const size_t per_plane = (size_t)N * K / 8;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < 3 * per_plane; c += (size_t)gridDim.x * blockDim.x) {
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < NPL * per_plane; c += (size_t)gridDim.x * blockDim.x) {
         const int pl = (int)(c / per_plane);
         const size_t o = c % per_plane;                       // chunk index inside the plane: ((nb*KB16 + kb16)*64 + lh*32 + l31)
         const int ln = (int)(o & 63), l31 = ln & 31, lh = ln >> 5;
@@ -726,16 +756,13 @@ __global__ void pack_split_w_kernel(const __bf16* __restrict__ in, int ldw, size
     }
 }
 
-// x -> three bf16 planes out[0], out[plane], out[2*plane]; exact: x == out0 + out1 + out2 in real arithmetic
-__global__ void split3_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n, size_t plane) {
+// x -> two fp16 planes out[0], out[plane]: x ~= out0 + out1 / 2048 (mmdm_split2, kernels.h)
+__global__ void split_kernel(const float* __restrict__ in, _Float16* __restrict__ out, size_t n, size_t plane) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float x = in[i];
-        const __bf16 b1 = (__bf16)x;
-        const float r1 = x - (float)b1;
-        const __bf16 b2 = (__bf16)r1;
-        out[i] = b1;
-        out[plane + i] = b2;
-        out[2 * plane + i] = (__bf16)(r1 - (float)b2);
+        _Float16 h, l;
+        mmdm_split2(in[i], h, l);
+        out[i] = h;
+        out[plane + i] = l;
     }
 }
 
@@ -767,11 +794,11 @@ bool mmdm_diag_gemm_split(const char* key, long long v) {
     return true;
 }
 
-extern "C" int mmdm_f32_split3(const float* in, void* out, int64_t n, int64_t plane_stride, void* stream) {
+extern "C" int mmdm_f32_split(const float* in, void* out, int64_t n, int64_t plane_stride, void* stream) {
     if (n <= 0) return MMDM_OK;
-    if (!in || !out || plane_stride < n) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_f32_split3: bad arguments");
-    hipLaunchKernelGGL(split3_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), in, static_cast<__bf16*>(out), (size_t)n, (size_t)plane_stride);
-    return mmdm_check_launch("f32_split3");
+    if (!in || !out || plane_stride < n) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_f32_split: bad arguments");
+    hipLaunchKernelGGL(split_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), in, static_cast<_Float16*>(out), (size_t)n, (size_t)plane_stride);
+    return mmdm_check_launch("f32_split");
 }
 
 extern "C" int mmdm_linear_split(const void* A, int lda, int64_t a_plane, const void* W, int ldw, int64_t w_plane, const float* bias, void* C, int ldc,
@@ -789,8 +816,8 @@ extern "C" int mmdm_split_pack_weight(const void* W, int ldw, int64_t w_plane, v
     if (!W || !out || N < 0 || K <= 0 || (N & 31) || (K & 15) || ldw < K || (ldw & 7) || (w_plane & 7) || out_plane < (int64_t)N * K || (out_plane & 7))
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_split_pack_weight: needs N %% 32 == 0, K %% 16 == 0, 16-byte aligned rows / planes (N=%d K=%d ldw=%d)", N, K, ldw);
     if ((reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_split_pack_weight: unaligned pointer");
-    hipLaunchKernelGGL(pack_split_w_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(W), ldw, (size_t)w_plane,
-                       static_cast<__bf16*>(out), (size_t)out_plane, N, K);
+    hipLaunchKernelGGL(pack_split_w_kernel, dim3(1024), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const _Float16*>(W), ldw, (size_t)w_plane,
+                       static_cast<_Float16*>(out), (size_t)out_plane, N, K);
     return mmdm_check_launch("split_pack_weight");
 }
 
@@ -820,7 +847,7 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
     if ((uint64_t)a_plane * 4 + 512ull * (uint64_t)lda >= (1ull << 32) || (uint64_t)w_plane * 4 + 512ull * (uint64_t)ldw >= (1ull << 32))
         return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split: operand planes beyond the 4 GB reach of a tile's buffer offsets");
     SArgs a;
-    a.A = static_cast<const __bf16*>(A); a.W = static_cast<const __bf16*>(W); a.bias = bias; a.C = C; a.extra = extra;
+    a.A = static_cast<const _Float16*>(A); a.W = static_cast<const _Float16*>(W); a.bias = bias; a.C = C; a.extra = extra;
     a.pa = (size_t)a_plane; a.pw = (size_t)w_plane; a.pc = (size_t)c_plane;
     a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ld_extra = ld_extra;
     a.M = M; a.N = N; a.K = K; a.epilogue = epilogue; a.period = period > 0 ? period : 1; a.out_split = out_split;
@@ -870,7 +897,7 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
     b.M = M - M1;
     b.row0 = M1;
     b.A = a.A + (size_t)M1 * lda;
-    b.C = out_split ? static_cast<void*>(static_cast<__bf16*>(C) + (size_t)M1 * ldc) : static_cast<void*>(static_cast<float*>(C) + (size_t)M1 * ldc);
+    b.C = out_split ? static_cast<void*>(static_cast<_Float16*>(C) + (size_t)M1 * ldc) : static_cast<void*>(static_cast<float*>(C) + (size_t)M1 * ldc);
     if (ext && epilogue == MMDM_EPI_BIAS_RESID) b.extra = extra + (size_t)M1 * ld_extra;
     return launch<22, 21>(b, st);
 }

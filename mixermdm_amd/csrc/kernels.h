@@ -65,6 +65,21 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x * (1.0f / (1.0f + expf(-1.702f * x))); }   // CLIP QuickGELU: x * sigmoid(1.702 x)
 
+// Operand format of the fp32-split precision mode (gemm_split.hip): x ~= h + l / 2048 with h = fp16(x), l = fp16((x - h) * 2048), both
+// round-to-nearest -- 11 + 11 significand bits, |x - (h + l/2048)| <= 2^-22 |x| (down to |x| = 2^-14; below that the absolute error stays under
+// 2^-36), the second plane carried at 2^11 so that it never meets fp16's subnormals.  |x| must stay below 65504 (inf and then NaN otherwise:
+// loud, not wrong).  One definition for every producer (AdaLN, attention, the GELU epilogue, the weight conversion).
+constexpr int MMDM_SPLIT_NPL = 2;
+constexpr float MMDM_SPLIT_SCALE = 2048.0f, MMDM_SPLIT_INV = 1.0f / 2048.0f;
+typedef _Float16 mmdm_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ _Float16 mmdm_split_hi(float x) { return (_Float16)x; }
+__device__ __forceinline__ _Float16 mmdm_split_lo(float x, _Float16 h) { return (_Float16)((x - (float)h) * MMDM_SPLIT_SCALE); }
+__device__ __forceinline__ void mmdm_split2(float x, _Float16& h, _Float16& l) { h = mmdm_split_hi(x); l = mmdm_split_lo(x, h); }
+__device__ __forceinline__ void mmdm_split2(const float (&x)[4], mmdm_h4& h, mmdm_h4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const _Float16 t = mmdm_split_hi(x[e]); h[e] = t; l[e] = mmdm_split_lo(x[e], t); }
+}
+
 constexpr int MMDM_NF = 262;      // pose features per person (src/models/in2in.py:426, INPUT_DIM)
 constexpr int MMDM_NJ = 22;       // joints
 

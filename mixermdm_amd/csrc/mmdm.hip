@@ -263,9 +263,9 @@ int build_stack(mmdm_handle h, StackW& st, const std::string& pfx, int D, int F,
     RC(dalloc(h, &st.ada_b, (size_t)L * st.n_ada * 2 * D));
     st.layers.resize(L);
     const bool bf = h->cfg.precision >= 1;
-    const size_t planes = h->cfg.precision == 2 ? 3 : 1;   // fp32-split: three bf16 planes per weight (gemm_split.hip)
+    const size_t planes = h->cfg.precision == 2 ? MMDM_SPLIT_NPL : 1;   // fp32-split: two fp16 planes per weight (gemm_split.hip)
     if (bf) st.layers_b.resize(L);
-    auto twin = [&](void** p, size_t n) -> int {          // n bf16 elements per plane
+    auto twin = [&](void** p, size_t n) -> int {          // n 16-bit elements per plane
         float* q = nullptr;
         RC(dalloc(h, &q, (planes * n + 1) / 2));
         *p = q;
@@ -484,10 +484,10 @@ int linear_8(const Ctx& c, const void* A, int lda, const float* a_scale, const v
     return prof_end(c, 2);
 }
 
-// fp32-split GEMM (precision == 2): A and W as three bf16 planes, fp32 accuracy on the bf16 matrix cores (gemm_split.hip)
+// fp32-split GEMM (precision == 2): A and W as two fp16 planes, fp32 accuracy on the 16-bit matrix cores (gemm_split.hip)
 int linear_s(const Ctx& c, const void* A, int lda, size_t a_plane, const void* W, int ldw, size_t w_plane, const float* bias, void* C, int ldc,
              size_t c_plane, int out_split, int M, int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) {
-    RC(prof_begin(c, 0, 2.0 * M * N * K, 6.0 * ((double)M * K + (double)N * K) + (out_split ? 6.0 : 4.0) * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
+    RC(prof_begin(c, 0, 2.0 * M * N * K, 2.0 * MMDM_SPLIT_NPL * ((double)M * K + (double)N * K) + 4.0 * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
     RC(mmdm_linear_split_ex(A, lda, (int64_t)a_plane, W, ldw, (int64_t)w_plane, bias, C, ldc, (int64_t)c_plane, out_split, M, N, K, epi, extra, ld_extra, 0,
                             s2.p, s2.ld, (int64_t)s2.plane, s2.cols, c.st));
     return prof_end(c, 0);
@@ -518,9 +518,9 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     const int D = w.D, F = w.F, R = r.nseq * r.T, dh = D / w.H;
     const int prec = c.h->cfg.precision;
     const bool bf = prec >= 1, f8 = prec == 3;
-    const int ob = f8 ? 1 : prec;           // output mode of the attention (operand of the out-projection): 0 fp32, 1 bf16, 2 three bf16 planes
+    const int ob = f8 ? 1 : prec;           // output mode of the attention (operand of the out-projection): 0 fp32, 1 bf16, 2 the two fp16 split planes
     auto bw = [](const void* base, size_t elems) { return static_cast<const void*>(static_cast<const uint16_t*>(base) + elems); };
-    // one GEMM of the stack: fp32 (A fp32, W fp32), bf16 (A bf16 from the producer, W twin) or fp32-split (three planes each).
+    // one GEMM of the stack: fp32 (A fp32, W fp32), bf16 (A bf16 from the producer, W twin) or fp32-split (two fp16 planes each).
     // wtot = elements of the whole weight matrix the twin was made from (its plane stride); the A plane stride is R*K.
     auto gemm = [&](const float* A, int lda, const float* Wf, const void* Wb, size_t woff, size_t wtot, const float* bias, float* C, int ldc, int out_b,
                     int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) -> int {
@@ -541,7 +541,7 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         return linear_8(c, A, K, unit_a ? nullptr : S.xs, static_cast<const uint8_t*>(W8) + row0 * K, w_frag ? 0 : K, Ws + row0, bias, C, ldc, out_mode, R, N, K, epi, extra, ld_extra, s2,
                         unit_a ? 1.0f / GSCALE : 1.0f, out_mode == 2 ? GSCALE : 1.0f);
     };
-    // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / three planes, or fp8 + per-row scales
+    // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / two fp16 planes, or fp8 + per-row scales
     auto norm = [&](const float* src, const float* ssp, int rows) -> int {
         if (f8) return mmdm_adaln_any(src, ssp, r.ss_ld, rows, S.xn, 3, S.xs, r.nseq, r.T, D, c.st);
         return mmdm_adaln_ex(src, ssp, r.ss_ld, rows, S.xn, ob, r.nseq, r.T, D, c.st);
@@ -948,8 +948,8 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     for (Scratch* sc : {&h->sa, &h->sb}) {
         if (sc == &h->sb && !two_models) break;
         const size_t d = sc == &h->sa ? Dx : (size_t)D, f = sc == &h->sa ? Fx : (size_t)F;
-        // GEMM-operand buffers (xn, att, f1) hold three bf16 planes in fp32-split mode: 6 bytes per element
-        const size_t opx = c.precision == 2 ? 3 : 2;       // in half-floats
+        // GEMM-operand buffers (xn, att, f1): fp32, or the two fp16 planes of the fp32-split mode -- 4 bytes per element either way
+        const size_t opx = c.precision == 2 ? MMDM_SPLIT_NPL : 2;       // in half-floats
         if ((rc = dalloc(h, &sc->h, R * d)) || (rc = dalloc(h, &sc->xn, R * d * opx / 2)) || (rc = dalloc(h, &sc->att, R * d * opx / 2)) ||
             (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f * opx / 2)) ||
             (rc = dalloc(h, &sc->xp, (size_t)2 * n * T * NFP)))
@@ -1080,7 +1080,7 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
             StackW& st = m->st;
             const int gran = split ? 128 : 256;             // the packed kernels' N / K granularity (gemm_split.hip: 128 x 128 tiles; gemm_bf16.hip: 128 x 256, K step 128 bytes)
             st.w_packed = !no_pack && !st.layers_b.empty() && st.D % gran == 0 && st.F % gran == 0;
-            if (st.w_packed) tmp_elems = std::max(tmp_elems, (size_t)(split ? 3 : 1) * std::max(3 * st.D, st.F) * st.D);
+            if (st.w_packed) tmp_elems = std::max(tmp_elems, (size_t)(split ? MMDM_SPLIT_NPL : 1) * std::max(3 * st.D, st.F) * st.D);
         }
         if (tmp_elems) HIPCHK(hipMalloc(&tmp, tmp_elems * 2));
         struct TmpFree { void* p; ~TmpFree() { if (p) (void)hipFree(p); } } tmp_free{tmp};
@@ -1091,8 +1091,8 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
                 if (int rc = mmdm_f32_to_bf16(src, tmp, n, nullptr)) return rc;
                 return mmdm_pack_weight_frag(tmp, 2 * K, dst, (int)(n / K), (int)(2 * K), nullptr);
             }
-            if (!pack_now) return mmdm_f32_split3(src, dst, n, n, nullptr);
-            if (int rc = mmdm_f32_split3(src, tmp, n, n, nullptr)) return rc;
+            if (!pack_now) return mmdm_f32_split(src, dst, n, n, nullptr);
+            if (int rc = mmdm_f32_split(src, tmp, n, n, nullptr)) return rc;
             return mmdm_split_pack_weight(tmp, (int)K, n, dst, n, (int)(n / K), (int)K, nullptr);
         };
         for (ModuleW* m : {&h->d1, &h->d2, &h->mx}) {

@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {      // OCP e4m3, RNE,
     return (unsigned)w;
 }
 
-// OMODE: 0 fp32, 1 bf16, 2 three bf16 planes (exact split, plane stride rows*D), 3 fp8 e4m3 with a per-row scale (row_scale[row] =
+// OMODE: 0 fp32, 1 bf16, 2 the two fp16 planes of the fp32-split mode (kernels.h mmdm_split2, plane stride rows*D), 3 fp8 e4m3 with a per-row scale (row_scale[row] =
 // max|y| / 448; the fp8 GEMM multiplies it back in its epilogue)
 template <int MAXV, int OMODE>
 __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h, const float* __restrict__ ss, int ss_ld, int ss_rows,
@@ -89,19 +89,13 @@ __global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h,
             const f32x4 sh = *reinterpret_cast<const f32x4*>(sp + D + 4 * c);
             const f32x4 y = (v[i] - mean) * rstd * (1.0f + sc) + sh;
             if (OMODE == 2) {
-                bf16x4 o1, o2, o3;
+                mmdm_h4 oh, ol;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o1[e] = (__bf16)y[e];
-                    const float r1 = y[e] - (float)o1[e];
-                    o2[e] = (__bf16)r1;
-                    o3[e] = (__bf16)(r1 - (float)o2[e]);
-                }
-                __bf16* op = static_cast<__bf16*>(outv) + (size_t)row * D + 4 * c;
+                for (int e = 0; e < 4; ++e) { const _Float16 t = mmdm_split_hi(y[e]); oh[e] = t; ol[e] = mmdm_split_lo(y[e], t); }
+                _Float16* op = static_cast<_Float16*>(outv) + (size_t)row * D + 4 * c;
                 const size_t plane = (size_t)rows * D;
-                *reinterpret_cast<bf16x4*>(op) = o1;
-                *reinterpret_cast<bf16x4*>(op + plane) = o2;
-                *reinterpret_cast<bf16x4*>(op + 2 * plane) = o3;
+                *reinterpret_cast<mmdm_h4*>(op) = oh;
+                *reinterpret_cast<mmdm_h4*>(op + plane) = ol;
             } else if (OMODE == 1) {
                 const bf16x4 o = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
                 *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(outv) + (size_t)row * D + 4 * c) = o;
@@ -263,7 +257,7 @@ extern "C" int mmdm_adaln_f32(const float* h, const float* ss, int ss_ld, int ss
 }
 
 extern "C" int mmdm_adaln_ex(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, int nseq, int T, int D, void* stream) {
-    if (out_bf16 < 0 || out_bf16 > 2) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_adaln_ex: output mode must be 0 (fp32), 1 (bf16) or 2 (three bf16 planes)");
+    if (out_bf16 < 0 || out_bf16 > 2) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_adaln_ex: output mode must be 0 (fp32), 1 (bf16) or 2 (the two fp16 planes of the fp32-split mode)");
     return mmdm_adaln_any(h, ss, ss_ld, ss_rows, out, out_bf16, nullptr, nseq, T, D, stream);
 }
 

@@ -251,21 +251,25 @@ def linear_bf16(x, weight, bias=None, epilogue="bias", extra=None, period=0, out
     return out.reshape(*x.shape[:-1], N)
 
 
-def split3(x):
-    """Exact 3-way bf16 split of an fp32 tensor: returns [3, *x.shape] torch.bfloat16 with x == out[0] + out[1] + out[2] (in real arithmetic)."""
+SPLIT_SCALE = 2048.0
+
+
+def split_f32(x):
+    """Operand format of the fp32-split mode: [2, *x.shape] torch.float16 with x ~= out[0] + out[1] / 2048 (relative error <= 2^-22;
+    out[0] = fp16(x), out[1] = fp16((x - out[0]) * 2048))."""
     _chk(x)
     x = x.contiguous()
-    out = torch.empty(3, *x.shape, device=x.device, dtype=torch.bfloat16)
+    out = torch.empty(2, *x.shape, device=x.device, dtype=torch.float16)
     n = x.numel()
-    check(load_library().mmdm_f32_split3(_p(x), C.c_void_p(out.data_ptr()), n, n, _stream()))
+    check(load_library().mmdm_f32_split(_p(x), C.c_void_p(out.data_ptr()), n, n, _stream()))
     return out
 
 
 def split_pack_weight(ws):
-    """Split weights ws [3, N, K] (split3) -> the same elements in MFMA fragment order, for linear_split(..., packed=True).
+    """Split weights ws [2, N, K] (split_f32) -> the same elements in MFMA fragment order, for linear_split(..., packed=True).
     N % 32 == 0, K % 16 == 0; the result keeps the shape so that N and K can be read back from it."""
-    if not ws.is_cuda or ws.dtype != torch.bfloat16 or ws.dim() != 3 or ws.shape[0] != 3 or not ws.is_contiguous():
-        raise TypeError("split_pack_weight expects a contiguous CUDA bfloat16 [3, N, K] tensor (ops.split3)")
+    if not ws.is_cuda or ws.dtype != torch.float16 or ws.dim() != 3 or ws.shape[0] != 2 or not ws.is_contiguous():
+        raise TypeError("split_pack_weight expects a contiguous CUDA float16 [2, N, K] tensor (ops.split_f32)")
     _, N, K = ws.shape
     out = torch.empty_like(ws)
     check(load_library().mmdm_split_pack_weight(C.c_void_p(ws.data_ptr()), K, N * K, C.c_void_p(out.data_ptr()), N * K, N, K, _stream()))
@@ -273,16 +277,16 @@ def split_pack_weight(ws):
 
 
 def linear_split(xs, ws, bias=None, epilogue="bias", extra=None, period=0, split_out=False, packed=False):
-    """fp32 y = x @ w.T + bias computed on the bf16 matrix cores from exactly split operands xs [3, M, K], ws [3, N, K] (split3).
-    Returns fp32 [M, N], or its split [3, M, N] when split_out.  packed: ws comes from split_pack_weight (W straight from global memory
+    """fp32 y = x @ w.T + bias computed on the 16-bit matrix cores from two-way fp16 splits xs [2, M, K], ws [2, N, K] (split_f32).
+    Returns fp32 [M, N], or its split [2, M, N] when split_out.  packed: ws comes from split_pack_weight (W straight from global memory
     in fragment order; bit-identical results)."""
     for t in (xs, ws):
-        if not t.is_cuda or t.dtype != torch.bfloat16 or t.shape[0] != 3 or not t.is_contiguous():
-            raise TypeError("linear_split expects contiguous CUDA bfloat16 [3, rows, K] operands (ops.split3)")
+        if not t.is_cuda or t.dtype != torch.float16 or t.shape[0] != 2 or not t.is_contiguous():
+            raise TypeError("linear_split expects contiguous CUDA float16 [2, rows, K] operands (ops.split_f32)")
     _chk(bias, extra)
     _, M, K = xs.shape
     N = ws.shape[1]
-    out = torch.empty((3, M, N) if split_out else (M, N), device=xs.device, dtype=torch.bfloat16 if split_out else torch.float32)
+    out = torch.empty((2, M, N) if split_out else (M, N), device=xs.device, dtype=torch.float16 if split_out else torch.float32)
     if packed:
         check(load_library().mmdm_linear_split_packed(C.c_void_p(xs.data_ptr()), K, M * K, C.c_void_p(ws.data_ptr()), N * K, _p(bias), C.c_void_p(out.data_ptr()), N,
                                                       M * N, int(split_out), M, N, K, EPI[epilogue], _p(extra), extra.stride(0) if extra is not None else 0, period, _stream()))
@@ -292,9 +296,18 @@ def linear_split(xs, ws, bias=None, epilogue="bias", extra=None, period=0, split
     return out
 
 
+def bf16_split3(x):
+    """Exact 3-way bf16 split of an fp32 tensor (torch arithmetic): [3, *x.shape] torch.bfloat16 with x == out[0] + out[1] + out[2]; the
+    operand format of attention_planes(NP = 3) (the split-mode GEMMs write it as their optional second output)."""
+    x1 = x.bfloat16()
+    r1 = x - x1.float()
+    x2 = r1.bfloat16()
+    return torch.stack([x1, x2, (r1 - x2.float()).bfloat16()])
+
+
 def attention_planes(qp, kp, v, num_heads, kv_seq_shift=0, zero_key=True, causal=False):
-    """Attention with Q K^T on the bf16 matrix cores.  qp [NP, nseq, Tq, H*dh], kp [NP, nseq, Tk, H*dh] torch.bfloat16 (NP = 3: exact splits
-    from split3 -> fp32-accurate scores; NP = 1: bf16), v [nseq, Tk, H*dh] fp32 (may be a column slice).  Returns fp32 [nseq, Tq, H*dh]."""
+    """Attention with Q K^T on the bf16 matrix cores.  qp [NP, nseq, Tq, H*dh], kp [NP, nseq, Tk, H*dh] torch.bfloat16 (NP = 3: exact three-way
+    bf16 splits x = x1 + x2 + x3, see bf16_split3 -> fp32-accurate scores; NP = 1: bf16), v [nseq, Tk, H*dh] fp32 (may be a column slice).  Returns fp32 [nseq, Tq, H*dh]."""
     _chk(v)
     NP, nseq, Tq, HD = qp.shape
     Tk = kp.shape[2]

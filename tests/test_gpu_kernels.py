@@ -150,7 +150,7 @@ def test_linear_split_and_bf16_write_only_their_window():
     d = dev()
     M, N, K = 19200 + 77, 1024, 512
     x, w, b = rnd(36, M, K), rnd(37, N, K, scale=1 / math.sqrt(K)), rnd(38, N)
-    xs, ws = ops.split3(x.to(d)), ops.split3(w.to(d))
+    xs, ws = ops.split_f32(x.to(d)), ops.split_f32(w.to(d))
     ref = F.linear(x[-300:].double(), w.double(), b.double()).float()
     got = ops.linear_split(xs, ws, b.to(d))
     assert got.shape == (M, N)
@@ -486,7 +486,7 @@ def test_attention_with_bf16_plane_scores(dh, H, T, zero_key, causal):
         return (torch.softmax(sc, -1) @ vs).transpose(1, 2).reshape(n, T, H * dh).float()
 
     qc, kc, vc = q.cpu(), k.cpu(), v.cpu()
-    got3 = ops.attention_planes(ops.split3(q.contiguous()), ops.split3(k.contiguous()), v, H, zero_key=zero_key, causal=causal)
+    got3 = ops.attention_planes(ops.bf16_split3(q.contiguous()), ops.bf16_split3(k.contiguous()), v, H, zero_key=zero_key, causal=causal)
     native = ops.attention(q, k, v, H, zero_key=zero_key, causal=causal)
     want = ref(qc, kc, vc)
     assert_close(got3, want, atol=2e-5, rtol=1e-4, what="attention, split planes")
@@ -506,7 +506,7 @@ def test_linear_split_packed_is_bitwise_the_plane_kernel(M, N, K):
     d = torch.device("cuda:0")
     g = torch.Generator().manual_seed(M * 7 + N)
     x, w, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
-    xs, ws = ops.split3(x.to(d)), ops.split3(w.to(d))
+    xs, ws = ops.split_f32(x.to(d)), ops.split_f32(w.to(d))
     wp = ops.split_pack_weight(ws)
     assert torch.equal(wp.flatten().sort().values, ws.flatten().sort().values)          # a permutation of the same elements
     for epi, extra in [("bias", None), ("gelu", None), ("silu", None), ("resid", r.to(d))]:
@@ -526,4 +526,4 @@ def test_linear_split_packed_is_bitwise_the_plane_kernel(M, N, K):
         torch.cuda.synchronize()
         assert torch.equal(out, ops.linear_split(xs, ws, b.to(d))[:, n0:])
     with pytest.raises(Exception):
-        ops.linear_split(ops.split3(x[:, :48].contiguous().to(d)), ops.split_pack_weight(ops.split3(w[:, :48].contiguous().to(d))), packed=True)   # K % 64
+        ops.linear_split(ops.split_f32(x[:, :48].contiguous().to(d)), ops.split_pack_weight(ops.split_f32(w[:, :48].contiguous().to(d))), packed=True)   # K % 64

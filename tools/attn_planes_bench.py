@@ -5,7 +5,7 @@ d = torch.device("cuda:0")
 for nseq, T, H, dh in [(64, 300, 8, 128), (128, 300, 8, 64)]:
     qkv = torch.randn(nseq, T, 3 * H * dh, device=d)
     q, k, v = qkv[..., :H * dh], qkv[..., H * dh:2 * H * dh], qkv[..., 2 * H * dh:]
-    qp3, kp3 = ops.split3(q.contiguous()), ops.split3(k.contiguous())
+    qp3, kp3 = ops.bf16_split3(q.contiguous()), ops.bf16_split3(k.contiguous())
     qp1, kp1 = q.contiguous().bfloat16()[None].contiguous(), k.contiguous().bfloat16()[None].contiguous()
     fl = 4.0 * nseq * H * T * (T + 1) * dh
     for name, fn in [("fp32 16x16x4", lambda: ops.attention(q, k, v, H)), ("QK^T 3 planes", lambda: ops.attention_planes(qp3, kp3, v, H)),

@@ -8,8 +8,8 @@ vp = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def split(x):
     n = x.numel()
-    out = torch.empty(3, *x.shape, device=d, dtype=torch.bfloat16)
-    assert lib.mmdm_f32_split3(vp(x), vp(out), n, n, st()) == 0
+    out = torch.empty(2, *x.shape, device=d, dtype=torch.float16)
+    assert lib.mmdm_f32_split(vp(x), vp(out), n, n, st()) == 0
     return out
 def lin_split(xs, ws, b, epi, extra, out, M, N, K):
     rc = lib.mmdm_linear_split(vp(xs), K, M * K, vp(ws), K, N * K, vp(b), vp(out), N, 0, 0, M, N, K, ops.EPI[epi], vp(extra), N if extra is not None else 0, 0, st())
@@ -22,7 +22,7 @@ x = torch.randn(M,K,device=d); w = torch.randn(N,K,device=d)/math.sqrt(K); b = t
 ref = (x.double() @ w.double().T + b.double())
 out = torch.empty(M,N,device=d)
 xs, ws = split(x), split(w)
-assert torch.equal((xs[0].float()+xs[1].float()+xs[2].float()), x), "split not exact"
+assert ((xs[0].double()+xs[1].double()/2048 - x.double()).abs() <= 2.0**-22 * x.double().abs() + 2.0**-36).all(), "split beyond 2^-22"
 lin_split(xs, ws, b, "bias", None, out, M, N, K)
 nat = ops.linear(x, w, b)
 sc = ref.abs().mean()

@@ -9,8 +9,8 @@ d = torch.device("cuda:0")
 vp = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def split(x):
-    out = torch.empty(3, *x.shape, device=d, dtype=torch.bfloat16); n = x.numel()
-    assert lib.mmdm_f32_split3(vp(x), vp(out), n, n, st()) == 0
+    out = torch.empty(2, *x.shape, device=d, dtype=torch.float16); n = x.numel()
+    assert lib.mmdm_f32_split(vp(x), vp(out), n, n, st()) == 0
     return out
 for cfg in [int(c) for c in os.environ.get("CFGS", "-1,5").split(",")]:
   lib.mmdm_diag_set(b"split_cfg", cfg)
