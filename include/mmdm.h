@@ -152,9 +152,9 @@ int mmdm_attention_opts(const float* Q, int ldq, const float* K, int ldk, const 
                         int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
 
 /* Attention with Q K^T on the bf16 matrix cores: Q and K are given as `nplanes` bf16 planes [plane][rows][ld] (plane strides in elements).
- * nplanes = 3: exact 3-way splits of the fp32 projections -> fp32-accurate scores from six v_mfma_f32_16x16x32_bf16 per block (the
- * fp32-split precision mode); nplanes = 1: bf16 Q and K (the bf16 path).  V is fp32; softmax, P.V and the output are those of
- * mmdm_attention_opts (out_mode: 0 fp32, 1 bf16, 2 three bf16 planes; flags as there; zero key by default).  dh = 64 or 128. */
+ * nplanes = 3: exact 3-way bf16 splits of the fp32 projections (x = x1 + x2 + x3) -> fp32-accurate scores from six
+ * v_mfma_f32_16x16x32_bf16 per block; nplanes = 1: bf16 Q and K (the bf16 path).  V is fp32; softmax, P.V and the output are those of
+ * mmdm_attention_opts (out_mode: 0 fp32, 1 bf16, 2 the two fp16 planes of mmdm_linear_split; flags as there; zero key by default).  dh = 64 or 128. */
 int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
                           void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
 
@@ -163,6 +163,14 @@ int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, const void* 
  * V read transposed from its row-major LDS image by ds_read_b64_tr_b16), fp32 accumulation and softmax.  dh = 64 or 128. */
 int mmdm_attention_bf16(const void* Qp, int ldq, const void* Kp, int ldk, const void* Vp, int ldv, void* O, int ldo, int out_mode, int flags,
                         int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
+
+/* The attention of the fp32-split precision mode: Q, K and V are each given as the two fp16 planes of mmdm_linear_split (h, l with
+ * x ~= h + l / 2048; [2][rows][ld], plane strides in elements) -- what the projection GEMM writes with out_split instead of fp32 rows.
+ * Scores: hi += kh qh, lo += kl qh + kh ql (three v_mfma_f32_16x16x32_f16 per 32-deep step), S = hi + lo / 2048; fp32 softmax; the
+ * probabilities are split the same way on the fly and P.V accumulates hi / lo likewise (three v_mfma_f32_16x16x16_f16 per 16 columns).
+ * As accurate against float64 as mmdm_attention_f32 (tests), ~2.5x faster.  out_mode / flags as mmdm_attention_planes.  dh = 64 or 128. */
+int mmdm_attention_split(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, const void* Vp, int ldv, int64_t v_plane,
+                         void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
 
 /* out[r,:] = silu(time_row[:] + txt[r,:]) for r < rows; time_row = time_tab + (*step_idx) * D.
  * Replaces `embed_timestep(t) + text_embed(c)` followed by AdaLN's SiLU  in2in.py:415-422, layers.py:9-10. */

@@ -59,6 +59,7 @@ SYMBOLS = {
     "mmdm_attention_opts": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "mmdm_attention_planes": (_I, [_VP, _I, C.c_int64, _VP, _I, C.c_int64, _I, _VP, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "mmdm_attention_bf16": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "mmdm_attention_split": (_I, [_VP, _I, C.c_int64, _VP, _I, C.c_int64, _VP, _I, C.c_int64, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "mmdm_dual_ddim_f32": (_I, [_VP, _VP, _VP, _I, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _I, _I, _I, _VP]),
     "mmdm_layernorm_f32": (_I, [_VP, _VP, _VP, _VP, _I, _I, C.c_float, _VP]),
     "mmdm_token_embed_f32": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP]),

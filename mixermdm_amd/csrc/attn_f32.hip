@@ -78,6 +78,7 @@ struct AttnArgs {
     size_t q_plane, k_plane;
     int ldqp, ldkp;
     const __bf16* Vp; int ldvp;        // bf16 V rows (attn_qkp_kernel<DH, 1, true>: P.V on the bf16 matrix cores); nullptr = fp32 V
+    size_t v_plane;                    // attn_qkp_kernel<DH, 2, true, true>: Q, K and V as the two fp16 planes of the fp32-split mode (Vp: plane stride v_plane)
 };
 
 int g_attn_ablate = 0;
@@ -463,10 +464,20 @@ __device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y
 // O[query 4g + r][column 16 j + lq].  One MFMA of 16 cycles per 16 output columns and 16 keys instead of four of 32.
 // V image swizzle (16-byte chunk c of key row r at c ^ x(r)): 256-byte rows (DH = 128) x = ((r & 3) << 2) | ((r >> 2) & 3), 128-byte rows
 // (DH = 64) x = ((r >> 1) & 3) << 1 -- without it the eight rows a 32-lane half reads sit on the same banks.
-template <int DH, int NP, bool PVB = false>
+// H2 (NP = 2, PVB): the fp32-split mode's attention.  Q, K and V arrive as the two fp16 planes the projection GEMM wrote INSTEAD of fp32 rows (same
+// bytes), x ~= h + l / 2048 (kernels.h).  Scores: hi += kh*qh, lo += kl*qh + kh*ql (three v_mfma_f32_16x16x32_f16 per 32-deep step), S = hi + lo / 2048;
+// softmax in fp32 as everywhere; P.V the same way: the probabilities are split on the fly (p < 2^8 with the deferred maximum), o_hi += ph*vh,
+// o_lo += ph*vl + pl*vh (three v_mfma_f32_16x16x16_f16 per 16 columns), O = (o_hi + o_lo / 2048) / l.  fp32-accurate like the split GEMMs (the same
+// argument: representation error 2^-22 per operand, below the fp32 accumulation error of the 32x32x2 / 16x16x4 fp32 MFMA chains it replaces), at
+// 36 short MFMAs per 16-key chunk instead of 64 long ones.
+template <int DH, int NP, bool PVB = false, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
-    static_assert(!PVB || NP == 1, "bf16 P.V goes with bf16 scores");
+    static_assert(!PVB || NP == 1 || H2, "bf16 P.V goes with bf16 scores");
+    static_assert(!H2 || (NP == 2 && PVB), "the fp16 two-plane form covers Q K^T and P.V together");
+    typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+    constexpr int NVP = H2 ? 2 : 1;             // V planes (16-bit V)
+    constexpr int VPLANE = KC * DH / 2;         // floats per 16-bit V plane
     constexpr int NJ = DH / 16;                 // 16-wide output column tiles (PV)
     constexpr int NS = DH / 32;                 // 32-deep reduction steps of Q K^T
     constexpr int CPRK = DH / 8;                // 16-byte chunks per K row (bf16)
@@ -475,10 +486,10 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
     constexpr int CPR = PVB ? DH / 8 : DH / 4;  // 16-byte chunks per V row (bf16 / fp32)
     constexpr int RPP = 64 / CPR;
     constexpr int NPV = KC / RPP;
-    constexpr int NPIECE = NP * NPK + NPV;
+    constexpr int NPIECE = NP * NPK + NVP * NPV;
     constexpr int NI = (NPIECE + 3) / 4;
     constexpr int KPLANE = KC * DH / 2;         // floats per K plane
-    constexpr int STAGE = NP * KPLANE + (PVB ? KC * DH / 2 : KC * DH);
+    constexpr int STAGE = NP * KPLANE + (PVB ? NVP * VPLANE : KC * DH);
     constexpr int NT = NP == 3 ? 6 : 1;
     constexpr int TK[6] = {1, 2, 0, 1, 0, 0}, TQ[6] = {1, 0, 2, 0, 1, 0};      // (K plane, Q plane) per term, small terms first
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 stages][K planes | V]
@@ -509,9 +520,11 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
             for (int s = 0; s < NS; ++s) qf[pl][s] = *reinterpret_cast<const bf16x8*>(qp + (size_t)pl * p.q_plane + 32 * s);
     }
 
-    f32x4 o[NJ];
+    f32x4 o[NJ], ol[H2 ? NJ : 1];               // ol: the lo accumulators of the two-plane form
 #pragma unroll
     for (int j = 0; j < NJ; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < (H2 ? NJ : 1); ++j) ol[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool nozero = (p.flags & MMDM_ATTN_NO_ZERO_KEY) != 0, causal = (p.flags & MMDM_ATTN_CAUSAL) != 0;
     float m_run = nozero ? -INFINITY : 0.f, l_run = nozero ? 0.f : 1.f;
 
@@ -528,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
     for (int u = 0; u < NI; ++u) {
         const int pq = wave + 4 * u;                                   // wave-uniform
         const bool isk = pq < NP * NPK;
-        const int pl = isk ? pq / NPK : 0, pp = isk ? pq % NPK : pq - NP * NPK;
+        const int pl = isk ? pq / NPK : (pq - NP * NPK) / NPV, pp = isk ? pq % NPK : (pq - NP * NPK) % NPV;       // (K or V) plane, piece inside it
         const int trow = isk ? RPPK * pp + lane / CPRK : RPP * pp + lane / CPR;
         const int pos = isk ? lane % CPRK : lane % CPR;
         const void* base; unsigned bytes;
@@ -538,9 +551,9 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
             dsto[u] = pl * KPLANE + RPPK * pp * (DH / 2);
         } else if constexpr (PVB) {
             const int xv = DH == 128 ? (((trow & 3) << 2) | ((trow >> 2) & 3)) : (((trow >> 1) & 3) << 1);
-            base = p.Vp + (size_t)kvseq * p.Tk * p.ldvp + head * DH; bytes = (unsigned)(((size_t)(p.Tk - 1) * p.ldvp + DH) * 2);
+            base = p.Vp + (H2 ? (size_t)pl * p.v_plane : 0) + (size_t)kvseq * p.Tk * p.ldvp + head * DH; bytes = (unsigned)(((size_t)(p.Tk - 1) * p.ldvp + DH) * 2);
             voff[u] = (trow * p.ldvp + 8 * (pos ^ xv)) * 2; rstep[u] = p.ldvp * 2;
-            dsto[u] = NP * KPLANE + RPP * pp * (DH / 2);
+            dsto[u] = NP * KPLANE + (H2 ? pl * VPLANE : 0) + RPP * pp * (DH / 2);
         } else {
             base = Vg; bytes = (unsigned)(((size_t)(p.Tk - 1) * p.ldv + DH) * 4);
             voff[u] = (trow * p.ldv + 4 * pos) * 4; rstep[u] = p.ldv * 4;              // V rows are stored unswizzled (load_v_row)
@@ -586,6 +599,27 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 kf[pl][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Ks[pl * KPLANE + lq * (DH / 2) + 4 * ((4 * s + g) ^ (lq & (CPRK - 1)))]));
+        f32x4 st[1];
+        if constexpr (H2) {
+            f32x4 sl[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sl[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto hb = [](const bf16x8& v) { return __builtin_bit_cast(h16x8, v); };
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sl[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb(kf[1][s]), hb(qf[0][s]), sl[s], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sl[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb(kf[0][s]), hb(qf[1][s]), sl[s], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sa[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb(kf[0][s]), hb(qf[0][s]), sa[s], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { MFMA_SETTLE(sa[s]); MFMA_SETTLE(sl[s]); }
+            f32x4 lo = sl[0];
+            st[0] = sa[0];
+#pragma unroll
+            for (int s = 1; s < NS; ++s) { st[0] += sa[s]; lo += sl[s]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[0][r] = __builtin_fmaf(lo[r], MMDM_SPLIT_INV, st[0][r]);
+        } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -593,10 +627,10 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
                 sa[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[NP == 3 ? TK[t] : 0][s], qf[NP == 3 ? TQ[t] : 0][s], sa[s], 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < NS; ++s) MFMA_SETTLE(sa[s]);
-        f32x4 st[1];
         st[0] = sa[0];
 #pragma unroll
         for (int s = 1; s < NS; ++s) st[0] += sa[s];
+        }
         st[0] *= p.scale2;
 
         if (c0 + KC > p.Tk || (causal && c0 + KC - 1 > q0)) {
@@ -624,9 +658,36 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];
+            if constexpr (H2) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ol[j][r] *= ar[r];
+            }
         }
 
-        if constexpr (PVB) {
+        if constexpr (H2) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+            mmdm_h4 ph, pl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const _Float16 t = mmdm_split_hi(st[0][r]); ph[r] = t; pl[r] = mmdm_split_lo(st[0][r], t); }
+            const int vrow = 4 * g + (lq >> 2), pp = lq & 3;
+            const int xv = DH == 128 ? (((vrow & 3) << 2) | ((vrow >> 2) & 3)) : (((vrow >> 1) & 3) << 1);
+            const char* vbase = reinterpret_cast<const char*>(Vs) + vrow * (DH * 2) + 8 * (pp & 1);
+            mmdm_h4 vh[NJ], vl[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                vh[j] = __builtin_bit_cast(mmdm_h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vbase + 16 * ((2 * j + (pp >> 1)) ^ xv))));
+                vl[j] = __builtin_bit_cast(mmdm_h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vbase + VPLANE * 4 + 16 * ((2 * j + (pp >> 1)) ^ xv))));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) ol[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, vl[j], ol[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) ol[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(pl, vh[j], ol[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) o[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, vh[j], o[j], 0, 0, 0);
+        } else if constexpr (PVB) {
             typedef short s16x4 __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
             const bf16x4a pb = {(__bf16)st[0][0], (__bf16)st[0][1], (__bf16)st[0][2], (__bf16)st[0][3]};
@@ -657,6 +718,14 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
+    if constexpr (H2) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            MFMA_SETTLE(ol[j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[j][r] = __builtin_fmaf(ol[j][r], MMDM_SPLIT_INV, o[j][r]);
+        }
+    }
     float lr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run, 4 * g + r);
@@ -676,13 +745,13 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
 #endif
 }
 
-template <int DH, int NP, bool PVB = false>
-constexpr int qkp_smem() { return 2 * (NP * KC * DH / 2 + (PVB ? KC * DH / 2 : KC * DH)) * 4; }
+template <int DH, int NP, bool PVB = false, bool H2 = false>
+constexpr int qkp_smem() { return 2 * (NP * KC * DH / 2 + (PVB ? (H2 ? 2 : 1) * KC * DH / 2 : KC * DH)) * 4; }
 
-template <int DH, int NP, bool PVB = false>
+template <int DH, int NP, bool PVB = false, bool H2 = false>
 int launch_qkp(const AttnArgs& a, hipStream_t st) {
-    constexpr int smem_bytes = qkp_smem<DH, NP, PVB>();
-    hipLaunchKernelGGL((attn_qkp_kernel<DH, NP, PVB>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), smem_bytes, st, a);
+    constexpr int smem_bytes = qkp_smem<DH, NP, PVB, H2>();
+    hipLaunchKernelGGL((attn_qkp_kernel<DH, NP, PVB, H2>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), smem_bytes, st, a);
     return mmdm_check_launch("attn_qkp");
 }
 
@@ -863,21 +932,29 @@ extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int 
 
 extern "C" int mmdm_attention_planes(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
                                      void* Ov, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
-    return mmdm_attention_planes_ex(Qp, ldq, q_plane, Kp, ldk, k_plane, nplanes, V, ldv, nullptr, 0, Ov, ldo, out_mode, flags, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);
+    if (nplanes == 2) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: the two-plane fp16 form is mmdm_attention_split (V as planes too)");
+    return mmdm_attention_planes_ex(Qp, ldq, q_plane, Kp, ldk, k_plane, nplanes, V, ldv, nullptr, 0, 0, Ov, ldo, out_mode, flags, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);
 }
 
 extern "C" int mmdm_attention_bf16(const void* Qp, int ldq, const void* Kp, int ldk, const void* Vp, int ldv, void* O, int ldo, int out_mode, int flags,
                                    int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
     if (!Vp) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_bf16: V is null");
-    return mmdm_attention_planes_ex(Qp, ldq, 8, Kp, ldk, 8, 1, nullptr, 0, Vp, ldv, O, ldo, out_mode, flags, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);     // no fp32 V
+    return mmdm_attention_planes_ex(Qp, ldq, 8, Kp, ldk, 8, 1, nullptr, 0, Vp, ldv, 0, O, ldo, out_mode, flags, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);     // no fp32 V
 }
 
-// Vp != nullptr (one plane only): V also as bf16 rows [rows][ldvp] -> P.V on the bf16 matrix cores (attn_qkp_kernel<DH, 1, true>)
+extern "C" int mmdm_attention_split(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, const void* Vp, int ldv, int64_t v_plane,
+                                    void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
+    if (!Vp) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_split: V is null");
+    return mmdm_attention_planes_ex(Qp, ldq, q_plane, Kp, ldk, k_plane, 2, nullptr, 0, Vp, ldv, v_plane, O, ldo, out_mode, flags, nseq, Tq, Tk, H, dh, kv_seq_shift, stream);
+}
+
+// Vp != nullptr, one plane: V also as bf16 rows [rows][ldvp] -> P.V on the bf16 matrix cores (attn_qkp_kernel<DH, 1, true>);
+// nplanes == 2: Q, K and V (Vp, plane stride v_plane) as the two fp16 planes of the fp32-split mode (attn_qkp_kernel<DH, 2, true, true>)
 int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
-                             const void* Vp, int ldvp, void* Ov, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
+                             const void* Vp, int ldvp, int64_t v_plane, void* Ov, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
     if (nseq == 0 || Tq == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
-    if (!Qp || !Kp || (!V && !Vp) || !Ov || nseq < 0 || Tq < 0 || Tk <= 0 || H <= 0 || (nplanes != 1 && nplanes != 3))
+    if (!Qp || !Kp || (!V && !Vp) || !Ov || nseq < 0 || Tq < 0 || Tk <= 0 || H <= 0 || (nplanes < 1 || nplanes > 3) || (nplanes == 2 && !Vp))
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: bad arguments nseq=%d Tq=%d Tk=%d H=%d planes=%d", nseq, Tq, Tk, H, nplanes);
     if (dh != 64 && dh != 128) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_attention_planes: head dim %d not supported (64, 128)", dh);
     if (flags & ~(MMDM_ATTN_NO_ZERO_KEY | MMDM_ATTN_CAUSAL)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: unknown flags 0x%x", flags);
@@ -892,9 +969,9 @@ int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const voi
     AttnArgs a;
     a.Q = nullptr; a.K = nullptr; a.V = V; a.O = static_cast<float*>(Ov); a.ldq = 0; a.ldk = 0; a.ldv = ldv; a.ldo = ldo;
     a.Qp = static_cast<const __bf16*>(Qp); a.Kp = static_cast<const __bf16*>(Kp); a.q_plane = (size_t)q_plane; a.k_plane = (size_t)k_plane; a.ldqp = ldq; a.ldkp = ldk;
-    a.Vp = static_cast<const __bf16*>(Vp); a.ldvp = ldvp;
-    if (Vp && (nplanes != 1 || (reinterpret_cast<uintptr_t>(Vp) & 15) || (ldvp & 7) || ldvp < H * dh))
-        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: bf16 V needs one plane, 16-byte aligned rows and a row stride >= H*dh");
+    a.Vp = static_cast<const __bf16*>(Vp); a.ldvp = ldvp; a.v_plane = (size_t)v_plane;
+    if (Vp && (nplanes == 3 || (reinterpret_cast<uintptr_t>(Vp) & 15) || (ldvp & 7) || ldvp < H * dh || (nplanes == 2 && (v_plane & 7))))
+        return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: 16-bit V needs one (bf16) or two (fp16 split) planes, 16-byte aligned rows / planes and a row stride >= H*dh");
     a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate; a.stamps = g_attn_stamps;
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
@@ -903,6 +980,7 @@ int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const voi
     a.scale2 = a.scale * 1.4426950408889634f;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (nplanes == 3) return dh == 128 ? launch_qkp<128, 3>(a, st) : launch_qkp<64, 3>(a, st);
+    if (nplanes == 2) return dh == 128 ? launch_qkp<128, 2, true, true>(a, st) : launch_qkp<64, 2, true, true>(a, st);
     if (Vp) return dh == 128 ? launch_qkp<128, 1, true>(a, st) : launch_qkp<64, 1, true>(a, st);
     return dh == 128 ? launch_qkp<128, 1>(a, st) : launch_qkp<64, 1>(a, st);
 }

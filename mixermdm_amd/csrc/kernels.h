@@ -114,4 +114,4 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
                        float a_const, float out_scale, void* stream);
 int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_mode, float* row_scale, int nseq, int T, int D, void* stream);
 int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
-                             const void* Vp, int ldvp, void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
+                             const void* Vp, int ldvp, int64_t v_plane, void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);

@@ -495,9 +495,9 @@ int linear_s(const Ctx& c, const void* A, int lda, size_t a_plane, const void* W
 
 // attention whose Q K^T runs on the bf16 matrix cores from the plane copies written by the projection GEMMs
 int attention_p(const Ctx& c, const void* Qp, int ldq, size_t q_plane, const void* Kp, int ldk, size_t k_plane, int np, const float* V, int ldv, void* O, int ldo,
-                int out_mode, int nseq, int Tq, int Tk, int H, int dh, int shift, const void* Vp = nullptr, int ldvp = 0) {
+                int out_mode, int nseq, int Tq, int Tk, int H, int dh, int shift, const void* Vp = nullptr, int ldvp = 0, size_t v_plane = 0) {
     RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh, 4.0 * nseq * H * dh * (2.0 * Tq + 2.0 * Tk)));
-    RC(mmdm_attention_planes_ex(Qp, ldq, (int64_t)q_plane, Kp, ldk, (int64_t)k_plane, np, V, ldv, Vp, ldvp, O, ldo, out_mode, 0, nseq, Tq, Tk, H, dh, shift, c.st));
+    RC(mmdm_attention_planes_ex(Qp, ldq, (int64_t)q_plane, Kp, ldk, (int64_t)k_plane, np, V, ldv, Vp, ldvp, (int64_t)v_plane, O, ldo, out_mode, 0, nseq, Tq, Tk, H, dh, shift, c.st));
     return prof_end(c, 1);
 }
 
@@ -529,8 +529,11 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         return linear(c, A, lda, Wf + woff, K, bias, C, ldc, R, N, K, epi, extra, ld_extra);
     };
     // bf16 path with a head size the plane kernel covers: the projection GEMMs also emit a bf16 copy of Q and K and the scores come from
-    // the bf16 matrix cores (attn_qkp_kernel): 20.1 -> 18.7 ms/step.  In fp32-split mode the three-plane copies cost more than the faster
-    // Q K^T gains (51.6 vs 49.8 ms/step: P.V and the softmax are 60 % of the kernel), so that mode keeps the fp32 attention (MMDM_QKP=1 forces it).
+    // the bf16 matrix cores (attn_qkp_kernel): 20.1 -> 18.7 ms/step.
+    // fp32-split mode: the projections are written as the two fp16 planes INSTEAD of fp32 rows (same bytes) and the attention works on the planes
+    // throughout (attn_qkp_kernel<DH, 2, true, true>); MMDM_NO_QKP=1 keeps fp32 projections + the fp32 attention kernel, MMDM_QKP=1 selects the
+    // round-2 experiment (extra three-way bf16 copies of Q | K for the scores only: measured slower than the fp32 kernel, 51.6 vs 49.8 ms/step).
+    const bool spa = prec == 2 && (dh == 64 || dh == 128) && !c.h->no_qkp && !c.h->force_qkp;
     const bool qkp = bf && (prec == 1 || prec == 3 || c.h->force_qkp) && (dh == 64 || dh == 128) && S.qk && !c.h->no_qkp;
     const int np = prec == 2 ? 3 : 1;
     // precision 3: one fp8 GEMM of the stack.  W8 / Ws: fp8 matrix [rows, K] and its per-output-channel scales, row0 = first output
@@ -557,12 +560,17 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         RC(norm(hbuf, ss_at(0, r.sa_row0), r.sa_rows));
         const int qkld = pvb ? 3 * D : 2 * D;           // row stride of the bf16 copy of the packed projection: Q|K or Q|K|V
         // all-bf16 attention: nothing reads the fp32 projection, so the GEMM writes bf16 only (a third of the bytes: the fp8 QKV GEMM is output-bound)
-        if (pvb) {
+        const _Float16* const qkvh = reinterpret_cast<const _Float16*>(S.qkv);      // spa: planes [2][R][3D] (self) / [2][R][D] (cross-attention queries)
+        const _Float16* const kvh = reinterpret_cast<const _Float16*>(S.kv);        // spa: planes [2][R][2D]
+        if (spa) RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 2, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+        else if (pvb) {
             if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qk, 3 * D, 1, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, Second(), w.w_packed));
             else RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, static_cast<float*>(S.qk), 3 * D, 1, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0));
         } else if (f8) RC(gemm8(S.xn, false, lb.sa_in_8, lb.sa_in_s, 0, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, qkld, qkld), w.w_packed));
         else RC(gemm(S.xn, D, lw.sa_in_w, lb.sa_in_w, 0, (size_t)3 * D * D, lw.sa_in_b, S.qkv, 3 * D, 0, 3 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, qkld, qkld)));
-        if (qkp) RC(attention_p(c, S.qk, qkld, (size_t)R * qkld, static_cast<const uint16_t*>(S.qk) + D, qkld, (size_t)R * qkld, np, S.qkv + 2 * D, 3 * D, S.att, D, ob,
+        if (spa) RC(attention_p(c, qkvh, 3 * D, (size_t)R * 3 * D, qkvh + D, 3 * D, (size_t)R * 3 * D, 2, nullptr, 0, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, 0,
+                                qkvh + 2 * D, 3 * D, (size_t)R * 3 * D));
+        else if (qkp) RC(attention_p(c, S.qk, qkld, (size_t)R * qkld, static_cast<const uint16_t*>(S.qk) + D, qkld, (size_t)R * qkld, np, S.qkv + 2 * D, 3 * D, S.att, D, ob,
                                 r.nseq, r.T, r.T, w.H, dh, 0, pvb ? static_cast<const uint16_t*>(S.qk) + 2 * D : nullptr, qkld));
         else RC(attention_b(c, S.qkv, 3 * D, S.qkv + D, 3 * D, S.qkv + 2 * D, 3 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, 0));
         if (r.ca_mode) {
@@ -571,7 +579,8 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
             const float* src = r.ca_mode == 1 ? hbuf : r.kv_src;
             RC(norm(src, ss_at(2, r.ca_row0), r.ca_rows));
             const int kvld = pvb ? 2 * D : D;             // bf16 copy of the cross-attention projection: K or K|V
-            if (pvb) {
+            if (spa) RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, S.kv, 2 * D, 2, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0));
+            else if (pvb) {
                 if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kvp, 2 * D, 1, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, Second(), w.w_packed));
                 else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, (size_t)D * D, (size_t)3 * D * D, lw.ca_in_b + D, static_cast<float*>(S.kvp), 2 * D, 1, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0));
             } else if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, D, lw.ca_in_b + D, S.kv, 2 * D, 0, 2 * D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.kvp, kvld, kvld), w.w_packed));
@@ -583,12 +592,15 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         // --- cross attention (layers.py:77-88)
         if (r.ca_mode) {
             RC(norm(hbuf, ss_at(1, r.ca_row0), r.ca_rows));
-            if (pvb) {
+            if (spa) RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, S.qkv, D, 2, D, D, MMDM_EPI_BIAS, nullptr, 0));
+            else if (pvb) {
                 if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qk, D, 1, D, D, MMDM_EPI_BIAS, nullptr, 0, Second(), w.w_packed));
                 else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, static_cast<float*>(S.qk), D, 1, D, D, MMDM_EPI_BIAS, nullptr, 0));
             } else if (f8) RC(gemm8(S.xn, false, lb.ca_in_8, lb.ca_in_s, 0, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D), w.w_packed));
             else RC(gemm(S.xn, D, lw.ca_in_w, lb.ca_in_w, 0, (size_t)3 * D * D, lw.ca_in_b, S.qkv, D, 0, D, D, MMDM_EPI_BIAS, nullptr, 0, second(S.qk, D, D)));
-            if (qkp) RC(attention_p(c, S.qk, D, (size_t)R * D, S.kvp, pvb ? 2 * D : D, (size_t)R * (pvb ? 2 * D : D), np, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
+            if (spa) RC(attention_p(c, qkvh, D, (size_t)R * D, kvh, 2 * D, (size_t)R * 2 * D, 2, nullptr, 0, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
+                                    r.ca_mode == 1 ? r.nseq / 2 : 0, kvh + D, 2 * D, (size_t)R * 2 * D));
+            else if (qkp) RC(attention_p(c, S.qk, D, (size_t)R * D, S.kvp, pvb ? 2 * D : D, (size_t)R * (pvb ? 2 * D : D), np, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh,
                                     r.ca_mode == 1 ? r.nseq / 2 : 0, pvb ? static_cast<const uint16_t*>(S.kvp) + D : nullptr, 2 * D));
             else RC(attention_b(c, S.qkv, D, S.kv, 2 * D, S.kv + D, 2 * D, S.att, D, ob, r.nseq, r.T, r.T, w.H, dh, r.ca_mode == 1 ? r.nseq / 2 : 0));
             RC(gemm(S.att, D, lw.ca_out_w, lb.ca_out_w, 0, (size_t)D * D, lw.ca_out_b, hbuf, D, 0, D, D, MMDM_EPI_BIAS_RESID, hbuf, D));

@@ -335,6 +335,22 @@ def attention_bf16(qb, kb, vb, num_heads, kv_seq_shift=0, zero_key=True, causal=
     return out
 
 
+def attention_split(qs, ks, vs, num_heads, kv_seq_shift=0, zero_key=True, causal=False, split_out=False):
+    """Attention of the fp32-split mode: qs [2, nseq, Tq, H*dh], ks / vs [2, nseq, Tk, H*dh] torch.float16 planes (split_f32; may be column
+    slices of a packed projection written with split_out); scores and P.V from three fp16 MFMAs per block with hi / lo accumulators, fp32 softmax.
+    Returns fp32 [nseq, Tq, H*dh] or its two planes."""
+    for t in (qs, ks, vs):
+        assert t.is_cuda and t.dtype == torch.float16 and t.shape[0] == 2 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2)
+    _, nseq, Tq, HD = qs.shape
+    Tk = ks.shape[2]
+    out = torch.empty((2, nseq, Tq, HD) if split_out else (nseq, Tq, HD), device=qs.device, dtype=torch.float16 if split_out else torch.float32)
+    flags = (0 if zero_key else ATTN_NO_ZERO_KEY) | (ATTN_CAUSAL if causal else 0)
+    check(load_library().mmdm_attention_split(C.c_void_p(qs.data_ptr()), qs.stride(2), qs.stride(0), C.c_void_p(ks.data_ptr()), ks.stride(2), ks.stride(0),
+                                              C.c_void_p(vs.data_ptr()), vs.stride(2), vs.stride(0), C.c_void_p(out.data_ptr()), HD, 2 if split_out else 0, flags,
+                                              nseq, Tq, Tk, num_heads, HD // num_heads, kv_seq_shift, _stream()))
+    return out
+
+
 def quantize_rows_fp8(x):
     """Row-wise OCP e4m3 quantisation of an fp32 [rows, K] tensor: returns (q uint8-viewed-as torch.float8_e4m3fn [rows, K], scale fp32 [rows])
     with x ~= q.float() * scale[:, None].  Per-output-channel weight quantisation is this on W [N, K]."""

@@ -497,6 +497,40 @@ def test_attention_with_bf16_plane_scores(dh, H, T, zero_key, causal):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dh,H,T,zero_key,causal,shift", [(128, 2, 300, True, False, 0), (64, 3, 77, True, False, 1), (128, 1, 45, False, False, 0), (64, 2, 130, False, True, 0),
+                                                          (128, 8, 299, True, False, 2)])
+def test_attention_on_the_fp16_split_planes_is_as_accurate_as_the_fp32_kernel(dh, H, T, zero_key, causal, shift):
+    """The fp32-split mode's attention (Q, K, V as two fp16 planes each, column slices of one packed projection as the sampler passes them; scores and P.V
+    from three fp16 MFMAs with hi / lo accumulators) against a float64 reference: error within 1.5x of the fp32 MFMA kernel's on the same inputs, with
+    large-magnitude rows (scores up to +-40) included; two-plane output = the split of the fp32 output."""
+    from mixermdm_amd import ops
+    import math
+    n = 4
+    qkv = rnd(23, n, T, 3 * H * dh)
+    qkv[1] *= 2.5                                   # peaked softmax rows
+    d = qkv.to(dev())
+    HD = H * dh
+    q, k, v = d[..., :HD], d[..., HD:2 * HD], d[..., 2 * HD:]
+    sp = lambda t: t.reshape(n, -1, H, dh).transpose(1, 2).double()
+    qs, ks, vs = sp(qkv[..., :HD]), sp(qkv[..., HD:2 * HD]).roll(-shift, 0), sp(qkv[..., 2 * HD:]).roll(-shift, 0)
+    if zero_key:
+        z = torch.zeros(n, H, 1, dh, dtype=torch.float64)
+        ks, vs = torch.cat([ks, z], 2), torch.cat([vs, z], 2)
+    sc = (qs @ ks.transpose(-1, -2)) / math.sqrt(dh)
+    if causal:
+        sc = sc + torch.full((T, T), float("-inf"), dtype=torch.float64).triu_(1)
+    want = (torch.softmax(sc, -1) @ vs).transpose(1, 2).reshape(n, T, HD)
+    planes = ops.split_f32(d)                       # [2, n, T, 3 HD]: what the QKV GEMM writes with split_out
+    got = ops.attention_split(planes[..., :HD], planes[..., HD:2 * HD], planes[..., 2 * HD:], H, kv_seq_shift=shift, zero_key=zero_key, causal=causal)
+    native = ops.attention(q, k, v, H, kv_seq_shift=shift, zero_key=zero_key, causal=causal)
+    es, en = (got.cpu().double() - want).abs(), (native.cpu().double() - want).abs()
+    assert_close(got, want.float(), atol=2e-5, rtol=1e-4, what="attention on fp16 split planes")
+    assert es.mean() <= 1.5 * en.mean() + 1e-9 and es.max() <= 2.0 * en.max() + 1e-7, (es.mean().item(), en.mean().item(), es.max().item(), en.max().item())
+    got2 = ops.attention_split(planes[..., :HD], planes[..., HD:2 * HD], planes[..., 2 * HD:], H, kv_seq_shift=shift, zero_key=zero_key, causal=causal, split_out=True)
+    assert torch.equal(got2, ops.split_f32(got))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(300, 128, 64), (257, 192, 128), (1000, 384, 1024), (64, 512, 512), (5, 1152, 192)])
 def test_linear_split_packed_is_bitwise_the_plane_kernel(M, N, K):
     """W in fragment order (mmdm_split_pack_weight) and fetched straight from global memory: every tile shape of the packed dispatch

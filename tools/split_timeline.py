@@ -1,6 +1,6 @@
 """Where a wave of the packed fp32-split GEMM spends its K step: s_memtime sums per phase (mmdm_diag_set "split_timeline").
-Phases of one step: 0 = 24 MFMAs of k-block 0 (+ A fragment reads, next step's B loads); 1 = 12 MFMAs of k-block 1; 2 = counted vmcnt wait;
-3 = barrier; 4 = last 12 MFMAs (+ next stage's A reads and LDS-DMA requests)."""
+Phases of one step (two-way fp16 form, TM x TN = 4 tiles per wave): 0 = 16 MFMAs (k-block 0 and ah*wl of k-block 1; + A fragment reads, next
+step's B loads, LDS-DMA requests); 2 = counted vmcnt wait; 3 = barrier; 4 = last 8 MFMAs (+ next stage's A reads)."""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, math, ctypes as C
 from mixermdm_amd import ops, load_library
@@ -30,7 +30,7 @@ for cfg in [int(c) for c in os.environ.get("CFGS", "-1,5").split(",")]:
       nkt = t[0, 0, 5].item()
       per = t[:, :, :5] / nkt                     # cycles per step and phase
       mean = per.mean(dim=(0, 1)); tot = mean.sum().item()
-      ideal = 48 * 32 * 2                          # 48 MFMAs x 32 cycles (8 passes x 4), two waves per SIMD
+      ideal = 24 * 32 * 2                          # 24 MFMAs x 32 cycles (8 passes x 4), two waves per SIMD
       mhz = (t[:, :, 7] / t[:, :, 6].clamp(min=1)).median().item() * 100
       print(f"s_memtime / s_memrealtime over the loop: {mhz:.0f} MHz; loop {t[:, :, 6].median().item() / 100:.1f} us per tile")
       print(f"{M}x{N}x{K}: {tot:.0f} shader clocks per step (MFMA-bound: {ideal}); phases " + " ".join(f"{v:.0f}" for v in mean.tolist())
