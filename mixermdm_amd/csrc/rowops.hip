@@ -30,7 +30,7 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {      // OCP e4m3, RNE,
 // OMODE: 0 fp32, 1 bf16, 2 the two fp16 planes of the fp32-split mode (kernels.h mmdm_split2, plane stride rows*D), 3 fp8 e4m3 with a per-row scale (row_scale[row] =
 // max|y| / 448; the fp8 GEMM multiplies it back in its epilogue)
 template <int MAXV, int OMODE>
-__global__ __launch_bounds__(256) void adaln_kernel(const float* __restrict__ h, const float* __restrict__ ss, int ss_ld, int ss_rows,
+__global__ __launch_bounds__(256, MAXV <= 4 ? 8 : 4) void adaln_kernel(const float* __restrict__ h, const float* __restrict__ ss, int ss_ld, int ss_rows,
                                                      void* __restrict__ outv, int rows, int T, int D, float* __restrict__ row_scale = nullptr) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;                                   // float4 per row (D % 4 == 0 checked on host)
