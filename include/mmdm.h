@@ -17,6 +17,7 @@
  * Environment variables the library reads (all optional; nothing else in the environment changes its behaviour):
  *   MMDM_NO_OVERLAP=1    mmdm_create: run the two denoisers and the two Influence calls of a step on ONE stream (profiling passes:
  *                        a kernel trace without concurrent kernels); results are bit-identical either way.
+ *   MMDM_NO_SPLIT_EMBED=1  precision 1-3: keep motion_embed on the fp32 MFMA kernel instead of the fp32-split kernel (A/B timing and accuracy)
  *   MMDM_GRAPH_CACHE=n   mmdm_create: capacity (1..64, default 8) of the handle's (B, T, S)-keyed cache of captured step graphs.
  *   MMDM_NO_PACK=1       keep the low-precision weight twins of precision 1-3 in row-major planes instead of MFMA fragment order (the
  *                        packed and the plane kernels are bit-identical; tests/test_gpu_packed_modes.py compares them).

@@ -402,6 +402,22 @@ __global__ void repack_pose_kernel(const float* __restrict__ src, int ld_src, fl
     dst[i] = c < MMDM_NF ? src[r * ld_src + (size_t)p * MMDM_NF + c] : 0.f;
 }
 
+// the same rows as the two fp16 planes of the fp32-split GEMM (kernels.h mmdm_split2): dst [npers][2][rows][ldp]
+__global__ void repack_pose_split_kernel(const float* __restrict__ src, int ld_src, _Float16* __restrict__ dst, int npers, int rows, int ldp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)rows * ldp;
+    if (i >= per * npers) return;
+    const int p = (int)(i / per);
+    const size_t rem = i - (size_t)p * per;
+    const size_t r = rem / ldp;
+    const int c = (int)(rem - r * ldp);
+    const float x = c < MMDM_NF ? src[r * ld_src + (size_t)p * MMDM_NF + c] : 0.f;
+    _Float16 h, l;
+    mmdm_split2(x, h, l);
+    dst[(size_t)p * 2 * per + rem] = h;
+    dst[(size_t)p * 2 * per + per + rem] = l;
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int n, int D) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n * D) return;
@@ -519,10 +535,12 @@ extern "C" int mmdm_dual_ddim_f32(const float* m_ind, const float* m_int, const 
     return mmdm_check_launch("dual_ddim");
 }
 
-int mmdm_repack_pose(const float* src, int ld_src, float* dst, int npers, int rows, int ldp, hipStream_t st) {
+// split != 0: dst receives [npers][2 planes][rows][ldp] fp16 (the A operand of mmdm_linear_split) instead of [npers][rows][ldp] fp32
+int mmdm_repack_pose(const float* src, int ld_src, float* dst, int npers, int rows, int ldp, int split, hipStream_t st) {
     const size_t total = (size_t)npers * rows * ldp;
     if (total == 0) return MMDM_OK;
-    hipLaunchKernelGGL(repack_pose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, ld_src, dst, npers, rows, ldp);
+    if (split) hipLaunchKernelGGL(repack_pose_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, ld_src, reinterpret_cast<_Float16*>(dst), npers, rows, ldp);
+    else hipLaunchKernelGGL(repack_pose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, ld_src, dst, npers, rows, ldp);
     return mmdm_check_launch("repack_pose");
 }
 

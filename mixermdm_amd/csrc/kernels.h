@@ -103,7 +103,7 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
 int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
                   int nseq, int T, int D, hipStream_t st);
 int mmdm_mdm_unpack(const float* src, float* dst, int nseq, int T, int D, hipStream_t st);
-int mmdm_repack_pose(const float* src, int ld_src, float* dst, int npers, int rows, int ldp, hipStream_t st);
+int mmdm_repack_pose(const float* src, int ld_src, float* dst, int npers, int rows, int ldp, int split, hipStream_t st);
 int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W, int ldw, int64_t w_plane, const float* bias, void* C, int ldc,
                          int64_t c_plane, int out_split, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period,
                          void* planes2, int ld2, int64_t plane2_stride, int planes2_cols, void* stream);

@@ -82,6 +82,7 @@ extern "C" const char* mmdm_version(void) { return "gfx950;mmdm-hip r3"; }
 namespace {
 
 constexpr int NF = MMDM_NF, NF2 = 2 * MMDM_NF;
+constexpr int NFS = 320;  // pose width of the embedding GEMM on the fp32-split kernel (precision >= 1): K a multiple of its 64-element packed step
 constexpr int NFP = 272;  // pose width padded to the GEMM's K step (16 floats): motion_embed weights are stored [D, 272] with zero columns and
                           // the embedding GEMMs read repacked, zero-padded pose rows (mmdm_repack_pose), so they run on the LDS-DMA kernel
 
@@ -127,6 +128,7 @@ struct ModuleW {         // denoiser or mixer front/back ends
     std::vector<EncLayerW> enc;                  // kind == 1
     float *pe = nullptr;                         // [5000, D]
     float *me_w = nullptr, *me_b = nullptr;      // motion_embed [D, 262] stored with ld NFP
+    void* me_s = nullptr;                        // precision >= 1: motion_embed as two fp16 planes [2][D][NFS] in fragment order (embedding on the fp32-split kernel)
     float *te_w = nullptr, *te_b = nullptr;      // text_embed [D, text_dim]
     float *t0_w = nullptr, *t0_b = nullptr, *t2_w = nullptr, *t2_b = nullptr;   // embed_timestep.time_embed.{0,2}
     float *out_w = nullptr, *out_b = nullptr;    // out.linear [262, D] / influence.out [nw, D]
@@ -135,7 +137,7 @@ struct ModuleW {         // denoiser or mixer front/back ends
 
 struct Scratch {          // transformer-stack work buffers (one set per concurrently running stack)
     float *h = nullptr, *xn = nullptr, *qkv = nullptr, *kv = nullptr, *att = nullptr, *f1 = nullptr;
-    float *xp = nullptr;      // [2][rows][NFP] repacked pose operands of the embedding GEMMs
+    float *xp = nullptr;      // [2][rows][NFP] repacked pose operands of the embedding GEMMs (fp32), or [2][2 planes][rows][NFS] fp16
     void *qk = nullptr, *kvp = nullptr;   // precision >= 1: bf16 plane copies of the attention's Q|K ([planes][R][2D]) and cross-attention K ([planes][R][D])
     float* xs = nullptr;                  // precision == 3: per-row scales of the fp8 AdaLN output in xn
 };
@@ -214,6 +216,7 @@ struct mmdm_handle_s {
     bool overlap = true;
     // switches read from the environment ONCE, at mmdm_create (include/mmdm.h lists them): a handle's behaviour never changes afterwards
     bool force_qkp = false, no_qkp = false, no_pvb = false, no_pack = false;      // MMDM_QKP, MMDM_NO_QKP, MMDM_NO_BF16_PV, MMDM_NO_PACK
+    bool no_split_embed = false;                                                  // MMDM_NO_SPLIT_EMBED
 
     Prof prof;
 };
@@ -342,6 +345,11 @@ int build_module(mmdm_handle h, ModuleW& m, const std::string& pfx, const std::s
     add_ignored(h, pfx + "embed_timestep.sequence_pos_encoder.pe");
     RC(add_slot(h, pfx + "motion_embed.weight", &m.me_w, D, NF, NFP));
     RC(add_slot(h, pfx + "motion_embed.bias", &m.me_b, D, 1));
+    if (h->cfg.precision >= 1 && D % 128 == 0) {      // the embedding of the low-precision modes runs on the fp32-split kernel (embed())
+        float* q = nullptr;
+        RC(dalloc(h, &q, (size_t)D * NFS));           // two fp16 planes [2][D][NFS]
+        m.me_s = q;
+    }
     RC(add_slot(h, pfx + "text_embed.weight", &m.te_w, D, td));
     RC(add_slot(h, pfx + "text_embed.bias", &m.te_b, D, 1));
     RC(add_slot(h, pfx + "embed_timestep.time_embed.0.weight", &m.t0_w, D, D));
@@ -486,11 +494,12 @@ int linear_8(const Ctx& c, const void* A, int lda, const float* a_scale, const v
 
 // fp32-split GEMM (precision == 2): A and W as two fp16 planes, fp32 accuracy on the 16-bit matrix cores (gemm_split.hip)
 int linear_s(const Ctx& c, const void* A, int lda, size_t a_plane, const void* W, int ldw, size_t w_plane, const float* bias, void* C, int ldc,
-             size_t c_plane, int out_split, int M, int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second()) {
-    RC(prof_begin(c, 0, 2.0 * M * N * K, 2.0 * MMDM_SPLIT_NPL * ((double)M * K + (double)N * K) + 4.0 * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
-    RC(mmdm_linear_split_ex(A, lda, (int64_t)a_plane, W, ldw, (int64_t)w_plane, bias, C, ldc, (int64_t)c_plane, out_split, M, N, K, epi, extra, ld_extra, 0,
+             size_t c_plane, int out_split, int M, int N, int K, int epi, const float* extra, int ld_extra, Second s2 = Second(), int period = 0) {
+    const int cls = c.h && c.h->cfg.precision != 2 ? 3 : 0;       // in a bf16 / fp8 handle this is one of the fp32-accurate side GEMMs
+    RC(prof_begin(c, cls, 2.0 * M * N * K, 2.0 * MMDM_SPLIT_NPL * ((double)M * K + (double)N * K) + 4.0 * M * N * (epi == MMDM_EPI_BIAS_RESID ? 2 : 1)));
+    RC(mmdm_linear_split_ex(A, lda, (int64_t)a_plane, W, ldw, (int64_t)w_plane, bias, C, ldc, (int64_t)c_plane, out_split, M, N, K, epi, extra, ld_extra, period,
                             s2.p, s2.ld, (int64_t)s2.plane, s2.cols, c.st));
-    return prof_end(c, 0);
+    return prof_end(c, cls);
 }
 
 // attention whose Q K^T runs on the bf16 matrix cores from the plane copies written by the projection GEMMs
@@ -627,9 +636,22 @@ int cond_vectors(const Ctx& c, const ModuleW& m, const float* txt, float* se, fl
 }
 
 // motion_embed + positional encoding of one person slice (in2in.py:426-431): x [nb*T rows, ld 524 or 262] -> h rows
-// xpad: one person's repacked rows [nb*T, NFP] (mmdm_repack_pose); pe_row0 = 1 for MDMDenoiser (token 0 is the conditioning token)
-int embed(const Ctx& c, const ModuleW& m, const float* xpad, float* hdst, int nb, int T, int pe_row0 = 0) {
-    return linear(c, xpad, NFP, m.me_w, NFP, m.me_b, hdst, m.st.D, nb * T, m.st.D, NFP, MMDM_EPI_BIAS_PE, m.pe + (size_t)pe_row0 * m.st.D, m.st.D, T, NFP);
+// xp: the repacked pose rows of `repack` below, `rows` = nb*T rows per person; pe_row0 = 1 for MDMDenoiser (token 0 is the conditioning token).
+// Low-precision handles (m.me_s): the embedding runs on the fp32-split kernel -- fp32-accurate like the fp32 MFMA kernel it replaces there, at a
+// third of its time (K = 262 is 10 steps of the packed kernel); the fp32 mode keeps the fp32 MFMA kernel.
+int embed(const Ctx& c, const ModuleW& m, const float* xp, int p, float* hdst, int nb, int T, int pe_row0 = 0) {
+    const float* pe = m.pe + (size_t)pe_row0 * m.st.D;
+    const size_t rows = (size_t)nb * T;
+    if (m.me_s) {
+        const _Float16* a = reinterpret_cast<const _Float16*>(xp) + (size_t)p * 2 * rows * NFS;
+        return linear_s(c, a, NFS, rows * NFS, m.me_s, c.h->no_pack ? NFS : 0, (size_t)m.st.D * NFS, m.me_b, hdst, m.st.D, 0, 0, nb * T, m.st.D, NFS, MMDM_EPI_BIAS_PE, pe,
+                        m.st.D, Second(), T);
+    }
+    return linear(c, xp + (size_t)p * rows * NFP, NFP, m.me_w, NFP, m.me_b, hdst, m.st.D, nb * T, m.st.D, NFP, MMDM_EPI_BIAS_PE, pe, m.st.D, T, NFP);
+}
+// pose rows x [rows, ldx] (npers persons side by side) -> the embedding GEMM's A operand: fp32 [npers][rows][NFP], or the two fp16 planes [npers][2][rows][NFS]
+int repack(const Ctx& c, const ModuleW& m, const float* x, int ldx, float* xp, int npers, int rows) {
+    return m.me_s ? mmdm_repack_pose(x, ldx, xp, npers, rows, NFS, 1, c.st) : mmdm_repack_pose(x, ldx, xp, npers, rows, NFP, 0, c.st);
 }
 
 // denoiser1 on the CFG-doubled batch n; xa [B or n rows...]: source rows are taken from `x` with `xrows` samples, repeated to n.
@@ -645,11 +667,11 @@ int run_denoiser(const Ctx& c, const ModuleW& m, bool interaction, const float* 
     r.ca_mode = interaction ? 1 : 0;
     r.kv_src = nullptr;
     // embed: `x` holds xb samples (xb == n, or xb == n/2 when cond/uncond halves share the same x: cfg_sampler.py:41-42)
-    RC(mmdm_repack_pose(x, ldx, c.s->xp, npers, xb * T, NFP, c.st));
+    RC(repack(c, m, x, ldx, c.s->xp, npers, xb * T));
     for (int p = 0; p < npers; ++p)
         for (int rep = 0; rep < n / xb; ++rep) {
             const size_t row0 = ((size_t)p * n + (size_t)rep * xb) * T;
-            RC(embed(c, m, c.s->xp + (size_t)p * xb * T * NFP, c.s->h + row0 * D, xb, T));
+            RC(embed(c, m, c.s->xp, p, c.s->h + row0 * D, xb, T));
         }
     RC(run_stack(c, m.st, c.s->h, r));
     for (int p = 0; p < npers; ++p)   // FinalLayer (layers.py:109-116), per person, concatenated on the channel axis (in2in.py:455-461)
@@ -689,10 +711,10 @@ int run_denoiser_mdm(const Ctx& c, const ModuleW& m, const float* x, int xb, int
     const Scratch& S = *c.s;
     const int D = m.st.D, nseq = npers * n;
     // pose embeddings + pe[1 + t] (token 0 is the conditioning token) into S.att, then assemble [nseq, T+1, D] in S.h
-    RC(mmdm_repack_pose(x, ldx, S.xp, npers, xb * T, NFP, c.st));
+    RC(repack(c, m, x, ldx, S.xp, npers, xb * T));
     for (int p = 0; p < npers; ++p)
         for (int rep = 0; rep < n / xb; ++rep)
-            RC(embed(c, m, S.xp + (size_t)p * xb * T * NFP, S.att + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T, 1));
+            RC(embed(c, m, S.xp, p, S.att + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T, 1));
     for (int p = 0; p < npers; ++p)
         RC(mmdm_mdm_pack(S.att + (size_t)p * n * T * D, cond + (size_t)p * D, ldc, m.time_tab, c.h->d_step, m.pe,
                          S.h + (size_t)p * n * (T + 1) * D, n, T, D, c.st));
@@ -714,10 +736,10 @@ int text_rows(const Ctx& c, const ModuleW& m, const float* cond, int ldc, int co
 // blocks in the reference, so its output is the LAST block applied once to the embedded input.
 int run_dual_individual(const Ctx& c, const ModuleW& m, const float* x, int xb, int n, int T, const float* ss, int ss_ld, float* out) {
     const int D = m.st.D;
-    RC(mmdm_repack_pose(x, NF2, c.s->xp, 2, xb * T, NFP, c.st));
+    RC(repack(c, m, x, NF2, c.s->xp, 2, xb * T));
     for (int p = 0; p < 2; ++p)
         for (int rep = 0; rep < n / xb; ++rep)
-            RC(embed(c, m, c.s->xp + (size_t)p * xb * T * NFP, c.s->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
+            RC(embed(c, m, c.s->xp, p, c.s->h + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T));
     StackRun r;
     r.nseq = n; r.T = T; r.ss = ss; r.ss_ld = ss_ld;
     r.ca_row0 = 0; r.ca_rows = n; r.ca_mode = 0; r.kv_src = nullptr;
@@ -737,8 +759,8 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     const mmdm_config& cf = H->cfg;
     RC(mmdm_mixer_pre_f32(H->o1, H->o2, H->d_stats, H->out1, H->out2, n, T, cf.align, c.st));
     // motion_embed + PE of the four streams (mixermdm.py:722-732); seq = p*n + b
-    RC(mmdm_repack_pose(H->out1, NF2, H->sa.xp, 2, n * T, NFP, c.st));
-    RC(mmdm_repack_pose(H->out2, NF2, H->sb.xp, 2, n * T, NFP, c.st));
+    RC(repack(c, H->mx, H->out1, NF2, H->sa.xp, 2, n * T));
+    RC(repack(c, H->mx, H->out2, NF2, H->sb.xp, 2, n * T));
     StackRun r;
     r.nseq = 2 * n; r.T = T; r.ss = H->ss_mx; r.ss_ld = ss_ld_of(H->mx);
     r.sa_row0 = 0; r.sa_rows = 2 * n;          // cond_i1 | cond_i2
@@ -747,8 +769,8 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     r.ca_mode = 2; r.kv_src = H->mI;
     const bool split = H->overlap && !H->prof.on && c.s == &H->sa && H->sb.h;      // the two Influence calls on two streams, each with its own scratch
     for (int p = 0; p < 2; ++p) {
-        RC(embed(c, H->mx, H->sa.xp + (size_t)p * n * T * NFP, c.s->h + (size_t)p * n * T * Dm, n, T));
-        RC(embed(c, H->mx, H->sb.xp + (size_t)p * n * T * NFP, H->mI + (size_t)p * n * T * Dm, n, T));
+        RC(embed(c, H->mx, H->sa.xp, p, c.s->h + (size_t)p * n * T * Dm, n, T));
+        RC(embed(c, H->mx, H->sb.xp, p, H->mI + (size_t)p * n * T * Dm, n, T));
     }
     if (split) {
         // the two Influence calls (mixermdm.py:735-736: person 1, person 2) are independent: one per stream (64.7 -> 64.2 ms/step)
@@ -964,7 +986,7 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
         const size_t opx = c.precision == 2 ? MMDM_SPLIT_NPL : 2;       // in half-floats
         if ((rc = dalloc(h, &sc->h, R * d)) || (rc = dalloc(h, &sc->xn, R * d * opx / 2)) || (rc = dalloc(h, &sc->att, R * d * opx / 2)) ||
             (rc = dalloc(h, &sc->qkv, R * 3 * d)) || (rc = dalloc(h, &sc->kv, R * 2 * d)) || (rc = dalloc(h, &sc->f1, R * f * opx / 2)) ||
-            (rc = dalloc(h, &sc->xp, (size_t)2 * n * T * NFP)))
+            (rc = dalloc(h, &sc->xp, (size_t)2 * n * T * (NFS > NFP ? NFS : NFP))))
             return fail(rc);
         if (c.precision >= 1) {
             const size_t npl = c.precision == 2 ? 3 : 1;
@@ -984,6 +1006,7 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     auto env_on = [](const char* k) { const char* v = getenv(k); return v != nullptr && strcmp(v, "0") != 0; };
     h->force_qkp = env_on("MMDM_QKP"); h->no_qkp = env_on("MMDM_NO_QKP"); h->no_pvb = env_on("MMDM_NO_BF16_PV");
     h->no_pack = env_on("MMDM_NO_PACK") || env_on("MMDM_SPLIT_NO_PACK");
+    h->no_split_embed = env_on("MMDM_NO_SPLIT_EMBED");
     const size_t PT = (size_t)n * T * (so == 1 ? NF : NF2);
     const size_t PB = (size_t)B * T * (so == 1 ? NF : NF2);
     if ((rc = dalloc(h, &h->x, PB)) || (rc = dalloc(h, &h->px1, PB))) return fail(rc);
@@ -1145,6 +1168,23 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
                 if (!rc && st.has_ca) rc = conv(lw.ca_out_w, lb.ca_out_w, D * D, D);
                 if (rc) return herr(h, rc);
             }
+        }
+        // motion_embed [D, NFP] fp32 -> zero-padded [D, NFS] -> two fp16 planes (-> fragment order unless MMDM_NO_PACK)
+        for (ModuleW* m : {&h->d1, &h->d2, &h->mx}) {
+            if (h->no_split_embed) m->me_s = nullptr;        // the embedding stays on the fp32 MFMA kernel (A/B switch)
+            if (!m->me_s) continue;
+            const int64_t D = m->st.D, n = D * NFS;
+            float* w32 = nullptr; void* pl = nullptr;
+            HIPCHK(hipMalloc(&w32, n * 4));
+            struct F1 { void* p; ~F1() { (void)hipFree(p); } } f1{w32};
+            HIPCHK(hipMalloc(&pl, n * 4));
+            struct F2 { void* p; ~F2() { (void)hipFree(p); } } f2{pl};
+            HIPCHK(hipMemsetAsync(w32, 0, n * 4, nullptr));
+            HIPCHK(hipMemcpy2DAsync(w32, NFS * sizeof(float), m->me_w, NFP * sizeof(float), NFP * sizeof(float), D, hipMemcpyDeviceToDevice, nullptr));
+            int rc = mmdm_f32_split(w32, no_pack ? m->me_s : pl, n, n, nullptr);
+            if (!rc && !no_pack) rc = mmdm_split_pack_weight(pl, NFS, n, m->me_s, n, (int)D, NFS, nullptr);
+            if (rc) return herr(h, rc);
+            HIPCHK(hipDeviceSynchronize());
         }
         HIPCHK(hipDeviceSynchronize());
     }

@@ -64,3 +64,32 @@ def test_a_wrong_channel_block_fails(pair, lo, hi, what):
     out["x2"][..., lo:hi] += 1e-2
     with pytest.raises(AssertionError, match="x2"):
         compare_step(out, r32, r64, what)
+
+
+def test_one_turned_joint_passes_only_where_the_oracle_itself_is_ill_conditioned(pair):
+    """Hard-bound rule of compare_step: a whole rot6d sextet (one joint of one frame) far off is accepted only if the CPU fp32 oracle's own distance
+    from float64 on that joint is >= ILL_JOINT x the tensor's median -- the signature of a near-collinear rot6d pair; the same deviation on a joint
+    the oracle finds well-conditioned fails, and so do two such joints."""
+    r32, r64, _ = pair
+    b, t, c0 = 1, 7, 262 + 132 + 6 * 20                       # person 2, joint 20
+    out = {k: v.clone() for k, v in r32.items()}
+    out["pred_xstart"][b, t, c0:c0 + 5] += torch.tensor([0.1, 1.5, 0.3, 0.8, 0.2])
+    with pytest.raises(AssertionError, match="well-conditioned"):
+        compare_step(out, r32, r64, "turned joint, well-conditioned")
+    ill32 = {k: v.clone() for k, v in r32.items()}
+    ill32["pred_xstart"][b, t, c0:c0 + 6] += 4e-4              # the fp32 oracle itself is 4e-4 from float64 on this joint
+    out2 = {k: v.clone() for k, v in ill32.items()}
+    out2["pred_xstart"][b, t, c0:c0 + 5] += torch.tensor([0.1, 1.5, 0.3, 0.8, 0.2])
+    compare_step(out2, ill32, r64, "turned joint, ill-conditioned")
+    ill32["pred_xstart"][0, 3, c0:c0 + 6] += 4e-4
+    out3 = {k: v.clone() for k, v in ill32.items()}
+    out3["pred_xstart"][b, t, c0:c0 + 5] += 1.0
+    out3["pred_xstart"][0, 3, c0:c0 + 5] += 1.0
+    with pytest.raises(AssertionError, match="2 joints"):
+        compare_step(out3, ill32, r64, "two turned joints")
+    out4 = {k: v.clone() for k, v in r32.items()}                 # round 3's allowance: two single components, no evidence asked, no event
+    out4["pred_xstart"][b, t, c0:c0 + 2] += 0.2
+    compare_step(out4, r32, r64, "two components")
+    assert compare_step.events == 0
+    compare_step(out2, {k: v.clone() for k, v in ill32.items()}, r64, "event")
+    assert compare_step.events == 1
