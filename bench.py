@@ -196,7 +196,7 @@ def main():
             p_ach = p_fl / (p_ms * 1e-3) / 1e12
             fp32_side = {"achieved": round(p_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(p_ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_per_step": p_n // args.profile_steps,
                          "avg_launch_us": round(p_ms * 1e3 / p_n, 2), "ms_per_step": round(p_ms / args.profile_steps, 3),
-                         "what": "embedding / conditioning / head GEMMs of this mode: fp32 operands on the fp32 kernel"}
+                         "what": "the fp32-accurate side GEMMs of this mode: motion_embed on the fp32-split kernel (fp16 planes, three MFMAs per block), conditioning projections and heads on the fp32 MFMA kernel; priced against the fp32 MFMA peak"}
         if args.precision == "bf16_fp8" and f_n:
             b_ach = g_fl / (g_ms * 1e-3) / 1e12
             other = {"achieved": round(b_ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(b_ach / PEAK_BF16_MFMA_TFLOPS, 4), "launches_per_step": g_n // args.profile_steps,
