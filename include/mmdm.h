@@ -168,7 +168,7 @@ int mmdm_attention_bf16(const void* Qp, int ldq, const void* Kp, int ldk, const 
 /* The attention of the fp32-split precision mode: Q, K and V are each given as the two fp16 planes of mmdm_linear_split (h, l with
  * x ~= h + l / 2048; [2][rows][ld], plane strides in elements) -- what the projection GEMM writes with out_split instead of fp32 rows.
  * Scores: hi += kh qh, lo += kl qh + kh ql (three v_mfma_f32_16x16x32_f16 per 32-deep step), S = hi + lo / 2048; fp32 softmax; the
- * probabilities are split the same way on the fly and P.V accumulates hi / lo likewise (three v_mfma_f32_16x16x16_f16 per 16 columns).
+ * probabilities are split the same way on the fly (kept <= 16 by the deferred running maximum) and P.V is three v_mfma_f32_16x16x16_f16 per 16 columns.
  * As accurate against float64 as mmdm_attention_f32 (tests), ~2.5x faster.  out_mode / flags as mmdm_attention_planes.  dh = 64 or 128. */
 int mmdm_attention_split(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, const void* Vp, int ldv, int64_t v_plane,
                          void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);

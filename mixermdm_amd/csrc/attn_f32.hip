@@ -466,12 +466,15 @@ __device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y
 // (DH = 64) x = ((r >> 1) & 3) << 1 -- without it the eight rows a 32-lane half reads sit on the same banks.
 // H2 (NP = 2, PVB): the fp32-split mode's attention.  Q, K and V arrive as the two fp16 planes the projection GEMM wrote INSTEAD of fp32 rows (same
 // bytes), x ~= h + l / 2048 (kernels.h).  Scores: hi += kh*qh, lo += kl*qh + kh*ql (three v_mfma_f32_16x16x32_f16 per 32-deep step), S = hi + lo / 2048;
-// softmax in fp32 as everywhere; P.V the same way: the probabilities are split on the fly (p < 2^8 with the deferred maximum), o_hi += ph*vh,
-// o_lo += ph*vl + pl*vh (three v_mfma_f32_16x16x16_f16 per 16 columns), O = (o_hi + o_lo / 2048) / l.  fp32-accurate like the split GEMMs (the same
-// argument: representation error 2^-22 per operand, below the fp32 accumulation error of the 32x32x2 / 16x16x4 fp32 MFMA chains it replaces), at
-// 36 short MFMAs per 16-key chunk instead of 64 long ones.
+// softmax in fp32 as everywhere; P.V the same way with the probabilities split on the fly -- and ONE accumulator set: the kernel lives on the number
+// of resident waves (LAB_NOTES, round 4), and a second set would cost 32 registers.  With the deferred running maximum at +4 instead of +8 every
+// probability is <= 16, so ph * 2048 (<= 32768) is an fp16 number and all three products can be formed AT THE SCALE 2^11:
+//   o += pl' * vh + ph * vl' + (ph * 2048) * vh        (pl' = (p - ph) * 2048 and vl' = (v - vh) * 2048 are the lo planes as stored)
+// (three v_mfma_f32_16x16x16_f16 per 16 columns), O = o / 2048 / l -- exact scalings.  fp32-accurate like the split GEMMs (the same argument:
+// representation error 2^-22 per operand, below the fp32 accumulation error of the 32x32x2 / 16x16x4 fp32 MFMA chains it replaces), at 36 short
+// MFMAs per 16-key chunk instead of 64 long ones.
 template <int DH, int NP, bool PVB = false, bool H2 = false>
-__global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {      // H2: four waves per SIMD (128 registers)
 #if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
     static_assert(!PVB || NP == 1 || H2, "bf16 P.V goes with bf16 scores");
     static_assert(!H2 || (NP == 2 && PVB), "the fp16 two-plane form covers Q K^T and P.V together");
@@ -520,11 +523,9 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
             for (int s = 0; s < NS; ++s) qf[pl][s] = *reinterpret_cast<const bf16x8*>(qp + (size_t)pl * p.q_plane + 32 * s);
     }
 
-    f32x4 o[NJ], ol[H2 ? NJ : 1];               // ol: the lo accumulators of the two-plane form
+    f32x4 o[NJ];                                // (H2: at the scale 2^11)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < (H2 ? NJ : 1); ++j) ol[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool nozero = (p.flags & MMDM_ATTN_NO_ZERO_KEY) != 0, causal = (p.flags & MMDM_ATTN_CAUSAL) != 0;
     float m_run = nozero ? -INFINITY : 0.f, l_run = nozero ? 0.f : 1.f;
 
@@ -601,22 +602,18 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
                 kf[pl][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Ks[pl * KPLANE + lq * (DH / 2) + 4 * ((4 * s + g) ^ (lq & (CPRK - 1)))]));
         f32x4 st[1];
         if constexpr (H2) {
-            f32x4 sl[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) sl[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // two accumulator chains per sum (even / odd 32-deep steps): 16 registers instead of 32, dependent MFMAs two apart
+            f32x4 sl[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             auto hb = [](const bf16x8& v) { return __builtin_bit_cast(h16x8, v); };
 #pragma unroll
-            for (int s = 0; s < NS; ++s) sl[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb(kf[1][s]), hb(qf[0][s]), sl[s], 0, 0, 0);
+            for (int s = 0; s < NS; ++s) sl[s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb(kf[1][s]), hb(qf[0][s]), sl[s & 1], 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) sl[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb(kf[0][s]), hb(qf[1][s]), sl[s], 0, 0, 0);
+            for (int s = 0; s < NS; ++s) sl[s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb(kf[0][s]), hb(qf[1][s]), sl[s & 1], 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) sa[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb(kf[0][s]), hb(qf[0][s]), sa[s], 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) { MFMA_SETTLE(sa[s]); MFMA_SETTLE(sl[s]); }
-            f32x4 lo = sl[0];
-            st[0] = sa[0];
-#pragma unroll
-            for (int s = 1; s < NS; ++s) { st[0] += sa[s]; lo += sl[s]; }
+            for (int s = 0; s < NS; ++s) sa[s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hb(kf[0][s]), hb(qf[0][s]), sa[s & 1], 0, 0, 0);
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sl[0]), "+v"(sl[1]));      // MFMA_SETTLE for the four chains at once
+            const f32x4 lo = sl[0] + sl[1];
+            st[0] = sa[0] + sa[1];
 #pragma unroll
             for (int r = 0; r < 4; ++r) st[0][r] = __builtin_fmaf(lo[r], MMDM_SPLIT_INV, st[0][r]);
         } else {
@@ -641,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
         }
         float cmax = vmax3(st[0][0], st[0][1], vmax(st[0][2], st[0][3]));
         cmax = rows_max(cmax);
-        const float m_new = cmax > m_run + 8.0f ? cmax : m_run;        // deferred reference, as in attn_mfma_kernel
+        const float m_new = cmax > m_run + (H2 ? 4.0f : 8.0f) ? cmax : m_run;        // deferred reference, as in attn_mfma_kernel (H2: p <= 2^4, see above)
         const float alpha = EXP2(m_run - m_new);
 #pragma unroll
         for (int r = 0; r < 4; ++r) st[0][r] = EXP2(st[0][r] - m_new);
@@ -658,35 +655,36 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];
-            if constexpr (H2) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ol[j][r] *= ar[r];
-            }
         }
 
         if constexpr (H2) {
             typedef short s16x4 __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-            mmdm_h4 ph, pl;
+            mmdm_h4 ph, pl, phs;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const _Float16 t = mmdm_split_hi(st[0][r]); ph[r] = t; pl[r] = mmdm_split_lo(st[0][r], t); }
+            for (int r = 0; r < 4; ++r) {
+                const _Float16 t = mmdm_split_hi(st[0][r]);
+                ph[r] = t; pl[r] = mmdm_split_lo(st[0][r], t); phs[r] = (_Float16)((float)t * MMDM_SPLIT_SCALE);       // exact: p <= 16
+            }
             const int vrow = 4 * g + (lq >> 2), pp = lq & 3;
             const int xv = DH == 128 ? (((vrow & 3) << 2) | ((vrow >> 2) & 3)) : (((vrow >> 1) & 3) << 1);
             const char* vbase = reinterpret_cast<const char*>(Vs) + vrow * (DH * 2) + 8 * (pp & 1);
-            mmdm_h4 vh[NJ], vl[NJ];
+            constexpr int JG = 4;                  // column tiles per group: the three MFMAs on an accumulator are JG apart, 4 JG registers of V fragments live
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                vh[j] = __builtin_bit_cast(mmdm_h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vbase + 16 * ((2 * j + (pp >> 1)) ^ xv))));
-                vl[j] = __builtin_bit_cast(mmdm_h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vbase + VPLANE * 4 + 16 * ((2 * j + (pp >> 1)) ^ xv))));
+            for (int j0 = 0; j0 < NJ; j0 += JG) {
+                mmdm_h4 vh[JG], vl[JG];
+#pragma unroll
+                for (int j = 0; j < JG; ++j) {
+                    vh[j] = __builtin_bit_cast(mmdm_h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vbase + 16 * ((2 * (j0 + j) + (pp >> 1)) ^ xv))));
+                    vl[j] = __builtin_bit_cast(mmdm_h4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vbase + VPLANE * 4 + 16 * ((2 * (j0 + j) + (pp >> 1)) ^ xv))));
+                }
+#pragma unroll
+                for (int j = 0; j < JG; ++j) o[j0 + j] = __builtin_amdgcn_mfma_f32_16x16x16f16(pl, vh[j], o[j0 + j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < JG; ++j) o[j0 + j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, vl[j], o[j0 + j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < JG; ++j) o[j0 + j] = __builtin_amdgcn_mfma_f32_16x16x16f16(phs, vh[j], o[j0 + j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) ol[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, vl[j], ol[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) ol[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(pl, vh[j], ol[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) o[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, vh[j], o[j], 0, 0, 0);
         } else if constexpr (PVB) {
             typedef short s16x4 __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
@@ -718,14 +716,6 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
-    if constexpr (H2) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            MFMA_SETTLE(ol[j]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[j][r] = __builtin_fmaf(ol[j][r], MMDM_SPLIT_INV, o[j][r]);
-        }
-    }
     float lr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run, 4 * g + r);
@@ -734,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkp_kernel(AttnArgs p) {
         const int qrow = q0 + 4 * g + r;
         if (qrow >= p.Tq) continue;
         if constexpr (PVB) {                        // element (j, r) is column 16 j + lq of row 4g + r
-            const float inv = 1.0f / lr[r];
+            const float inv = (1.0f / lr[r]) * (H2 ? MMDM_SPLIT_INV : 1.0f);       // H2: the accumulators carry the scale 2^11 (an exact scaling)
             const size_t off = ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH + lq;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) store_out(p, off + 16 * j, o[j][r] * inv);
