@@ -409,6 +409,21 @@ def test_split_linear_is_as_accurate_as_the_fp32_mfma():
         ops.linear_split(ops.split_f32(x[:, :40].contiguous().to(dev())), ops.split_f32(w[:, :40].contiguous().to(dev())))
 
 
+def test_split_operand_beyond_the_fp16_range_is_loud_not_wrong():
+    """The fp32-split operand format covers |x| < 65504 (kernels.h); a value beyond it must surface as inf / NaN in every output it touches, never
+    as a finite wrong number, and must leave the other rows alone."""
+    from mixermdm_amd import ops
+    M, N, K = 64, 128, 64
+    x, w = rnd(301, M, K), rnd(302, N, K, scale=0.05)
+    x[5, 7] = 1.0e5
+    got = ops.linear_split(ops.split_f32(x.to(dev())), ops.split_f32(w.to(dev()))).cpu()
+    assert not torch.isfinite(got[5]).any()
+    rows = [r for r in range(M) if r != 5]
+    ref = (x.double() @ w.double().T).float()
+    assert torch.isfinite(got[rows]).all()
+    assert_close(got[rows], ref[rows], atol=1e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("B,T", [(2, 17), (1, 299), (3, 64)])
 def test_fp32_split_path_matches_oracle_like_the_fp32_path(full_small, B, T):
     """precision="fp32_split" against the CPU oracle at real head sizes, SAME tolerance as the native fp32 path (STEP_TOL), and at
