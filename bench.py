@@ -326,7 +326,8 @@ def main():
         which = "configs[1]" if single else ("configs[3] (batch 256 over 8 GPUs = 32 per GPU)" if world == 8 and B == 32 else
                                              "configs[3]'s per-GPU shard (32) on %d GPU(s)" % world if B == 32 else "configs[2]" if (B, T, args.sampler) == (16, 300, "ddim1000") else
                                              "the reference's own caller shape (src/scripts/infer/mixermdm.py:73,117-124; src/evaluation/datasets.py:58,100-116)" if args.sampler == "ddim50" else "configs[2] shape family")
-        wl = ("BASELINE configs[1]: single-person in2IN (individual denoiser, CFG 3.5), T=%d, %s (eta=0), batch %d per GPU, %s, random-init weights" % (T, args.sampler, B, args.precision)) if single else \
+        which1 = "configs[1]" if (B, T, args.sampler) == (32, 196, "ddim1000") else "configs[0] (the reference's CPU-runnable case, here on the GPU)" if (B, T, args.sampler) == (1, 120, "ddim50") else "configs[1] shape family"
+        wl = ("BASELINE %s: single-person in2IN (individual denoiser, CFG 3.5), T=%d, %s (eta=0), batch %d per GPU, %s, random-init weights" % (which1, T, args.sampler, B, args.precision)) if single else \
              ("BASELINE %s: 2-person MixerMDM (in2IN individual + in2IN interaction + Mixer mode 4, align, CFG 3.5), "
               "T=%d, %s (eta=0), batch %d per GPU, %s, random-init weights" % (which, T, args.sampler, B, {"fp32": "fp32", "fp32_split": "fp32 via two-way fp16 operand split (three fp16 MFMAs per product block)", "bf16": "bf16 GEMM operands / fp32 accumulate (configs[4]-style)", "bf16_fp8": "configs[4]: bf16 path with fp8 e4m3 QKV / FFN GEMM operands, fp32 accumulate"}[args.precision]))
         line = {

@@ -19,6 +19,7 @@
  *                        a kernel trace without concurrent kernels); results are bit-identical either way.
  *   MMDM_NO_SPLIT_EMBED=1  precision 1-3: keep motion_embed on the fp32 MFMA kernel instead of the fp32-split kernel (A/B timing and accuracy)
  *   MMDM_GRAPH_CACHE=n   mmdm_create: capacity (1..64, default 8) of the handle's (B, T, S)-keyed cache of captured step graphs.
+ *   MMDM_RAG_BUCKET=n    mmdm_create: row granularity (1..4096, default 128) to which a ragged call's group of frames is padded (mmdm_begin_ragged).
  *   MMDM_NO_PACK=1       keep the low-precision weight twins of precision 1-3 in row-major planes instead of MFMA fragment order (the
  *                        packed and the plane kernels are bit-identical; tests/test_gpu_packed_modes.py compares them).
  *   MMDM_QKP / MMDM_NO_QKP / MMDM_NO_BF16_PV   precision >= 1: force / forbid the bf16-plane Q K^T and the bf16 P V forms of the attention.
@@ -143,6 +144,13 @@ int mmdm_attention_f32(const float* Q, int ldq, const float* K, int ldk, const f
 /* Same with a selectable output type (fp32 Q/K/V in, fp32 softmax and accumulation; O fp32 or bf16). */
 int mmdm_attention_ex(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O, int ldo, int out_bf16,
                       int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
+
+/* mmdm_attention_f32 over a RAGGED batch: sequence s owns rows [seq_off[s], seq_off[s] + seq_len[s]) of Q / K / V / O (DEVICE int arrays of nseq
+ * entries; the K/V sequence of s is (s + kv_seq_shift) % nseq and may have another length); max_len >= every length sizes the grid; total_rows =
+ * rows of O.  dh = 64 or 128.  Per sequence bit-identical to mmdm_attention_f32 on that sequence alone.  (The 16-bit forms have the same ragged
+ * instantiations inside the sampler: mmdm_begin_ragged.) */
+int mmdm_attention_ragged_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                              int nseq, const int* seq_off, const int* seq_len, int max_len, int total_rows, int H, int dh, int kv_seq_shift, void* stream);
 
 /* Same with options.  flags: MMDM_ATTN_NO_ZERO_KEY = plain softmax over the Tk keys (nn.MultiheadAttention default, as inside
  * nn.TransformerEncoderLayer: MDMDenoiser.seqTransEncoder src/models/mdm.py:252-264, clipTransEncoder src/models/mixermdm.py:246-258);
@@ -302,7 +310,13 @@ typedef struct {
                         * 3: "bf16_fp8" (BASELINE configs[4]): as 1, with the QKV / cross-attention input projections and both FFN GEMMs on
                         *    fp8 e4m3 operands -- weights quantised per output channel at mmdm_prepare, AdaLN outputs quantised per row by
                         *    the AdaLN kernel, GELU outputs at unit scale -- fp32 accumulation and de-quantisation (mmdm_linear_fp8); the
-                        *    attention output projections stay bf16 */
+                        *    attention output projections stay bf16
+                        * RANGE PRECONDITION of precision 1, 2 and 3: some GEMM operands are carried in fp16 planes (precision 2: every operand of the
+                        *    transformer stacks -- AdaLN outputs, Q|K|V, attention outputs, GELU hidden; precision 1 and 3: the pose rows entering
+                        *    motion_embed, which run on the fp32-split kernel), so those values must satisfy |x| < 65504.  A larger pose or activation
+                        *    value becomes inf and then NaN in whole output rows (loud, never silently wrong); nothing clamps or checks at the boundary.
+                        *    Poses in the models' normalised space are O(10); precision 0 has no such limit.  MMDM_NO_SPLIT_EMBED=1 keeps the embedding
+                        *    of precision 1 / 3 handles on the fp32 MFMA kernel (no range limit there). */
     int model1_kind;   /* 0 = in2IN individual denoiser, 1 = MDMDenoiser (post-norm nn.TransformerEncoder with a conditioning token,
                         *    src/models/mdm.py:234-298; MODEL1.NAME == "MDM", src/models/mixermdm.py:32-40, 264-265).  Its cond slices are
                         *    latent-sized (mdm.py:279), so the mixer's cond rows are [3*text_dim | 2*d1_latent | 3*text_dim] */
@@ -310,6 +324,15 @@ typedef struct {
 } mmdm_config;
 
 int mmdm_create(const mmdm_config* cfg, mmdm_handle* out);
+/* A second sampler handle over the SAME weights: `parent` (prepared) keeps owning the parameter set, its low-precision twins and the normaliser
+ * statistics; the new handle borrows them by reference (the block is freed when the last handle that holds it is destroyed, in any order) and
+ * gets its own workspace sized for (max_batch, max_frames), its own streams, schedule tables, step state, history descriptor and graph cache.
+ * Same configuration otherwise.  K such handles on K streams keep K independent sampling calls in flight over one 1.46 GB weight copy -- the
+ * reference's callers sample one item at a time (src/scripts/infer/mixermdm.py:184-188 ten times B = 1; src/evaluation/datasets.py:100-116 per
+ * item), which fills ~60 % of one round of GEMM tiles on 256 CUs; two co-resident items overlap.  A motion's bits do not depend on what runs
+ * beside it.  mmdm_set_weight / mmdm_set_norm_stats on a shared handle return MMDM_ERR_STATE (set them on the parent; a parent re-prepared
+ * after mmdm_set_weight is seen by every holder); mmdm_prepare is a no-op there.  Handles are still not thread-safe individually. */
+int mmdm_create_shared(mmdm_handle parent, int max_batch, int max_frames, mmdm_handle* out);
 void mmdm_destroy(mmdm_handle h);
 const char* mmdm_handle_error(mmdm_handle h);
 
@@ -336,6 +359,25 @@ int mmdm_prepare(mmdm_handle h);
 /* Begin a sampling call: cond [B, 8*text_dim] (layout src/models/mixermdm.py:342-354) or [B, text_dim] (single_only),
  * x_T [B,T,524] (or [B,T,262]); both chains start from x_T (gaussian_diffusion.py:1863).  Precomputes the text embeddings. */
 int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, int B, int T, void* stream);
+
+/* RAGGED sampling call: B items of DIFFERENT lengths in one batch -- the shape of the reference's evaluation callers, which sample one item at
+ * a time with that item's own length (src/evaluation/datasets.py:58, 100-116: B = 1 or mm_num_repeats per call; per-item `motion_lens`), and
+ * of any service that batches requests.  lens_host: B HOST ints (frames of every item, 1 .. max_frames; consumed before the call returns);
+ * x_T: the items' frames back to back, [sum(lens), 524] (or 262); cond as mmdm_begin.  Layout during the call: the B items form a GROUP of
+ * `rows` frame rows (sum(lens) rounded up to the handle's row bucket, MMDM_RAG_BUCKET, default 128; padding rows are zero-initialised,
+ * processed like any row and never read by a real one); every buffer of k B sequences is k groups.  Where a sequence starts, its length and
+ * the (sequence, frame) of every row are DEVICE arrays written on `stream` by this call: GEMMs and row kernels see sum(lens) rows, the
+ * attention / PE / AdaLN-conditioning / geometry kernels index through the maps, and a captured step graph depends on (B, rows, query tiles of the
+ * longest item, S) only -- it is reused by every ragged batch of the same bucket.  Every item's result is BIT-IDENTICAL to sampling it alone
+ * with mmdm_begin (no kernel's arithmetic depends on a row's position in the batch; tests/test_gpu_ragged.py).  mmdm_get_state then points at
+ * [rows, 524] buffers whose first sum(lens) rows are the items back to back; history slots (mmdm_set_history) are [2 * rows, C] with the
+ * uncond half at row `rows`; mmdm_call_rows returns (rows, sum(lens)).  Covers the two-chain sampler and the single-person sampler over
+ * in2IN / InterGen denoisers with head sizes 64 / 128, every precision mode; B <= min(max_batch, 256), sum(lens) <= max_batch * max_frames;
+ * otherwise MMDM_ERR_UNSUPPORTED / MMDM_ERR_ARG.  mmdm_run / mmdm_seek / mmdm_set_history as after mmdm_begin. */
+int mmdm_begin_ragged(mmdm_handle h, const float* cond, const float* x_T, int B, const int* lens_host, void* stream);
+/* Frame rows per half of the CFG-doubled batch in the begun call's buffers (uniform: B * T), the frames that are real (ragged: sum(lens)),
+ * and whether the call is ragged.  Each pointer may be NULL. */
+int mmdm_call_rows(mmdm_handle h, int* rows, int* real_rows, int* ragged);
 
 /* Optional history side outputs (src/models/mixermdm.py:794-796, 805-808), CFG-doubled batch 2B.  Each pointer may be NULL.
  * Slot k of a buffer receives the step whose position in the loop is k*every (k = 0 .. ceil(S/every)-1).

@@ -74,6 +74,7 @@ SYMBOLS = {
     "mmdm_adaln_fp8": (_I, [_VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _VP]),
     "mmdm_set_dual_weights": (_I, [_VP, _VP, _I]),
     "mmdm_create": (_I, [C.POINTER(Config), C.POINTER(_VP)]),
+    "mmdm_create_shared": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
     "mmdm_destroy": (None, [_VP]),
     "mmdm_handle_error": (C.c_char_p, [_VP]),
     "mmdm_set_weight": (_I, [_VP, C.c_char_p, _VP, C.c_int64, C.c_int64, _VP]),
@@ -81,6 +82,9 @@ SYMBOLS = {
     "mmdm_set_schedule": (_I, [_VP, _VP, _VP, _I, _VP]),
     "mmdm_prepare": (_I, [_VP]),
     "mmdm_begin": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
+    "mmdm_begin_ragged": (_I, [_VP, _VP, _VP, _I, _VP, _VP]),
+    "mmdm_call_rows": (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "mmdm_attention_ragged_f32": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _I, _I, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "mmdm_set_history": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I]),
     "mmdm_run": (_I, [_VP, _I, _I, _VP]),
     "mmdm_seek": (_I, [_VP, _I, _VP]),

@@ -79,7 +79,20 @@ struct AttnArgs {
     int ldqp, ldkp;
     const __bf16* Vp; int ldvp;        // bf16 V rows (attn_qkp_kernel<DH, 1, true>: P.V on the bf16 matrix cores); nullptr = fp32 V
     size_t v_plane;                    // attn_qkp_kernel<DH, 2, true, true>: Q, K and V as the two fp16 planes of the fp32-split mode (Vp: plane stride v_plane)
+    size_t o_plane;                    // out_bf16 == 2: element stride between the two fp16 planes of O (= rows of O x ldo)
+    // RAGGED batch (the RAG instantiations; kernels.h mmdm_rag_seq): sequence s owns rows [seq_off[s], seq_off[s] + seq_len[s]) of every operand, lengths
+    // differ per sequence and live in device memory (one captured graph serves every batch of the same row bucket).  Tq / Tk are then the
+    // LONGEST sequence (grid size only); a query tile past its sequence's end leaves at once.
+    const int* seq_off; const int* seq_len;
 };
+
+// (Tq, Tk, first Q / O row, first K / V row) of a workgroup's (sequence, key sequence): kernel arguments in the uniform layout, two loads each in the ragged one
+struct SeqGeom { int Tq, Tk; size_t qrow0, krow0; };
+template <bool RAG>
+__device__ __forceinline__ SeqGeom seq_geom(const AttnArgs& p, int seq, int kvseq) {
+    if constexpr (RAG) return SeqGeom{p.seq_len[seq], p.seq_len[kvseq], (size_t)p.seq_off[seq], (size_t)p.seq_off[kvseq]};
+    else return SeqGeom{p.Tq, p.Tk, (size_t)seq * p.Tq, (size_t)kvseq * p.Tk};
+}
 
 int g_attn_ablate = 0;
 unsigned long long* g_attn_stamps = nullptr;
@@ -102,7 +115,7 @@ __device__ __forceinline__ void store_o_row(const P& p, const f32x4 (&o)[DH / 16
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const _Float16 t = mmdm_split_hi(y[e]); oh[e] = t; ol[e] = mmdm_split_lo(y[e], t); }
             _Float16* op = reinterpret_cast<_Float16*>(p.O) + off;
-            const size_t plane = (size_t)p.nseq * p.Tq * p.ldo;
+            const size_t plane = p.o_plane;
             *reinterpret_cast<mmdm_h4*>(op) = oh;
             *reinterpret_cast<mmdm_h4*>(op + plane) = ol;
         } else if (p.out_bf16) {
@@ -160,7 +173,7 @@ __device__ __forceinline__ float rows_sum(float x) {
 // four waves per SIMD stay; two 8-wave workgroups per CU share each K / V stage among twice as many waves and T = 300 gives exactly three
 // rounds of 512 slots) was measured 13 % SLOWER (236 vs 209 us at 64 x 8 x 300 x 128; bit-identical results): four independent
 // workgroups per CU de-synchronise, two 8-wave ones put pairs of lock-stepped waves on every SIMD.  Not instantiated (LAB_NOTES.md).
-template <int DH, bool DIAG = false, int QT = 1, int NW = 4>
+template <int DH, bool DIAG = false, int QT = 1, int NW = 4, bool RAG = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
     const int ablate = DIAG ? p.ablate : 0;
@@ -188,6 +201,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
     const int head = sh % p.H;
     const int seq = sh / p.H;
     const int kvseq = (seq + p.shift) % p.nseq;
+    const SeqGeom G = seq_geom<RAG>(p, seq, kvseq);
+    if constexpr (RAG) { if (qt * QBW >= G.Tq) return; }      // (wave-uniform, before any barrier: the whole workgroup leaves)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
     // live tiles of this wave: tiles are ordered by query, so tile t live implies tile t - 1 live
     int nact = 0;
 #pragma unroll
-    for (int t = 0; t < QT; ++t) nact += (q0 + QBT * t < p.Tq) ? 1 : 0;
+    for (int t = 0; t < QT; ++t) nact += (q0 + QBT * t < G.Tq) ? 1 : 0;
     nact = __builtin_amdgcn_readfirstlane(nact);
     unsigned long long t_qk = 0, t_sm = 0, t_pv = 0, t_a = 0;
     if (stamps && tid == 0) {
@@ -218,16 +233,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
 #pragma unroll
     for (int t = 0; t < QT; ++t) { m_run[t] = nozero ? -INFINITY : 0.f; l_run[t] = nozero ? 0.f : 1.f; }
 
-    const float* Kg = p.K + (size_t)kvseq * p.Tk * p.ldk + head * p.dh;
-    const float* Vg = p.V + (size_t)kvseq * p.Tk * p.ldv + head * p.dh;
+    const float* Kg = p.K + G.krow0 * p.ldk + head * p.dh;
+    const float* Vg = p.V + G.krow0 * p.ldv + head * p.dh;
 
     // DMA pieces of this wave: piece pq = wave + 4u; pq < NPIECE/2 -> K rows RPP*pq.., else V rows.  Buffer-addressed (gemm_f32.hip has
     // the measurement): one resource per operand over this (sequence, head)'s rows, a per-lane byte offset that is fixed for the whole
     // launch (row inside the chunk, swizzled 16-byte column) and ONE scalar offset per chunk -- the 64-bit per-lane address arithmetic
     // that used to precede every piece is gone from the loop.  Rows past Tk fall outside the resource and arrive as zeros (their
     // scores are masked to -inf below, so the values never matter).
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Kg), 0, (unsigned)(((size_t)(p.Tk - 1) * p.ldk + p.dh) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vg), 0, (unsigned)(((size_t)(p.Tk - 1) * p.ldv + p.dh) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Kg), 0, (unsigned)(((size_t)(G.Tk - 1) * p.ldk + p.dh) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vg), 0, (unsigned)(((size_t)(G.Tk - 1) * p.ldv + p.dh) * 4), 0x00020000);
     int voff[NI], dsto[NI];
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
@@ -249,9 +264,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
         }
     };
 
-    int nchunks = (p.Tk + KC - 1) / KC;
+    int nchunks = (G.Tk + KC - 1) / KC;
     if (causal) {                               // keys past the workgroup's last query are never visible (same count for all 4 waves: barriers)
-        const int last_q = min(qt * QBW + QBW - 1, p.Tq - 1);
+        const int last_q = min(qt * QBW + QBW - 1, G.Tq - 1);
         nchunks = min(nchunks, last_q / KC + 1);
     }
 
@@ -284,8 +299,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
             const int q0t = q0 + QBT * t;
-            if (c0 + KC > p.Tk || (causal && c0 + KC - 1 > q0t)) {   // keys past Tk (last chunk) or above the diagonal (wave-uniform branch)
-                const int kmax = causal ? min(p.Tk - 1, q0t + lq) : p.Tk - 1;
+            if (c0 + KC > G.Tk || (causal && c0 + KC - 1 > q0t)) {   // keys past Tk (last chunk) or above the diagonal (wave-uniform branch)
+                const int kmax = causal ? min(G.Tk - 1, q0t + lq) : G.Tk - 1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (c0 + 4 * g + r > kmax) st[t][r] = -INFINITY;
@@ -360,8 +375,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         int qrow = q0 + QBT * t + lq;
-        if (qrow >= p.Tq) qrow = p.Tq - 1;
-        const float* qp = p.Q + ((size_t)seq * p.Tq + qrow) * p.ldq + head * p.dh + 4 * g;
+        if (qrow >= G.Tq) qrow = G.Tq - 1;
+        const float* qp = p.Q + (G.qrow0 + qrow) * p.ldq + head * p.dh + 4 * g;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const bool in = 16 * j + 4 * g < p.dh;                       // dh % 4 == 0: a 16-byte group is wholly inside or outside
@@ -420,8 +435,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int qrow = q0 + QBT * t + 4 * g + r;
-            if (qrow >= p.Tq) continue;
-            store_o_row<DH>(p, o[t], r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * p.dh, lq);
+            if (qrow >= G.Tq) continue;
+            store_o_row<DH>(p, o[t], r, 1.0f / lr[r], (G.qrow0 + qrow) * p.ldo + head * p.dh, lq);
         }
     }
     if (stamps) {
@@ -437,7 +452,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y) {
     if (p.out_bf16 == 2) {
         _Float16* op = reinterpret_cast<_Float16*>(p.O) + idx;
-        const size_t plane = (size_t)p.nseq * p.Tq * p.ldo;
+        const size_t plane = p.o_plane;
         const _Float16 t = mmdm_split_hi(y);
         op[0] = t;
         op[plane] = mmdm_split_lo(y, t);
@@ -473,7 +488,7 @@ __device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y
 // (three v_mfma_f32_16x16x16_f16 per 16 columns), O = o / 2048 / l -- exact scalings.  fp32-accurate like the split GEMMs (the same argument:
 // representation error 2^-22 per operand, below the fp32 accumulation error of the 32x32x2 / 16x16x4 fp32 MFMA chains it replaces), at 36 short
 // MFMAs per 16-key chunk instead of 64 long ones.
-template <int DH, int NP, bool PVB = false, bool H2 = false>
+template <int DH, int NP, bool PVB = false, bool H2 = false, bool RAG = false>
 __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {      // H2: four waves per SIMD (128 registers)
 #if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
     static_assert(!PVB || NP == 1 || H2, "bf16 P.V goes with bf16 scores");
@@ -505,6 +520,8 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
     const int head = sh % p.H;
     const int seq = sh / p.H;
     const int kvseq = (seq + p.shift) % p.nseq;
+    const SeqGeom G = seq_geom<RAG>(p, seq, kvseq);
+    if constexpr (RAG) { if (qt * QB >= G.Tq) return; }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -515,8 +532,8 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
     bf16x8 qf[NP][NS];
     {
         int qrow = q0 + lq;
-        if (qrow >= p.Tq) qrow = p.Tq - 1;
-        const __bf16* qp = p.Qp + ((size_t)seq * p.Tq + qrow) * p.ldqp + head * DH + 8 * g;
+        if (qrow >= G.Tq) qrow = G.Tq - 1;
+        const __bf16* qp = p.Qp + (G.qrow0 + qrow) * p.ldqp + head * DH + 8 * g;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
@@ -529,8 +546,8 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
     const bool nozero = (p.flags & MMDM_ATTN_NO_ZERO_KEY) != 0, causal = (p.flags & MMDM_ATTN_CAUSAL) != 0;
     float m_run = nozero ? -INFINITY : 0.f, l_run = nozero ? 0.f : 1.f;
 
-    const __bf16* Kg = p.Kp + (size_t)kvseq * p.Tk * p.ldkp + head * DH;
-    const float* Vg = p.V + (size_t)kvseq * p.Tk * p.ldv + head * DH;
+    const __bf16* Kg = p.Kp + G.krow0 * p.ldkp + head * DH;
+    const float* Vg = p.V + G.krow0 * p.ldv + head * DH;
 
     // DMA pieces of this wave (piece pq = wave + 4u): buffer-addressed as in attn_mfma_kernel -- one resource per piece over this (sequence,
     // head)'s rows of its operand (a K plane, or V), a per-lane byte offset that is fixed for the whole launch and ONE scalar offset per
@@ -547,16 +564,16 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
         const int pos = isk ? lane % CPRK : lane % CPR;
         const void* base; unsigned bytes;
         if (isk) {
-            base = Kg + (size_t)pl * p.k_plane; bytes = (unsigned)(((size_t)(p.Tk - 1) * p.ldkp + DH) * 2);
+            base = Kg + (size_t)pl * p.k_plane; bytes = (unsigned)(((size_t)(G.Tk - 1) * p.ldkp + DH) * 2);
             voff[u] = (trow * p.ldkp + 8 * (pos ^ (trow & (CPRK - 1)))) * 2; rstep[u] = p.ldkp * 2;
             dsto[u] = pl * KPLANE + RPPK * pp * (DH / 2);
         } else if constexpr (PVB) {
             const int xv = DH == 128 ? (((trow & 3) << 2) | ((trow >> 2) & 3)) : (((trow >> 1) & 3) << 1);
-            base = p.Vp + (H2 ? (size_t)pl * p.v_plane : 0) + (size_t)kvseq * p.Tk * p.ldvp + head * DH; bytes = (unsigned)(((size_t)(p.Tk - 1) * p.ldvp + DH) * 2);
+            base = p.Vp + (H2 ? (size_t)pl * p.v_plane : 0) + G.krow0 * p.ldvp + head * DH; bytes = (unsigned)(((size_t)(G.Tk - 1) * p.ldvp + DH) * 2);
             voff[u] = (trow * p.ldvp + 8 * (pos ^ xv)) * 2; rstep[u] = p.ldvp * 2;
             dsto[u] = NP * KPLANE + (H2 ? pl * VPLANE : 0) + RPP * pp * (DH / 2);
         } else {
-            base = Vg; bytes = (unsigned)(((size_t)(p.Tk - 1) * p.ldv + DH) * 4);
+            base = Vg; bytes = (unsigned)(((size_t)(G.Tk - 1) * p.ldv + DH) * 4);
             voff[u] = (trow * p.ldv + 4 * pos) * 4; rstep[u] = p.ldv * 4;              // V rows are stored unswizzled (load_v_row)
             dsto[u] = NP * KPLANE + RPP * pp * DH;
         }
@@ -570,9 +587,9 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
         }
     };
 
-    int nchunks = (p.Tk + KC - 1) / KC;
+    int nchunks = (G.Tk + KC - 1) / KC;
     if (causal) {
-        const int last_q = min(qt * QB + QB - 1, p.Tq - 1);
+        const int last_q = min(qt * QB + QB - 1, G.Tq - 1);
         nchunks = min(nchunks, last_q / KC + 1);
     }
     stage(0, 0);
@@ -589,7 +606,7 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
         const float* Ks = smem + cur * STAGE;
         const float* Vs = Ks + NP * KPLANE;
 
-        if (q0 >= p.Tq) continue;        // a wave with no query inside Tq keeps staging and the barriers, nothing else (attn_mfma_kernel)
+        if (q0 >= G.Tq) continue;        // a wave with no query inside Tq keeps staging and the barriers, nothing else (attn_mfma_kernel)
         // S^T tile (16 keys x 16 queries): one accumulator per 32-deep reduction step so that consecutive MFMAs are independent
         f32x4 sa[NS];
 #pragma unroll
@@ -630,8 +647,8 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
         }
         st[0] *= p.scale2;
 
-        if (c0 + KC > p.Tk || (causal && c0 + KC - 1 > q0)) {
-            const int kmax = causal ? min(p.Tk - 1, q0 + lq) : p.Tk - 1;
+        if (c0 + KC > G.Tk || (causal && c0 + KC - 1 > q0)) {
+            const int kmax = causal ? min(G.Tk - 1, q0 + lq) : G.Tk - 1;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (c0 + 4 * g + r > kmax) st[0][r] = -INFINITY;
@@ -722,14 +739,14 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int qrow = q0 + 4 * g + r;
-        if (qrow >= p.Tq) continue;
+        if (qrow >= G.Tq) continue;
         if constexpr (PVB) {                        // element (j, r) is column 16 j + lq of row 4g + r
             const float inv = (1.0f / lr[r]) * (H2 ? MMDM_SPLIT_INV : 1.0f);       // H2: the accumulators carry the scale 2^11 (an exact scaling)
-            const size_t off = ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH + lq;
+            const size_t off = (G.qrow0 + qrow) * p.ldo + head * DH + lq;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) store_out(p, off + 16 * j, o[j][r] * inv);
         } else {
-            store_o_row<DH>(p, o, r, 1.0f / lr[r], ((size_t)seq * p.Tq + qrow) * p.ldo + head * DH, lq);
+            store_o_row<DH>(p, o, r, 1.0f / lr[r], (G.qrow0 + qrow) * p.ldo + head * DH, lq);
         }
     }
 #endif
@@ -741,7 +758,11 @@ constexpr int qkp_smem() { return 2 * (NP * KC * DH / 2 + (PVB ? (H2 ? 2 : 1) * 
 template <int DH, int NP, bool PVB = false, bool H2 = false>
 int launch_qkp(const AttnArgs& a, hipStream_t st) {
     constexpr int smem_bytes = qkp_smem<DH, NP, PVB, H2>();
-    hipLaunchKernelGGL((attn_qkp_kernel<DH, NP, PVB, H2>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), smem_bytes, st, a);
+    if (a.seq_off) {
+        // ragged batches: the production forms only (all-bf16 and the fp16 planes); the three-plane / fp32-V experiments stay uniform
+        if constexpr (PVB) hipLaunchKernelGGL((attn_qkp_kernel<DH, NP, PVB, H2, true>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), smem_bytes, st, a);
+        else return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "attention on ragged batches: this operand form has no ragged instantiation");
+    } else hipLaunchKernelGGL((attn_qkp_kernel<DH, NP, PVB, H2>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), smem_bytes, st, a);
     return mmdm_check_launch("attn_qkp");
 }
 
@@ -840,7 +861,8 @@ constexpr int attn_smem() { return NST * 2 * KCF * DH * 4; }
 template <int DH>
 int launch_mfma(const AttnArgs& a, hipStream_t st) {
     const dim3 grid(8 * a.pairs_per_xcd * a.qtiles), block(256);
-    if (a.ablate || a.stamps) hipLaunchKernelGGL((attn_mfma_kernel<DH, true>), grid, block, attn_smem<DH>(), st, a);
+    if (a.seq_off) hipLaunchKernelGGL((attn_mfma_kernel<DH, false, 1, 4, true>), grid, block, attn_smem<DH>(), st, a);
+    else if (a.ablate || a.stamps) hipLaunchKernelGGL((attn_mfma_kernel<DH, true>), grid, block, attn_smem<DH>(), st, a);
     else hipLaunchKernelGGL((attn_mfma_kernel<DH>), grid, block, attn_smem<DH>(), st, a);
     return mmdm_check_launch("attn_mfma");
 }
@@ -863,6 +885,8 @@ int mmdm_attn_init(void) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<64, 3>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<128, 1>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkp_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, qkp_smem<64, 1>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<128, false, 1, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem<128>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<64, false, 1, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, attn_smem<64>());
     if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(attn): %s", hipGetErrorString(e));
     return MMDM_OK;
 }
@@ -879,6 +903,19 @@ extern "C" int mmdm_attention_ex(const float* Q, int ldq, const float* K, int ld
 
 extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* Ov, int ldo, int out_bf16,
                                    int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
+    return mmdm_attention_opts_rag(Q, ldq, K, ldk, V, ldv, Ov, ldo, out_bf16, flags, nseq, Tq, Tk, H, dh, kv_seq_shift, nullptr, stream);
+}
+
+extern "C" int mmdm_attention_ragged_f32(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                                         int nseq, const int* seq_off, const int* seq_len, int max_len, int total_rows, int H, int dh, int kv_seq_shift, void* stream) {
+    if (!seq_off || !seq_len || max_len <= 0 || total_rows <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_ragged_f32: bad sequence description");
+    const mmdm_rag_seq rg{seq_off, seq_len, total_rows, max_len};
+    return mmdm_attention_opts_rag(Q, ldq, K, ldk, V, ldv, O, ldo, 0, 0, nseq, max_len, max_len, H, dh, kv_seq_shift, &rg, stream);
+}
+
+// rg != nullptr: ragged batch (kernels.h mmdm_rag_seq); Tq = Tk = the longest sequence
+int mmdm_attention_opts_rag(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* Ov, int ldo, int out_bf16,
+                            int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, const mmdm_rag_seq* rg, void* stream) {
     float* O = static_cast<float*>(Ov);
     if (nseq == 0 || Tq == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
@@ -893,6 +930,9 @@ extern "C" int mmdm_attention_opts(const float* Q, int ldq, const float* K, int 
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.Vp = nullptr; a.ldvp = 0;
     a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate; a.stamps = g_attn_stamps;
     a.Qp = a.Kp = nullptr; a.q_plane = a.k_plane = 0; a.ldqp = a.ldkp = 0;
+    a.seq_off = rg ? rg->off : nullptr; a.seq_len = rg ? rg->len : nullptr;
+    a.o_plane = (size_t)(rg ? (size_t)rg->total_rows : (size_t)nseq * Tq) * ldo;
+    if (rg && (flags || !(dh == 128 || dh == 64))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "attention on ragged batches: head sizes 64 / 128, zero key, no mask (dh=%d flags=0x%x)", dh, flags);
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
     a.pairs_per_xcd = (nseq * H + 7) / 8;
@@ -941,7 +981,8 @@ extern "C" int mmdm_attention_split(const void* Qp, int ldq, int64_t q_plane, co
 // Vp != nullptr, one plane: V also as bf16 rows [rows][ldvp] -> P.V on the bf16 matrix cores (attn_qkp_kernel<DH, 1, true>);
 // nplanes == 2: Q, K and V (Vp, plane stride v_plane) as the two fp16 planes of the fp32-split mode (attn_qkp_kernel<DH, 2, true, true>)
 int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
-                             const void* Vp, int ldvp, int64_t v_plane, void* Ov, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream) {
+                             const void* Vp, int ldvp, int64_t v_plane, void* Ov, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream,
+                             const mmdm_rag_seq* rg) {
     if (nseq == 0 || Tq == 0) return MMDM_OK;
     if (int rc = mmdm_kernels_init()) return rc;
     if (!Qp || !Kp || (!V && !Vp) || !Ov || nseq < 0 || Tq < 0 || Tk <= 0 || H <= 0 || (nplanes < 1 || nplanes > 3) || (nplanes == 2 && !Vp))
@@ -963,6 +1004,9 @@ int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const voi
     if (Vp && (nplanes == 3 || (reinterpret_cast<uintptr_t>(Vp) & 15) || (ldvp & 7) || ldvp < H * dh || (nplanes == 2 && (v_plane & 7))))
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: 16-bit V needs one (bf16) or two (fp16 split) planes, 16-byte aligned rows / planes and a row stride >= H*dh");
     a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate; a.stamps = g_attn_stamps;
+    a.seq_off = rg ? rg->off : nullptr; a.seq_len = rg ? rg->len : nullptr;
+    a.o_plane = (size_t)(rg ? (size_t)rg->total_rows : (size_t)nseq * Tq) * ldo;
+    if (rg && flags) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "attention on ragged batches: zero key, no mask (flags=0x%x)", flags);
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
     a.qtiles = (Tq + QB - 1) / QB;
     a.pairs_per_xcd = (nseq * H + 7) / 8;

@@ -87,7 +87,8 @@ __device__ __forceinline__ bool bf16_late_ext(const BArgs& p, int n0, int BN) {
     return p.tst && !p.P2 && n0 + BN <= p.N && p.out_bf16 == 0 && (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE);
 }
 
-template <int TM, int TN, int ET, int BM, int BN, int NWAVES>
+// SMEM = bytes of dynamic LDS the launch really has (the operand stages): the image of a phase is sized against THAT, not against a constant.
+template <int TM, int TN, int ET, int BM, int BN, int NWAVES, int SMEM>
 __device__ __forceinline__ bool bf16_finish_t(const BArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, float* smem) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     if (p.P2 || n0 + BN > p.N) return false;
@@ -98,9 +99,10 @@ __device__ __forceinline__ bool bf16_finish_t(const BArgs& p, f32x16 (&acc)[TM][
         constexpr int EBO = OUT == 0 ? 4 : (OUT == 1 ? 2 : 1);                 // bytes per output element
         constexpr int RB = BN * EBO, CPR = RB / 16;                            // bytes / 16-byte chunks per image row
         constexpr int NRT = BM / 32;                                           // 32-row tiles of the workgroup tile
-        constexpr int FIT = (48 * 1024) / (32 * RB);                           // row tiles the 48 KB of operand stages hold
+        constexpr int FIT = SMEM / (32 * RB);                                  // row tiles the launch's operand stages hold
         constexpr int RPP = FIT >= NRT ? NRT : (FIT >= 4 ? 4 : (FIT >= 2 ? 2 : 1));      // row tiles per phase (a power of two that divides NRT)
         static_assert(FIT >= 1 && NRT % RPP == 0, "image does not fit the operand stages");
+        static_assert(32 * RPP * RB <= SMEM, "a phase's image must lie inside the launch's dynamic LDS");
         static_assert(CPR <= 64, "a row of the image is at most one store instruction");
         constexpr int LPR = CPR, RPI = 64 / LPR;                               // lanes per row, rows per store instruction
         constexpr int ROWS = 32 * RPP, RPW = ROWS / NWAVES;                    // rows per phase, rows each wave stores per phase
@@ -447,7 +449,7 @@ __global__ __launch_bounds__((BCfg<TM_, TN_>::THREADS), (BCfg<TM_, TN_>::THREADS
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
 
-    if (!(p.tst && bf16_finish_t<TM, TN, ET, BM, BN, C_::NWAVES>(p, acc, m0, n0, wm, wn, lane, smem)))
+    if (!(p.tst && bf16_finish_t<TM, TN, ET, BM, BN, C_::NWAVES, C_::SMEM_BYTES>(p, acc, m0, n0, wm, wn, lane, smem)))
         bf16_finish<TM, TN, ET, BM>(p, acc, m0, n0, wm, wn, l31, lh);
 #endif
 }
@@ -477,6 +479,7 @@ int set_attr() {
 // next and the next step's B fragments are requested behind the MFMAs of the step's first k-block.  Two workgroups per CU (registers).
 // W: mmdm_pack_weight_frag -- block (32 rows, 32 bytes of k) = the 1 KiB one wave-wide 16-byte load delivers, lane (l31, lh) <- row l31, bytes 16 lh.
 // Accumulators start as in gemm_bf16_kernel and k ascends the same way: bit-identical results.
+constexpr int WSMEM_BYTES = 3 * 2 * 128 * 16 * 4;      // dynamic LDS of gemm_bf16w_kernel: three A stages of two 64-byte-row images (48 KB)
 template <int ET, int TN = 2, bool TL = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
     if constexpr (TL) { t_r1 = __builtin_amdgcn_s_memrealtime(); t_c1 = __builtin_readcyclecounter(); }
-    if (!(p.tst && bf16_finish_t<TM, TN, ET, BM, BN, NW>(p, acc, m0, n0, wm, wn, lane, smem)))
+    if (!(p.tst && bf16_finish_t<TM, TN, ET, BM, BN, NW, WSMEM_BYTES>(p, acc, m0, n0, wm, wn, lane, smem)))
         bf16_finish<TM, TN, ET, BM>(p, acc, m0, n0, wm, wn, l31, lh);
     if constexpr (TL) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -769,8 +772,8 @@ int launch_w(BArgs a, hipStream_t st) {
     a.mt = (a.M + 127) / 128;
     a.nt = a.N / (128 * TN);
     mmdm_note_gemm("%s<14,4%d>", ET == 1 ? "gemm_fp8w" : "gemm_bf16w", TN);
-    if (a.tl) hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN, true>), dim3(a.mt * a.nt), dim3(256), 3 * 2 * 128 * 16 * 4, st, a);
-    else hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN>), dim3(a.mt * a.nt), dim3(256), 3 * 2 * 128 * 16 * 4, st, a);
+    if (a.tl) hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN, true>), dim3(a.mt * a.nt), dim3(256), WSMEM_BYTES, st, a);
+    else hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN>), dim3(a.mt * a.nt), dim3(256), WSMEM_BYTES, st, a);
     return mmdm_check_launch(ET == 1 ? "gemm_fp8w" : "gemm_bf16w");
 }
 
@@ -830,7 +833,7 @@ int mmdm_gemm_bf16_init(void) {
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 2>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 2, true>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 2, true>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1, true>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1, true>)}) {
-        hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 128 * 16 * 4);
+        hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WSMEM_BYTES);
         if (e2 != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16w): %s", hipGetErrorString(e2));
     }
     return MMDM_OK;

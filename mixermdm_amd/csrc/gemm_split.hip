@@ -846,6 +846,9 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
         return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split: needs N %% 4 == 0 and 16-byte aligned output / bias / residual rows");
     if ((uint64_t)a_plane * 4 + 512ull * (uint64_t)lda >= (1ull << 32) || (uint64_t)w_plane * 4 + 512ull * (uint64_t)ldw >= (1ull << 32))
         return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split: operand planes beyond the 4 GB reach of a tile's buffer offsets");
+    // plane output: the lo plane is addressed as a 32-bit scalar offset (c_plane * 2 bytes) beside a 32-bit per-lane offset inside the tile's rows
+    if (out_split && (uint64_t)c_plane * 2 + 512ull * (uint64_t)ldc >= (1ull << 32))
+        return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_split: output planes beyond the 4 GB reach of a tile's buffer offsets (c_plane=%lld)", (long long)c_plane);
     SArgs a;
     a.A = static_cast<const _Float16*>(A); a.W = static_cast<const _Float16*>(W); a.bias = bias; a.C = C; a.extra = extra;
     a.pa = (size_t)a_plane; a.pw = (size_t)w_plane; a.pc = (size_t)c_plane;

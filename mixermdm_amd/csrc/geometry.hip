@@ -89,17 +89,33 @@ __device__ __forceinline__ void rot6d_roundtrip(const float d[6], float out[6]) 
 // Mixer pre-processing: denormalise both denoiser outputs, align the individual prediction to the interaction one.
 // grid: n * 2 persons * T blocks of 32 threads?  -> flat: one thread per (b, p, t, j), j in [0, 22).
 // ---------------------------------------------------------------------------------------------------------
+// RAG: ragged batch (kernels.h mmdm_rag) -- `n` counts GROUPS of rg.rows frame rows (cond | uncond halves), a thread is (frame row, person, joint),
+// frame 0 / the last frame of its item come from the row maps; padding rows leave at once.  The arithmetic is the uniform kernel's.
+template <bool RAG>
 __global__ __launch_bounds__(256) void mixer_pre_kernel(const float* __restrict__ o1, const float* __restrict__ o2, const float* __restrict__ stats,
-                                                         float* __restrict__ out1, float* __restrict__ out2, int n, int T, int align) {
+                                                         float* __restrict__ out1, float* __restrict__ out2, int n, int T, int align, mmdm_rag rg) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = n * 2 * T * NJ;
-    if (idx >= total) return;
-    const int j = idx % NJ;
-    const int t = (idx / NJ) % T;
-    const int p = (idx / (NJ * T)) % 2;
-    const int b = idx / (NJ * T * 2);
+    int j, t, p;
+    size_t seq;
+    if constexpr (RAG) {
+        if (idx >= n * rg.rows * 2 * NJ) return;
+        j = idx % NJ;
+        p = (idx / NJ) % 2;
+        const int r = idx / (NJ * 2), rl = r % rg.rows, item = rg.row_item[rl];
+        if (item < 0) return;
+        t = rg.row_pos[rl];
+        T = rg.item_len[item];
+        seq = (size_t)(r - t) * NF2 + (size_t)p * NF;
+    } else {
+        const int total = n * 2 * T * NJ;
+        if (idx >= total) return;
+        j = idx % NJ;
+        t = (idx / NJ) % T;
+        p = (idx / (NJ * T)) % 2;
+        const int b = idx / (NJ * T * 2);
+        seq = (size_t)b * T * NF2 + (size_t)p * NF;      // start of (b, frame 0, person p)
+    }
     const float* mh = stats, *sh = stats + NF, *mi = stats + 2 * NF, *si = stats + 3 * NF;
-    const size_t seq = (size_t)b * T * NF2 + (size_t)p * NF;      // start of (b, frame 0, person p)
     const size_t off = seq + (size_t)t * NF2;
     const float* a = o1 + off;   // individual denoiser, HML3D normalisation
     const float* c = o2 + off;   // interaction denoiser, InterHuman normalisation
@@ -186,42 +202,47 @@ __device__ __forceinline__ long hist_slot(const int* loop_pos, int every) {
 // hd != nullptr: history pointers / stride come from the descriptor (the explicit pointer arguments are ignored).
 // nwh: channels of an influence history row: 262 (modes 3, 4: the expanded tensor) or 1 (modes 1, 2: the reference appends the
 // un-expanded [2B, T, 1] tensor, mixermdm.py:739-745, 794-796).
+template <bool RAG>
 __global__ __launch_bounds__(256) void blend_cfg_kernel(const float* __restrict__ out1, const float* __restrict__ out2, const float* __restrict__ w,
                                                          int Tw, int nw, int use_force, float force, float s,
                                                          float* __restrict__ model_out, float* __restrict__ hist_i1, float* __restrict__ hist_i2,
                                                          float* __restrict__ hist_mix, const mmdm_hist_desc* __restrict__ hd,
-                                                         const int* __restrict__ loop_pos, int nwh, int B, int T) {
+                                                         const int* __restrict__ loop_pos, int nwh, int B, int T, mmdm_rag rg) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)B * T * NF2;
+    // frames of one half of the CFG-doubled batch: B * T, or the ragged batch's group stride (padding rows included: history slots are [2 * rows, C])
+    const size_t half = RAG ? (size_t)rg.rows : (size_t)B * T;
+    const size_t total = half * NF2;
     if (idx >= total) return;
     int every = 1;
     if (hd) { hist_i1 = hd->i1; hist_i2 = hd->i2; hist_mix = hd->mix; every = hd->every; }
     const long slot = hist_slot(loop_pos, every);
     if (slot < 0) { hist_i1 = nullptr; hist_i2 = nullptr; hist_mix = nullptr; }
     else {
-        if (hist_i1) hist_i1 += (size_t)slot * 2 * B * T * nwh;
-        if (hist_i2) hist_i2 += (size_t)slot * 2 * B * T * nwh;
-        if (hist_mix) hist_mix += (size_t)slot * 2 * B * T * NF2;
+        if (hist_i1) hist_i1 += (size_t)slot * 2 * half * nwh;
+        if (hist_i2) hist_i2 += (size_t)slot * 2 * half * nwh;
+        if (hist_mix) hist_mix += (size_t)slot * 2 * half * NF2;
     }
     const int ch = (int)(idx % NF2);
-    const int t = (int)((idx / NF2) % T);
-    const int b = (int)(idx / ((size_t)NF2 * T));
+    const size_t fr = idx / NF2;                        // frame row inside the half
+    int b;
+    if constexpr (RAG) { b = rg.row_item[fr]; if (b < 0) return; }
+    else b = (int)(fr / T);
     const int p = ch >= NF ? 1 : 0;
     const int c = ch - p * NF;
     const int wi = nw == 1 ? 0 : influence_index(c);
-    const int tw = Tw == 1 ? 0 : t;
     float mix[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                       // u = 0: cond row b, u = 1: uncond row B + b
-        const int row = b + u * B;
-        const size_t e = ((size_t)row * T + t) * NF2 + ch;
-        float wv = w[(((size_t)p * 2 * B + row) * Tw + tw) * nw + wi];
+        const size_t frow = (size_t)u * half + fr;      // frame row of the doubled batch (= (b + u B) T + t in the uniform layout)
+        const size_t e = frow * NF2 + ch;
+        // w: [2 persons][2B sequences][Tw][nw] -- per frame (Tw = T: the Influence head's rows, person-major like the stack's) or per sequence (Tw = 1)
+        float wv = Tw == 1 ? w[((size_t)p * 2 * B + (b + u * B)) * nw + wi] : w[((size_t)p * 2 * half + frow) * nw + wi];
         if (use_force) wv = 1.0f * force;
         const float v1 = out1[e], v2 = out2[e];
         mix[u] = v2 + wv * (v1 - v2);
         if (hist_mix) hist_mix[e] = mix[u];
         float* hi = p ? hist_i2 : hist_i1;
-        if (hi && c < nwh) hi[((size_t)row * T + t) * nwh + c] = wv;
+        if (hi && c < nwh) hi[frow * nwh + c] = wv;
     }
     model_out[idx] = s * mix[0] + (1.0f - s) * mix[1];
 }
@@ -230,9 +251,12 @@ __global__ __launch_bounds__(256) void blend_cfg_kernel(const float* __restrict_
 // process_xstart + two-chain DDIM update.
 // ---------------------------------------------------------------------------------------------------------
 // floor[b, p] = min over (t, joint) of position Y   (center_motion "Put on Floor", alignment.py:182-184)
-__global__ __launch_bounds__(256) void floor_kernel(const float* __restrict__ m, float* __restrict__ floor_ws, int T) {
+template <bool RAG>
+__global__ __launch_bounds__(256) void floor_kernel(const float* __restrict__ m, float* __restrict__ floor_ws, int T, mmdm_rag rg) {
     const int bp = blockIdx.x;                   // b * 2 + p
-    const float* base = m + (size_t)(bp >> 1) * T * NF2 + (size_t)(bp & 1) * NF;
+    size_t row0 = (size_t)(bp >> 1) * T;
+    if constexpr (RAG) { row0 = (size_t)rg.item_off[bp >> 1]; T = rg.item_len[bp >> 1]; }
+    const float* base = m + row0 * NF2 + (size_t)(bp & 1) * NF;
     float v = INFINITY;
     for (int i = threadIdx.x; i < T * NJ; i += blockDim.x) {
         const int t = i / NJ, j = i % NJ;
@@ -251,22 +275,36 @@ __device__ __forceinline__ float ddim(float x, float x0, float c0, float c1, flo
     return x0 * c2 + c3 * eps;                   // eta = 0 mean             :1949-1956
 }
 
+template <bool RAG>
 __global__ __launch_bounds__(256) void xstart_ddim_kernel(const float* __restrict__ m, const float* __restrict__ stats, const float* __restrict__ coef,
                                                            int S, const int* __restrict__ step_idx, float* __restrict__ x, float* __restrict__ x2,
                                                            float* __restrict__ px1, float* __restrict__ px2, const float* __restrict__ floor_ws,
-                                                           int B, int T, int align) {
+                                                           int B, int T, int align, mmdm_rag rg) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = B * 2 * T * NJ;
-    if (idx >= total) return;
-    const int j = idx % NJ;
-    const int t = (idx / NJ) % T;
-    const int p = (idx / (NJ * T)) % 2;
-    const int b = idx / (NJ * T * 2);
+    int j, t, p, b;
+    size_t seq;
+    if constexpr (RAG) {                         // thread = (frame row, person, joint) of the ragged batch (mixer_pre_kernel)
+        if (idx >= rg.rows * 2 * NJ) return;
+        j = idx % NJ;
+        p = (idx / NJ) % 2;
+        const int r = idx / (NJ * 2);
+        b = rg.row_item[r];
+        if (b < 0) return;
+        t = rg.row_pos[r];
+        seq = (size_t)(r - t) * NF2 + (size_t)p * NF;
+    } else {
+        const int total = B * 2 * T * NJ;
+        if (idx >= total) return;
+        j = idx % NJ;
+        t = (idx / NJ) % T;
+        p = (idx / (NJ * T)) % 2;
+        b = idx / (NJ * T * 2);
+        seq = (size_t)b * T * NF2 + (size_t)p * NF;
+    }
     const int i = *step_idx;
     const float c0 = coef[i], c1 = coef[S + i], c2 = coef[2 * S + i], c3 = coef[3 * S + i];
     const bool norm = i > 0;                                     // `if t[0] > 0`  gaussian_diffusion.py:2052
     const float* mh = stats, *sh = stats + NF, *mi = stats + 2 * NF, *si = stats + 3 * NF;
-    const size_t seq = (size_t)b * T * NF2 + (size_t)p * NF;
     const size_t off = seq + (size_t)t * NF2;
     const float* mo = m + off;
 
@@ -431,8 +469,15 @@ extern "C" int mmdm_mixer_pre_f32(const float* o1, const float* o2, const float*
     if (n == 0 || T == 0) return MMDM_OK;
     if (!o1 || !o2 || !stats || !out1 || !out2 || n < 0 || T < 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_mixer_pre_f32: bad arguments");
     const int total = n * 2 * T * MMDM_NJ;
-    hipLaunchKernelGGL(mixer_pre_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), o1, o2, stats, out1, out2, n, T, align);
+    hipLaunchKernelGGL(mixer_pre_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), o1, o2, stats, out1, out2, n, T, align, mmdm_rag{});
     return mmdm_check_launch("mixer_pre");
+}
+
+// ragged batch: `groups` groups of rg.rows frame rows (the cond | uncond halves of the CFG-doubled batch)
+int mmdm_mixer_pre_rag(const float* o1, const float* o2, const float* stats, float* out1, float* out2, int groups, int align, const mmdm_rag& rg, hipStream_t st) {
+    const int total = groups * rg.rows * 2 * MMDM_NJ;
+    hipLaunchKernelGGL(mixer_pre_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, st, o1, o2, stats, out1, out2, groups, 0, align, rg);
+    return mmdm_check_launch("mixer_pre_rag");
 }
 
 extern "C" int mmdm_blend_cfg_f32(const float* out1, const float* out2, const float* w, int mode, int use_force, float force,
@@ -444,9 +489,9 @@ extern "C" int mmdm_blend_cfg_f32(const float* out1, const float* out2, const fl
     const int Tw = (mode == 2 || mode == 4) ? T : 1;
     const int nw = (mode >= 3) ? 23 : 1;
     const size_t total = (size_t)B * T * NF2;
-    hipLaunchKernelGGL(blend_cfg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(blend_cfg_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        out1, out2, w, Tw, nw, use_force, force, cfg_scale, model_out, hist_i1, hist_i2, hist_mix,
-                       (const mmdm_hist_desc*)nullptr, (const int*)nullptr, MMDM_NF, B, T);
+                       (const mmdm_hist_desc*)nullptr, (const int*)nullptr, MMDM_NF, B, T, mmdm_rag{});
     return mmdm_check_launch("blend_cfg");
 }
 
@@ -458,10 +503,65 @@ int mmdm_blend_cfg_dyn(const float* out1, const float* out2, const float* w, int
     const int Tw = (mode == 2 || mode == 4) ? T : 1;
     const int nw = (mode >= 3) ? 23 : 1;
     const size_t total = (size_t)B * T * NF2;
-    hipLaunchKernelGGL(blend_cfg_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(blend_cfg_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        out1, out2, w, Tw, nw, use_force, force, cfg_scale, model_out, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                       hd, loop_pos, mode >= 3 ? MMDM_NF : 1, B, T);
+                       hd, loop_pos, mode >= 3 ? MMDM_NF : 1, B, T, mmdm_rag{});
     return mmdm_check_launch("blend_cfg");
+}
+
+// ragged batch: history slots are [2 * rg.rows, C] (padding rows are never written)
+int mmdm_blend_cfg_rag(const float* out1, const float* out2, const float* w, int mode, int use_force, float force, float cfg_scale,
+                       float* model_out, const mmdm_hist_desc* hd, const int* loop_pos, const mmdm_rag& rg, hipStream_t st) {
+    if (mode < 1 || mode > 4) return mmdm_set_error(MMDM_ERR_ARG, "Mixing mode not recognized");
+    const int Tw = (mode == 2 || mode == 4) ? 2 : 1;        // (only "per frame" vs "per sequence" matters to the ragged form)
+    const int nw = (mode >= 3) ? 23 : 1;
+    const size_t total = (size_t)rg.rows * NF2;
+    hipLaunchKernelGGL(blend_cfg_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       out1, out2, w, Tw, nw, use_force, force, cfg_scale, model_out, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       hd, loop_pos, mode >= 3 ? MMDM_NF : 1, rg.B, 0, rg);
+    return mmdm_check_launch("blend_cfg_rag");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Ragged batches: the row maps of one sampling call, built ON THE DEVICE from the item lengths (passed by value: no host buffer to keep
+// alive, no synchronisation) -- item offsets / lengths, item and frame index of every frame row of a group (-1 / 0 for the padding rows
+// between the sum of lengths and the group stride `rows`), and per sequence of the `groups` x B sequences its first row and length.
+// ---------------------------------------------------------------------------------------------------------
+struct RagLens { int v[MMDM_RAG_MAX_ITEMS]; };
+__global__ __launch_bounds__(256) void rag_setup_kernel(RagLens L, int B, int rows, int groups, int* __restrict__ item_off, int* __restrict__ item_len,
+                                                        int* __restrict__ row_item, int* __restrict__ row_pos, int* __restrict__ row_seq,
+                                                        int* __restrict__ seq_off, int* __restrict__ seq_len) {
+    __shared__ int off[MMDM_RAG_MAX_ITEMS + 1];
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int b = 0; b < B; ++b) { off[b] = a; a += L.v[b]; }
+        off[B] = a;
+    }
+    __syncthreads();
+    const int RT = off[B];
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int r = tid; r < groups * rows; r += nth) {
+        const int g = r / rows, rl = r % rows;
+        int item = -1, pos = 0;
+        if (rl < RT) {
+            int lo = 0, hi = B - 1;                       // largest b with off[b] <= rl
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[mid] <= rl) lo = mid; else hi = mid - 1; }
+            item = lo; pos = rl - off[lo];
+        }
+        if (g == 0) { row_item[rl] = item; row_pos[rl] = pos; }
+        row_seq[r] = g * B + (item < 0 ? 0 : item);
+    }
+    for (int s = tid; s < groups * B; s += nth) { seq_off[s] = (s / B) * rows + off[s % B]; seq_len[s] = L.v[s % B]; }
+    for (int b = tid; b < B; b += nth) { item_off[b] = off[b]; item_len[b] = L.v[b]; }
+}
+
+int mmdm_rag_setup(const int* lens_host, int B, int rows, int groups, int* item_off, int* item_len, int* row_item, int* row_pos, int* row_seq,
+                   int* seq_off, int* seq_len, hipStream_t st) {
+    if (B <= 0 || B > MMDM_RAG_MAX_ITEMS) return mmdm_set_error(MMDM_ERR_ARG, "ragged batch: %d items (1 .. %d)", B, MMDM_RAG_MAX_ITEMS);
+    RagLens L;
+    for (int b = 0; b < MMDM_RAG_MAX_ITEMS; ++b) L.v[b] = b < B ? lens_host[b] : 0;
+    hipLaunchKernelGGL(rag_setup_kernel, dim3(64), dim3(256), 0, st, L, B, rows, groups, item_off, item_len, row_item, row_pos, row_seq, seq_off, seq_len);
+    return mmdm_check_launch("rag_setup");
 }
 
 int mmdm_hist_copy(const float* src, const mmdm_hist_desc* hd, int which, size_t count, const int* loop_pos, hipStream_t st) {
@@ -495,13 +595,26 @@ extern "C" int mmdm_xstart_ddim_f32(const float* model_out, const float* stats, 
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_xstart_ddim_f32: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (align) {
-        hipLaunchKernelGGL(floor_kernel, dim3(B * 2), dim3(256), 0, st, model_out, floor_ws, T);
+        hipLaunchKernelGGL(floor_kernel<false>, dim3(B * 2), dim3(256), 0, st, model_out, floor_ws, T, mmdm_rag{});
         if (int rc = mmdm_check_launch("floor")) return rc;
     }
     const int total = B * 2 * T * MMDM_NJ;
-    hipLaunchKernelGGL(xstart_ddim_kernel, dim3((total + 255) / 256), dim3(256), 0, st, model_out, stats, coef, S, step_idx, x, x2,
-                       pred_xstart, pred_xstart2, floor_ws, B, T, align);
+    hipLaunchKernelGGL(xstart_ddim_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, st, model_out, stats, coef, S, step_idx, x, x2,
+                       pred_xstart, pred_xstart2, floor_ws, B, T, align, mmdm_rag{});
     return mmdm_check_launch("xstart_ddim");
+}
+
+// ragged batch (rg.B items, rg.rows frame rows incl. padding): same arithmetic per item
+int mmdm_xstart_ddim_rag(const float* model_out, const float* stats, const float* coef, int S, const int* step_idx,
+                         float* x, float* x2, float* pred_xstart, float* pred_xstart2, float* floor_ws, int align, const mmdm_rag& rg, hipStream_t st) {
+    if (align) {
+        hipLaunchKernelGGL(floor_kernel<true>, dim3(rg.B * 2), dim3(256), 0, st, model_out, floor_ws, 0, rg);
+        if (int rc = mmdm_check_launch("floor_rag")) return rc;
+    }
+    const int total = rg.rows * 2 * MMDM_NJ;
+    hipLaunchKernelGGL(xstart_ddim_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, st, model_out, stats, coef, S, step_idx, x, x2,
+                       pred_xstart, pred_xstart2, floor_ws, rg.B, 0, align, rg);
+    return mmdm_check_launch("xstart_ddim_rag");
 }
 
 extern "C" int mmdm_cfg_ddim_f32(const float* m, const float* coef, int S, const int* step_idx, float cfg_scale,

@@ -98,6 +98,22 @@ int mmdm_set_hist_desc(mmdm_hist_desc* d, const mmdm_hist_desc& v, hipStream_t s
 int mmdm_hist_copy(const float* src, const mmdm_hist_desc* hd, int which, size_t count, const int* loop_pos, hipStream_t st);
 int mmdm_blend_cfg_dyn(const float* out1, const float* out2, const float* w, int mode, int use_force, float force, float cfg_scale,
                        float* model_out, const mmdm_hist_desc* hd, const int* loop_pos, int B, int T, hipStream_t st);
+// A RAGGED batch as the geometry kernels see it (device arrays written by mmdm_rag_setup; one group = the B items' frames back to back, padded to `rows`)
+constexpr int MMDM_RAG_MAX_ITEMS = 256;      // item lengths travel to the device by value (kernel argument)
+struct mmdm_rag {
+    const int* row_item;   // [rows] item of a frame row; -1 = padding row
+    const int* row_pos;    // [rows] frame index inside its item
+    const int* item_off;   // [B] first frame row of an item
+    const int* item_len;   // [B]
+    int B, rows;           // items; group stride in frame rows (sum of lengths rounded up to the handle's row bucket)
+};
+int mmdm_rag_setup(const int* lens_host, int B, int rows, int groups, int* item_off, int* item_len, int* row_item, int* row_pos, int* row_seq,
+                   int* seq_off, int* seq_len, hipStream_t st);
+int mmdm_mixer_pre_rag(const float* o1, const float* o2, const float* stats, float* out1, float* out2, int groups, int align, const mmdm_rag& rg, hipStream_t st);
+int mmdm_blend_cfg_rag(const float* out1, const float* out2, const float* w, int mode, int use_force, float force, float cfg_scale,
+                       float* model_out, const mmdm_hist_desc* hd, const int* loop_pos, const mmdm_rag& rg, hipStream_t st);
+int mmdm_xstart_ddim_rag(const float* model_out, const float* stats, const float* coef, int S, const int* step_idx,
+                         float* x, float* x2, float* pred_xstart, float* pred_xstart2, float* floor_ws, int align, const mmdm_rag& rg, hipStream_t st);
 int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw, const float* bias, float* C, int ldc,
                        int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* stream);
 int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
@@ -112,6 +128,14 @@ int mmdm_linear_bf16_ex(const void* A, int lda, const void* W, int ldw, const fl
 int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, const float* bias, void* C, int ldc,
                        int out_mode, int M, int N, int K, int epilogue, const float* extra, int ld_extra, int period, void* bf16_copy, int ld2, int copy_cols,
                        float a_const, float out_scale, void* stream);
-int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_mode, float* row_scale, int nseq, int T, int D, void* stream);
+int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_mode, float* row_scale, int nseq, int T, int D, void* stream,
+                   const int* row_seq = nullptr, int rows_rag = 0);
+int mmdm_mean_time_rag(const float* h, float* out, int nseq, const int* seq_off, const int* seq_len, int D, hipStream_t st);
+// Sequences of a RAGGED batch as the attention kernels see them (device arrays: one captured graph serves every batch of the same row bucket):
+// sequence s owns rows [off[s], off[s] + len[s]) of Q / K / V / O; total_rows = rows of O (plane stride of a split output); max_len sizes the grid.
+struct mmdm_rag_seq { const int* off; const int* len; int total_rows; int max_len; };
 int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
-                             const void* Vp, int ldvp, int64_t v_plane, void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream);
+                             const void* Vp, int ldvp, int64_t v_plane, void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream,
+                             const mmdm_rag_seq* rg = nullptr);
+int mmdm_attention_opts_rag(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O, int ldo, int out_bf16,
+                            int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, const mmdm_rag_seq* rg, void* stream);

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -133,6 +134,7 @@ struct ModuleW {         // denoiser or mixer front/back ends
     float *t0_w = nullptr, *t0_b = nullptr, *t2_w = nullptr, *t2_b = nullptr;   // embed_timestep.time_embed.{0,2}
     float *out_w = nullptr, *out_b = nullptr;    // out.linear [262, D] / influence.out [nw, D]
     float *time_tab = nullptr;                   // [S, D] = time_embed(pe[timestep_map])  (built by set_schedule)
+    float *pe_r = nullptr;                       // ragged call: [rows, D] = pe[frame index of every row of a group] (gathered by mmdm_begin_ragged; this handle's own)
 };
 
 struct Scratch {          // transformer-stack work buffers (one set per concurrently running stack)
@@ -140,6 +142,21 @@ struct Scratch {          // transformer-stack work buffers (one set per concurr
     float *xp = nullptr;      // [2][rows][NFP] repacked pose operands of the embedding GEMMs (fp32), or [2][2 planes][rows][NFS] fp16
     void *qk = nullptr, *kvp = nullptr;   // precision >= 1: bf16 plane copies of the attention's Q|K ([planes][R][2D]) and cross-attention K ([planes][R][D])
     float* xs = nullptr;                  // precision == 3: per-row scales of the fp8 AdaLN output in xn
+};
+
+// Row geometry of the current sampling call.  Uniform: B items x T frames, sequence s = rows [s T, (s + 1) T).  Ragged (mmdm_begin_ragged): the B
+// items' frames lie back to back in a GROUP of `rows` rows (sum of the lengths, rounded up to the handle's row bucket); a buffer of k B
+// sequences is k groups; where a sequence starts, how long it is and which sequence / frame a row belongs to are DEVICE arrays, so a captured
+// step graph depends on (B, rows, query tiles of the longest item) only.
+struct Geom {
+    int B = 0, T = 0;                // items; frames (ragged: the longest item -- sizes the attention grid only)
+    bool rag = false;
+    int rows = 0;                    // frame rows of one group of B sequences (uniform: B * T)
+    int real_rows = 0;               // ragged: sum of the lengths (rows - real_rows padding rows per group)
+    double tt1 = 0;                  // sum over the items of T_i (T_i + 1): attention FLOP accounting
+    const int *seq_off = nullptr, *seq_len = nullptr, *row_seq = nullptr;
+    mmdm_rag rg{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    size_t rows_of(int nseq) const { return rag ? (size_t)(nseq / B) * rows : (size_t)nseq * T; }
 };
 
 struct Prof {
@@ -154,10 +171,29 @@ struct Prof {
 
 }  // namespace
 
+// Device memory of a handle's WEIGHTS (fp32 parameters, packed AdaLN matrices, the low-precision twins made by mmdm_prepare, normaliser
+// statistics): owned by this block, which the creating handle and every handle made from it by mmdm_create_shared hold by reference -- K
+// sampler handles (own workspace, streams, schedule tables and graph cache each) over ONE copy of the 1.46 GB parameter set.  Freed when the
+// last holder is destroyed, on the device it was allocated on.
+struct mmdm_weight_block {
+    std::vector<void*> allocs;
+    int device = 0;
+    ~mmdm_weight_block() {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    }
+};
+
 struct mmdm_handle_s {
     mmdm_config cfg;
     char err[512] = "";
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;                       // workspace, schedule tables, step state: this handle's own
+    std::shared_ptr<mmdm_weight_block> wb;           // weights: shared with the handles created from this one (mmdm_create_shared)
+    bool alloc_weights = false;                      // dalloc() target while the weight slots are being laid out
+    bool shared_child = false;                       // created by mmdm_create_shared: weights are set / prepared through the parent only
     std::unordered_map<std::string, Slot> slots;
     ModuleW d1, d2, mx;
     int nw = 23;
@@ -177,6 +213,10 @@ struct mmdm_handle_s {
     // call state
     int B = 0, T = 0;
     bool begun = false;
+    Geom geom;                                             // row geometry of the begun call (uniform or ragged)
+    int rag_bucket = 128;                                  // ragged calls: the group stride is the sum of the lengths rounded up to this many rows (MMDM_RAG_BUCKET)
+    int *d_rag = nullptr;                                  // ragged row maps: item_off | item_len | row_item | row_pos | row_seq | seq_off | seq_len
+    int *d_item_off = nullptr, *d_item_len = nullptr, *d_row_item = nullptr, *d_row_pos = nullptr, *d_row_seq = nullptr, *d_seq_off = nullptr, *d_seq_len = nullptr;
 
     // workspace
     Scratch sa, sb;                                        // sa: denoiser1 + Influence, sb: denoiser2 (runs concurrently)
@@ -202,7 +242,8 @@ struct mmdm_handle_s {
     // Captured step graphs, least-recently-used cache keyed by everything a captured node bakes in: (B, T, S).  History
     // destinations, schedule tables, conditioning and the step index are device-side data, not node arguments, so the eval
     // caller's alternating (B, T) requests (src/evaluation/datasets.py:101-122, 438) replay cached graphs instead of re-capturing.
-    struct GraphEntry { int B, T, S; hipGraphExec_t exec; uint64_t used; hipEvent_t done; };      // done: recorded behind the entry's last replay
+    // (ragged calls: T = query tiles of the longest item, rows = the group stride; uniform calls: rows = 0)
+    struct GraphEntry { int B, T, S, rows; hipGraphExec_t exec; uint64_t used; hipEvent_t done; };      // done: recorded behind the entry's last replay
     std::vector<GraphEntry> graphs;
     size_t graph_cap = 8;
     uint64_t graph_clock = 0;
@@ -232,7 +273,7 @@ int dalloc(mmdm_handle h, float** p, size_t nfloats) {
     void* q = nullptr;
     if (nfloats == 0) nfloats = 1;
     HIPCHK(hipMalloc(&q, nfloats * sizeof(float)));
-    h->allocs.push_back(q);
+    (h->alloc_weights ? h->wb->allocs : h->allocs).push_back(q);
     *p = static_cast<float*>(q);
     return MMDM_OK;
 }
@@ -358,7 +399,6 @@ int build_module(mmdm_handle h, ModuleW& m, const std::string& pfx, const std::s
     RC(add_slot(h, pfx + "embed_timestep.time_embed.2.bias", &m.t2_b, D, 1));
     RC(add_slot(h, out_name + ".weight", &m.out_w, out_rows, D));
     RC(add_slot(h, out_name + ".bias", &m.out_b, out_rows, 1));
-    RC(dalloc(h, &m.time_tab, (size_t)h->Smax * D));
     return MMDM_OK;
 }
 
@@ -393,7 +433,6 @@ int build_module_mdm(mmdm_handle h, ModuleW& m, const std::string& pfx, int D, i
         RC(add_slot(h, b + "norm2.weight", &e.n2_g, D, 1));
         RC(add_slot(h, b + "norm2.bias", &e.n2_b, D, 1));
     }
-    RC(dalloc(h, &m.time_tab, (size_t)h->Smax * D));
     return MMDM_OK;
 }
 
@@ -404,6 +443,9 @@ struct Ctx {
     mmdm_handle h;
     hipStream_t st;
     const Scratch* s;
+    const Geom* g = nullptr;      // row geometry (nullptr: uniform, sizes as passed)
+    bool rag() const { return g && g->rag; }
+    size_t rows_of(int nseq, int T) const { return g ? g->rows_of(nseq) : (size_t)nseq * T; }
 };
 
 // the row-split rule of the fp32 GEMM dispatch is thread-local state: set for the duration of one step / module forward, then restored
@@ -503,17 +545,36 @@ int linear_s(const Ctx& c, const void* A, int lda, size_t a_plane, const void* W
 }
 
 // attention whose Q K^T runs on the bf16 matrix cores from the plane copies written by the projection GEMMs
+// algorithmic work of one attention launch: 4 dh (T (T + 1)) per (sequence, head) -- summed over the items' own lengths in a ragged batch
+double attn_flops(const Ctx& c, int nseq, int H, int Tq, int Tk, int dh) {
+    if (c.rag()) return 4.0 * (nseq / c.g->B) * H * dh * c.g->tt1;
+    return 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh;
+}
+double attn_bytes(const Ctx& c, int nseq, int H, int Tq, int Tk, int dh) {
+    if (c.rag()) return 4.0 * (nseq / c.g->B) * H * dh * 4.0 * c.g->real_rows;
+    return 4.0 * nseq * H * dh * (2.0 * Tq + 2.0 * Tk);
+}
+// the ragged call's sequence description for the attention kernels (nullptr in the uniform layout); `nseq` sequences = nseq / B groups
+const mmdm_rag_seq* rag_seq(const Ctx& c, int nseq, mmdm_rag_seq& tmp) {
+    if (!c.rag()) return nullptr;
+    tmp = mmdm_rag_seq{c.g->seq_off, c.g->seq_len, (int)c.g->rows_of(nseq), c.g->T};
+    return &tmp;
+}
+
 int attention_p(const Ctx& c, const void* Qp, int ldq, size_t q_plane, const void* Kp, int ldk, size_t k_plane, int np, const float* V, int ldv, void* O, int ldo,
                 int out_mode, int nseq, int Tq, int Tk, int H, int dh, int shift, const void* Vp = nullptr, int ldvp = 0, size_t v_plane = 0) {
-    RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh, 4.0 * nseq * H * dh * (2.0 * Tq + 2.0 * Tk)));
-    RC(mmdm_attention_planes_ex(Qp, ldq, (int64_t)q_plane, Kp, ldk, (int64_t)k_plane, np, V, ldv, Vp, ldvp, (int64_t)v_plane, O, ldo, out_mode, 0, nseq, Tq, Tk, H, dh, shift, c.st));
+    mmdm_rag_seq tmp;
+    RC(prof_begin(c, 1, attn_flops(c, nseq, H, Tq, Tk, dh), attn_bytes(c, nseq, H, Tq, Tk, dh)));
+    RC(mmdm_attention_planes_ex(Qp, ldq, (int64_t)q_plane, Kp, ldk, (int64_t)k_plane, np, V, ldv, Vp, ldvp, (int64_t)v_plane, O, ldo, out_mode, 0, nseq, Tq, Tk, H, dh, shift, c.st,
+                                rag_seq(c, nseq, tmp)));
     return prof_end(c, 1);
 }
 
 int attention_b(const Ctx& c, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, void* O, int ldo, int out_bf16,
                 int nseq, int Tq, int Tk, int H, int dh, int shift) {
-    RC(prof_begin(c, 1, 4.0 * nseq * H * (double)Tq * (Tk + 1) * dh, 4.0 * nseq * H * dh * (2.0 * Tq + 2.0 * Tk)));
-    RC(mmdm_attention_ex(Q, ldq, K, ldk, V, ldv, O, ldo, out_bf16, nseq, Tq, Tk, H, dh, shift, c.st));
+    mmdm_rag_seq tmp;
+    RC(prof_begin(c, 1, attn_flops(c, nseq, H, Tq, Tk, dh), attn_bytes(c, nseq, H, Tq, Tk, dh)));
+    RC(mmdm_attention_opts_rag(Q, ldq, K, ldk, V, ldv, O, ldo, out_bf16, 0, nseq, Tq, Tk, H, dh, shift, rag_seq(c, nseq, tmp), c.st));
     return prof_end(c, 1);
 }
 
@@ -524,8 +585,9 @@ int ss_ld_of(const ModuleW& m) { return m.st.L * m.st.n_ada * 2 * m.st.D; }
 // the residual stream h, the Q/K/V projections, softmax and all accumulation stay fp32.
 int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     const Scratch& S = *c.s;
-    const int D = w.D, F = w.F, R = r.nseq * r.T, dh = D / w.H;
+    const int D = w.D, F = w.F, R = (int)c.rows_of(r.nseq, r.T), dh = D / w.H;
     const int prec = c.h->cfg.precision;
+    const int* const row_seq = c.rag() ? c.g->row_seq : nullptr;      // ragged: the AdaLN kernel looks a row's sequence up instead of dividing by T
     const bool bf = prec >= 1, f8 = prec == 3;
     const int ob = f8 ? 1 : prec;           // output mode of the attention (operand of the out-projection): 0 fp32, 1 bf16, 2 the two fp16 split planes
     auto bw = [](const void* base, size_t elems) { return static_cast<const void*>(static_cast<const uint16_t*>(base) + elems); };
@@ -555,8 +617,7 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     };
     // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / two fp16 planes, or fp8 + per-row scales
     auto norm = [&](const float* src, const float* ssp, int rows) -> int {
-        if (f8) return mmdm_adaln_any(src, ssp, r.ss_ld, rows, S.xn, 3, S.xs, r.nseq, r.T, D, c.st);
-        return mmdm_adaln_ex(src, ssp, r.ss_ld, rows, S.xn, ob, r.nseq, r.T, D, c.st);
+        return mmdm_adaln_any(src, ssp, r.ss_ld, rows, S.xn, f8 ? 3 : ob, f8 ? S.xs : nullptr, r.nseq, r.T, D, c.st, row_seq, R);
     };
     auto second = [&](void* buf, int ld, int cols) { Second s2; if (qkp) { s2.p = buf; s2.ld = ld; s2.cols = cols; s2.plane = (size_t)R * ld; } return s2; };
     // one-plane (bf16 / fp8) modes: the projection GEMMs' bf16 copy also covers V, and P.V runs on the bf16 matrix cores (attn_qkp_kernel<DH, 1, true>)
@@ -639,15 +700,18 @@ int cond_vectors(const Ctx& c, const ModuleW& m, const float* txt, float* se, fl
 // xp: the repacked pose rows of `repack` below, `rows` = nb*T rows per person; pe_row0 = 1 for MDMDenoiser (token 0 is the conditioning token).
 // Low-precision handles (m.me_s): the embedding runs on the fp32-split kernel -- fp32-accurate like the fp32 MFMA kernel it replaces there, at a
 // third of its time (K = 262 is 10 steps of the packed kernel); the fp32 mode keeps the fp32 MFMA kernel.
+// Ragged call: the PE rows were gathered per frame row of a group at mmdm_begin_ragged (m.pe_r [rows, D]) and the epilogue's `row % period`
+// runs over the group stride -- the GEMM kernels are untouched.
 int embed(const Ctx& c, const ModuleW& m, const float* xp, int p, float* hdst, int nb, int T, int pe_row0 = 0) {
-    const float* pe = m.pe + (size_t)pe_row0 * m.st.D;
-    const size_t rows = (size_t)nb * T;
+    const float* pe = c.rag() ? m.pe_r : m.pe + (size_t)pe_row0 * m.st.D;
+    const size_t rows = c.rows_of(nb, T);
+    const int period = c.rag() ? c.g->rows : T;
     if (m.me_s) {
         const _Float16* a = reinterpret_cast<const _Float16*>(xp) + (size_t)p * 2 * rows * NFS;
-        return linear_s(c, a, NFS, rows * NFS, m.me_s, c.h->no_pack ? NFS : 0, (size_t)m.st.D * NFS, m.me_b, hdst, m.st.D, 0, 0, nb * T, m.st.D, NFS, MMDM_EPI_BIAS_PE, pe,
-                        m.st.D, Second(), T);
+        return linear_s(c, a, NFS, rows * NFS, m.me_s, c.h->no_pack ? NFS : 0, (size_t)m.st.D * NFS, m.me_b, hdst, m.st.D, 0, 0, (int)rows, m.st.D, NFS, MMDM_EPI_BIAS_PE, pe,
+                        m.st.D, Second(), period);
     }
-    return linear(c, xp + (size_t)p * rows * NFP, NFP, m.me_w, NFP, m.me_b, hdst, m.st.D, nb * T, m.st.D, NFP, MMDM_EPI_BIAS_PE, pe, m.st.D, T, NFP);
+    return linear(c, xp + (size_t)p * rows * NFP, NFP, m.me_w, NFP, m.me_b, hdst, m.st.D, (int)rows, m.st.D, NFP, MMDM_EPI_BIAS_PE, pe, m.st.D, period, NFP);
 }
 // pose rows x [rows, ldx] (npers persons side by side) -> the embedding GEMM's A operand: fp32 [npers][rows][NFP], or the two fp16 planes [npers][2][rows][NFS]
 int repack(const Ctx& c, const ModuleW& m, const float* x, int ldx, float* xp, int npers, int rows) {
@@ -667,15 +731,15 @@ int run_denoiser(const Ctx& c, const ModuleW& m, bool interaction, const float* 
     r.ca_mode = interaction ? 1 : 0;
     r.kv_src = nullptr;
     // embed: `x` holds xb samples (xb == n, or xb == n/2 when cond/uncond halves share the same x: cfg_sampler.py:41-42)
-    RC(repack(c, m, x, ldx, c.s->xp, npers, xb * T));
+    RC(repack(c, m, x, ldx, c.s->xp, npers, (int)c.rows_of(xb, T)));
     for (int p = 0; p < npers; ++p)
         for (int rep = 0; rep < n / xb; ++rep) {
-            const size_t row0 = ((size_t)p * n + (size_t)rep * xb) * T;
+            const size_t row0 = c.rows_of(p * n + rep * xb, T);
             RC(embed(c, m, c.s->xp, p, c.s->h + row0 * D, xb, T));
         }
     RC(run_stack(c, m.st, c.s->h, r));
     for (int p = 0; p < npers; ++p)   // FinalLayer (layers.py:109-116), per person, concatenated on the channel axis (in2in.py:455-461)
-        RC(linear(c, c.s->h + (size_t)p * n * T * D, D, m.out_w, D, m.out_b, out + (size_t)p * NF, ldo, n * T, NF, D));
+        RC(linear(c, c.s->h + c.rows_of(p * n, T) * D, D, m.out_w, D, m.out_b, out + (size_t)p * NF, ldo, (int)c.rows_of(n, T), NF, D));
     return MMDM_OK;
 }
 
@@ -757,10 +821,13 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     mmdm_handle H = c.h;
     const int n = 2 * B, Dm = H->mx.st.D;
     const mmdm_config& cf = H->cfg;
-    RC(mmdm_mixer_pre_f32(H->o1, H->o2, H->d_stats, H->out1, H->out2, n, T, cf.align, c.st));
+    const bool rag = c.rag();
+    const size_t nT = c.rows_of(n, T);               // frame rows of the CFG-doubled batch (uniform: n * T)
+    if (rag) RC(mmdm_mixer_pre_rag(H->o1, H->o2, H->d_stats, H->out1, H->out2, n / B, cf.align, c.g->rg, c.st));
+    else RC(mmdm_mixer_pre_f32(H->o1, H->o2, H->d_stats, H->out1, H->out2, n, T, cf.align, c.st));
     // motion_embed + PE of the four streams (mixermdm.py:722-732); seq = p*n + b
-    RC(repack(c, H->mx, H->out1, NF2, H->sa.xp, 2, n * T));
-    RC(repack(c, H->mx, H->out2, NF2, H->sb.xp, 2, n * T));
+    RC(repack(c, H->mx, H->out1, NF2, H->sa.xp, 2, (int)nT));
+    RC(repack(c, H->mx, H->out2, NF2, H->sb.xp, 2, (int)nT));
     StackRun r;
     r.nseq = 2 * n; r.T = T; r.ss = H->ss_mx; r.ss_ld = ss_ld_of(H->mx);
     r.sa_row0 = 0; r.sa_rows = 2 * n;          // cond_i1 | cond_i2
@@ -769,20 +836,20 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     r.ca_mode = 2; r.kv_src = H->mI;
     const bool split = H->overlap && !H->prof.on && c.s == &H->sa && H->sb.h;      // the two Influence calls on two streams, each with its own scratch
     for (int p = 0; p < 2; ++p) {
-        RC(embed(c, H->mx, H->sa.xp, p, c.s->h + (size_t)p * n * T * Dm, n, T));
-        RC(embed(c, H->mx, H->sb.xp, p, H->mI + (size_t)p * n * T * Dm, n, T));
+        RC(embed(c, H->mx, H->sa.xp, p, c.s->h + (size_t)p * nT * Dm, n, T));
+        RC(embed(c, H->mx, H->sb.xp, p, H->mI + (size_t)p * nT * Dm, n, T));
     }
     if (split) {
         // the two Influence calls (mixermdm.py:735-736: person 1, person 2) are independent: one per stream (64.7 -> 64.2 ms/step)
-        Ctx c2{H, H->st2, &H->sb};
+        Ctx c2{H, H->st2, &H->sb, c.g};
         StackRun r1 = r, r2 = r;
         r1.nseq = r2.nseq = n;
         r1.sa_rows = r2.sa_rows = n;
         r2.sa_row0 = n;
-        r2.kv_src = H->mI + (size_t)n * T * Dm;
+        r2.kv_src = H->mI + nT * Dm;
         HIPCHK(hipEventRecord(H->ev_fork2, c.st));
         HIPCHK(hipStreamWaitEvent(H->st2, H->ev_fork2, 0));
-        RC(run_stack(c2, H->mx.st, c.s->h + (size_t)n * T * Dm, r2));
+        RC(run_stack(c2, H->mx.st, c.s->h + nT * Dm, r2));
         RC(run_stack(c, H->mx.st, c.s->h, r1));
         HIPCHK(hipEventRecord(H->ev_join2, H->st2));
         HIPCHK(hipStreamWaitEvent(c.st, H->ev_join2, 0));
@@ -793,17 +860,19 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     // Influence.out + sigmoid (influence.py:124-125) as a GEMM with a sigmoid epilogue: N = 1 or 23 columns of a 64-wide MFMA tile --
     // wasteful per flop and still 8x faster than a wave-per-row dot-product kernel at 19 200 rows
     if (mode == 1 || mode == 3) {
-        RC(mmdm_mean_time_f32(c.s->h, H->hpool, 2 * n, T, Dm, c.st));
+        if (rag) RC(mmdm_mean_time_rag(c.s->h, H->hpool, 2 * n, c.g->seq_off, c.g->seq_len, Dm, c.st));
+        else RC(mmdm_mean_time_f32(c.s->h, H->hpool, 2 * n, T, Dm, c.st));
         RC(linear(c, H->hpool, Dm, H->mx.out_w, Dm, H->mx.out_b, H->w23, H->nw, 2 * n, H->nw, Dm, MMDM_EPI_BIAS_SIGMOID));
     } else {
-        RC(linear(c, c.s->h, Dm, H->mx.out_w, Dm, H->mx.out_b, H->w23, H->nw, 2 * n * T, H->nw, Dm, MMDM_EPI_BIAS_SIGMOID));
+        RC(linear(c, c.s->h, Dm, H->mx.out_w, Dm, H->mx.out_b, H->w23, H->nw, (int)(2 * nT), H->nw, Dm, MMDM_EPI_BIAS_SIGMOID));
     }
     // history destinations come from the device-side descriptor: the launches below are identical whether or not (and where) a call
     // keeps history, so one captured graph serves all of them; the two copy kernels return at once on a null destination
     const int* lp = H->d_step + 1;
-    RC(mmdm_blend_cfg_dyn(H->out1, H->out2, H->w23, mode, cf.use_force, cf.force_val, cf.cfg_scale, H->model_out, H->d_hist, lp, B, T, c.st));
-    RC(mmdm_hist_copy(H->out1, H->d_hist, 0, (size_t)n * T * NF2, lp, c.st));
-    RC(mmdm_hist_copy(H->out2, H->d_hist, 1, (size_t)n * T * NF2, lp, c.st));
+    if (rag) RC(mmdm_blend_cfg_rag(H->out1, H->out2, H->w23, mode, cf.use_force, cf.force_val, cf.cfg_scale, H->model_out, H->d_hist, lp, c.g->rg, c.st));
+    else RC(mmdm_blend_cfg_dyn(H->out1, H->out2, H->w23, mode, cf.use_force, cf.force_val, cf.cfg_scale, H->model_out, H->d_hist, lp, B, T, c.st));
+    RC(mmdm_hist_copy(H->out1, H->d_hist, 0, nT * NF2, lp, c.st));
+    RC(mmdm_hist_copy(H->out2, H->d_hist, 1, nT * NF2, lp, c.st));
     (void)dyn_hist;
     return MMDM_OK;
 }
@@ -822,7 +891,9 @@ int run_step(const Ctx& c) {
             RC(cond_vectors(c, H->d1, H->txt_d1, H->se_d1, H->ss_d1, n));
             RC(run_denoiser(c, H->d1, false, H->x, B, 1, NF, n, T, H->ss_d1, ss_ld_of(H->d1), H->o1, NF));
         }
-        RC(mmdm_cfg_ddim_f32(H->o1, H->d_coef, H->S, H->d_step, H->cfg.cfg_scale, H->x, H->px1, B, T, NF, c.st));
+        // (ragged: one "item" of `rows` frames -- the combine is element-wise over a half of the CFG-doubled batch, padding rows included)
+        if (c.rag()) RC(mmdm_cfg_ddim_f32(H->o1, H->d_coef, H->S, H->d_step, H->cfg.cfg_scale, H->x, H->px1, 1, c.g->rows, NF, c.st));
+        else RC(mmdm_cfg_ddim_f32(H->o1, H->d_coef, H->S, H->d_step, H->cfg.cfg_scale, H->x, H->px1, B, T, NF, c.st));
         return mmdm_step_dec(H->d_step, H->d_step + 1, c.st);
     }
     if (H->cfg.single_only == 2) {   // stand-alone interaction denoiser, 4 CFG copies of x (cfg_sampler.py:70-71)
@@ -844,7 +915,7 @@ int run_step(const Ctx& c) {
     if (H->overlap && !H->prof.on) {
         // fork: denoiser2 (with its AdaLN-projection GEMM) on the auxiliary stream with its own scratch; denoiser1 and the mixer's
         // projections on the caller's stream (denoiser1 is the shorter model); join before the mixer
-        Ctx c2{H, H->st2, &H->sb};
+        Ctx c2{H, H->st2, &H->sb, c.g};
         HIPCHK(hipEventRecord(H->ev_fork, c.st));
         HIPCHK(hipStreamWaitEvent(H->st2, H->ev_fork, 0));
         RC(cond_vectors(c2, H->d2, H->txt_d2, H->se_d2, H->ss_d2, 3 * n));
@@ -867,8 +938,10 @@ int run_step(const Ctx& c) {
         return mmdm_step_dec(H->d_step, H->d_step + 1, c.st);
     }
     RC(mixer_core(c, B, T, true));
-    RC(mmdm_xstart_ddim_f32(H->model_out, H->d_stats, H->d_coef, H->S, H->d_step, H->x, H->x2, H->px1, H->px2, H->floor_ws,
-                            B, T, H->cfg.xstart_align, c.st));
+    if (c.rag()) RC(mmdm_xstart_ddim_rag(H->model_out, H->d_stats, H->d_coef, H->S, H->d_step, H->x, H->x2, H->px1, H->px2, H->floor_ws,
+                                         H->cfg.xstart_align, c.g->rg, c.st));
+    else RC(mmdm_xstart_ddim_f32(H->model_out, H->d_stats, H->d_coef, H->S, H->d_step, H->x, H->x2, H->px1, H->px2, H->floor_ws,
+                                 B, T, H->cfg.xstart_align, c.st));
     return mmdm_step_dec(H->d_step, H->d_step + 1, c.st);
 }
 
@@ -929,7 +1002,8 @@ int push_hist(mmdm_handle h, hipStream_t st) { return mmdm_set_hist_desc(h->d_hi
 // ------------------------------------------------------------------------------------------------------
 extern "C" const char* mmdm_handle_error(mmdm_handle h) { return h ? h->err : "null handle"; }
 
-extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
+// mmdm_create (parent == nullptr) and mmdm_create_shared (parent = the handle whose weights the new one borrows)
+static int create_impl(const mmdm_config* cfg, mmdm_handle parent, mmdm_handle* out) {
     if (!cfg || !out) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create: null argument");
     if (cfg->nfeats != NF) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_create: nfeats must be 262");
     const int so = cfg->single_only;
@@ -961,6 +1035,7 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     mmdm_handle h = new mmdm_handle_s();
     h->cfg = *cfg;
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return mmdm_set_error(MMDM_ERR_HIP, "mmdm_create: hipGetDevice failed"); }
+    if (parent && parent->device != h->device) { delete h; return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create_shared: the parent handle lives on device %d, the current device is %d", parent->device, h->device); }
     const mmdm_config& c = h->cfg;
     h->nw = (c.mixing_mode >= 3) ? 23 : 1;
     int rc = MMDM_OK;
@@ -969,13 +1044,34 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     const int Dm = has_mx ? c.m_latent : 4, Fm = has_mx ? c.m_ff : 4;
     h->td1 = mdm ? D1 : td;                                  // MDMDenoiser adds its cond slice to the timestep embedding: latent-sized (mdm.py:279)
     h->cond_w = so == 0 ? 6 * td + 2 * h->td1 : so == 1 ? h->td1 : so == 2 ? 3 * td : 5 * td;
-    if (has_d1) {
-        rc = mdm ? build_module_mdm(h, h->d1, "denoiser1.", D1, F1, L1, H1)
-                 : build_module(h, h->d1, "denoiser1.", "denoiser1.", D1, F1, L1, H1, false, true, "denoiser1.out.linear", NF);
-        if (rc) return fail(rc);
+    if (parent) {
+        // borrow the parent's weights: the module descriptors are tables of pointers into the shared weight block (incl. the low-precision
+        // twins and their layout flags as mmdm_prepare left them); everything that depends on a call or a schedule is this handle's own
+        h->wb = parent->wb;
+        h->shared_child = true;
+        h->d1 = parent->d1; h->d2 = parent->d2; h->mx = parent->mx;
+        h->d1.time_tab = h->d2.time_tab = h->mx.time_tab = nullptr;
+        h->d1.pe_r = h->d2.pe_r = h->mx.pe_r = nullptr;
+        h->d_stats = parent->d_stats; h->stats_set = parent->stats_set;
+        h->prepared = true;
+    } else {
+        h->wb = std::make_shared<mmdm_weight_block>();
+        h->wb->device = h->device;
+        h->alloc_weights = true;
+        if (has_d1) {
+            rc = mdm ? build_module_mdm(h, h->d1, "denoiser1.", D1, F1, L1, H1)
+                     : build_module(h, h->d1, "denoiser1.", "denoiser1.", D1, F1, L1, H1, false, true, "denoiser1.out.linear", NF);
+            if (rc) return fail(rc);
+        }
+        if (has_d2 && (rc = build_module(h, h->d2, "denoiser2.", "denoiser2.", D, F, c.d_layers, c.d_heads, true, false, "denoiser2.out.linear", NF))) return fail(rc);
+        if (has_mx && (rc = build_module(h, h->mx, "", "influence.", Dm, Fm, c.m_layers, c.m_heads, true, false, "influence.out", h->nw))) return fail(rc);
+        if ((rc = dalloc(h, &h->d_stats, 4 * NF))) return fail(rc);
+        h->alloc_weights = false;
     }
-    if (has_d2 && (rc = build_module(h, h->d2, "denoiser2.", "denoiser2.", D, F, c.d_layers, c.d_heads, true, false, "denoiser2.out.linear", NF))) return fail(rc);
-    if (has_mx && (rc = build_module(h, h->mx, "", "influence.", Dm, Fm, c.m_layers, c.m_heads, true, false, "influence.out", h->nw))) return fail(rc);
+    // per-schedule timestep-embedding tables: this handle's own (a shared handle may run another sampling strategy than its parent)
+    if (has_d1 && (rc = dalloc(h, &h->d1.time_tab, (size_t)h->Smax * D1))) return fail(rc);
+    if (has_d2 && (rc = dalloc(h, &h->d2.time_tab, (size_t)h->Smax * D))) return fail(rc);
+    if (has_mx && (rc = dalloc(h, &h->mx.time_tab, (size_t)h->Smax * Dm))) return fail(rc);
     const int npers = so == 1 ? 1 : 2;
     const size_t R = (size_t)npers * n * (T + 1);            // + 1: MDMDenoiser's conditioning token
     const size_t Dx = max2(max2(has_d1 ? D1 : 4, has_d2 ? D : 4), Dm), Fx = max2(max2(has_d1 ? F1 : 4, has_d2 ? F : 4), Fm);
@@ -1004,9 +1100,13 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
         return fail(mmdm_set_error(MMDM_ERR_HIP, "mmdm_create: stream/event creation failed"));
     h->overlap = getenv("MMDM_NO_OVERLAP") == nullptr;
     auto env_on = [](const char* k) { const char* v = getenv(k); return v != nullptr && strcmp(v, "0") != 0; };
-    h->force_qkp = env_on("MMDM_QKP"); h->no_qkp = env_on("MMDM_NO_QKP"); h->no_pvb = env_on("MMDM_NO_BF16_PV");
-    h->no_pack = env_on("MMDM_NO_PACK") || env_on("MMDM_SPLIT_NO_PACK");
-    h->no_split_embed = env_on("MMDM_NO_SPLIT_EMBED");
+    if (parent) {       // the switches that decide the FORMAT of the shared weights (and the kernels that read them) are the parent's
+        h->force_qkp = parent->force_qkp; h->no_qkp = parent->no_qkp; h->no_pvb = parent->no_pvb; h->no_pack = parent->no_pack; h->no_split_embed = parent->no_split_embed;
+    } else {
+        h->force_qkp = env_on("MMDM_QKP"); h->no_qkp = env_on("MMDM_NO_QKP"); h->no_pvb = env_on("MMDM_NO_BF16_PV");
+        h->no_pack = env_on("MMDM_NO_PACK") || env_on("MMDM_SPLIT_NO_PACK");
+        h->no_split_embed = env_on("MMDM_NO_SPLIT_EMBED");
+    }
     const size_t PT = (size_t)n * T * (so == 1 ? NF : NF2);
     const size_t PB = (size_t)B * T * (so == 1 ? NF : NF2);
     if ((rc = dalloc(h, &h->x, PB)) || (rc = dalloc(h, &h->px1, PB))) return fail(rc);
@@ -1032,7 +1132,7 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     }
     if ((rc = dalloc(h, &h->cond_cat, (size_t)n * h->cond_w))) return fail(rc);
     if ((rc = dalloc(h, &h->tt_tmp, (size_t)h->Smax * Dx)) || (rc = dalloc(h, &h->tt_tmp2, (size_t)h->Smax * Dx)) || (rc = dalloc(h, &h->tt_stash, 3 * Dx))) return fail(rc);
-    if ((rc = dalloc(h, &h->d_coef, (size_t)4 * h->Smax)) || (rc = dalloc(h, &h->d_stats, 4 * NF)) || (rc = dalloc(h, &h->dual_w, h->Smax))) return fail(rc);
+    if ((rc = dalloc(h, &h->d_coef, (size_t)4 * h->Smax)) || (rc = dalloc(h, &h->dual_w, h->Smax))) return fail(rc);
     float* tmp = nullptr;
     if ((rc = dalloc(h, &tmp, h->Smax))) return fail(rc);
     h->d_tmap = reinterpret_cast<int*>(tmp);
@@ -1043,8 +1143,30 @@ extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) {
     if (hipMemcpy(h->d_hist, &h->hist, sizeof(mmdm_hist_desc), hipMemcpyHostToDevice) != hipSuccess)
         return fail(mmdm_set_error(MMDM_ERR_HIP, "mmdm_create: history descriptor upload failed"));
     if (const char* e = getenv("MMDM_GRAPH_CACHE")) { long v = atol(e); if (v >= 1 && v <= 64) h->graph_cap = (size_t)v; }
+    // ragged calls (mmdm_begin_ragged): row maps for up to 4 groups of max_batch * max_frames rows, and per module the PE rows of a group
+    if (so <= 1 && !mdm) {
+        const size_t cap = (size_t)B * T, nb = (size_t)(B < MMDM_RAG_MAX_ITEMS ? B : MMDM_RAG_MAX_ITEMS), G = 4;
+        if ((rc = dalloc(h, &tmp, 2 * nb + 2 * cap + G * cap + 2 * G * nb))) return fail(rc);
+        h->d_rag = reinterpret_cast<int*>(tmp);
+        h->d_item_off = h->d_rag; h->d_item_len = h->d_item_off + nb; h->d_row_item = h->d_item_len + nb; h->d_row_pos = h->d_row_item + cap;
+        h->d_row_seq = h->d_row_pos + cap; h->d_seq_off = h->d_row_seq + G * cap; h->d_seq_len = h->d_seq_off + G * nb;
+        if (has_d1 && (rc = dalloc(h, &h->d1.pe_r, cap * D1))) return fail(rc);
+        if (has_d2 && (rc = dalloc(h, &h->d2.pe_r, cap * D))) return fail(rc);
+        if (has_mx && (rc = dalloc(h, &h->mx.pe_r, cap * Dm))) return fail(rc);
+        if (const char* e = getenv("MMDM_RAG_BUCKET")) { long v = atol(e); if (v >= 1 && v <= 4096) h->rag_bucket = (int)v; }
+    }
     *out = h;
     return MMDM_OK;
+}
+
+extern "C" int mmdm_create(const mmdm_config* cfg, mmdm_handle* out) { return create_impl(cfg, nullptr, out); }
+
+extern "C" int mmdm_create_shared(mmdm_handle parent, int max_batch, int max_frames, mmdm_handle* out) {
+    if (!parent || !out) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_create_shared: null argument");
+    if (!parent->prepared) return herr(parent, mmdm_set_error(MMDM_ERR_STATE, "mmdm_create_shared: load the weights and call mmdm_prepare on the parent first"));
+    mmdm_config c = parent->cfg;
+    c.max_batch = max_batch; c.max_frames = max_frames;
+    return create_impl(&c, parent, out);
 }
 
 extern "C" void mmdm_destroy(mmdm_handle h) {
@@ -1069,6 +1191,7 @@ extern "C" void mmdm_destroy(mmdm_handle h) {
 
 extern "C" int mmdm_set_weight(mmdm_handle h, const char* name, const float* src, int64_t rows, int64_t cols, void* stream) {
     if (!h || !name) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_weight: null argument");
+    if (h->shared_child) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_set_weight(%s): this handle borrows its weights (mmdm_create_shared); set them on the parent", name));
     auto it = h->slots.find(name);
     if (it == h->slots.end()) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "Unexpected key in state_dict: \"%s\"", name));
     Slot& s = it->second;
@@ -1087,6 +1210,7 @@ extern "C" int mmdm_set_weight(mmdm_handle h, const char* name, const float* src
 
 extern "C" int mmdm_set_norm_stats(mmdm_handle h, const float* stats_host) {
     if (!h || !stats_host) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_set_norm_stats: null argument");
+    if (h->shared_child) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_set_norm_stats: this handle borrows its weights and statistics (mmdm_create_shared); set them on the parent"));
     hipError_t e = hipMemcpy(h->d_stats, stats_host, 4 * NF * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) return herr(h, mmdm_set_error(MMDM_ERR_HIP, "mmdm_set_norm_stats: %s", hipGetErrorString(e)));
     h->stats_set = true;
@@ -1095,6 +1219,7 @@ extern "C" int mmdm_set_norm_stats(mmdm_handle h, const float* stats_host) {
 
 extern "C" int mmdm_prepare(mmdm_handle h) {
     if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_prepare: null handle");
+    if (h->shared_child) return MMDM_OK;               // prepared through the parent (mmdm_create_shared requires it)
     std::string missing;
     int nmiss = 0;
     for (auto& kv : h->slots)
@@ -1225,14 +1350,56 @@ extern "C" int mmdm_set_dual_weights(mmdm_handle h, const float* w_host, int S) 
     return MMDM_OK;
 }
 
-extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, int B, int T, void* stream) {
+// mmdm_begin (lens == nullptr: B items of T frames) and mmdm_begin_ragged (lens = B host ints, x_T = the items' frames back to back)
+static int begin_impl(mmdm_handle h, const float* cond, const float* x_T, int B, int T, const int* lens, void* stream) {
     if (!h || !cond || !x_T) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_begin: null argument");
     if (!h->prepared || h->S == 0) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_begin: prepare() and set_schedule() first"));
-    if (B <= 0 || B > h->cfg.max_batch || T <= 0 || T > h->cfg.max_frames)
-        return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_begin: B=%d T=%d exceed the handle's max_batch=%d / max_frames=%d", B, T, h->cfg.max_batch, h->cfg.max_frames));
+    Geom g;
+    if (lens) {
+        if (h->cfg.single_only > 1 || h->d1.kind == 1 || !h->d_rag)
+            return herr(h, mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_begin_ragged: ragged batches cover the two-chain MixerMDM sampler and the single-person sampler over in2IN / InterGen denoisers"));
+        const StackW* sts[3] = {h->cfg.single_only != 2 ? &h->d1.st : nullptr, h->cfg.single_only != 1 ? &h->d2.st : nullptr, h->cfg.single_only == 0 ? &h->mx.st : nullptr};
+        for (const StackW* w : sts)
+            if (w && w->D / w->H != 64 && w->D / w->H != 128)
+                return herr(h, mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_begin_ragged: head size %d (the ragged attention kernels cover 64 and 128)", w->D / w->H));
+        if (B <= 0 || B > h->cfg.max_batch || B > MMDM_RAG_MAX_ITEMS)
+            return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_begin_ragged: B=%d outside [1, min(max_batch=%d, %d)]", B, h->cfg.max_batch, MMDM_RAG_MAX_ITEMS));
+        long sum = 0; int mx = 0; double tt1 = 0;
+        for (int b = 0; b < B; ++b) {
+            if (lens[b] <= 0 || lens[b] > h->cfg.max_frames)
+                return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_begin_ragged: item %d has %d frames (1 .. max_frames=%d)", b, lens[b], h->cfg.max_frames));
+            sum += lens[b]; mx = lens[b] > mx ? lens[b] : mx; tt1 += (double)lens[b] * (lens[b] + 1);
+        }
+        const long cap = (long)h->cfg.max_batch * h->cfg.max_frames;
+        if (sum > cap) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_begin_ragged: %ld frames in all exceed the workspace (max_batch x max_frames = %ld)", sum, cap));
+        long rows = (sum + h->rag_bucket - 1) / h->rag_bucket * h->rag_bucket;
+        if (rows > cap) rows = cap;
+        T = mx;
+        g.rag = true; g.rows = (int)rows; g.real_rows = (int)sum; g.tt1 = tt1;
+        g.seq_off = h->d_seq_off; g.seq_len = h->d_seq_len; g.row_seq = h->d_row_seq;
+        g.rg = mmdm_rag{h->d_row_item, h->d_row_pos, h->d_item_off, h->d_item_len, B, (int)rows};
+    } else {
+        if (B <= 0 || B > h->cfg.max_batch || T <= 0 || T > h->cfg.max_frames)
+            return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_begin: B=%d T=%d exceed the handle's max_batch=%d / max_frames=%d", B, T, h->cfg.max_batch, h->cfg.max_frames));
+        g.rows = B * T; g.real_rows = B * T; g.tt1 = (double)B * T * (T + 1);
+    }
+    g.B = B; g.T = T;
     hipStream_t st = static_cast<hipStream_t>(stream);
     Ctx c{h, st, &h->sa};
     const int n = 2 * B, td = h->cfg.text_dim;
+    // frames handed over / frame rows of the chains' buffers (ragged: the padding rows of the group are zeroed -- they are embedded and
+    // normalised like any row, never read by a real one)
+    const size_t fr = (size_t)g.real_rows, frp = (size_t)g.rows;
+    auto load_x = [&](float* dst, int width) -> int {
+        HIPCHK(hipMemcpyAsync(dst, x_T, fr * width * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (frp > fr) HIPCHK(hipMemsetAsync(dst + fr * width, 0, (frp - fr) * width * sizeof(float), st));
+        return MMDM_OK;
+    };
+    if (g.rag) {
+        RC(herr(h, mmdm_rag_setup(lens, B, g.rows, 4, h->d_item_off, h->d_item_len, h->d_row_item, h->d_row_pos, h->d_row_seq, h->d_seq_off, h->d_seq_len, st)));
+        for (ModuleW* m : {&h->d1, &h->d2, &h->mx})
+            if (m->pe_r && m->pe) RC(herr(h, mmdm_gather_rows(m->pe, h->d_row_pos, m->pe_r, g.rows, m->st.D, st)));
+    }
     if (h->cfg.single_only == 3 && !h->dual_w_set) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_begin: call mmdm_set_dual_weights after mmdm_set_schedule"));
     ProfPause pause(h->prof);
     int rc = MMDM_OK;
@@ -1254,7 +1421,7 @@ extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, in
         HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n * cw * sizeof(float), st));
         HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * cw * sizeof(float), hipMemcpyDeviceToDevice, st));
         if (h->d1.kind == 0) rc = linear(c, h->cond_cat, td, h->d1.te_w, td, h->d1.te_b, h->txt_d1, h->d1.st.D, n, h->d1.st.D, td);
-        HIPCHK(hipMemcpyAsync(h->x, x_T, (size_t)B * T * NF * sizeof(float), hipMemcpyDeviceToDevice, st));
+        RC(load_x(h->x, NF));
     } else {
         // mixer: cond [B, 6*td + 2*td1] (mixermdm.py:342-354); dual: cond [B, 5*td] (in2in.py:299-305) -- same column order for the
         // first five slices, so text_all serves both
@@ -1262,18 +1429,37 @@ extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, in
         HIPCHK(hipMemsetAsync(h->cond_cat, 0, (size_t)n * cw * sizeof(float), st));
         HIPCHK(hipMemcpyAsync(h->cond_cat, cond, (size_t)B * cw * sizeof(float), hipMemcpyDeviceToDevice, st));
         rc = text_all(c, h->cond_cat, n);
-        HIPCHK(hipMemcpyAsync(h->x, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        if (h->x2) HIPCHK(hipMemcpyAsync(h->x2, x_T, (size_t)B * T * NF2 * sizeof(float), hipMemcpyDeviceToDevice, st));   // img2 = img.clone()
+        RC(load_x(h->x, NF2));
+        if (h->x2) RC(load_x(h->x2, NF2));                  // img2 = img.clone()
     }
     if (rc) return herr(h, rc);
     RC(mmdm_set_step(h->d_step, h->d_step + 1, h->S - 1, 0, st));
     h->host_step = h->S - 1;
     h->B = B; h->T = T; h->begun = true;
+    h->geom = g;
     h->call_stream = st;
     // a new call keeps no history until mmdm_set_history says so: the descriptor is rewritten ON THE STREAM, behind any step of the
     // previous call still in flight, so an earlier call's buffers can never be written again (graphs do not bake them in)
     h->hist = mmdm_hist_desc{nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0};
     return herr(h, push_hist(h, st));
+}
+
+extern "C" int mmdm_begin(mmdm_handle h, const float* cond, const float* x_T, int B, int T, void* stream) {
+    return begin_impl(h, cond, x_T, B, T, nullptr, stream);
+}
+
+extern "C" int mmdm_begin_ragged(mmdm_handle h, const float* cond, const float* x_T, int B, const int* lens_host, void* stream) {
+    if (!lens_host) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_begin_ragged: null lengths");
+    return begin_impl(h, cond, x_T, B, 0, lens_host, stream);
+}
+
+extern "C" int mmdm_call_rows(mmdm_handle h, int* rows, int* real_rows, int* ragged) {
+    if (!h) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_call_rows: null handle");
+    if (!h->begun) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_call_rows: call mmdm_begin / mmdm_begin_ragged first"));
+    if (rows) *rows = h->geom.rows;
+    if (real_rows) *real_rows = h->geom.real_rows;
+    if (ragged) *ragged = h->geom.rag ? 1 : 0;
+    return MMDM_OK;
 }
 
 extern "C" int mmdm_set_history(mmdm_handle h, float* influence_i1, float* influence_i2, float* out1, float* out2, float* out_influenced, int every) {
@@ -1292,14 +1478,16 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
     if (nsteps < 0 || nsteps > h->host_step + 1)
         return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: %d steps requested, %d left in the schedule", nsteps, h->host_step + 1));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    Ctx c{h, st, &h->sa};
+    Ctx c{h, st, &h->sa, &h->geom};
     if (use_graph && !h->prof.on) {
         if (!st) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: graph capture needs a non-default stream"));
         if (nsteps == 0) return MMDM_OK;
         hipGraphExec_t exec = nullptr;
         hipEvent_t done = nullptr;
+        // what a captured node bakes in: uniform (B, T, S); ragged (B, query tiles of the longest item, S, group stride) -- the lengths are device data
+        const int kT = h->geom.rag ? (h->T + 63) / 64 : h->T, kR = h->geom.rag ? h->geom.rows : 0;
         for (auto& g : h->graphs)
-            if (g.B == h->B && g.T == h->T && g.S == h->S) { exec = g.exec; done = g.done; g.used = ++h->graph_clock; break; }
+            if (g.B == h->B && g.T == kT && g.S == h->S && g.rows == kR) { exec = g.exec; done = g.done; g.used = ++h->graph_clock; break; }
         if (!exec) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
@@ -1330,7 +1518,7 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
                 (void)hipGraphExecDestroy(exec);
                 return herr(h, mmdm_set_error(MMDM_ERR_HIP, "mmdm_run: hipEventCreate: %s", hipGetErrorString(e)));
             }
-            h->graphs.push_back({h->B, h->T, h->S, exec, ++h->graph_clock, done});
+            h->graphs.push_back({h->B, kT, h->S, kR, exec, ++h->graph_clock, done});
             ++h->n_captures;
         }
         for (int k = 0; k < nsteps; ++k) HIPCHK(hipGraphLaunch(exec, st));

@@ -31,7 +31,8 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {      // OCP e4m3, RNE,
 // max|y| / 448; the fp8 GEMM multiplies it back in its epilogue)
 template <int MAXV, int OMODE>
 __global__ __launch_bounds__(256, MAXV <= 4 ? 8 : 4) void adaln_kernel(const float* __restrict__ h, const float* __restrict__ ss, int ss_ld, int ss_rows,
-                                                     void* __restrict__ outv, int rows, int T, int D, float* __restrict__ row_scale = nullptr) {
+                                                     void* __restrict__ outv, int rows, int T, int D, float* __restrict__ row_scale = nullptr,
+                                                     const int* __restrict__ row_seq = nullptr) {     // ragged batch: sequence of every row (T unused)
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;                                   // float4 per row (D % 4 == 0 checked on host)
     // persistent: a fixed grid of wave slots walks the rows (one launch of ~2000 blocks instead of rows/4 short-lived ones)
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256, MAXV <= 4 ? 8 : 4) void adaln_kernel(const flo
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-6f);
-    const float* sp = ss + (size_t)((row / T) % ss_rows) * ss_ld;
+    const int sq = row_seq ? row_seq[row] : row / T;              // (wave-uniform)
+    const float* sp = ss + (size_t)(sq % ss_rows) * ss_ld;
     if constexpr (OMODE == 3) {
         float amax = 0.f;
 #pragma unroll
@@ -203,6 +205,18 @@ __global__ void mean_time_kernel(const float* __restrict__ h, float* __restrict_
     out[(size_t)seq * D + d] = s / (float)T;
 }
 
+// ragged batch: sequence s = rows [seq_off[s], seq_off[s] + seq_len[s]) of h (same summation order as mean_time_kernel: bit-identical per sequence)
+__global__ void mean_time_rag_kernel(const float* __restrict__ h, float* __restrict__ out, const int* __restrict__ seq_off, const int* __restrict__ seq_len, int D) {
+    const int seq = blockIdx.y;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const int T = seq_len[seq];
+    const float* p = h + (size_t)seq_off[seq] * D + d;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += p[(size_t)t * D];
+    out[(size_t)seq * D + d] = s / (float)T;
+}
+
 // w[row, o] = sigmoid(h[row,:] . Wout[o,:] + b[o]); one wave per row, nw <= 23 outputs.
 // Reference: Influence.forward tail src/models/utils/influence.py:124-125.
 __global__ __launch_bounds__(256) void influence_head_kernel(const float* __restrict__ h, const float* __restrict__ W, const float* __restrict__ b,
@@ -266,7 +280,10 @@ extern "C" int mmdm_adaln_fp8(const float* h, const float* ss, int ss_ld, int ss
     return mmdm_adaln_any(h, ss, ss_ld, ss_rows, out, 3, row_scale, nseq, T, D, stream);
 }
 
-int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, float* row_scale, int nseq, int T, int D, void* stream) {
+// row_seq != nullptr: ragged batch -- `rows_rag` rows in all, row r belongs to sequence row_seq[r] (device array); nseq / T are then unused
+int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, float* row_scale, int nseq, int T, int D, void* stream,
+                   const int* row_seq, int rows_rag) {
+    if (row_seq) { nseq = 1; T = rows_rag; }
     if (nseq == 0 || T == 0) return MMDM_OK;
     if (!h || !ss || !out || nseq < 0 || T < 0 || D <= 0 || ss_rows <= 0 || ss_ld < 2 * D)
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_adaln_f32: bad arguments nseq=%d T=%d D=%d ss_ld=%d ss_rows=%d", nseq, T, D, ss_ld, ss_rows);
@@ -278,10 +295,10 @@ int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void
     dim3 grid(min((rows + 3) / 4, 2048)), block(256);          // 256 CUs x 8 resident blocks
 #define ADALN_LAUNCH(V)                                                                                                   \
     do {                                                                                                                  \
-        if (out_bf16 == 3) hipLaunchKernelGGL((adaln_kernel<V, 3>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, row_scale);       \
-        else if (out_bf16 == 2) hipLaunchKernelGGL((adaln_kernel<V, 2>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, (float*)nullptr);       \
-        else if (out_bf16) hipLaunchKernelGGL((adaln_kernel<V, 1>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, (float*)nullptr);       \
-        else hipLaunchKernelGGL((adaln_kernel<V, 0>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, (float*)nullptr);                     \
+        if (out_bf16 == 3) hipLaunchKernelGGL((adaln_kernel<V, 3>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, row_scale, row_seq);       \
+        else if (out_bf16 == 2) hipLaunchKernelGGL((adaln_kernel<V, 2>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, (float*)nullptr, row_seq);       \
+        else if (out_bf16) hipLaunchKernelGGL((adaln_kernel<V, 1>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, (float*)nullptr, row_seq);       \
+        else hipLaunchKernelGGL((adaln_kernel<V, 0>), grid, block, 0, st, h, ss, ss_ld, ss_rows, out, rows, T, D, (float*)nullptr, row_seq);                     \
     } while (0)
     if (D <= 256) ADALN_LAUNCH(1);
     else if (D <= 512) ADALN_LAUNCH(2);
@@ -342,6 +359,12 @@ extern "C" int mmdm_mean_time_f32(const float* h, float* out, int nseq, int T, i
     if (!h || !out || nseq < 0 || T <= 0 || D <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_mean_time_f32: bad arguments");
     hipLaunchKernelGGL(mean_time_kernel, dim3((D + 255) / 256, nseq), dim3(256), 0, static_cast<hipStream_t>(stream), h, out, T, D);
     return mmdm_check_launch("mean_time");
+}
+
+int mmdm_mean_time_rag(const float* h, float* out, int nseq, const int* seq_off, const int* seq_len, int D, hipStream_t st) {
+    if (nseq == 0) return MMDM_OK;
+    hipLaunchKernelGGL(mean_time_rag_kernel, dim3((D + 255) / 256, nseq), dim3(256), 0, st, h, out, seq_off, seq_len, D);
+    return mmdm_check_launch("mean_time_rag");
 }
 
 extern "C" int mmdm_influence_head_f32(const float* h, const float* Wout, const float* bout, float* w, int rows, int D, int nw, void* stream) {

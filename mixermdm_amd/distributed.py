@@ -139,11 +139,15 @@ def shard_items(n_items, world=None, rank=None):
     return list(range(rank, n_items, world))
 
 
-def gather_items(local, n_items):
+def gather_items(local, n_items, device=None):
     """Every rank's {item index: result} dictionaries merged into one list in item order on every rank (host objects: the evaluation
-    harness keeps numpy arrays and strings, src/evaluation/datasets.py:117-163)."""
+    harness keeps numpy arrays and strings, src/evaluation/datasets.py:117-163).  Under the RCCL backend the pickled objects are staged
+    through the CURRENT device: `device` (the model's) is made current first, so every rank stages on its own GPU whatever the caller's
+    current device was."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [local[i] for i in range(n_items)]
+    if device is not None and torch.device(device).type == "cuda" and dist.get_backend() == "nccl":
+        torch.cuda.set_device(torch.device(device))
     parts = [None] * dist.get_world_size()
     dist.all_gather_object(parts, local)
     merged = {}

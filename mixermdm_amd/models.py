@@ -375,6 +375,140 @@ class MixerMDM(nn.Module):
         m.history_out1, m.history_out2, m.history_out_influenced = as_list("out1"), as_list("out2"), as_list("out_influenced")
         return out
 
+    # ---- many calls at once: the reference's callers, redesigned --------------------------------------------------
+    def _set_schedule_on(self, smp, sch):
+        if getattr(smp, "_strategy", None) != sch.key():
+            import ctypes as C
+            from ._lib import check
+            tmap = np.ascontiguousarray(np.array(sch.timestep_map, dtype=np.int32))
+            coef = np.ascontiguousarray(sch.device_coefficients())
+            with torch.cuda.device(smp.device):
+                check(smp.lib.mmdm_set_schedule(smp.h, tmap.ctypes.data_as(C.c_void_p), coef.ctypes.data_as(C.c_void_p), sch.num_timesteps, smp._s()), smp.h)
+            smp.schedule, smp._strategy = sch, sch.key()
+
+    def _pool(self, k, B, T):
+        """k samplers over ONE weight set: the facade's own handle plus k - 1 handles that borrow its weights (mmdm_create_shared), each with its
+        own stream, workspace (B, T), schedule tables and graph cache."""
+        main = self._sampler_for(B, T)
+        pool = getattr(self, "_shared", None)
+        if pool is None or pool["parent"] is not main or pool["B"] < B or pool["T"] < T:
+            if pool is not None:
+                for c in pool["kids"]:
+                    c.close()
+            pool = {"parent": main, "B": B, "T": T, "kids": []}
+            self._shared = pool
+        while len(pool["kids"]) < k - 1:
+            pool["kids"].append(main.share(max_batch=B, max_frames=max(T, self.num_frames)))
+        return [main] + pool["kids"][:k - 1]
+
+    def sample_many(self, batches, mode="eval_intermediate", batching="ragged", inflight=2, max_rows=4800, max_items=64, keep_history=None):
+        """Many sampling calls in one go -- what the reference's callers do one after the other: the inference script calls ``model(batch)`` ten
+        times at B = 1 (src/scripts/infer/mixermdm.py:184-188), the evaluation datasets call ``forward_test`` once per item with that item's
+        own length (src/evaluation/datasets.py:100-116).  `batches`: reference-style batch dicts (text lists or a precomputed 'cond' [b, 8*768];
+        'motion_lens'[0] = T; optionally 'x_T' [b, T, 524]).  Returns one result dict per batch, as ``forward`` (mode="eval") /
+        ``forward_test`` (mode="eval_intermediate") would -- every motion BIT-IDENTICAL to that call's on the same x_T.
+
+        batching: "sequential" = the reference's loop (one call after the other on one handle);
+                  "inflight"   = `inflight` handles over one weight set, calls dealt round-robin, each on its own stream (a B = 1 call fills
+                                 ~60 % of one round of GEMM tiles on 256 CUs: two co-resident calls overlap);
+                  "ragged"     = the calls' motions packed into ragged batches of <= max_rows frames / <= max_items motions
+                                 (mmdm_begin_ragged: per-sequence lengths as device data; GEMMs at the efficiency of a full batch).
+        keep_history: None = what the mode says (store_influence -> influence lists; "eval" -> out1 / out2 / out_influenced), False = outputs only."""
+        if batching not in ("sequential", "inflight", "ragged"):
+            raise ValueError(f"batching {batching!r} not recognized")
+        m = self.mixing
+        m.mode = mode
+        names = []
+        if keep_history is None or keep_history:
+            if m.store_influence:
+                names += ["influence_i1", "influence_i2"]
+            if mode == "eval":
+                names += ["out1", "out2", "out_influenced"]
+        with torch.no_grad():
+            conds = [self.generate_cond(b) for b in batches]
+        Ts = [int(b["motion_lens"][0]) for b in batches]
+        Bs = [int(c.shape[0]) for c in conds]
+        dev = self.device
+        xs = [b["x_T"].to(dev, torch.float32) if "x_T" in b else torch.randn(nb, T, self.nfeats * 2, device=dev) for b, nb, T in zip(batches, Bs, Ts)]
+        sch = MixerDiffusion(use_timesteps=space_timesteps(self.diffusion_steps, self.sampling_strategy), betas=self.betas).schedule
+        slots = (sch.num_timesteps + self.history_every - 1) // self.history_every
+        keys = ("influence_i1", "influence_i2") + (("out1", "out2", "out_influenced") if mode == "eval" else ())
+        results = [{"output": None, **{k: [] for k in keys}} for _ in batches]
+        if batching == "sequential":
+            for i, (b, c, x) in enumerate(zip(batches, conds, xs)):
+                bb = dict(b)
+                bb["cond"], bb["x_T"] = c, x
+                keep = m.store_influence
+                if not names:
+                    m.store_influence = False
+                try:
+                    results[i] = self.forward(bb) if mode == "eval" else self.forward_test(bb)
+                finally:
+                    m.store_influence = keep
+            return results
+        if batching == "inflight":
+            pool = self._pool(max(1, int(inflight)), max(Bs), max(Ts))
+            pend = []
+            for i, (c, x) in enumerate(zip(conds, xs)):
+                smp = pool[i % len(pool)]
+                self._set_schedule_on(smp, sch)
+                out, hist, ev = smp.sample_async(c, x, history=names or None, history_every=self.history_every)
+                pend.append((i, out, hist, ev, smp))
+            for i, out, hist, ev, smp in pend:
+                ev.synchronize()
+                results[i]["output"] = out
+                for k, v in (hist or {}).items():
+                    results[i][k] = list(v.unbind(0))
+            for smp in pool:
+                torch.cuda.current_stream(dev).wait_stream(smp.stream)
+            return results
+        # ragged: motions in call order, cut into groups of <= max_rows frames and <= max_items motions
+        motions = [(i, j) for i, nb in enumerate(Bs) for j in range(nb)]
+        groups, cur, rows = [], [], 0
+        for (i, j) in motions:
+            if cur and (rows + Ts[i] > max_rows or len(cur) >= max_items):
+                groups.append(cur)
+                cur, rows = [], 0
+            cur.append((i, j))
+            rows += Ts[i]
+        if cur:
+            groups.append(cur)
+        gmax_items = max(len(g) for g in groups)
+        gmax_rows = max(sum(Ts[i] for i, _ in g) for g in groups)
+        Tm = max(max(Ts), self.num_frames)
+        smp = self._sampler_for(max(gmax_items, -(-gmax_rows // Tm)), Tm)
+        self._set_schedule_on(smp, sch)
+        wi = 262 if m.mixing_mode >= 3 else 1
+        outs = [[None] * nb for nb in Bs]
+        hists = [[None] * nb for nb in Bs]
+        pend = []
+        for g in groups:
+            lens = [Ts[i] for i, _ in g]
+            need = slots * 2 * (sum(lens) + 128) * 4 * sum(wi if n.startswith("influence") else 524 for n in names)
+            if need > HISTORY_BUDGET_BYTES:
+                raise MemoryError(f"history side outputs of a ragged batch of {sum(lens)} frames need {need / 2**30:.1f} GiB; lower max_rows, set "
+                                  "model.history_every, or pass keep_history=False")
+            cond_g = torch.cat([conds[i][j:j + 1] for i, j in g], 0)
+            x_g = [xs[i][j] for i, j in g]
+            items, hist, ev = smp.sample_ragged_async(cond_g, x_g, lens, history=names or None, history_every=self.history_every)
+            pend.append((g, items, hist, ev, smp.item_slices(), smp.rows))
+        for g, items, hist, ev, slices, rows in pend:
+            ev.synchronize()
+            for (i, j), it, (o, t) in zip(g, items, slices):
+                outs[i][j] = it
+                if hist:
+                    # the reference's [2B, T, C] history rows of this motion: its cond row and its uncond row
+                    hists[i][j] = {k: (v[:, 0, o:o + t], v[:, 1, o:o + t]) for k, v in hist.items()}
+        torch.cuda.current_stream(dev).wait_stream(smp.stream)
+        for i, nb in enumerate(Bs):
+            results[i]["output"] = torch.stack(outs[i], 0)
+            if names:
+                for k in names:
+                    cond_rows = torch.stack([hists[i][j][k][0] for j in range(nb)], 1)      # [slots, b, T, C]
+                    unc_rows = torch.stack([hists[i][j][k][1] for j in range(nb)], 1)
+                    results[i][k] = list(torch.cat([cond_rows, unc_rows], 1).unbind(0))     # [2b, T, C] per kept step
+        return results
+
     def _sample(self, batch, mode):
         self.mixing.mode = mode
         cond = self.generate_cond(batch)

@@ -55,6 +55,27 @@ class Sampler:
         self.schedule = None
         self._strategy = None
         self._hist = None
+        self._parent = None
+        self.lens, self.rows = None, 0
+
+    def share(self, max_batch=None, max_frames=None):
+        """A second Sampler over THIS sampler's weights (mmdm_create_shared): own workspace, stream, schedule tables and graph cache, one
+        copy of the parameters.  K shared samplers keep K sampling calls in flight on K streams -- the reference's callers sample one
+        item at a time (src/scripts/infer/mixermdm.py:184-188, src/evaluation/datasets.py:100-116), which leaves the GPU 40 % empty at B = 1.
+        The weights must be loaded and prepared on `self`; load_state_dict / set_norm_stats / prepare are the parent's."""
+        s = object.__new__(Sampler)
+        s.lib, s.device, s.single_only = self.lib, self.device, self.single_only
+        cfg = Config.from_buffer_copy(self.cfg)
+        cfg.max_batch = int(max_batch or self.cfg.max_batch)
+        cfg.max_frames = int(max_frames or self.cfg.max_frames)
+        s.cfg = cfg
+        s.h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_create_shared(self.h, cfg.max_batch, cfg.max_frames, C.byref(s.h)), self.h)
+            s.stream = torch.cuda.Stream(device=self.device)
+        s.schedule, s._strategy, s._hist, s._parent = None, None, None, self
+        s.lens, s.rows = None, 0
+        return s
 
     def close(self):
         """Frees the handle (mmdm_destroy selects the handle's own device before synchronising and freeing).  Tensors returned by
@@ -147,24 +168,66 @@ class Sampler:
         x_T = x_T.to(self.device, torch.float32).contiguous()
         B, T = x_T.shape[:2]
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        # the copies into the handle run on the sampler's stream, possibly long after this call returns (several calls in flight):
+        # keep the allocator from handing the inputs' memory out again before that stream has passed this point
+        cond.record_stream(self.stream)
+        x_T.record_stream(self.stream)
         with torch.cuda.device(self.device):
             check(self.lib.mmdm_begin(self.h, C.c_void_p(cond.data_ptr()), C.c_void_p(x_T.data_ptr()), B, T, self._s()), self.h)
         self._keep = (cond, x_T)
         self.B, self.T = B, T
+        self.lens, self.rows = None, B * T
         self._hist = None
         return self
 
+    def begin_ragged(self, cond, x_T, lens):
+        """Begin a RAGGED call (mmdm_begin_ragged): B items of different lengths in one batch.  cond [B, .]; lens: B ints; x_T: the items' frames
+        back to back [sum(lens), C], or a list of B tensors [T_i, C].  Every item's result is bit-identical to sampling it alone."""
+        lens = [int(v) for v in lens]
+        if isinstance(x_T, (list, tuple)):
+            x_T = torch.cat([t.to(self.device, torch.float32).reshape(-1, t.shape[-1]) for t in x_T], 0)
+        cond = cond.to(self.device, torch.float32).contiguous()
+        x_T = x_T.to(self.device, torch.float32).contiguous()
+        B = len(lens)
+        if cond.shape[0] != B or x_T.dim() != 2 or x_T.shape[0] != sum(lens):
+            raise ValueError(f"begin_ragged: cond rows {cond.shape[0]}, x_T {tuple(x_T.shape)} do not match {B} items of {sum(lens)} frames in all")
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        cond.record_stream(self.stream)
+        x_T.record_stream(self.stream)
+        arr = (C.c_int * B)(*lens)
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_begin_ragged(self.h, C.c_void_p(cond.data_ptr()), C.c_void_p(x_T.data_ptr()), B, arr, self._s()), self.h)
+        rows, real, rag = C.c_int(), C.c_int(), C.c_int()
+        check(self.lib.mmdm_call_rows(self.h, C.byref(rows), C.byref(real), C.byref(rag)), self.h)
+        self._keep = (cond, x_T)
+        self.B, self.T = B, max(lens)
+        self.lens, self.rows = lens, rows.value
+        self._hist = None
+        return self
+
+    def item_slices(self):
+        """(first row, length) of every item inside a group of a ragged call's buffers."""
+        out, o = [], 0
+        for t in self.lens:
+            out.append((o, t))
+            o += t
+        return out
+
     def set_history(self, names=("influence_i1", "influence_i2", "out1", "out2", "out_influenced"), every=1):
         """Allocate history buffers [slots, 2B, T, C] for the requested side outputs (mixermdm.py:794-796, 805-808).  C = 524 for
-        out1 / out2 / out_influenced; for the influences 262 in mixing modes 3-4 and 1 in modes 1-2 (the reference's shapes)."""
+        out1 / out2 / out_influenced; for the influences 262 in mixing modes 3-4 and 1 in modes 1-2 (the reference's shapes).
+        Ragged call: [slots, 2, rows, C] -- cond half, uncond half, each a group of the call's frame rows (item_slices())."""
         S = self.schedule.num_timesteps
         slots = (S + every - 1) // every
         n = 2 * self.B
         bufs = {}
+        rag = getattr(self, "lens", None) is not None
         for nm in ("influence_i1", "influence_i2", "out1", "out2", "out_influenced"):
             if nm in names:
                 Cc = (262 if self.cfg.mixing_mode >= 3 else 1) if nm.startswith("influence") else 524
-                bufs[nm] = torch.empty(slots, n, self.T, Cc, device=self.device, dtype=torch.float32)
+                bufs[nm] = torch.empty((slots, 2, self.rows, Cc) if rag else (slots, n, self.T, Cc), device=self.device, dtype=torch.float32)
+        for b in bufs.values():
+            b.record_stream(self.stream)
         ptr = lambda nm: C.c_void_p(bufs[nm].data_ptr() if nm in bufs else 0)
         with torch.cuda.device(self.device):
             check(self.lib.mmdm_set_history(self.h, ptr("influence_i1"), ptr("influence_i2"), ptr("out1"), ptr("out2"), ptr("out_influenced"), every), self.h)
@@ -187,13 +250,15 @@ class Sampler:
     def synchronize(self):
         self.stream.synchronize()
 
-    def state(self):
-        """Views (no copy) of the handle's x, x2, pred_xstart, pred_xstart2, model_out after the queued work completes."""
+    def state(self, sync=True):
+        """Views (no copy) of the handle's x, x2, pred_xstart, pred_xstart2, model_out -- after the queued work completes (sync=True), or
+        at once for use ON the sampler's stream (sync=False: sample_async)."""
         ptrs = [C.c_void_p() for _ in range(5)]
         check(self.lib.mmdm_get_state(self.h, *[C.byref(p) for p in ptrs]), self.h)
-        self.stream.synchronize()
+        if sync:
+            self.stream.synchronize()
         Cc = 262 if self.single_only == 1 else 524
-        shape = (self.B, self.T, Cc)
+        shape = (self.rows, Cc) if getattr(self, "lens", None) is not None else (self.B, self.T, Cc)      # ragged: the group's frame rows (first sum(lens) real)
         out = {}
         for nm, p in zip(("x", "x2", "pred_xstart", "pred_xstart2", "model_out"), ptrs):
             out[nm] = _from_ptr(p.value, shape, self.device) if p.value else None
@@ -208,6 +273,40 @@ class Sampler:
         res = st["pred_xstart"] if self.single_only else st["pred_xstart2"]
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return (res.clone(), hist) if history else res.clone()
+
+    def sample_async(self, cond, x_T, use_graph=True, history=None, history_every=1):
+        """sample() without a host synchronisation: the whole loop and the copy of its result are queued on the sampler's stream and the call
+        returns at once -> (result tensor, history buffers or None, event recorded behind them).  Wait for the event (or synchronise the
+        stream) before reading either from the host or another stream.  Several shared samplers (share()) driven this way overlap."""
+        self.begin(cond, x_T)
+        hist = self.set_history(history, history_every) if history else None
+        self.run(None, use_graph)
+        st = self.state(sync=False)
+        with torch.cuda.stream(self.stream):
+            res = (st["pred_xstart"] if self.single_only else st["pred_xstart2"]).clone()
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return res, hist, ev
+
+    def sample_ragged_async(self, cond, x_T, lens, use_graph=True, history=None, history_every=1):
+        """A whole ragged sampling call queued on the sampler's stream (no host synchronisation): -> (list of per-item results [T_i, C], history
+        buffers [slots, 2, rows, C] or None, event).  Wait for the event before reading from the host or another stream."""
+        self.begin_ragged(cond, x_T, lens)
+        hist = self.set_history(history, history_every) if history else None
+        self.run(None, use_graph)
+        st = self.state(sync=False)
+        with torch.cuda.stream(self.stream):
+            res = (st["pred_xstart"] if self.single_only else st["pred_xstart2"])[:sum(self.lens)].clone()
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return [res[o:o + t] for o, t in self.item_slices()], hist, ev
+
+    def sample_ragged(self, cond, x_T, lens, use_graph=True):
+        """Ragged MixerDiffusion.ddim_sample_loop: list of B results [T_i, C]."""
+        items, _, ev = self.sample_ragged_async(cond, x_T, lens, use_graph)
+        ev.synchronize()
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return items
 
     # ---- teacher-forced module forwards (tests / swappable inner protocol) ----------------------------
     def module_forward(self, which, x, cond, t, x2=None):

@@ -35,7 +35,7 @@ def _noisy(r32, rel):
 def test_rounding_level_noise_passes(pair):
     r32, r64, _ = pair
     out = _noisy(r32, 2e-7)
-    worst, amp = compare_step(out, r32, r64, "noise")
+    worst, amp, ev = compare_step(out, r32, r64, "noise")
     assert worst <= 2e-3
     e = yardstick(out, r32, r64, "noise")
     assert e["ok"]
@@ -75,21 +75,21 @@ def test_one_turned_joint_passes_only_where_the_oracle_itself_is_ill_conditioned
     out = {k: v.clone() for k, v in r32.items()}
     out["pred_xstart"][b, t, c0:c0 + 5] += torch.tensor([0.1, 1.5, 0.3, 0.8, 0.2])
     with pytest.raises(AssertionError, match="well-conditioned"):
-        compare_step(out, r32, r64, "turned joint, well-conditioned")
+        compare_step(out, r32, r64, "turned joint, well-conditioned", hard_joints=1)
     ill32 = {k: v.clone() for k, v in r32.items()}
     ill32["pred_xstart"][b, t, c0:c0 + 6] += 4e-4              # the fp32 oracle itself is 4e-4 from float64 on this joint
     out2 = {k: v.clone() for k, v in ill32.items()}
     out2["pred_xstart"][b, t, c0:c0 + 5] += torch.tensor([0.1, 1.5, 0.3, 0.8, 0.2])
-    compare_step(out2, ill32, r64, "turned joint, ill-conditioned")
+    compare_step(out2, ill32, r64, "turned joint, ill-conditioned", hard_joints=1)
+    with pytest.raises(AssertionError, match="0 allowed"):       # the native-fp32 mode (and every caller that does not ask) allows none
+        compare_step(out2, ill32, r64, "turned joint, ill-conditioned, strict")
     ill32["pred_xstart"][0, 3, c0:c0 + 6] += 4e-4
     out3 = {k: v.clone() for k, v in ill32.items()}
     out3["pred_xstart"][b, t, c0:c0 + 5] += 1.0
     out3["pred_xstart"][0, 3, c0:c0 + 5] += 1.0
     with pytest.raises(AssertionError, match="2 joints"):
-        compare_step(out3, ill32, r64, "two turned joints")
+        compare_step(out3, ill32, r64, "two turned joints", hard_joints=1)
     out4 = {k: v.clone() for k, v in r32.items()}                 # round 3's allowance: two single components, no evidence asked, no event
     out4["pred_xstart"][b, t, c0:c0 + 2] += 0.2
-    compare_step(out4, r32, r64, "two components")
-    assert compare_step.events == 0
-    compare_step(out2, {k: v.clone() for k, v in ill32.items()}, r64, "event")
-    assert compare_step.events == 1
+    assert compare_step(out4, r32, r64, "two components")[2] == 0
+    assert compare_step(out2, {k: v.clone() for k, v in ill32.items()}, r64, "event", hard_joints=1)[2] == 1
