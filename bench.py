@@ -62,6 +62,11 @@ def main():
     ap.add_argument("--no-full-loop", action="store_true", help="skip the real 1000-step sample() from x_T to x_0 reported as `full_loop`")
     ap.add_argument("--no-clock", action="store_true", help="skip the in-loop shader-clock measurement (301 extra GEMM launches; tools/profile_round.sh passes it so that "
                                                              "the committed kernel traces hold the step's launches only)")
+    ap.add_argument("--eval-items", type=int, default=0, metavar="N",
+                    help="the reference's evaluation caller instead of the headline step: N items with their own lengths (T uniform in [60, 300], ddim50 unless --sampler says "
+                         "otherwise), one forward_test each (src/evaluation/datasets.py:100-116) -- timed as the reference's sequential loop, with 2 / 4 items in flight over "
+                         "one weight set (mmdm_create_shared), and as ragged batches (mmdm_begin_ragged); reports items/s, roofline and cpu_baseline per strategy")
+    ap.add_argument("--eval-max-rows", type=int, default=4800, help="--eval-items: frames per ragged batch (default 4800 = 16 x 300)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks meet on gloo, time a barrier, rank 0 prints a line")
     args = ap.parse_args()
     if args.cpu_worker:
@@ -109,6 +114,9 @@ def main():
     from mixermdm_amd.sampler import Sampler
     from mixermdm_amd.synthetic import synthetic_state_dict, mixer_shapes, synthetic_stats, synthetic_inputs, FULL_DIMS
     from mixermdm_amd.distributed import broadcast_state_dict
+
+    if args.eval_items:
+        return eval_items_bench(args, device, rank, world)
 
     single = args.workload == "single"
     # motions per GPU: configs[2] = 16 on one GPU (the headline); configs[3] = 256 over 8 GPUs = 32 per GPU, and the same 32 per GPU at
@@ -407,6 +415,101 @@ def loop_clock(precision, M, peak, achieved):
     return {"shader_mhz_in_k_loop": round(mhz), "kernel": kern, "peak_at_that_clock": round(pk, 1), "frac_of_peak_at_that_clock": round(achieved / pk, 4),
             "how": "s_memtime / s_memrealtime between K-loop entry and exit of every workgroup (median) on one %dx%dx%d launch after 300 warm ones; "
                    "`peak` above is the guide's 2.4 GHz figure" % (M, N, K)}
+
+
+def eval_items_bench(args, device, rank, world):
+    """The reference's evaluation caller (src/evaluation/datasets.py:58, 100-116: one forward_test per item, B = 1, the item's own length) on N
+    synthetic items, T uniform in [60, 300]: today's sequential loop against items in flight over one weight set and against ragged batches.
+    Every strategy produces the same bits per item (checked here on the outputs).  One JSON line; `value` = items/s of the ragged strategy."""
+    import numpy as np
+    import torch
+    from mixermdm_amd.configs import get_config
+    from mixermdm_amd.models import MixerMDM
+    from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_stats, FULL_DIMS
+    if world != 1:
+        raise SystemExit("--eval-items measures one GPU (items shard over ranks without any collective: generation.generate_for_evaluation(shard_items=True))")
+    sampler = "ddim50" if args.sampler == "ddim1000" else args.sampler
+    N = args.eval_items
+    rng = np.random.RandomState(0)
+    lens = [int(v) for v in rng.randint(60, 301, size=N)]
+    sd_cpu = synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, **FULL_DIMS)
+    stats = synthetic_stats()
+    model = MixerMDM(get_config(os.path.join(ROOT, "configs", "models", "MixerMDM.yaml")), num_frames=300, sampling_strategy=sampler, config_root=ROOT)
+    model.precision = args.precision
+    model.load_state_dict({"mixing." + k: v for k, v in sd_cpu.items()})
+    model.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+    model = model.to(device).eval()
+    batches = []
+    for i, T in enumerate(lens):
+        g = torch.Generator().manual_seed(100 + i)
+        batches.append({"cond": torch.randn(1, 8 * 768, generator=g).to(device), "x_T": torch.randn(1, T, 524, generator=g).to(device), "motion_lens": torch.tensor([T])})
+    S = int(sampler[4:]) if sampler.startswith("ddim") else 1000
+    flops = sum(algorithmic_flops_per_motion_step(T) for T in lens) * S
+    peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "bf16_fp8": PEAK_FP8_MFMA_TFLOPS}[args.precision]
+
+    def run(name, fn, warm):
+        with torch.no_grad():
+            fn(batches[:warm])                       # untimed: library / allocator warm-up, the first graph captures
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = fn(batches)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        outs = [r["output"] for r in res]
+        tf = flops / dt / 1e12
+        return outs, {"wall_s": round(dt, 3), "items_per_s": round(N / dt, 4), "seconds_per_item": round(dt / N, 4), "achieved_tflops_algorithmic": round(tf, 2),
+                      "frac_of_peak": round(tf / peak, 4), "outputs_finite": bool(all(torch.isfinite(o).all().item() for o in outs))}
+
+    strat = {}
+    ref, strat["sequential_forward_test"] = run("seq", lambda b: [model.forward_test(dict(x)) for x in b], 3)
+    strat["sequential_forward_test"]["what"] = "the reference's loop as shipped in round 4: model.forward_test(batch) per item (B = 1, influence histories kept as the reference does), one handle, one stream"
+    variants = [("sequential", dict(batching="sequential"), "the same loop without the influence history side outputs (the evaluation harness discards them)"),
+                ("inflight2", dict(batching="inflight", inflight=2), "2 handles over ONE weight set (mmdm_create_shared), items dealt round-robin, each on its own stream"),
+                ("inflight4", dict(batching="inflight", inflight=4), "4 handles over one weight set"),
+                ("ragged", dict(batching="ragged", max_rows=args.eval_max_rows), "items packed in call order into ragged batches of <= %d frames (mmdm_begin_ragged: per-sequence lengths as device data)" % args.eval_max_rows)]
+    same = {}
+    for name, kw, what in variants:
+        outs, strat[name] = run(name, lambda b, kw=kw: model.sample_many([dict(x) for x in b], mode="eval_intermediate", keep_history=False, **kw), 6)
+        strat[name]["what"] = what
+        same[name] = bool(all(torch.equal(a, b) for a, b in zip(outs, ref)))
+        strat[name]["speedup_vs_sequential_forward_test"] = round(strat["sequential_forward_test"]["wall_s"] / strat[name]["wall_s"], 3)
+    # dominant kernel of the ragged strategy: live HIP-event pairs around every GEMM launch of two eager steps of the first ragged batch
+    roof = None
+    if args.profile_steps > 0:
+        rows, grp = 0, []
+        for i, T in enumerate(lens):
+            if grp and rows + T > args.eval_max_rows:
+                break
+            grp.append(i); rows += T
+        smp = model._sampler_for(len(grp), 300)
+        smp.begin_ragged(torch.cat([batches[i]["cond"] for i in grp], 0), [batches[i]["x_T"][0] for i in grp], [lens[i] for i in grp])
+        smp.profile(True)
+        smp.run(args.profile_steps, use_graph=False)
+        g_ms, g_n, g_fl, g_by = smp.profile_read(0)
+        a_ms, a_n, a_fl, _ = smp.profile_read(1)
+        smp.profile(False)
+        ach = g_fl / (g_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "the precision mode's GEMM kernel (see the default line) on the first ragged batch: %d items, %d frames in a group of %d rows" % (len(grp), rows, smp.rows),
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
+                "attention": {"achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a_ms / args.profile_steps, 3), "launches_per_step": a_n // args.profile_steps}}
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the oracle on ONE item of the median length, a few steps after the thread calibration, extrapolated to the S steps of an item
+        Tm = int(np.median(lens))
+        c = cpu_baseline(sd_cpu, stats, Tm, args.cpu_steps, False, sampler, S, 1, whole_host=False)
+        cpu = {"value": c["value"], "unit": "items/s", "cores": c.get("cores"), "kind": c.get("kind", "port"),
+               "sample": "one item of the median length T = %d on the host cores: " % Tm + c.get("sample", ""), "seconds_per_item": c.get("seconds_per_motion")}
+    best = strat["ragged"]
+    line = {"metric": "evaluation items/s (one forward_test per item, B = 1, %s, T uniform in [60, 300]: src/evaluation/datasets.py:100-116)" % sampler,
+            "value": best["items_per_s"], "unit": "items/s", "n_gpus": 1, "steps": N, "warmup": 6, "ms_per_step": round(best["wall_s"] / N * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32_split": "f32 (2xfp16 operand split, fp32 accumulate)", "bf16": "bf16", "bf16_fp8": "bf16 + fp8 e4m3 QKV/FFN operands"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": "the reference's evaluation caller: %d items, T uniform in [60, 300] (mean %.0f), %s, 2-person MixerMDM through mixermdm_amd.models.MixerMDM; a 'step' of this line is one item" % (N, float(np.mean(lens)), sampler),
+                       "items": N, "sampler": sampler, "precision": args.precision, "max_rows": args.eval_max_rows},
+            "strategies": strat, "bit_identical_to_sequential": same, "roofline": roof, "cpu_baseline": cpu,
+            "graph_cache": dict(zip(("captures", "replays", "cached"), model._sampler.graph_stats()))}
+    print(json.dumps(line), flush=True)
 
 
 def measured_traffic(single, precision="fp32", B=16, T=300):

@@ -331,7 +331,12 @@ int mmdm_create(const mmdm_config* cfg, mmdm_handle* out);
  * reference's callers sample one item at a time (src/scripts/infer/mixermdm.py:184-188 ten times B = 1; src/evaluation/datasets.py:100-116 per
  * item), which fills ~60 % of one round of GEMM tiles on 256 CUs; two co-resident items overlap.  A motion's bits do not depend on what runs
  * beside it.  mmdm_set_weight / mmdm_set_norm_stats on a shared handle return MMDM_ERR_STATE (set them on the parent; a parent re-prepared
- * after mmdm_set_weight is seen by every holder); mmdm_prepare is a no-op there.  Handles are still not thread-safe individually. */
+ * after mmdm_set_weight is seen by every holder); mmdm_prepare is a no-op there.  Handles are still not thread-safe individually, and the
+ * handles of one process should be driven from ONE host thread: graph captures, instantiations, evictions and replays are serialised against
+ * each other inside the library, but replaying graphs from two host threads was seen to crash inside this runtime's hipGraphLaunch
+ * (ROCm 7.0 / 7.2, hip::Graph::UpdateStreams) -- every call here is asynchronous, one thread keeps K streams queued.
+ * Measured (tools/inflight_probe.py, B = 1, T = 180, fp32): the GPU overlaps two such streams hardly at all -- 1.00-1.03 x with 2-4 handles
+ * (1.22 x eager with 16 hardware queues); packing the calls into one ragged batch (mmdm_begin_ragged) is what fills the machine: 1.95 x. */
 int mmdm_create_shared(mmdm_handle parent, int max_batch, int max_frames, mmdm_handle* out);
 void mmdm_destroy(mmdm_handle h);
 const char* mmdm_handle_error(mmdm_handle h);
@@ -403,6 +408,12 @@ int mmdm_seek(mmdm_handle h, int step_index, void* stream);
 
 /* Device pointers owned by the handle, valid until destroy: current chains and the last pred_xstart(2). */
 int mmdm_get_state(mmdm_handle h, float** x, float** x2, float** pred_xstart, float** pred_xstart2, float** model_out);
+
+/* The sampling call's result so far -- the last pred_xstart2 (two-chain sampler; MixerDiffusion.ddim_sample_loop's return value,
+ * gaussian_diffusion.py:1820) or pred_xstart (single-chain samplers) -- copied into caller memory ON `stream` (no host synchronisation):
+ * [B, T, 524 or 262], ragged call: the items back to back [sum(lens), .].  With mmdm_begin / mmdm_set_history / mmdm_run this is a whole
+ * sampling call in plain C calls, e.g. from one host thread per shared handle. */
+int mmdm_copy_result(mmdm_handle h, float* dst, void* stream);
 
 /* Teacher-forced pieces for parity tests (operate on caller buffers, CFG-doubled batch n = 2B rows in x/cond):
  *   which: 0 = denoiser1 (individual; x [n,T,262], cond [n,text_dim]) -> out [n,T,262]

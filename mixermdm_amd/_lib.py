@@ -91,6 +91,7 @@ SYMBOLS = {
     "mmdm_graph_stats": (_I, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_I)]),
     "mmdm_last_gemm_kernel": (C.c_char_p, []),
     "mmdm_get_state": (_I, [_VP] + [C.POINTER(_VP)] * 5),
+    "mmdm_copy_result": (_I, [_VP, _VP, _VP]),
     "mmdm_module_forward": (_I, [_VP, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _VP]),
     "mmdm_profile_enable": (_I, [_VP, _I]),
     "mmdm_diag_set": (_I, [C.c_char_p, C.c_longlong]),

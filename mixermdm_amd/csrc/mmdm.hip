@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <memory>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -45,6 +47,10 @@ int mmdm_kernels_init(void) {
     return rc;
 }
 
+// Several handles may be driven from several host threads (mmdm_create_shared).  This runtime survives concurrent graph LAUNCHES, but not a
+// capture / instantiation / exec destruction beside another thread's capture or launch (segfaults inside hipGraphLaunch, seen with two
+// threads at the real model sizes): captures, instantiations and evictions take this lock exclusively, replays take it shared.
+static std::shared_mutex g_graph_mu;
 static thread_local char g_gemm_note[160] = "";
 void mmdm_note_gemm_reset(void) { g_gemm_note[0] = 0; }
 void mmdm_note_gemm(const char* fmt, ...) {
@@ -978,9 +984,22 @@ int build_time_tab(const Ctx& c, ModuleW& m) {
 
 size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
+// Destroys a graph exec -- unless other handles share this handle's weights (mmdm_create_shared: several calls in flight).  In this runtime
+// (ROCm 7.0 / 7.2) destroying an exec while ANOTHER handle's execs are alive made that handle's next hipGraphLaunch crash inside
+// hip::Graph::UpdateStreams (seen with 2 and 4 handles at the real model sizes as soon as a graph cache evicted; waiting for the whole device
+// first does not help, never destroying does): such execs are parked for the life of the process instead.  Bounded by the number of distinct
+// shapes captured while handles shared weights; a handle that never shared frees its execs as before.  Caller holds g_graph_mu exclusively.
+std::vector<hipGraphExec_t> g_parked_execs;
+void retire_exec(mmdm_handle h, hipGraphExec_t exec) {
+    if (!exec) return;
+    if (h->wb && h->wb.use_count() > 1) g_parked_execs.push_back(exec);
+    else (void)hipGraphExecDestroy(exec);
+}
+
 void drop_graphs(mmdm_handle h) {
+    std::unique_lock<std::shared_mutex> lock(g_graph_mu);
     for (auto& g : h->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        retire_exec(h, g.exec);
         if (g.done) (void)hipEventDestroy(g.done);
     }
     h->graphs.clear();
@@ -1484,12 +1503,16 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
         if (nsteps == 0) return MMDM_OK;
         hipGraphExec_t exec = nullptr;
         hipEvent_t done = nullptr;
+        int first = 0;
         // what a captured node bakes in: uniform (B, T, S); ragged (B, query tiles of the longest item, S, group stride) -- the lengths are device data
         const int kT = h->geom.rag ? (h->T + 63) / 64 : h->T, kR = h->geom.rag ? h->geom.rows : 0;
         for (auto& g : h->graphs)
             if (g.B == h->B && g.T == kT && g.S == h->S && g.rows == kR) { exec = g.exec; done = g.done; g.used = ++h->graph_clock; break; }
         if (!exec) {
             hipGraph_t g = nullptr;
+            // one capture at a time in the process: several handles may be driven from several host threads (mmdm_create_shared), and two
+            // concurrent captures take this runtime down; replays and eager launches of other handles go on beside a capture (relaxed mode)
+            std::unique_lock<std::shared_mutex> capture_lock(g_graph_mu);
             HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
             int rc = run_step(c);
             hipError_t e = hipStreamEndCapture(st, &g);
@@ -1503,13 +1526,13 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
                 for (size_t i = 1; i < h->graphs.size(); ++i)
                     if (h->graphs[i].used < h->graphs[lru].used) lru = i;
                 // its replays may still be queued, possibly on another stream than this call's: wait for the event recorded behind its LAST
-                // replay -- not for the whole device, which would stall other handles' streams and is illegal while another thread captures
+                // replay -- not for the whole device, which would stall other handles' streams
                 e = hipEventSynchronize(h->graphs[lru].done);
                 if (e != hipSuccess) {
                     (void)hipGraphExecDestroy(exec);
                     return herr(h, mmdm_set_error(MMDM_ERR_HIP, "mmdm_run: waiting for the last replay of the graph being evicted: %s", hipGetErrorString(e)));
                 }
-                (void)hipGraphExecDestroy(h->graphs[lru].exec);
+                retire_exec(h, h->graphs[lru].exec);
                 (void)hipEventDestroy(h->graphs[lru].done);
                 h->graphs.erase(h->graphs.begin() + lru);
             }
@@ -1520,9 +1543,16 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
             }
             h->graphs.push_back({h->B, kT, h->S, kR, exec, ++h->graph_clock, done});
             ++h->n_captures;
+            // the FIRST launch of a fresh exec binds the runtime's internal branch streams to it (hip::Graph::UpdateStreams): still inside the
+            // exclusive section -- beside another thread's launch that is where the runtime was seen to crash
+            HIPCHK(hipGraphLaunch(exec, st));
+            first = 1;
         }
-        for (int k = 0; k < nsteps; ++k) HIPCHK(hipGraphLaunch(exec, st));
-        HIPCHK(hipEventRecord(done, st));
+        {
+            std::shared_lock<std::shared_mutex> launch_lock(g_graph_mu);
+            for (int k = first; k < nsteps; ++k) HIPCHK(hipGraphLaunch(exec, st));
+            HIPCHK(hipEventRecord(done, st));
+        }
         h->n_replays += nsteps;
     } else {
         for (int k = 0; k < nsteps; ++k) {
@@ -1550,6 +1580,15 @@ extern "C" int mmdm_get_state(mmdm_handle h, float** x, float** x2, float** pred
     if (pred_xstart) *pred_xstart = h->px1;
     if (pred_xstart2) *pred_xstart2 = h->px2;
     if (model_out) *model_out = h->model_out;
+    return MMDM_OK;
+}
+
+extern "C" int mmdm_copy_result(mmdm_handle h, float* dst, void* stream) {
+    if (!h || !dst) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_copy_result: null argument");
+    if (!h->begun) return herr(h, mmdm_set_error(MMDM_ERR_STATE, "mmdm_copy_result: call mmdm_begin / mmdm_begin_ragged first"));
+    const float* src = h->cfg.single_only ? h->px1 : h->px2;       // the loop's return value: last pred_xstart2 (two-chain) / pred_xstart (single chain)
+    const size_t n = (size_t)h->geom.real_rows * (h->cfg.single_only == 1 ? NF : NF2);
+    HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
     return MMDM_OK;
 }
 

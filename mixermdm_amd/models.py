@@ -448,19 +448,29 @@ class MixerMDM(nn.Module):
             return results
         if batching == "inflight":
             pool = self._pool(max(1, int(inflight)), max(Bs), max(Ts))
-            pend = []
-            for i, (c, x) in enumerate(zip(conds, xs)):
-                smp = pool[i % len(pool)]
-                self._set_schedule_on(smp, sch)
-                out, hist, ev = smp.sample_async(c, x, history=names or None, history_every=self.history_every)
-                pend.append((i, out, hist, ev, smp))
-            for i, out, hist, ev, smp in pend:
-                ev.synchronize()
-                results[i]["output"] = out
-                for k, v in (hist or {}).items():
-                    results[i][k] = list(v.unbind(0))
             for smp in pool:
-                torch.cuda.current_stream(dev).wait_stream(smp.stream)
+                self._set_schedule_on(smp, sch)
+            # ONE host thread drives every handle (calls dealt round-robin, nothing synchronised in between).  One thread per handle was built
+            # and measured (tools/inflight_probe.py: 4 handles 3.65 vs 4.27 ms per item-step) and is not used: graph launches from two host
+            # threads crash inside this runtime's hipGraphLaunch (hip::Graph::UpdateStreams) as soon as the threads also capture new shapes,
+            # whatever the locking around captures (LAB_NOTES.md, round 5).  Buffers are allocated up front; the calls are C-ABI calls only.
+            conds = [c.to(dev, torch.float32).contiguous() for c in conds]
+            xs = [x.contiguous() for x in xs]
+            wi = 262 if m.mixing_mode >= 3 else 1
+            outs = [torch.empty_like(x) for x in xs]
+            hists = [{nm: torch.empty(slots, 2 * nb, T, (wi if nm.startswith("influence") else 524), device=dev) for nm in names} for nb, T in zip(Bs, Ts)]
+            cur = torch.cuda.current_stream(dev)
+            for smp in pool:                         # inputs and buffers were produced on the caller's stream: order every handle's stream behind it
+                smp.stream.wait_stream(cur)
+            for i in range(len(conds)):
+                pool[i % len(pool)].enqueue(conds[i], xs[i], outs[i], hists[i], self.history_every)
+            for smp in pool:
+                cur.wait_stream(smp.stream)
+                smp.stream.synchronize()
+            for i in range(len(conds)):
+                results[i]["output"] = outs[i]
+                for k, v in hists[i].items():
+                    results[i][k] = list(v.unbind(0))
             return results
         # ragged: motions in call order, cut into groups of <= max_rows frames and <= max_items motions
         motions = [(i, j) for i, nb in enumerate(Bs) for j in range(nb)]

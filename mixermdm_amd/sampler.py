@@ -288,6 +288,22 @@ class Sampler:
             ev.record(self.stream)
         return res, hist, ev
 
+    def enqueue(self, cond, x_T, out, hist=None, history_every=1, use_graph=True):
+        """A whole uniform sampling call through the C ABI ONLY (mmdm_begin, mmdm_set_history, mmdm_run, mmdm_copy_result on the sampler's
+        stream): no tensor is created, no torch stream or allocator call is made -- safe to call from a worker thread while other threads
+        capture step graphs (the caching allocator's event queries are not allowed beside a capture).  Everything is the caller's: cond
+        [B, .] and x_T [B, T, C] contiguous fp32 on the device and ordered before the sampler's stream, `out` [B, T, C] preallocated, `hist`
+        {name: preallocated [slots, 2B, T, C] buffer}; all must stay alive until the stream has passed the call."""
+        B, T = x_T.shape[:2]
+        h = hist or {}
+        ptr = lambda nm: C.c_void_p(h[nm].data_ptr() if nm in h else 0)
+        check(self.lib.mmdm_begin(self.h, C.c_void_p(cond.data_ptr()), C.c_void_p(x_T.data_ptr()), B, T, self._s()), self.h)
+        if h:
+            check(self.lib.mmdm_set_history(self.h, ptr("influence_i1"), ptr("influence_i2"), ptr("out1"), ptr("out2"), ptr("out_influenced"), history_every), self.h)
+        check(self.lib.mmdm_run(self.h, self.schedule.num_timesteps, int(use_graph), self._s()), self.h)
+        check(self.lib.mmdm_copy_result(self.h, C.c_void_p(out.data_ptr()), self._s()), self.h)
+        self.B, self.T, self.lens, self.rows = B, T, None, B * T
+
     def sample_ragged_async(self, cond, x_T, lens, use_graph=True, history=None, history_every=1):
         """A whole ragged sampling call queued on the sampler's stream (no host synchronisation): -> (list of per-item results [T_i, C], history
         buffers [slots, 2, rows, C] or None, event).  Wait for the event before reading from the host or another stream."""

@@ -261,3 +261,7 @@ def test_bench_runs_its_rccl_path_under_torchrun_on_the_gpu_box():
     assert "2-person MixerMDM" in line["config"]["workload"] and "batch 32 per GPU" in line["config"]["workload"]
     assert line["ms_per_step"] > 0 and abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3 * 1000)) < 1e-3
     assert line["ms_per_step_ranks"]["min"] == line["ms_per_step_ranks"]["max"]          # the all_gather of the per-rank timings ran (one rank)
+    # what the first real `bench.py --gpus 8` line will be checked against: the per-GPU shard is configs[3]'s 32 motions, and no HBM-traffic
+    # figure is claimed for a batch no PMC pass was taken at (profiles/gemm_traffic.json is the B = 16 headline's)
+    assert line["per_gpu_batch"] == 32 and line["n_gpus"] == 1 and line["config"]["parallelism"].startswith("batch-sharded x1")
+    assert line["roofline"] is None or line["roofline"]["traffic"] is None

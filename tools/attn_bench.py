@@ -10,7 +10,10 @@ lib.mmdm_diag_set(b"attn_ablate", int(os.environ.get("ABL","0")))
 d = torch.device("cuda:0")
 _w = torch.randn(4096, 4096, device=d)
 for _ in range(40): ops.linear(_w, _w)          # clock ramp
-for nseq,T,H,dh,name in [(64,300,8,128,"d.sa"),(64,300,8,64,"m.sa"),(128,300,8,128,"d.sa B=32"),(64,196,8,128,"single T=196")]:
+shapes = [(64,300,8,128,"d.sa"),(64,300,8,64,"m.sa"),(128,300,8,128,"d.sa B=32"),(64,196,8,128,"single T=196")]
+if os.environ.get("TAIL") == "1":      # what a perfect query / key tail could buy at configs[1]'s T = 196: the neighbouring lengths that have no tail
+    shapes = [(64,T,8,128,"single T=%d" % T) for T in (176, 192, 196, 208, 240, 256, 300)]
+for nseq,T,H,dh,name in shapes:
     D=H*dh
     qkv = torch.randn(nseq,T,3*D,device=d)
     line = f"{name} nseq={nseq} T={T} H={H} dh={dh}:"

@@ -5,11 +5,16 @@ import torch, math, ctypes as C
 from mixermdm_amd import ops, load_library
 lib = load_library(); d = torch.device("cuda:0")
 vp = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+FP8 = os.environ.get("FP8") == "1"          # FP8=1: the fp8-operand instantiations (QKV -> bf16, FFN-2 + residual -> fp32, ...)
 for M, N, K, epi in [(19200, 3072, 1024, "bias"), (19200, 1024, 1024, "resid"), (19200, 1024, 2048, "resid"), (8192, 8192, 8192, "bias")]:
     x = torch.randn(M, K, device=d); w = torch.randn(N, K, device=d) / math.sqrt(K); b = torch.randn(N, device=d)
-    xb, wb = ops.to_bf16(x), ops.to_bf16(w); wp = ops.pack_weight_frag(wb)
     extra = torch.randn(M, N, device=d) if epi == "resid" else None
-    call = lambda: ops.linear_bf16(xb, wp, b, epi, extra, packed=True)
+    if FP8:
+        xq, xs = ops.quantize_rows_fp8(x); wq, ws = ops.quantize_rows_fp8(w); wp = ops.pack_weight_frag(wq)
+        call = lambda: ops.linear_fp8(xq, xs, wp, ws, b, epi, extra, out_dtype=torch.float32 if epi == "resid" else torch.bfloat16, packed=True)
+    else:
+        xb, wb = ops.to_bf16(x), ops.to_bf16(w); wp = ops.pack_weight_frag(wb)
+        call = lambda: ops.linear_bf16(xb, wp, b, epi, extra, packed=True)
     for _ in range(int(os.environ.get("WARM", "400"))): call()
     kern = lib.mmdm_last_gemm_kernel().decode()
     bn = 256 if kern.endswith("42>") else 128

@@ -4,8 +4,14 @@ import torch, math, statistics
 from mixermdm_amd import ops, load_library
 lib = load_library(); d = torch.device("cuda:0")
 shapes = [(19200,3072,1024,"qkv","bias",torch.bfloat16),(19200,1024,1024,"ca q","bias",torch.bfloat16),(19200,2048,1024,"ca kv","bias",torch.bfloat16),(19200,2048,1024,"ffn1","gelu",torch.float8_e4m3fn),(19200,1024,2048,"ffn2","resid",torch.float32),(8192,8192,8192,"sq8k","bias",torch.bfloat16)]
+# FP8_SHAPES=qkv,ffn2 selects shapes by name prefix; FP8_ITERS=1 (profiler passes: tools/pmc_fp8.sh) skips the warm-up GEMMs and times one repeat
+sel = [t.strip() for t in os.environ.get("FP8_SHAPES", "").split(",") if t.strip()]
+if sel: shapes = [sh for sh in shapes if any(sh[3].replace(" ", "").startswith(t) for t in sel)]
+ITERS = int(os.environ.get("FP8_ITERS", "5"))
+MB = int(os.environ.get("FP8_M", "0"))
+if MB: shapes = [(MB,) + sh[1:] for sh in shapes]
 _w = torch.randn(4096, 4096, device=d)
-for _ in range(60): ops.linear(_w, _w)
+for _ in range(60 if ITERS > 1 else 2): ops.linear(_w, _w)
 for M,N,K,name,epi,od in shapes:
     x = torch.randn(M,K,device=d); w = torch.randn(N,K,device=d)/math.sqrt(K); b = torch.randn(N,device=d)
     xq, xs = ops.quantize_rows_fp8(x); wq, ws = ops.quantize_rows_fp8(w); wp = ops.pack_weight_frag(wq)
@@ -21,7 +27,7 @@ for M,N,K,name,epi,od in shapes:
             # (residual epilogues: the transposed form adds the residual last, (b + sum) + r, the direct form starts from b + r: same value, other rounding)
             if key in ref and epi != "resid": assert torch.equal(o.view(torch.uint8), ref[key].view(torch.uint8)), f"transposed epilogue changed bits: {name} {tag}"
             else: ref[key] = o
-            for r in range(5):
+            for r in range(ITERS):
                 e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e0.record()
                 for _ in range(4): f()
                 e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
