@@ -89,7 +89,7 @@ __device__ __forceinline__ bool bf16_late_ext(const BArgs& p, int n0, int BN) {
 
 // SMEM = bytes of dynamic LDS the launch really has (the operand stages): the image of a phase is sized against THAT, not against a constant.
 template <int TM, int TN, int ET, int BM, int BN, int NWAVES, int SMEM>
-__device__ __forceinline__ bool bf16_finish_t(const BArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, float* smem) {
+__device__ __forceinline__ bool bf16_finish_t(const BArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, float* smem, const float* sc = nullptr) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     if (p.P2 || n0 + BN > p.N) return false;
     const int l31 = lane & 31, lh = lane >> 5, wave = threadIdx.x >> 6;
@@ -114,6 +114,12 @@ __device__ __forceinline__ bool bf16_finish_t(const BArgs& p, f32x16 (&acc)[TM][
         const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(p.C) + (size_t)m0 * p.ldc * EBO, 0, rows_here * p.ldc * EBO, 0x00020000);
         char* img = reinterpret_cast<char*>(smem);
         const int rr = lane / LPR, rc = lane % LPR;                            // phase (2): this lane's row inside a store instruction's row group, its 16-byte column
+        // fp8: the de-quantisation operands of the workgroup's tile -- a_scale of its BM rows, w_scale and bias of its BN columns -- may sit in LDS
+        // (`sc`: [BM | BN | BN] floats behind the operand stages, filled by the kernel's prologue: gemm_bf16w_kernel).  Loaded from global memory
+        // where they are used, behind run-time null tests, every (row tile, column quad) group is followed by its own s_waitcnt vmcnt(0): 16 memory
+        // latencies in sequence per wave after the K loop (tools/bf16w_timeline.py: 7.0 us of a 15.2 us workgroup on the QKV shape; 4.8 us with
+        // the operands in LDS).  (Reading them from LDS in ONE batch ahead of the phases was measured too: 181 registers instead of 168 -- two
+        // workgroups per CU instead of three -- not kept; neither was s_setprio 3 for the epilogue: no change.)
 #pragma unroll
         for (int ph = 0; ph < NRT / RPP; ++ph) {
             // (0) the residual / PE quads this lane adds in phase (2): requested first, they land behind the image write and the barrier
@@ -137,7 +143,7 @@ __device__ __forceinline__ bool bf16_finish_t(const BArgs& p, f32x16 (&acc)[TM][
                 const int ir = (rt % RPP) * 32 + l31;                          // image row
                 const int row = m0 + rt * 32 + l31, rowc = min(row, p.M - 1);
                 float sa = 1.f;
-                if constexpr (ET == 1) sa = p.a_scale ? p.a_scale[rowc] : p.a_const;
+                if constexpr (ET == 1) sa = sc ? sc[rt * 32 + l31] : (p.a_scale ? p.a_scale[rowc] : p.a_const);
                 const int er = p.epilogue == MMDM_EPI_BIAS_PE ? rowc % p.period : rowc;
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
@@ -147,8 +153,13 @@ __device__ __forceinline__ bool bf16_finish_t(const BArgs& p, f32x16 (&acc)[TM][
                         const int col = n0 + lc;
                         f32x4 v, add = {0.f, 0.f, 0.f, 0.f}, sw4 = {1.f, 1.f, 1.f, 1.f};
                         if constexpr (ET == 1) {
-                            if (p.w_scale) sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + col);
-                            if (p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + col);
+                            if (sc) {
+                                sw4 = *reinterpret_cast<const f32x4*>(sc + BM + lc);
+                                add = *reinterpret_cast<const f32x4*>(sc + BM + BN + lc);
+                            } else {
+                                if (p.w_scale) sw4 = *reinterpret_cast<const f32x4*>(p.w_scale + col);
+                                if (p.bias) add = *reinterpret_cast<const f32x4*>(p.bias + col);
+                            }
                             if (ext) add += *reinterpret_cast<const f32x4*>(p.extra + (size_t)er * p.ld_extra + col);
                         }
 #pragma unroll
@@ -479,7 +490,8 @@ int set_attr() {
 // next and the next step's B fragments are requested behind the MFMAs of the step's first k-block.  Two workgroups per CU (registers).
 // W: mmdm_pack_weight_frag -- block (32 rows, 32 bytes of k) = the 1 KiB one wave-wide 16-byte load delivers, lane (l31, lh) <- row l31, bytes 16 lh.
 // Accumulators start as in gemm_bf16_kernel and k ascends the same way: bit-identical results.
-constexpr int WSMEM_BYTES = 3 * 2 * 128 * 16 * 4;      // dynamic LDS of gemm_bf16w_kernel: three A stages of two 64-byte-row images (48 KB)
+constexpr int WSMEM_BYTES = 3 * 2 * 128 * 16 * 4;      // operand stages of gemm_bf16w_kernel: three A stages of two 64-byte-row images (48 KB)
+constexpr int wsmem_total(int ET, int TN) { return WSMEM_BYTES + (ET == 1 ? (128 + 2 * 128 * TN) * 4 : 0); }      // fp8: + [a_scale | w_scale | bias] of the tile
 template <int ET, int TN = 2, bool TL = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -552,6 +564,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 
 
     f32x16 acc[TM][TN];
+    float* const sc = smem + WSMEM_BYTES / 4;               // fp8: [BM] a_scale | [BN] w_scale | [BN] bias of this tile (read by the epilogue)
+    float sc_a = 0.f, sc_w[(BN + 255) / 256], sc_b[(BN + 255) / 256];
     if constexpr (ET == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -559,6 +573,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        // the epilogue's per-row / per-column operands (128 + 2 BN floats; thread t takes element t of each run of 256) are requested now, ahead
+        // of the first operand stages, and parked in LDS once those requests are out (below): their latency passes under the pipeline's own
+        {
+            const int rowc = min(m0 + (tid & 127), p.M - 1);
+            sc_a = p.a_const;
+            if (p.a_scale) sc_a = p.a_scale[rowc];
+#pragma unroll
+            for (int c = 0; c < (BN + 255) / 256; ++c) {
+                const int col = min(n0 + 256 * c + tid, p.N - 1);
+                sc_w[c] = 1.f; sc_b[c] = 0.f;
+                if (p.w_scale) sc_w[c] = p.w_scale[col];
+                if (p.bias) sc_b[c] = p.bias[col];
+            }
+        }
     } else {
         const bool has_bias = p.bias != nullptr;
         const bool has_ext = (p.epilogue == MMDM_EPI_BIAS_RESID || p.epilogue == MMDM_EPI_BIAS_PE) && !bf16_late_ext(p, n0, BN);
@@ -730,7 +758,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
     if constexpr (HALFB) ldbh(0, 0, bl);
     else ldb(0, bx);
     stage(1, 1);
+    if constexpr (ET == 1) {                               // (older than every request above: the wait the compiler puts here leaves those in flight)
+        if (tid < 128) sc[tid] = sc_a;
+#pragma unroll
+        for (int c = 0; c < (BN + 255) / 256; ++c)
+            if (256 * c + tid < BN) { sc[BM + 256 * c + tid] = sc_w[c]; sc[BM + BN + 256 * c + tid] = sc_b[c]; }
+    }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     rda(0, 0, fa0);
     int cur = 0;
@@ -755,13 +790,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
     if constexpr (TL) { t_r1 = __builtin_amdgcn_s_memrealtime(); t_c1 = __builtin_readcyclecounter(); }
-    if (!(p.tst && bf16_finish_t<TM, TN, ET, BM, BN, NW, WSMEM_BYTES>(p, acc, m0, n0, wm, wn, lane, smem)))
+    if (!(p.tst && bf16_finish_t<TM, TN, ET, BM, BN, NW, WSMEM_BYTES>(p, acc, m0, n0, wm, wn, lane, smem, ET == 1 ? sc : nullptr)))
         bf16_finish<TM, TN, ET, BM>(p, acc, m0, n0, wm, wn, l31, lh);
     if constexpr (TL) {
+        const unsigned long long t_iss = __builtin_amdgcn_s_memrealtime();      // every instruction of the epilogue issued; its stores may be in flight
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (p.tl && tid == 0) {
             unsigned long long* o = p.tl + 4 * (size_t)blockIdx.x;
-            o[0] = t_c1 - t_c0; o[1] = t_r1 - t_r0; o[2] = __builtin_amdgcn_s_memrealtime() - t_entry; o[3] = (unsigned long long)nkt;
+            o[0] = t_c1 - t_c0; o[1] = (t_r1 - t_r0) | ((t_iss - t_r1) << 32); o[2] = __builtin_amdgcn_s_memrealtime() - t_entry;
+            o[3] = (unsigned long long)nkt | ((t_r0 - t_entry) << 32);      // upper half: ticks from kernel entry to the loop (accumulator start + first requests)
         }
     }
 #endif
@@ -772,8 +809,8 @@ int launch_w(BArgs a, hipStream_t st) {
     a.mt = (a.M + 127) / 128;
     a.nt = a.N / (128 * TN);
     mmdm_note_gemm("%s<14,4%d>", ET == 1 ? "gemm_fp8w" : "gemm_bf16w", TN);
-    if (a.tl) hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN, true>), dim3(a.mt * a.nt), dim3(256), WSMEM_BYTES, st, a);
-    else hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN>), dim3(a.mt * a.nt), dim3(256), WSMEM_BYTES, st, a);
+    if (a.tl) hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN, true>), dim3(a.mt * a.nt), dim3(256), wsmem_total(ET, TN), st, a);
+    else hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN>), dim3(a.mt * a.nt), dim3(256), wsmem_total(ET, TN), st, a);
     return mmdm_check_launch(ET == 1 ? "gemm_fp8w" : "gemm_bf16w");
 }
 
@@ -833,7 +870,7 @@ int mmdm_gemm_bf16_init(void) {
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 2>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 2, true>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 2, true>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1, true>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1, true>)}) {
-        hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WSMEM_BYTES);
+        hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wsmem_total(1, 2));
         if (e2 != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16w): %s", hipGetErrorString(e2));
     }
     return MMDM_OK;

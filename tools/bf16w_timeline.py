@@ -21,10 +21,16 @@ for M, N, K, epi in [(19200, 3072, 1024, "bias"), (19200, 1024, 1024, "resid"), 
     nwg = ((M + 127) // 128) * (N // bn)
     tl = torch.zeros(nwg * 4, device=d, dtype=torch.int64)
     lib.mmdm_diag_set(b"bf16_timeline", tl.data_ptr()); call(); torch.cuda.synchronize(); lib.mmdm_diag_set(b"bf16_timeline", 0)
+    raw1 = tl.view(nwg, 4)[:, 1].cpu()
+    iss = (raw1 >> 32).double()                     # ticks from the end of the K loop until the epilogue's last instruction has issued
+    tl.view(nwg, 4)[:, 1] &= 0xffffffff
     t = tl.view(nwg, 4).double().cpu()
     mhz = (100.0 * t[:, 0] / t[:, 1].clamp(min=1)).median().item()
-    nkt = t[0, 3].item()
+    raw3 = tl.view(nwg, 4)[:, 3].cpu()
+    nkt = float(raw3[0].item() & 0xffffffff)
+    pro = (raw3 >> 32).double()                     # ticks from kernel entry to the K loop
+    t[:, 3] = nkt
     per_step = (t[:, 0] / nkt).median().item()
     mf = (2 if "fp8" in kern else 1) * 4 * (bn // 128) * 4          # MFMAs per wave and step
     print(f"{M}x{N}x{K} {epi:5s} {kern}: loop {t[:, 1].median().item() / 100:.1f} us of a {t[:, 2].median().item() / 100:.1f} us workgroup "
-          f"({100 * (t[:, 1] / t[:, 2]).median().item():.0f} %), {per_step:.0f} shader clocks per K step (matrix pipe never idle: {mf * 32 * 2}), clock in the loop {mhz:.0f} MHz")
+          f"({100 * (t[:, 1] / t[:, 2]).median().item():.0f} %), {per_step:.0f} shader clocks per K step (matrix pipe never idle: {mf * 32 * 2}), clock in the loop {mhz:.0f} MHz; before the loop {pro.median().item() / 100:.1f} us, after it {(t[:, 2] - t[:, 1] - pro).median().item() / 100:.1f} us (epilogue issued after {iss.median().item() / 100:.1f} us, then its stores drain)")

@@ -18,9 +18,11 @@ for M,N,K,name,epi,od in shapes:
     extra = torch.randn(M,N,device=d) if epi=="resid" else None
     line = f"{name:5s} {M}x{N}x{K} {epi:5s} -> {str(od)[6:]:14s}"
     ref = {}
+    ONLY = os.environ.get("FP8_ONLY", "")          # e.g. "packed-t": one kernel form only (profiler passes)
     for tst in (1, 0):                       # 1: results leave through the workgroup's LDS transposition (whole lines); 0: direct row-per-lane stores
         lib.mmdm_diag_set(b"bf16_tst", tst)
         for tag, wgt, pk in (("staged", wq, False), ("packed", wp, True)):
+            if ONLY and ONLY != f"{tag}-{'t' if tst else 'd'}": continue
             f = lambda: ops.linear_fp8(xq, xs, wgt, ws, b, epi, extra, out_dtype=od, packed=pk)
             o = f(); res=[]
             key = tag

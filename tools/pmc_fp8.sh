@@ -12,7 +12,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCL
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_F8 GRBM_GUI_ACTIVE" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  FP8_SHAPES=${FP8_SHAPES:-qkv,ffn2} FP8_ITERS=1 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pass$i -- python3 $R/tools/gemm_fp8_bench.py > $O/pass$i.log 2>&1
+  FP8_ONLY=${FP8_ONLY:-packed-t} FP8_SHAPES=${FP8_SHAPES:-qkv,ffn2} FP8_ITERS=1 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pass$i -- python3 $R/tools/gemm_fp8_bench.py > $O/pass$i.log 2>&1
 done
 cd $R
 python3 tools/pmc_fp8_summary.py $O > $O/summary.txt; cat $O/summary.txt

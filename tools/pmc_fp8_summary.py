@@ -14,7 +14,7 @@ for p in sorted(glob.glob(out + "/pass*")):
             k = r["Kernel_Name"]
             if "gemm_bf16" not in k:
                 continue
-            key = (k.split("(")[0][-48:], r["Grid_Size"])
+            key = (k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-48:], r["Grid_Size"])
             c = r["Counter_Name"]
             cnt[key][c] += float(r["Counter_Value"]); n[key][c] += 1
             if c == "GRBM_GUI_ACTIVE":
