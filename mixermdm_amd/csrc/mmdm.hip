@@ -684,7 +684,7 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
         // --- FFN (layers.py:99-106)
         RC(norm(hbuf, ss_at(ffn_slot, r.ffn_row0), r.ffn_rows));
         if (f8) {               // FFN on fp8 operands: the GELU output is written as e4m3 at unit scale and read back as the down-projection's A
-            RC(gemm8(S.xn, false, lb.f1_8, lb.f1_s, 0, lw.f1_b, S.f1, F, 2, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
+            RC(gemm8(S.xn, false, lb.f1_8, lb.f1_s, 0, lw.f1_b, S.f1, F, 2, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0, Second(), w.w_packed));
             RC(gemm8(S.f1, true, lb.f2_8, lb.f2_s, 0, lw.f2_b, hbuf, D, 0, D, F, MMDM_EPI_BIAS_RESID, hbuf, D, Second(), w.w_packed && F >= 2048));
         } else {
             RC(gemm(S.xn, D, lw.f1_w, lb.f1_w, 0, (size_t)F * D, lw.f1_b, S.f1, F, ob, F, D, MMDM_EPI_BIAS_GELU, nullptr, 0));
@@ -1291,10 +1291,11 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
                         return r2 ? r2 : mmdm_pack_weight_frag(tmp, cols, dst, rows, cols, nullptr);
                     };
                     // Round 3, with the block-scaled 64-deep fp8 MFMA in both kernels (tools/gemm_fp8_bench.py, M = 19 200): the packed kernel now wins
-                    // on the projections (QKV 1203 vs 988 TFLOP/s) and on K = 2048 (FFN-2 917 vs 685); FFN-1 stays staged (1048 vs 988)
+                    // on the projections (QKV 1203 vs 988 TFLOP/s) and on K = 2048 (FFN-2 917 vs 685); FFN-1 stayed staged until round 5 (1048 vs 988)
                     rc = pack_now ? q8p(lw.sa_in_w, lb.sa_in_8, lb.sa_in_s, (int)(3 * D), (int)D) : q8(lw.sa_in_w, lb.sa_in_8, lb.sa_in_s, (int)(3 * D), (int)D);
                     if (!rc) rc = conv(lw.sa_out_w, lb.sa_out_w, D * D, D);
-                    if (!rc) rc = q8(lw.f1_w, lb.f1_8, lb.f1_s, (int)F, (int)D);
+                    // (round 5: with the epilogue's de-quantisation operands in LDS the packed kernel wins on FFN-1 too -- 67.7 vs 76.7 us at M = 19 200)
+                    if (!rc) rc = pack_now ? q8p(lw.f1_w, lb.f1_8, lb.f1_s, (int)F, (int)D) : q8(lw.f1_w, lb.f1_8, lb.f1_s, (int)F, (int)D);
                     if (!rc && pack_now && F >= 2048) {       // the one fp8 GEMM with K = 2048 (16 steps of the packed kernel): 1039 vs 901 TFLOP/s
                         rc = mmdm_quantize_rows_fp8(lw.f2_w, (int)F, tmp, (int)F, lb.f2_s, (int)D, (int)F, nullptr);
                         if (!rc) rc = mmdm_pack_weight_frag(tmp, F, lb.f2_8, (int)D, (int)F, nullptr);
