@@ -520,7 +520,13 @@ def measured_traffic(single, precision="fp32", B=16, T=300):
     is absent, was taken at another batch / length (bytes per launch scale with M = rows of the batch), or on other kernel sources than the
     ones this run executes."""
     from mixermdm_amd.build import sources_sha
-    path = os.path.join(ROOT, "profiles", "gemm_traffic.json" if precision == "fp32" else "gemm_traffic_%s.json" % precision)
+    # the headline workload's file, or -- for another (batch, frames) -- the file of a PMC pass taken at exactly that workload
+    # (profiles/gemm_traffic[_<mode>]_b<B>t<T>.json: tools/profile_b1.sh writes the reference's B = 1, T = 299 call shape)
+    stem = "gemm_traffic" if precision == "fp32" else "gemm_traffic_%s" % precision
+    path = os.path.join(ROOT, "profiles", stem + ".json")
+    alt = os.path.join(ROOT, "profiles", "%s_b%dt%d.json" % (stem, B, T))
+    if os.path.exists(alt):
+        path = alt
     if single or not os.path.exists(path):
         return None
     with open(path) as f:

@@ -1,13 +1,14 @@
 #!/bin/bash
 # Round bench lines (GPU box): every bench.py line profiles/README.md quotes, at HEAD.  Output: gpurun_out/bench_$TAG/*.json
-# (then: python tools/collect_bench.py $TAG, here).  usage: tools/bench_round.sh [tag, default r04]   (~18 minutes)
-TAG=${1:-r04}
+# (then: python tools/collect_bench.py $TAG, here).  usage: tools/bench_round.sh [tag, default r05]   (~22 minutes)
+TAG=${1:-r05}
 O=gpurun_out/bench_$TAG; rm -rf $O; mkdir -p $O
 # roofline.traffic needs the PMC traffic files of THESE sources: take them from a profile round that ran in the same call (tools/profile_round.sh)
 for pm in fp32: fp32_split:_fp32_split bf16_fp8:_bf16_fp8; do
   f=gpurun_out/prof_$TAG/summary_${pm%%:*}/gemm_traffic.json
   [ -f $f ] && cp $f profiles/gemm_traffic${pm##*:}.json
 done
+f=gpurun_out/prof_b1_$TAG/summary_fp32/gemm_traffic.json; [ -f $f ] && cp $f profiles/gemm_traffic_b1t299.json       # tools/profile_b1.sh of the same call
 Q="--no-cpu-baseline --no-alt --no-full-loop"
 python bench.py > $O/default.json 2> $O/default.err                                    # the driver's command: headline + fp32_split + full loop + CPU port
 python bench.py --workload single $Q > $O/single.json 2> $O/single.err                  # configs[1]
@@ -21,6 +22,9 @@ python bench.py --batch 32 --precision fp32_split $Q > $O/b32_split.json 2> $O/b
 python bench.py --batch 1 --frames 299 --sampler ddim50 --facade --steps 20 --warmup 3 > $O/infer_b1.json 2> $O/infer_b1.err
 python bench.py --batch 15 --frames 299 --sampler ddim50 --facade --steps 20 --warmup 3 --no-cpu-baseline > $O/infer_b15.json 2> $O/infer_b15.err
 python bench.py --workload single --batch 1 --frames 120 --sampler ddim50 --steps 20 --warmup 3 > $O/configs0.json 2> $O/configs0.err
+# the reference's evaluation caller (src/evaluation/datasets.py:100-116): 64 items of their own lengths as the sequential loop, in-flight handles and ragged batches
+python bench.py --eval-items 64 > $O/eval64.json 2> $O/eval64.err
+python bench.py --eval-items 64 --precision fp32_split --no-cpu-baseline > $O/eval64_split.json 2> $O/eval64_split.err
 python tools/full_loop.py > $O/full_loops.txt 2> $O/full_loops.err
 for f in $O/*.json; do echo $(basename $f) $(grep -o '"ms_per_step": [0-9.]*' $f | head -1) $(grep -o '"value": [0-9.]*' $f | head -1); done
 tail -6 $O/full_loops.txt

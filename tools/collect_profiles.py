@@ -2,7 +2,7 @@
 usage: python tools/collect_profiles.py [round-tag, default r04]"""
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles")
 for n in ("serial", "overlap", "fp32_split_serial", "bf16_serial", "bf16_fp8_serial", "single_serial"):
     st = os.path.join(src, "summary", f"kernel_stats_{n}.csv")
@@ -26,6 +26,25 @@ for p in ("fp32", "fp32_split", "bf16_fp8"):
         t = json.load(open(out))
         print(f"traffic {p:11s} sha {t['kernel_sources_sha']}  {t['traffic_bytes_per_launch'] / 1e6:.0f} MB/launch  L2 hit {t['l2_hit_rate']}  MFMA busy {t.get('mfma_busy_frac')}  "
               f"clock {t.get('clock_ghz')} GHz  {t.get('hbm_side_TBps')} TB/s beyond L2")
+# the reference's own call shape (tools/profile_b1.sh): B = 1, T = 299, ddim50 through the facade
+b1 = os.path.join(ROOT, "gpurun_out", f"prof_b1_{tag}")
+for n in ("serial", "overlap"):
+    st = os.path.join(b1, "summary", f"kernel_stats_{n}.csv")
+    if os.path.exists(st):
+        shutil.copy(st, os.path.join(dst, f"{tag}_kernel_stats_infer_b1_{n}.csv"))
+        for line in open(os.path.join(b1, f"{n}.json")):
+            if line.startswith("{"):
+                d = json.loads(line)
+                json.dump(d, open(os.path.join(dst, f"{tag}_bench_infer_b1_{n}_under_rocprof.json"), "w"), indent=1)
+                print(f"infer_b1 {n:8s} {d['ms_per_step']:7.3f} ms/step  GEMM live frac {d['roofline']['frac']}  facade {d.get('facade')}")
+if os.path.exists(os.path.join(b1, "summary_fp32", "pmc_summary.json")):
+    shutil.copy(os.path.join(b1, "summary_fp32", "pmc_summary.json"), os.path.join(dst, f"{tag}_pmc_infer_b1.json"))
+    if os.path.exists(os.path.join(b1, "summary_fp32", "gemm_traffic.json")):
+        shutil.copy(os.path.join(b1, "summary_fp32", "gemm_traffic.json"), os.path.join(dst, "gemm_traffic_b1t299.json"))
+# the stand-alone fp8 GEMM under the counters (tools/pmc_fp8.sh)
+f8 = os.path.join(ROOT, "gpurun_out", f"pmc_fp8_{tag}", "summary.txt")
+if os.path.exists(f8):
+    shutil.copy(f8, os.path.join(dst, f"{tag}_pmc_fp8_gemm.json"))
 rows = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats_serial.csv"))))
 g = [r for r in rows if r["Name"].startswith("gemm_glds_kernel")]
 tot, n = sum(float(r["TotalDurationNs"]) for r in g), sum(int(r["Calls"]) for r in g)
