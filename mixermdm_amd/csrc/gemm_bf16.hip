@@ -578,7 +578,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 
     f32x16 acc[TM][TN];
     float* const sc = smem + WSMEM_BYTES / 4;               // fp8: [BM] a_scale | [BN] w_scale | [BN] bias of this tile (read by the epilogue)
-    float sc_a = 0.f, sc_w[(BN + 255) / 256], sc_b[(BN + 255) / 256];
+    static_assert(BN <= 256, "one w_scale / bias element per thread");
+    float sc_a = 0.f, sc_w = 1.f, sc_b = 0.f;
     if constexpr (ET == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -586,19 +587,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        // the epilogue's per-row / per-column operands (128 + 2 BN floats; thread t takes element t of each run of 256) are requested now, ahead
+        // the epilogue's per-row / per-column operands (128 + 2 BN floats; thread t takes element t of each) are requested now, ahead
         // of the first operand stages, and parked in LDS once those requests are out (below): their latency passes under the pipeline's own
         {
             const int rowc = min(m0 + (tid & 127), p.M - 1);
             sc_a = p.a_const;
             if (p.a_scale) sc_a = p.a_scale[rowc];
-#pragma unroll
-            for (int c = 0; c < (BN + 255) / 256; ++c) {
-                const int col = min(n0 + 256 * c + tid, p.N - 1);
-                sc_w[c] = 1.f; sc_b[c] = 0.f;
-                if (p.w_scale) sc_w[c] = p.w_scale[col];
-                if (p.bias) sc_b[c] = p.bias[col];
-            }
+            const int col = min(n0 + tid, p.N - 1);
+            if (p.w_scale) sc_w = p.w_scale[col];
+            if (p.bias) sc_b = p.bias[col];
         }
     } else {
         const bool has_bias = p.bias != nullptr;
@@ -773,9 +770,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
     stage(1, 1);
     if constexpr (ET == 1) {                               // (older than every request above: the wait the compiler puts here leaves those in flight)
         if (tid < 128) sc[tid] = sc_a;
-#pragma unroll
-        for (int c = 0; c < (BN + 255) / 256; ++c)
-            if (256 * c + tid < BN) { sc[BM + 256 * c + tid] = sc_w[c]; sc[BM + BN + 256 * c + tid] = sc_b[c]; }
+        if (tid < BN) { sc[BM + tid] = sc_w; sc[BM + BN + tid] = sc_b; }
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

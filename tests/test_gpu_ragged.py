@@ -234,6 +234,36 @@ def test_full_size_ragged_batch_is_bitwise_the_stand_alone_calls(full, precision
             assert torch.equal(st[k][o:o + t], alone[b][k]), (precision, b, k, (st[k][o:o + t] - alone[b][k]).abs().max().item())
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32_split", "bf16_fp8"])
+def test_full_size_handles_side_by_side_keep_their_bits(full, precision):
+    """Three handles over one weight set at the real sizes, eight calls dealt round-robin with nothing synchronised in between: every motion is
+    the sequential loop's, bit for bit, in every precision mode.  (Round 5 found that step graphs of two LOW-PRECISION handles running beside each
+    other give wrong motions -- tools/handle_overlap_bits.py -- although every kernel and every module is bit-stable under concurrency; the library
+    therefore serialises the sampling calls of different handles on the device unless the precision is 0: this test is what that rule protects.)"""
+    get, _, _ = full
+    s = get(precision)
+    s.set_schedule("ddim20")
+    kids = [s.share(max_batch=1), s.share(max_batch=1)]
+    for k in kids:
+        k.set_schedule("ddim20")
+    pool = [s] + kids
+    items = []
+    for i, T in enumerate((181, 97, 263, 140, 181, 97, 263, 140)):
+        g = torch.Generator().manual_seed(70 + i)
+        items.append((torch.randn(1, 8 * 768, generator=g).cuda(), torch.randn(1, T, 524, generator=g).cuda()))
+    ref = [s.sample(c, x) for c, x in items]
+    for rnd in range(2):
+        outs = [torch.empty_like(x) for _, x in items]
+        torch.cuda.synchronize()
+        for i, (c, x) in enumerate(items):
+            pool[i % 3].enqueue(c, x, outs[i])
+        torch.cuda.synchronize()
+        for i, (o, r) in enumerate(zip(outs, ref)):
+            assert torch.equal(o, r), (precision, rnd, i, (o - r).abs().max().item())
+    for k in kids:
+        k.close()
+
+
 def test_full_size_ragged_step_against_the_oracle(full):
     """One DDIM step of a ragged batch (T = 32 and 24) at D = 1024 / 512, L = 8 / 4 against the oracle's step on every item alone: element-wise
     at the float64-derived tolerance + the float64 yardstick (tests/parity_tol.py) -- the ragged path's own parity statement."""
