@@ -1014,10 +1014,13 @@ size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 // hip::Graph::UpdateStreams (seen with 2 and 4 handles at the real model sizes as soon as a graph cache evicted; waiting for the whole device
 // first does not help, never destroying does): such execs are parked for the life of the process instead.  Bounded by the number of distinct
 // shapes captured while handles shared weights; a handle that never shared frees its execs as before.  Caller holds g_graph_mu exclusively.
+// Once an exec has been parked, parked execs are alive for good -- so from then on EVERY exec of the process is parked rather than destroyed (the
+// full GPU suite crashed in a later, unrelated handle's hipGraphLaunch after the shared-handle test had parked some execs and later tests destroyed
+// theirs).  A process that never lets two handles share weights (bench.py's headline, one Sampler) never parks and frees its execs as before.
 std::vector<hipGraphExec_t> g_parked_execs;
 void retire_exec(mmdm_handle h, hipGraphExec_t exec) {
     if (!exec) return;
-    if (h->wb && h->wb.use_count() > 1) g_parked_execs.push_back(exec);
+    if ((h->wb && h->wb.use_count() > 1) || !g_parked_execs.empty()) g_parked_execs.push_back(exec);
     else (void)hipGraphExecDestroy(exec);
 }
 
