@@ -9,6 +9,16 @@ LIB = os.path.join(HERE, "libmmdm_hip.so")
 SOURCES = ["mmdm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "attn_f32.hip", "rowops.hip", "geometry.hip"]
 
 
+# Translation units compiled WITHOUT the packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).  Measured in round 5
+# (tools/canary.hip, tools/overlap_bisect.py; LAB_NOTES.md): on gfx950 a v_pk_*_f32 result read by a dependent VALU instruction one or two
+# issue slots later can arrive STALE when the wave shares a SIMD with waves of the packed-W GEMM kernels (gemm_splitw / gemm_bf16w) -- pure
+# register arithmetic of an unrelated kernel gives other bits, and the rotation round trip of the geometry kernels amplifies one such bit
+# into a turned joint.  Without these instructions nothing moves (0 of 1e10 evaluations).  The geometry / row kernels are HBM-bound: the
+# flag costs them nothing.
+NO_PACKED_FP32 = {"geometry.hip", "rowops.hip"}
+NO_PACKED_FP32_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+
+
 SHA_FILES = {"fp32": ("gemm_f32.hip", "mmdm.hip", "kernels.h"), "fp32_split": ("gemm_split.hip", "mmdm.hip", "kernels.h"),
              "bf16": ("gemm_bf16.hip", "mmdm.hip", "kernels.h"), "bf16_fp8": ("gemm_bf16.hip", "mmdm.hip", "kernels.h")}
 
@@ -49,6 +59,8 @@ def build(force=False, verbose=True):
             continue                                  # object is newer than its source and the shared headers
         # -fvisibility=hidden: the shared library exports exactly what include/mmdm.h declares (its declarations sit inside a visibility pragma)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-c", path, "-o", obj]
+        if src in NO_PACKED_FP32:
+            cmd[5:5] = NO_PACKED_FP32_FLAGS
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))    # translation units are independent: compile them side by side
