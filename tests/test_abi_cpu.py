@@ -131,3 +131,26 @@ int main(void) {
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)], text=True).strip().split("|")
     assert out[0].startswith("gfx950;") and int(out[1]) != 0 and "nfeats must be 262" in out[2]
+
+
+def test_geometry_and_row_kernels_hold_no_packed_fp32_instruction(tmp_path):
+    """Round 5: on gfx950 a v_pk_*_f32 result read one or two issue slots later can arrive stale while the wave shares a SIMD with the packed-W
+    GEMM kernels (tools/canary.hip is the reproducer; LAB_NOTES.md).  The bit-sensitive VALU kernels -- the rotation round trips of geometry.hip,
+    the AdaLN / LayerNorm rows of rowops.hip -- are therefore compiled without those instructions (mixermdm_amd/build.py NO_PACKED_FP32).  This
+    disassembles the built objects and holds that in place."""
+    import subprocess
+    from mixermdm_amd.build import build, CSRC, NO_PACKED_FP32
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")):
+        pytest.skip("no LLVM binutils in this image")
+    build(verbose=False)
+    assert NO_PACKED_FP32 == {"geometry.hip", "rowops.hip"}
+    for src in sorted(NO_PACKED_FP32):
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        fat, dev = str(tmp_path / "fat.bin"), str(tmp_path / "dev.o")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + dev])
+        isa = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", dev], capture_output=True, text=True, check=True).stdout
+        assert "v_fma_f32" in isa or "v_fmac_f32" in isa, src            # the disassembly is what it should be
+        assert not re.findall(r"v_pk_(?:mul|fma|add)_f32", isa), src
