@@ -1,12 +1,14 @@
-"""scratch: build/libmmdm_noserial.so = the library without the low-precision serialisation (MMDM_SERIAL unset) plus three debug keys of
-mmdm_diag_set taking a handle: snap_handle / diff_handle (which of the handle's allocations changed since the snapshot) / poison_handle."""
+"""Debug build of the library for tools/overlap_bisect.py and tools/overlap_stray.py (build container or GPU box): build/libmmdm_debug.so = the
+shipped translation units with csrc/mmdm.hip patched in memory (nothing is written into the tree) -- select it with MMDM_LIB=build/libmmdm_debug.so.
+Extra mmdm_diag_set keys, each taking a handle pointer as its value: snap_handle / snap_weights / diff_handle / diff_weights (which of the handle's
+allocations, by the name of the pointer they were allocated for, changed since the snapshot -- and the first differing values of out1 / out2),
+poison_handle (every allocation filled with 0x7f), poison_scratch (the per-step buffers filled with NaN), and dbg_skip <mask>: helper classes of
+mmdm.hip that launch nothing while the mask is set (1 fp32 GEMM, 2 fp32 attention, 4 bf16 GEMM, 8 fp8 GEMM, 16 split GEMM, 32 plane attention,
+64 bf16 attention, 128 AdaLN) -- a step graph captured under a mask is the aggressor with those kernels left out."""
 import os, re, subprocess
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cs = os.path.join(root, "mixermdm_amd", "csrc")
 s = open(os.path.join(cs, "mmdm.hip")).read()
-n0 = s.count('if (h->cfg.precision == 0) return MMDM_OK;')
-assert n0 == 2
-s = s.replace('if (h->cfg.precision == 0) return MMDM_OK;', 'if (h->cfg.precision == 0 || getenv("MMDM_SERIAL") == nullptr) return MMDM_OK;')
 s = s.replace('extern "C" int mmdm_diag_set(const char* key, long long value) {', 'int mmdm_debug_handle(const char* key, long long value);\nextern "C" int mmdm_diag_set(const char* key, long long value) {\n    if (key && mmdm_debug_handle(key, value)) return MMDM_OK;', 1)
 s = s.replace('int dalloc(mmdm_handle h, float** p, size_t nfloats) {', 'int dalloc_real(mmdm_handle h, float** p, size_t nfloats) {', 1)
 marker = 'int add_slot(mmdm_handle h, const std::string& name'
@@ -89,7 +91,7 @@ try:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-c", tmp, "-o", os.path.join(root, "build", "mmdm_dbg.o")])
     objs = [os.path.join(cs, f + ".o") for f in ("attn_f32", "gemm_bf16", "gemm_f32", "gemm_split", "geometry", "rowops")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(cs, "libmmdm.map"), "-o",
-                           os.path.join(root, "build", "libmmdm_noserial.so"), os.path.join(root, "build", "mmdm_dbg.o")] + objs)
+                           os.path.join(root, "build", "libmmdm_debug.so"), os.path.join(root, "build", "mmdm_dbg.o")] + objs)
 finally:
     os.remove(tmp)
 print("built")

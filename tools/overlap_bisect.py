@@ -1,8 +1,17 @@
-"""scratch: two low-precision handles side by side, ONE step at a time (needs a library without the serialisation: MMDM_LIB=build/libmmdm_noserial.so).
+"""Two handles side by side, ONE step at a time -- the hunt for round 5's wrong motions (LAB_NOTES.md: a packed-fp32 hazard on gfx950).
 
-Every step is an independent trial: both handles are put back on the sequential run's state of step k-1, one step of each is queued back to
-back (nothing synchronised in between), and the five state buffers are compared with the sequential run's.  Prints where the first wrong
-numbers sit.  MODE=steps (default) | aggressor (victim: a whole sampling call; beside it torch matmuls / elementwise kernels on another stream)."""
+usage: [MODE=...] python tools/overlap_bisect.py [precision of handle A] [precision of handle B]
+  MODE=steps (default): every step is an independent trial -- both handles are put back on the sequential run's state of step k-1, one step of
+      each is queued back to back (nothing synchronised in between), the five state buffers are compared with the sequential run's and the place
+      of the wrong numbers is printed.  PROBE_EAGER=1: eager launches; NSTEP=.
+  MODE=aggressor / victim_torch / gemm_aggr: torch kernels beside a handle, a torch matmul as the victim, ONE stand-alone library GEMM as the aggressor.
+  MODE=canary: tools/canary.hip (build/libcanary.so; CANARY_LIB= another build of it) beside the steps; CANARY_TRANS=1 the rotation round trip,
+      CANARY_OPS=1 single operations, CANARY_CHAIN=1 the first intermediate that moves; CANARY_AGGR=1 adds library GEMMs and torch matmuls as
+      aggressors, CANARY_VARIANTS=1 the packed kernels' variants, CANARY_MICRO=1 the micro-aggressors, CU_SPLIT=1 victim and aggressor on
+      disjoint halves of the CUs.
+  MODE=skip / which (+ POISON=1): need the debug build of tools/mk_debug_lib.py (MMDM_LIB=build/libmmdm_debug.so): kernel classes left out of B's
+      step graph; A's allocations that differ, by name, after an overlapped step.
+With the shipped library (geometry / row kernels built without packed-fp32 instructions) every mode reports zero."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
-"""scratch: does one low-precision handle WRITE into (or READ from) another handle's device memory?  Needs the debug build of tools/_mk_debug_lib.py
-(MMDM_LIB=build/libmmdm_noserial.so): snapshot every allocation of handle A, run handle B alone, list A's allocations that changed; then poison
+"""scratch: does one low-precision handle WRITE into (or READ from) another handle's device memory?  Needs the debug build of tools/mk_debug_lib.py
+(MMDM_LIB=build/libmmdm_debug.so): snapshot every allocation of handle A, run handle B alone, list A's allocations that changed; then poison
 B's memory and see whether A's result moves."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
