@@ -343,7 +343,7 @@ int mmdm_create(const mmdm_config* cfg, mmdm_handle* out);
  * A CALLER's own kernels that run beside a low-precision handle on the same device are exposed to the same hazard if they use packed-fp32
  * arithmetic in bit-sensitive code (hipcc: -Xclang -target-feature -Xclang -packed-fp32-ops removes it).
  * Measured (tools/inflight_probe.py, B = 1, T = 180, fp32): the GPU overlaps two such streams hardly at all -- 1.00-1.03 x with 2-4 handles
- * (1.22 x eager with 16 hardware queues); packing the calls into one ragged batch (mmdm_begin_ragged) is what fills the machine: 1.95 x. */
+ * (1.22 x eager with 16 hardware queues); packing the calls into one ragged batch (mmdm_begin_ragged) is what fills the machine: 1.86-1.95 x. */
 int mmdm_create_shared(mmdm_handle parent, int max_batch, int max_frames, mmdm_handle* out);
 void mmdm_destroy(mmdm_handle h);
 const char* mmdm_handle_error(mmdm_handle h);
