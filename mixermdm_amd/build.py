@@ -13,9 +13,11 @@ SOURCES = ["mmdm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "attn_
 # (tools/canary.hip, tools/overlap_bisect.py; LAB_NOTES.md): on gfx950 a v_pk_*_f32 result read by a dependent VALU instruction one or two
 # issue slots later can arrive STALE when the wave shares a SIMD with waves of the packed-W GEMM kernels (gemm_splitw / gemm_bf16w) -- pure
 # register arithmetic of an unrelated kernel gives other bits, and the rotation round trip of the geometry kernels amplifies one such bit
-# into a turned joint.  Without these instructions nothing moves (0 of 1e10 evaluations).  The geometry / row kernels are HBM-bound: the
-# flag costs them nothing.
-NO_PACKED_FP32 = {"geometry.hip", "rowops.hip"}
+# into a turned joint.  Without these instructions nothing moves (0 of 1e10 evaluations).  The geometry kernels run once per step: the flag
+# costs nothing.  (rowops.hip -- AdaLN, 640 launches per step beside the other stream's GEMMs -- was built this way too for one profile round:
+# +1.3 ms per fp32 step; its kernels were never seen to move -- the denoiser outputs were bit-equal in every wrong step of the hunt, and
+# tools/adaln_victim.py holds 0 of its launches moving beside the packed GEMMs -- so it keeps the packed instructions.)
+NO_PACKED_FP32 = {"geometry.hip"}
 NO_PACKED_FP32_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
