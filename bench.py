@@ -229,6 +229,9 @@ def main():
                 "gflop_per_launch": round(g_fl / g_n / 1e9, 3), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
                 "attention": {"achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a_ms / args.profile_steps, 3),
                               "launches_per_step": a_n // args.profile_steps}}
+        small = small_launch_note(single, B, T)
+        if small:
+            roof["note"] = small
         if other:
             roof["bf16_launches"] = other
             roof.update(blended)
@@ -281,6 +284,8 @@ def main():
                                "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1), "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
                                "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
                                "attention": {"achieved": round(a2_fl / (a2_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a2_ms / args.profile_steps, 3), "launches_per_step": a2_n // args.profile_steps}}
+            if small_launch_note(single, B, T):
+                alt["roofline"]["note"] = small_launch_note(single, B, T)
             if q_n:
                 alt["roofline"]["fp32_launches"] = {"achieved": round(q_fl / (q_ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "launches_per_step": q_n // args.profile_steps,
                                                     "ms_per_step": round(q_ms / args.profile_steps, 3)}
@@ -510,6 +515,18 @@ def eval_items_bench(args, device, rank, world):
             "strategies": strat, "bit_identical_to_sequential": same, "roofline": roof, "cpu_baseline": cpu,
             "graph_cache": dict(zip(("captures", "replays", "cached"), model._sampler.graph_stats()))}
     print(json.dumps(line), flush=True)
+
+
+def small_launch_note(single, B, T):
+    """A line for `roofline` when the call is too small to fill the machine (nit 7): at the reference's B = 1 call the GEMMs have
+    M = 4 T rows -- fewer 128 x 128 tiles at N = 1024 than the chip has CUs -- so the library runs smaller tiles and a launch is ONE tile's K loop
+    long: `frac` then reads launch fill and latency, not the kernel's quality."""
+    rows = (2 if single else 4) * B * T
+    tiles = -(-rows // 128) * 8
+    if tiles >= 256:
+        return None
+    return ("M = %d rows: %d tiles of 128 x 128 at N = 1024 on 256 CUs -- the library halves the tiles (64 x 64 fp32, 64 x 128 split / bf16: gemm_f32.hip, gemm_split.hip) and a launch is "
+            "one tile's K loop long: `frac` reads launch fill and latency here, not kernel quality" % (rows, tiles))
 
 
 def measured_traffic(single, precision="fp32", B=16, T=300):
