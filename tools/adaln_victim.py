@@ -1,4 +1,4 @@
-"""Is the AdaLN kernel (built WITH packed-fp32 instructions) a victim of the gfx950 packed-fp32 hazard (LAB_NOTES.md, round 5)?  The kernel at the
+"""Are the AdaLN kernel and the fp32 attention kernel (built WITH packed-fp32 instructions) victims of the gfx950 packed-fp32 hazard (LAB_NOTES.md, round 5)?  The kernel at the
 step's shape (19 200 rows, D = 1024; and the B = 1 shape) launched over and over on one stream, each result compared bit for bit with the first,
 while the packed-W GEMMs -- the aggressors of tools/canary.hip -- run on another stream.  Prints launches whose output moved."""
 import sys, os
@@ -14,12 +14,16 @@ aux, side = torch.cuda.Stream(), torch.cuda.Stream()
 for rows, T in ((19200, 300), (1196, 299)):
     nseq = rows // T
     h = torch.randn(rows, 1024, generator=g).cuda(); ss = (torch.randn(nseq, 2048, generator=g) * 0.3).cuda()
-    forms = {"fp32 rows": lambda: ops.adaln(h.view(nseq, T, 1024), ss)}
+    forms = {"AdaLN fp32 rows": lambda: ops.adaln(h.view(nseq, T, 1024), ss)}
     if hasattr(ops, "adaln_fp8"):
         def f8():
             q, sc = ops.adaln_fp8(h.view(nseq, T, 1024), ss)
             return torch.cat([q.view(torch.uint8).flatten().float(), sc.flatten()])
-        forms["fp8 rows + scales"] = f8
+        forms["AdaLN fp8 rows + scales"] = f8
+    if rows == 19200:
+        qkv = torch.randn(64, T, 3 * 1024, generator=g).cuda()
+        forms["fp32 attention (attn_mfma_kernel: 46 op_sel producers read by the next instruction), 64 x 8 heads x 300 x 128"] = \
+            lambda: ops.attention(qkv[..., :1024], qkv[..., 1024:2048], qkv[..., 2048:], 8)
     for what, f in forms.items():
         with torch.cuda.stream(side):
             ref = f().clone()
@@ -36,4 +40,4 @@ for rows, T in ((19200, 300), (1196, 299)):
                 busy = af is not None and not aux.query()
                 torch.cuda.synchronize()
                 moved += sum(int(not torch.equal(o, ref)) for o in outs); launches += len(outs)
-            print("AdaLN %s, %d rows, beside %s: %d of %d launches moved (aggressor still running at the end of the last round: %s)" % (what, rows, aggr, moved, launches, busy), flush=True)
+            print("%s, %d rows, beside %s: %d of %d launches moved (aggressor still running at the end of the last round: %s)" % (what, rows, aggr, moved, launches, busy), flush=True)
