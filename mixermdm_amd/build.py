@@ -10,8 +10,9 @@ SOURCES = ["mmdm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "attn_
 
 
 # Translation units compiled WITHOUT the packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).  Measured in round 5
-# (tools/canary.hip, tools/overlap_bisect.py; LAB_NOTES.md): on gfx950 a v_pk_*_f32 result read by a dependent VALU instruction one or two
-# issue slots later can arrive STALE when the wave shares a SIMD with waves of the packed-W GEMM kernels (gemm_splitw / gemm_bf16w) -- pure
+# (tools/canary.hip, tools/overlap_bisect.py; LAB_NOTES.md): on gfx950 a packed-fp32 instruction (seen: the low lane of v_pk_mul_f32 ... op_sel_hi:[1,0])
+# transiently delivers a WRONG result when its wave shares a SIMD with waves of the packed-W GEMM kernels (gemm_splitw / gemm_bf16w); wait
+# states behind it (up to 8, hand-assembled) change nothing -- pure
 # register arithmetic of an unrelated kernel gives other bits, and the rotation round trip of the geometry kernels amplifies one such bit
 # into a turned joint.  Without these instructions nothing moves (0 of 1e10 evaluations).  The geometry kernels run once per step: the flag
 # costs nothing.  (rowops.hip -- AdaLN, 640 launches per step beside the other stream's GEMMs -- was built this way too for one profile round:

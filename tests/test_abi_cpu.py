@@ -134,7 +134,7 @@ int main(void) {
 
 
 def test_geometry_kernels_hold_no_packed_fp32_instruction(tmp_path):
-    """Round 5: on gfx950 a v_pk_*_f32 result read one or two issue slots later can arrive stale while the wave shares a SIMD with the packed-W
+    """Round 5: on gfx950 a v_pk_*_f32 instruction can transiently deliver a wrong result while its wave shares a SIMD with the packed-W
     GEMM kernels (tools/canary.hip is the reproducer; LAB_NOTES.md).  The bit-sensitive VALU kernels -- the rotation round trips of geometry.hip --
     are therefore compiled without those instructions (mixermdm_amd/build.py NO_PACKED_FP32).  This
     disassembles the built objects and holds that in place."""

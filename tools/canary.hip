@@ -3,6 +3,12 @@
 // shared object for tools/overlap_bisect.py (MODE=canary):
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/canary.hip -o build/libcanary.so
 // report[0..3] = mismatches seen in (LDS, registers, global memory, LDS-DMA image); report[4] = checks made.
+// The other kernels below are the ARITHMETIC canaries that found round 5's gfx950 hazard (LAB_NOTES.md): canary_trans_kernel (the rotation round trip of
+// csrc/geometry.hip on fixed inputs, bit-compared with the same thread's first result), canary_ops_kernel (single operations), canary_chain_kernel (the first
+// intermediate that moves) and aggressor_kernel (micro-aggressors).  Variants: -Xclang -target-feature -Xclang -packed-fp32-ops builds the canaries that never
+// move; the hand-assembled route (wait states behind every v_pk_*_f32: they change nothing) is
+//   hipcc --offload-arch=gfx950 -O3 --cuda-device-only -S tools/canary.hip -o c.s;  <insert s_nop N behind each v_pk_*_f32>;
+//   clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c c.s -o c.o;  ld.lld -shared c.o -o build/canary_nopN.hsaco;  CANARY_HSACO=build/canary_nopN.hsaco
 #include <hip/hip_runtime.h>
 
 typedef __attribute__((address_space(3))) void* lptr_t;

@@ -223,11 +223,26 @@ elif os.environ.get("MODE") == "canary":
                     "micro: fp32 MFMAs + LDS-DMA": micro(12, 3000)}
         for f in aggr.values(): f()
         torch.cuda.synchronize()
-    for what in ["alone", "beside B's step", "beside A's and B's steps"] + list(aggr) + ["alone"]:
+    # CANARY_HSACO=<code object>: the canary kernels from a hand-assembled build (tools/canary.hip compiled to assembly, e.g. with an s_nop behind every
+    # packed-fp32 instruction, assembled with clang -x assembler and linked with ld.lld) instead of build/libcanary.so
+    mfn = None
+    if os.environ.get("CANARY_HSACO"):
+        hipm = C.CDLL("libamdhip64.so")
+        mod = C.c_void_p(); rc_ = hipm.hipModuleLoad(C.byref(mod), os.environ["CANARY_HSACO"].encode()); assert rc_ == 0, rc_
+        mfn = C.c_void_p()
+        rc_ = hipm.hipModuleGetFunction(C.byref(mfn), mod, b"_Z19canary_chain_kernelPjPKfi" if os.environ.get("CANARY_CHAIN") == "1" else b"_Z19canary_trans_kernelPjPKfi"); assert rc_ == 0, rc_
+    only = os.environ.get("CANARY_ONLY")
+    if only:
+        aggr = {k: v for k, v in aggr.items() if only in k}
+    for what in (["alone"] if only else ["alone", "beside B's step", "beside A's and B's steps"]) + list(aggr) + ["alone"]:
         tot = torch.zeros(80, dtype=torch.int64)
         for k in range(NSTEP):
             report.zero_(); torch.cuda.synchronize()
-            if os.environ.get("CANARY_CHAIN") == "1":
+            if mfn is not None:
+                a0, a1, a2 = C.c_void_p(report.data_ptr()), C.c_void_p(tin.data_ptr()), C.c_int(spin)
+                params = (C.c_void_p * 3)(C.addressof(a0), C.addressof(a1), C.addressof(a2))
+                rc = hipm.hipModuleLaunchKernel(mfn, nwg, 1, 1, 256, 1, 1, 0, C.c_void_p(side.cuda_stream), params, None)
+            elif os.environ.get("CANARY_CHAIN") == "1":
                 rc = lib.canary_chain_launch(C.c_void_p(report.data_ptr()), C.c_void_p(tin.data_ptr()), nwg, spin, C.c_void_p(side.cuda_stream))
             elif os.environ.get("CANARY_OPS") == "1":
                 rc = lib.canary_ops_launch(C.c_void_p(report.data_ptr()), C.c_void_p(tin.data_ptr()), nwg, spin, C.c_void_p(side.cuda_stream))

@@ -1,5 +1,6 @@
-"""Static exposure to the gfx950 packed-fp32 hazard of round 5 (LAB_NOTES.md): per kernel of a disassembled translation unit, the sites where the
-result of a v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 is read by a plain (non-packed) VALU instruction one or two instructions later.
+"""A census made on the FIRST reading of round 5's gfx950 packed-fp32 hazard (LAB_NOTES.md: "a late result"; the hand-assembled s_nop canaries later showed the result
+is wrong, not late): per kernel of a disassembled translation unit, the sites where the result of a v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 is read by a plain
+(non-packed) VALU instruction one or two instructions later.
 usage: bash tools/kernel_isa.sh mixermdm_amd/csrc/attn_f32.o . > /tmp/attn.s; python tools/pk_hazard_scan.py /tmp/attn.s [...]"""
 import re,sys,collections
 def regs(tok):
