@@ -215,6 +215,58 @@ extern "C" __attribute__((visibility("default"))) int canary_chain_launch(unsign
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+// WHAT is the wrong result?  One explicit `v_pk_mul_f32 d, a, b op_sel_hi:[1,0]` (d.lo = a.lo * b.lo, d.hi = a.hi * b.lo) per iteration, its destination pre-set to a
+// sentinel pair, between a few dependent plain FMAs (dense VALU code around it, as in the round trip).  A mismatch is recorded with its operands:
+// rec[8 i ..] = a.lo, a.hi, b.lo, b.hi, d.lo, d.hi, which lane (1 lo, 2 hi, 3 both), iteration.  report[5] mismatches, report[6] evaluations (per workgroup).
+typedef float f32x2c __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void canary_pk_kernel(unsigned* report, float* rec, const float* inputs, int spin_us) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int tid = threadIdx.x, gid = blockIdx.x * 256 + tid;
+    f32x2c a{inputs[(size_t)gid * 6], inputs[(size_t)gid * 6 + 1]}, b{inputs[(size_t)gid * 6 + 2], inputs[(size_t)gid * 6 + 3]};
+    float f = inputs[(size_t)gid * 6 + 4], g = inputs[(size_t)gid * 6 + 5];
+    __shared__ int stop;
+    unsigned evals = 0, bad = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (tid == 0) stop = __builtin_amdgcn_s_memrealtime() - t0 >= (unsigned long long)spin_us * 100;
+        __syncthreads();
+        if (stop) break;
+        for (int rep = 0; rep < 16; ++rep) {
+            asm volatile("" : "+v"(a), "+v"(b), "+v"(f), "+v"(g));
+            float want_lo, want_hi;                                   // by the plain multiply, in asm (the compiler would form the same packed instruction again)
+            { const float a0 = a[0], a1 = a[1], b0 = b[0];
+              asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4" : "=&v"(want_lo), "=&v"(want_hi) : "v"(a0), "v"(a1), "v"(b0)); }
+            f32x2c d{777.0f, 888.0f};
+            float t1 = f, t2 = g;
+            asm volatile("v_fma_f32 %1, %1, %5, %6\n\t"
+                         "v_fma_f32 %2, %2, %6, %5\n\t"
+                         "v_pk_mul_f32 %0, %3, %4 op_sel_hi:[1,0]\n\t"
+                         "v_fma_f32 %1, %1, %2, %5\n\t"
+                         "v_fma_f32 %2, %2, %1, %6"
+                         : "+v"(d), "+v"(t1), "+v"(t2) : "v"(a), "v"(b), "v"(f), "v"(g));
+            const bool blo = __float_as_uint(d[0]) != __float_as_uint(want_lo), bhi = __float_as_uint(d[1]) != __float_as_uint(want_hi);
+            if (blo || bhi) {
+                const unsigned slot = atomicAdd(report + 5, 1u);
+                if (slot < 256) {
+                    float* r = rec + 8 * slot;
+                    r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1]; r[4] = d[0]; r[5] = d[1]; r[6] = (float)((blo ? 1 : 0) | (bhi ? 2 : 0)); r[7] = (float)evals;
+                }
+                ++bad;
+            }
+            if (t1 == 12345.5f && t2 == 54321.5f) f += 1.0f;          // keep the FMAs alive
+            ++evals;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) atomicAdd(report + 6, evals);
+#endif
+}
+
+extern "C" __attribute__((visibility("default"))) int canary_pk_launch(unsigned* report, float* rec, const float* inputs, int nwg, int spin_us, void* stream) {
+    hipLaunchKernelGGL(canary_pk_kernel, dim3(nwg), dim3(256), 0, static_cast<hipStream_t>(stream), report, rec, inputs, spin_us);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 // Which operation moves?  One op per slot on fixed per-thread inputs, compared bit for bit with the same sequence's first result.
 // report[8 + slot] = evaluations that moved: 0 fma chain, 1 division, 2 sqrtf, 3 sinf, 4 cosf, 5 atan2f, 6 expf, 7 erff, 8 integer mix, 9 v_rcp_f32, 10 v_sin_f32 (native), 11-13 packed-fp32 fma / mul / add
 __global__ __launch_bounds__(256) void canary_ops_kernel(unsigned* report, const float* inputs, int spin_us) {

@@ -156,7 +156,7 @@ elif os.environ.get("MODE") == "canary":
     nwg = int(os.environ.get("CANARY_WG", "512")); lds = int(os.environ.get("CANARY_LDS", "32768")); spin = int(os.environ.get("CANARY_US", "5000"))
     report = torch.zeros(80, dtype=torch.int32, device="cuda"); gbuf = torch.zeros(nwg * 4096, dtype=torch.int32, device="cuda")
     pattern = torch.randint(-2**31, 2**31 - 1, (32768,), dtype=torch.int32, device="cuda")
-    tin = torch.randn(nwg * 256, 6, device="cuda")
+    tin = torch.randn(nwg * 256, 6, device="cuda"); rec = torch.zeros(256 * 8, device="cuda")
     B.begin(*ib); A.begin(*ia); torch.cuda.synchronize()
     aggr = {}
     if os.environ.get("CANARY_AGGR") == "1":
@@ -238,7 +238,10 @@ elif os.environ.get("MODE") == "canary":
         tot = torch.zeros(80, dtype=torch.int64)
         for k in range(NSTEP):
             report.zero_(); torch.cuda.synchronize()
-            if mfn is not None:
+            if os.environ.get("CANARY_PK") == "1":
+                rec.zero_()
+                rc = lib.canary_pk_launch(C.c_void_p(report.data_ptr()), C.c_void_p(rec.data_ptr()), C.c_void_p(tin.data_ptr()), nwg, spin, C.c_void_p(side.cuda_stream))
+            elif mfn is not None:
                 a0, a1, a2 = C.c_void_p(report.data_ptr()), C.c_void_p(tin.data_ptr()), C.c_int(spin)
                 params = (C.c_void_p * 3)(C.addressof(a0), C.addressof(a1), C.addressof(a2))
                 rc = hipm.hipModuleLaunchKernel(mfn, nwg, 1, 1, 256, 1, 1, 0, C.c_void_p(side.cuda_stream), params, None)
@@ -258,6 +261,17 @@ elif os.environ.get("MODE") == "canary":
                 B.run(2, G)
             torch.cuda.synchronize()
             tot += report.cpu().to(torch.int64)
+        if os.environ.get("CANARY_PK") == "1":
+            print("pk canary %s: %d mismatches of the explicit v_pk_mul_f32 ... op_sel_hi:[1,0] in %d x 256 evaluations" % (what, tot[5], tot[6]), flush=True)
+            r_ = rec.cpu().view(-1, 8)
+            for row in r_[:min(int(report[5].item()), 10)]:
+                a0, a1, b0, b1, d0, d1, lane, it = [float(v) for v in row]
+                import struct
+                f32 = lambda x: struct.unpack("f", struct.pack("f", x))[0]
+                cands = {"a.lo*b.lo": f32(a0 * b0), "a.hi*b.lo": f32(a1 * b0), "a.lo*b.hi": f32(a0 * b1), "a.hi*b.hi": f32(a1 * b1), "sentinel lo": 777.0, "sentinel hi": 888.0, "zero": 0.0}
+                name = lambda v: next((k for k, c in cands.items() if c == v), "?")
+                print("    lanes wrong %d  a = (%.6g, %.6g) b = (%.6g, %.6g)  got (%.6g = %s, %.6g = %s)  expected (%.6g, %.6g)" % (int(lane), a0, a1, b0, b1, d0, name(d0), d1, name(d1), cands["a.lo*b.lo"], cands["a.hi*b.lo"]), flush=True)
+            continue
         if os.environ.get("CANARY_CHAIN") == "1":
             nm = "b1x b1y b1z dt b2x b2y b2z b3x b3y b3z qw qx qy qz nrm half s1 ax ay az ang2 s2 r i j k two_s o0 o1 o2 o3 o4 o5".split()
             print("chain canary %s: %d x 256 evaluations; first intermediate that moved: %s" % (what, tot[6], ", ".join("%s %d" % (nm[i], tot[32 + i]) for i in range(33) if tot[32 + i]) or "none"), flush=True)
