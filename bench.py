@@ -36,6 +36,38 @@ def algorithmic_flops_per_motion_step(T, D=1024, F=2048, L=8, Dm=512, Fm=1024, L
     return 4 * d1 + 2 * d2 + 4 * inf + 8 * (2 * T * 262 * Dm) + ada
 
 
+def lib_stamp():
+    """Which library this process ran, for every line: mmdm_version() of the loaded .so, its path (relative to the repo when inside it) and
+    whether MMDM_LIB selected another build than the in-tree one (mixermdm_amd/_lib.py) -- a number measured on an A/B build must say so."""
+    from mixermdm_amd._lib import load_library, lib_path, lib_override
+    path = os.path.abspath(lib_path())
+    return {"mmdm_version": load_library().mmdm_version().decode(), "lib": os.path.relpath(path, ROOT) if path.startswith(ROOT + os.sep) else path,
+            "lib_override": lib_override()}
+
+
+def n1_same_batch(B, precision):
+    """For the N > 1 lines (32 motions per GPU) the one-GPU figure AT THE SAME per-GPU batch: the default N = 1 line runs configs[2]'s 16 motions,
+    whose motions/s/GPU differs from the 32-motion shard's by configuration, not by scaling.  Not measured in this run: the committed one-GPU
+    bench line of the newest round that has one (profiles/rNN_bench_b32*.json), labelled as such."""
+    import glob
+    import re
+    suffix = {"fp32": "", "fp32_split": "_split"}.get(precision)
+    if suffix is None or B != 32:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_b32%s.json" % suffix)))
+    files = [f for f in files if re.search(r"r\d\d_bench_b32%s\.json$" % suffix, f)]
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "per_gpu_batch": d.get("per_gpu_batch", 32), "n_gpus": 1,
+                "source": os.path.relpath(files[-1], ROOT), "measured_in_this_run": False,
+                "what": "one GPU at the SAME 32 motions per GPU (a committed one-GPU run of bench.py --batch 32, another box): the reference point for this line's scaling efficiency"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +92,9 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-alt", action="store_true", help="skip the extra fp32_split measurement reported next to the fp32 headline (N=1 only)")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the real 1000-step sample() from x_T to x_0 reported as `full_loop`")
+    ap.add_argument("--no-side", action="store_true", help="skip the two side measurements of the default line: `bf16_fp8` (configs[4]'s arithmetic on the same workload) and "
+                                                            "`eval_items` (the reference's evaluation caller on 16 items: sequential loop vs ragged batches)")
+    ap.add_argument("--side-eval-items", type=int, default=16, help="items of the default line's `eval_items` side measurement")
     ap.add_argument("--no-clock", action="store_true", help="skip the in-loop shader-clock measurement (301 extra GEMM launches; tools/profile_round.sh passes it so that "
                                                              "the committed kernel traces hold the step's launches only)")
     ap.add_argument("--eval-items", type=int, default=0, metavar="N",
@@ -180,9 +215,8 @@ def main():
     rank_ms = {"min": round(min(per_rank) / args.steps * 1e3, 3), "max": round(max(per_rank) / args.steps * 1e3, 3)}
     finite = bool(torch.isfinite(smp.state()["x"]).all().item())
 
-    # dominant kernel: the fp32 MFMA GEMM -- live HIP-event timing of every launch, eager, on the handle's stream
-    roof = None
-    if rank == 0 and args.profile_steps > 0:
+    # dominant kernel of a precision mode: live HIP-event timing of every GEMM launch of an eager pass, on the handle's stream
+    def live_roofline(smp, prec, with_clock=True):
         if args.warmup + args.steps + args.profile_steps > S:
             smp.begin(cond, xT)          # a short schedule (ddim50): profile the first steps of a fresh call
         smp.profile(True)
@@ -197,7 +231,7 @@ def main():
         # (e4m3 operands, unit E8M0 scales: twice the bf16 rate, 5 PFLOP/s dense) and are the dominant kernel: `achieved` / `peak` / `frac` are
         # theirs.  The attention output projections and embeddings are bf16 launches priced against 2.5 PFLOP/s in `bf16_launches`;
         # `frac_blended` = (time both classes would take at their own peaks) / (time they took).
-        peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "bf16_fp8": PEAK_FP8_MFMA_TFLOPS}[args.precision]
+        peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "bf16_fp8": PEAK_FP8_MFMA_TFLOPS}[prec]
         other = None
         fp32_side = None
         if p_n:
@@ -205,7 +239,7 @@ def main():
             fp32_side = {"achieved": round(p_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(p_ach / PEAK_F32_MFMA_TFLOPS, 4), "launches_per_step": p_n // args.profile_steps,
                          "avg_launch_us": round(p_ms * 1e3 / p_n, 2), "ms_per_step": round(p_ms / args.profile_steps, 3),
                          "what": "the fp32-accurate side GEMMs of this mode: motion_embed on the fp32-split kernel (fp16 planes, three MFMAs per block), conditioning projections and heads on the fp32 MFMA kernel; priced against the fp32 MFMA peak"}
-        if args.precision == "bf16_fp8" and f_n:
+        if prec == "bf16_fp8" and f_n:
             b_ach = g_fl / (g_ms * 1e-3) / 1e12
             other = {"achieved": round(b_ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(b_ach / PEAK_BF16_MFMA_TFLOPS, 4), "launches_per_step": g_n // args.profile_steps,
                      "avg_launch_us": round(g_ms * 1e3 / g_n, 2), "ms_per_step": round(g_ms / args.profile_steps, 3)}
@@ -221,9 +255,9 @@ def main():
                  "bf16": "gemm_bf16w_kernel (v_mfma_f32_32x32x16_bf16; weights in MFMA fragment order fetched straight from global memory, A through three LDS-DMA stages, 128x256 tiles, K step 128 bytes)",
                  "fp32_split": "gemm_splitw_kernel (fp32 result from 3 x v_mfma_f32_32x32x16_f16 on two-way fp16 operand splits, hi / lo accumulators; weights in MFMA fragment order fetched straight from global memory, 128x128 tiles, two workgroups per CU; peak = 2500/3 algorithmic TFLOP/s)",
                  "bf16_fp8": "gemm_bf16w_kernel<ET=fp8> / gemm_bf16_kernel<ET=fp8> (v_mfma_scale_f32_32x32x64_f8f6f4: e4m3 operands, unit E8M0 block scales, per-row / "
-                             "per-output-channel scales in the epilogue, fp32 accumulate; packed weights straight from global memory where the shape allows)"}[args.precision]
+                             "per-output-channel scales in the epilogue, fp32 accumulate; packed weights straight from global memory where the shape allows)"}[prec]
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(single, args.precision, B, T),
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(single, prec, B, T),
                 "algorithmic_mb_per_launch": round(g_by / g_n / 1e6, 1),
                 "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2),
                 "gflop_per_launch": round(g_fl / g_n / 1e9, 3), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
@@ -238,9 +272,13 @@ def main():
         if fp32_side:
             roof["fp32_launches"] = fp32_side
         try:
-            roof["clock"] = None if args.no_clock else loop_clock(args.precision, 4 * B * T if not single else 2 * B * T, peak, ach)
+            roof["clock"] = None if (args.no_clock or not with_clock) else loop_clock(prec, 4 * B * T if not single else 2 * B * T, peak, ach)
         except Exception as e:          # a diagnostic next to the measurement, never a reason to lose the line
             roof["clock"] = {"error": repr(e)}
+        return roof
+
+    roof = live_roofline(smp, args.precision) if (rank == 0 and args.profile_steps > 0) else None
+
     if dist.is_initialized():
         dist.barrier()
 
@@ -294,6 +332,45 @@ def main():
             except Exception as e:
                 alt["roofline"]["clock"] = {"error": repr(e)}
         alt_smp.close()
+
+    # configs[4]'s arithmetic (bf16 path, fp8 e4m3 QKV / FFN GEMM operands) on the SAME workload and inputs, under the same clock as the headline:
+    # a throughput configuration with a stated accuracy, reported beside the headline, never as it.  Its `roofline` prices
+    # the fp8 launches against the 5 PFLOP/s dense fp8 peak and the bf16 launches against 2.5 (live HIP-event pairs, as above).
+    fp8 = None
+    if world == 1 and args.precision == "fp32" and not args.no_side and not single and not args.facade:
+        f_smp = Sampler(d_heads=8, m_heads=8, max_batch=B, max_frames=T, precision="bf16_fp8", **FULL_DIMS)
+        f_smp.load_state_dict(sd_cpu)
+        f_smp.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
+        f_smp.prepare()
+        f_smp.set_schedule(args.sampler)
+        f_smp.begin(cond, xT)
+        f_smp.run(max(args.warmup, 5), use_graph)
+        torch.cuda.synchronize()
+        nst = max(args.steps, 20)
+        t1 = time.perf_counter()
+        f_smp.run(nst, use_graph)
+        torch.cuda.synchronize()
+        f_ms = (time.perf_counter() - t1) / nst * 1e3
+        fp8 = {"mode": "bf16_fp8 (BASELINE configs[4]: bf16 path, QKV / cross-attention input / FFN GEMMs on fp8 e4m3 operands through v_mfma_scale_f32_32x32x64_f8f6f4; "
+                       "residual stream, softmax statistics, geometry, blend and DDIM fp32) -- stated accuracy, not a parity claim",
+               "steps": nst, "ms_per_step": round(f_ms, 3), "value": round(B / (f_ms * 1e-3 * S), 5), "unit": "motions/s",
+               "outputs_finite": bool(torch.isfinite(f_smp.state()["x"]).all().item()),
+               "achieved_tflops_algorithmic": round(algorithmic_flops_per_motion_step(T) * B / (f_ms * 1e-3) / 1e12, 2)}
+        if args.profile_steps > 0:
+            f_smp.begin(cond, xT)
+            fp8["roofline"] = live_roofline(f_smp, "bf16_fp8", with_clock=False)
+        f_smp.close()
+
+    # The reference's evaluation caller (src/evaluation/datasets.py:100-116: one forward_test per item, the item's own length) on a few items:
+    # the sequential loop as shipped against ragged batches, bit-identity asserted in the object (bench.py --eval-items N is the full line)
+    ev = None
+    if world == 1 and args.precision == "fp32" and not args.no_side and not single and not args.facade and args.sampler == "ddim1000":
+        try:
+            e = eval_items_bench(args, device, rank, world, as_side=True)
+            ev = {k: e[k] for k in ("metric", "value", "unit", "strategies", "bit_identical_to_sequential", "roofline", "graph_cache")}
+            ev["items"], ev["sampler"] = e["config"]["items"], e["config"]["sampler"]
+        except Exception as ex:          # a side measurement: never a reason to lose the line
+            ev = {"error": repr(ex)}
 
     # The metric itself, not an extrapolation: one whole sample() from x_T to x_0 (S graph replays + the begin() set-up), every rank
     # on its own shard, wall time = max over ranks.
@@ -354,8 +431,11 @@ def main():
             "achieved_tflops_algorithmic": round(flops * B * world / (ms_per_step * 1e-3) / 1e12, 2),
             "frac_of_f32_mfma_peak": round(flops * B / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if args.precision in ("fp32", "fp32_split") else None,
             "outputs_finite": finite,
-            "full_loop": full, "facade": fac, "roofline": roof, "cpu_baseline": cpu, "fp32_split": alt,
+            "full_loop": full, "facade": fac, "roofline": roof, "cpu_baseline": cpu, "fp32_split": alt, "bf16_fp8": fp8, "eval_items": ev,
         }
+        if world > 1:
+            line["n1_same_batch"] = n1_same_batch(B, args.precision)
+        line.update(lib_stamp())
         print(json.dumps(line), flush=True)
     if model is None:
         smp.close()
@@ -422,10 +502,12 @@ def loop_clock(precision, M, peak, achieved):
                    "`peak` above is the guide's 2.4 GHz figure" % (M, N, K)}
 
 
-def eval_items_bench(args, device, rank, world):
+def eval_items_bench(args, device, rank, world, as_side=False):
     """The reference's evaluation caller (src/evaluation/datasets.py:58, 100-116: one forward_test per item, B = 1, the item's own length) on N
     synthetic items, T uniform in [60, 300]: today's sequential loop against items in flight over one weight set and against ragged batches.
-    Every strategy produces the same bits per item (checked here on the outputs).  One JSON line; `value` = items/s of the ragged strategy."""
+    Every strategy produces the same bits per item (checked here on the outputs).  One JSON line; `value` = items/s of the ragged strategy.
+    as_side: the `eval_items` side object of the default line -- args.side_eval_items items, fp32, ddim50, the shipped sequential loop against ragged
+    batches only, no CPU leg -- returned, not printed."""
     import numpy as np
     import torch
     from mixermdm_amd.configs import get_config
@@ -434,13 +516,14 @@ def eval_items_bench(args, device, rank, world):
     if world != 1:
         raise SystemExit("--eval-items measures one GPU (items shard over ranks without any collective: generation.generate_for_evaluation(shard_items=True))")
     sampler = "ddim50" if args.sampler == "ddim1000" else args.sampler
-    N = args.eval_items
+    N = args.side_eval_items if as_side else args.eval_items
+    precision = "fp32" if as_side else args.precision
     rng = np.random.RandomState(0)
     lens = [int(v) for v in rng.randint(60, 301, size=N)]
     sd_cpu = synthetic_state_dict(seed=0, std=0.02, bias_std=0.0, **FULL_DIMS)
     stats = synthetic_stats()
     model = MixerMDM(get_config(os.path.join(ROOT, "configs", "models", "MixerMDM.yaml")), num_frames=300, sampling_strategy=sampler, config_root=ROOT)
-    model.precision = args.precision
+    model.precision = precision
     model.load_state_dict({"mixing." + k: v for k, v in sd_cpu.items()})
     model.set_norm_stats(stats["mean_hml"], stats["std_hml"], stats["mean_ih"], stats["std_ih"])
     model = model.to(device).eval()
@@ -450,7 +533,7 @@ def eval_items_bench(args, device, rank, world):
         batches.append({"cond": torch.randn(1, 8 * 768, generator=g).to(device), "x_T": torch.randn(1, T, 524, generator=g).to(device), "motion_lens": torch.tensor([T])})
     S = int(sampler[4:]) if sampler.startswith("ddim") else 1000
     flops = sum(algorithmic_flops_per_motion_step(T) for T in lens) * S
-    peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "bf16_fp8": PEAK_FP8_MFMA_TFLOPS}[args.precision]
+    peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "fp32_split": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "bf16_fp8": PEAK_FP8_MFMA_TFLOPS}[precision]
 
     def run(name, fn, warm):
         with torch.no_grad():
@@ -472,6 +555,8 @@ def eval_items_bench(args, device, rank, world):
                 ("inflight2", dict(batching="inflight", inflight=2), "2 handles over ONE weight set (mmdm_create_shared), items dealt round-robin, each on its own stream"),
                 ("inflight4", dict(batching="inflight", inflight=4), "4 handles over one weight set"),
                 ("ragged", dict(batching="ragged", max_rows=args.eval_max_rows), "items packed in call order into ragged batches of <= %d frames (mmdm_begin_ragged: per-sequence lengths as device data)" % args.eval_max_rows)]
+    if as_side:
+        variants = [v for v in variants if v[0] == "ragged"]
     same = {}
     for name, kw, what in variants:
         outs, strat[name] = run(name, lambda b, kw=kw: model.sample_many([dict(x) for x in b], mode="eval_intermediate", keep_history=False, **kw), 6)
@@ -495,11 +580,11 @@ def eval_items_bench(args, device, rank, world):
         smp.profile(False)
         ach = g_fl / (g_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "the precision mode's GEMM kernel (see the default line) on the first ragged batch: %d items, %d frames in a group of %d rows" % (len(grp), rows, smp.rows),
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": ragged_traffic(precision, smp.rows),
                 "launches_per_step": g_n // args.profile_steps, "avg_launch_us": round(g_ms * 1e3 / g_n, 2), "gemm_ms_per_step": round(g_ms / args.profile_steps, 3),
                 "attention": {"achieved": round(a_fl / (a_ms * 1e-3) / 1e12, 2), "ms_per_step": round(a_ms / args.profile_steps, 3), "launches_per_step": a_n // args.profile_steps}}
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and not as_side:
         # the oracle on ONE item of the median length, a few steps after the thread calibration, extrapolated to the S steps of an item
         Tm = int(np.median(lens))
         c = cpu_baseline(sd_cpu, stats, Tm, args.cpu_steps, False, sampler, S, 1, whole_host=False)
@@ -508,12 +593,16 @@ def eval_items_bench(args, device, rank, world):
     best = strat["ragged"]
     line = {"metric": "evaluation items/s (one forward_test per item, B = 1, %s, T uniform in [60, 300]: src/evaluation/datasets.py:100-116)" % sampler,
             "value": best["items_per_s"], "unit": "items/s", "n_gpus": 1, "steps": N, "warmup": 6, "ms_per_step": round(best["wall_s"] / N * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32_split": "f32 (2xfp16 operand split, fp32 accumulate)", "bf16": "bf16", "bf16_fp8": "bf16 + fp8 e4m3 QKV/FFN operands"}[args.precision],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp32_split": "f32 (2xfp16 operand split, fp32 accumulate)", "bf16": "bf16", "bf16_fp8": "bf16 + fp8 e4m3 QKV/FFN operands"}[precision],
             "data": "synthetic",
             "config": {"workload": "the reference's evaluation caller: %d items, T uniform in [60, 300] (mean %.0f), %s, 2-person MixerMDM through mixermdm_amd.models.MixerMDM; a 'step' of this line is one item" % (N, float(np.mean(lens)), sampler),
-                       "items": N, "sampler": sampler, "precision": args.precision, "max_rows": args.eval_max_rows},
+                       "items": N, "sampler": sampler, "precision": precision, "max_rows": args.eval_max_rows},
             "strategies": strat, "bit_identical_to_sequential": same, "roofline": roof, "cpu_baseline": cpu,
             "graph_cache": dict(zip(("captures", "replays", "cached"), model._sampler.graph_stats()))}
+    line.update(lib_stamp())
+    if as_side:
+        model._sampler.close()
+        return line
     print(json.dumps(line), flush=True)
 
 
@@ -552,6 +641,21 @@ def measured_traffic(single, precision="fp32", B=16, T=300):
         return None
     if rec.get("kernel_sources_sha") != sources_sha(precision):
         print("bench.py: %s was measured on other kernel sources (%s != %s): roofline.traffic = null" % (os.path.basename(path), rec.get("kernel_sources_sha"), sources_sha(precision)), file=sys.stderr)
+        return None
+    return rec["traffic_bytes_per_launch"]
+
+
+def ragged_traffic(precision, rows):
+    """HBM-side bytes per GEMM launch of a ragged batch from the committed PMC pass of that workload (profiles/gemm_traffic_ragged.json: one ragged
+    batch of `rows` frame rows, fp32; tools/profile_ragged.sh) -- under the same conditions as measured_traffic: same kernel sources, same row
+    bucket (bytes per launch scale with the rows of the group)."""
+    from mixermdm_amd.build import sources_sha
+    path = os.path.join(ROOT, "profiles", "gemm_traffic_ragged.json")
+    if precision != "fp32" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f)
+    if rec.get("rows") != rows or rec.get("kernel_sources_sha") != sources_sha("fp32"):
         return None
     return rec["traffic_bytes_per_launch"]
 

@@ -7,8 +7,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous fp32 unless it is documented as host memory;
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing synchronises the host
- *     except mmdm_sample_sync / mmdm_destroy;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); no entry point synchronises the host except mmdm_destroy
+ *     (which waits for the device) and mmdm_run when its graph cache has to evict an entry whose replays are still queued;
  *   - the callee never frees or keeps caller memory (weights are copied into the handle's packed layout);
  *   - return value: 0 = MMDM_OK, otherwise an mmdm_status; mmdm_last_error() gives the message
  *     (thread-local for the stateless kernels, per handle otherwise);
@@ -21,6 +21,9 @@
  *   MMDM_NO_SPLIT_EMBED=1  precision 1-3: keep motion_embed on the fp32 MFMA kernel instead of the fp32-split kernel (A/B timing and accuracy)
  *   MMDM_GRAPH_CACHE=n   mmdm_create: capacity (1..64, default 8) of the handle's (B, T, S)-keyed cache of captured step graphs.
  *   MMDM_RAG_BUCKET=n    mmdm_create: row granularity (1..4096, default 128) to which a ragged call's group of frames is padded (mmdm_begin_ragged).
+ *   MMDM_SERIALIZE_HANDLES=1  the first mmdm_create of the process: every sampling call (mmdm_run) waits ON THE DEVICE for the previous sampling call
+ *                        of any handle of the process (one process-wide event; no host synchronisation).  Off by default: handles of every
+ *                        precision overlap bit-exactly (tests/test_gpu_ragged.py); the switch exists so that overlap can be ruled out in the field.
  *   MMDM_NO_PACK=1       keep the low-precision weight twins of precision 1-3 in row-major planes instead of MFMA fragment order (the
  *                        packed and the plane kernels are bit-identical; tests/test_gpu_packed_modes.py compares them).
  *   MMDM_QKP / MMDM_NO_QKP / MMDM_NO_BF16_PV   precision >= 1: force / forbid the bf16-plane Q K^T and the bf16 P V forms of the attention.
@@ -328,22 +331,26 @@ int mmdm_create(const mmdm_config* cfg, mmdm_handle* out);
 /* A second sampler handle over the SAME weights: `parent` (prepared) keeps owning the parameter set, its low-precision twins and the normaliser
  * statistics; the new handle borrows them by reference (the block is freed when the last handle that holds it is destroyed, in any order) and
  * gets its own workspace sized for (max_batch, max_frames), its own streams, schedule tables, step state, history descriptor and graph cache.
- * Same configuration otherwise.  K such handles on K streams keep K independent sampling calls in flight over one 1.46 GB weight copy -- the
- * reference's callers sample one item at a time (src/scripts/infer/mixermdm.py:184-188 ten times B = 1; src/evaluation/datasets.py:100-116 per
- * item), which fills ~60 % of one round of GEMM tiles on 256 CUs; two co-resident items overlap.  A motion's bits do not depend on what runs
- * beside it.  mmdm_set_weight / mmdm_set_norm_stats on a shared handle return MMDM_ERR_STATE (set them on the parent; a parent re-prepared
- * after mmdm_set_weight is seen by every holder); mmdm_prepare is a no-op there.  Handles are still not thread-safe individually, and the
- * handles of one process should be driven from ONE host thread: graph captures, instantiations, evictions and replays are serialised against
- * each other inside the library, but replaying graphs from two host threads was seen to crash inside this runtime's hipGraphLaunch
- * (ROCm 7.0 / 7.2, hip::Graph::UpdateStreams) -- every call here is asynchronous, one thread keeps K streams queued.
- * Sampling calls of different handles overlap on the device in every precision mode, bit-exactly (tests/test_gpu_ragged.py).  What made
- * two low-precision handles side by side give wrong motions for most of round 5 was a hardware hazard, not the calls: on gfx950 a packed-fp32
- * VALU instruction (v_pk_*_f32) can transiently deliver a wrong result while its wave shares a SIMD with the packed-W GEMM kernels;
- * the library's geometry kernels are built without those instructions (build.py; tools/canary.hip is the stand-alone reproducer).
- * A CALLER's own kernels that run beside a low-precision handle on the same device are exposed to the same hazard if they use packed-fp32
- * arithmetic in bit-sensitive code (hipcc: -Xclang -target-feature -Xclang -packed-fp32-ops removes it).
- * Measured (tools/inflight_probe.py, B = 1, T = 180, fp32): the GPU overlaps two such streams hardly at all -- 1.00-1.03 x with 2-4 handles
- * (1.22 x eager with 16 hardware queues); packing the calls into one ragged batch (mmdm_begin_ragged) is what fills the machine: 1.86-1.95 x. */
+ * Same configuration otherwise.  K such handles on K streams keep K independent sampling calls queued over one 1.46 GB weight copy.  What that
+ * is good for: independent requests that arrive at different times share one weight copy.  What it is NOT: a throughput lever -- measured
+ * (tools/inflight_probe.py, bench.py --eval-items: B = 1, fp32) the GPU co-schedules two such streams hardly at all, 1.00-1.03 x with 2-4 handles
+ * (best case anywhere 1.22 x, eager with 16 hardware queues); packing the calls into one ragged batch (mmdm_begin_ragged) is what fills the
+ * machine: 1.9 x (the reference's callers sample one item at a time: src/scripts/infer/mixermdm.py:184-188, src/evaluation/datasets.py:100-116).
+ * A motion's bits do not depend on what runs beside it.  mmdm_set_weight / mmdm_set_norm_stats on a shared handle return MMDM_ERR_STATE (set
+ * them on the parent; a parent re-prepared after mmdm_set_weight is seen by every holder); mmdm_prepare is a no-op there.  Handles are still
+ * not thread-safe individually, and the handles of one process should be driven from ONE host thread: graph captures, instantiations,
+ * evictions and replays are serialised against each other inside the library, but replaying graphs from two host threads was seen to crash
+ * inside this runtime's hipGraphLaunch (ROCm 7.0 / 7.2, hip::Graph::UpdateStreams) -- every call here is asynchronous, one thread keeps K
+ * streams queued.  Graph execs: destroying an exec beside another handle's live execs crashed that handle's next launch in this runtime, so
+ * while handles share weights (and from then on in the process) a handle's graph cache does not evict: it grows to the number of DISTINCT
+ * shapes the handle has sampled and every shape is captured once (mmdm_graph_parked counts the execs kept past their handle's life).
+ * Sampling calls of different handles overlap on the device in every precision mode, bit-exactly (tests/test_gpu_ragged.py: every precision
+ * pair; MMDM_SERIALIZE_HANDLES=1 serialises them).  What made two low-precision handles side by side give wrong motions for most of round 5
+ * was the hardware, not the calls: on gfx950 dense VALU code with packed-fp32 instructions (v_pk_*_f32) in it transiently computes other bits
+ * while its wave shares a SIMD with the packed-W GEMM kernels (root cause not isolated: LAB_NOTES.md); the library's geometry kernels, and
+ * every row kernel of a precision 1-3 handle, are built without those instructions (build.py; tools/canary.hip is the stand-alone
+ * reproducer).  A CALLER's own kernels that run beside a low-precision handle on the same device are exposed to the same hazard if they use
+ * packed-fp32 arithmetic in bit-sensitive code (hipcc: -Xclang -target-feature -Xclang -packed-fp32-ops removes it). */
 int mmdm_create_shared(mmdm_handle parent, int max_batch, int max_frames, mmdm_handle* out);
 void mmdm_destroy(mmdm_handle h);
 const char* mmdm_handle_error(mmdm_handle h);
@@ -407,6 +414,9 @@ int mmdm_set_history(mmdm_handle h, float* influence_i1, float* influence_i2, fl
 int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream);
 /* Counters of the graph cache: steps captured so far, steps replayed, entries currently cached (each pointer may be NULL). */
 int mmdm_graph_stats(mmdm_handle h, int64_t* captures, int64_t* replays, int* cached);
+/* Graph execs of the PROCESS that outlived their cache entry (kept, not destroyed: see mmdm_create_shared).  With the no-eviction rule these are
+ * the execs of destroyed handles only; a process that never lets two handles share weights reads 0. */
+int mmdm_graph_parked(void);
 
 /* Move a begun call to respaced step `step_index` (S-1 = first step of the loop, 0 = last): the next mmdm_run continues from there
  * with the chains as they stand (history slots follow the loop position S-1-step_index).  Lets a caller resume a loop, or drive

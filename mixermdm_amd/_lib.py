@@ -11,8 +11,15 @@ class MMDMError(RuntimeError):
 
 
 def lib_path():
-    # MMDM_LIB: an alternative build of the same library (A/B experiments of tools/: e.g. one translation unit compiled with another macro)
+    """The library this process binds.  MMDM_LIB (DECLARED here and in INTEGRATION.md, "Diagnostics and environment"): an alternative build of
+    the same ABI for A/B experiments of tools/ (e.g. one translation unit compiled with another macro; tools/ab_lib.sh).  bench.py stamps the path
+    it ran and `"lib_override": true` into every line when the variable is set, so that a number measured on another build cannot pass for the
+    in-tree library's."""
     return os.environ.get("MMDM_LIB") or os.path.join(_HERE, "libmmdm_hip.so")
+
+
+def lib_override():
+    return bool(os.environ.get("MMDM_LIB"))
 
 
 class Config(C.Structure):
@@ -89,6 +96,7 @@ SYMBOLS = {
     "mmdm_run": (_I, [_VP, _I, _I, _VP]),
     "mmdm_seek": (_I, [_VP, _I, _VP]),
     "mmdm_graph_stats": (_I, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_I)]),
+    "mmdm_graph_parked": (_I, []),
     "mmdm_last_gemm_kernel": (C.c_char_p, []),
     "mmdm_get_state": (_I, [_VP] + [C.POINTER(_VP)] * 5),
     "mmdm_copy_result": (_I, [_VP, _VP, _VP]),

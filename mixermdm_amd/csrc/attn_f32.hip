@@ -84,7 +84,27 @@ struct AttnArgs {
     // differ per sequence and live in device memory (one captured graph serves every batch of the same row bucket).  Tq / Tk are then the
     // LONGEST sequence (grid size only); a query tile past its sequence's end leaves at once.
     const int* seq_off; const int* seq_len;
+    const int* seq_order; int order_items;      // kernels.h mmdm_rag_seq::order / items (nullptr: sequences in index order)
 };
+
+// Which (sequence, head) pair a workgroup works on.  Uniform layout: XCD x owns the contiguous pairs [x ppx, (x + 1) ppx) -- all sequences cost the same.
+// Ragged: pair slots are dealt ROUND-ROBIN over the XCDs (slot j -> XCD j % 8; all query tiles of a pair still share one XCD's L2) and walk the
+// sequences LONGEST FIRST through the batch's length order: a launch whose workgroups live 30-80 us must not start a 300-frame sequence last, and
+// no XCD may get all the long ones.  Re-numbering only: what a workgroup computes for its (sequence, head, query tile) is unchanged.
+template <bool RAG, class P>
+__device__ __forceinline__ bool pair_of(const P& p, int xcd, int local, int& seq, int& head) {
+    const int slot = RAG ? (local / p.qtiles) * 8 + xcd : xcd * p.pairs_per_xcd + local / p.qtiles;
+    if (slot >= p.nseq * p.H) return false;
+    head = slot % p.H;
+    seq = slot / p.H;
+    if constexpr (RAG) {
+        if (p.seq_order) {
+            const int k = p.nseq / p.order_items;
+            seq = (seq % k) * p.order_items + p.seq_order[seq / k];
+        }
+    }
+    return true;
+}
 
 // (Tq, Tk, first Q / O row, first K / V row) of a workgroup's (sequence, key sequence): kernel arguments in the uniform layout, two loads each in the ragged one
 struct SeqGeom { int Tq, Tk; size_t qrow0, krow0; };
@@ -196,10 +216,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_mfma_kernel(Att
     const int bid = blockIdx.x;
     const int local = bid >> 3, xcd = bid & 7;
     const int qt = local % p.qtiles;
-    const int sh = xcd * p.pairs_per_xcd + local / p.qtiles;
-    if (sh >= p.nseq * p.H) return;
-    const int head = sh % p.H;
-    const int seq = sh / p.H;
+    int seq, head;
+    if (!pair_of<RAG>(p, xcd, local, seq, head)) return;
     const int kvseq = (seq + p.shift) % p.nseq;
     const SeqGeom G = seq_geom<RAG>(p, seq, kvseq);
     if constexpr (RAG) { if (qt * QBW >= G.Tq) return; }      // (wave-uniform, before any barrier: the whole workgroup leaves)
@@ -515,10 +533,8 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
     const int bid = blockIdx.x;
     const int local = bid >> 3, xcd = bid & 7;
     const int qt = local % p.qtiles;
-    const int sh = xcd * p.pairs_per_xcd + local / p.qtiles;
-    if (sh >= p.nseq * p.H) return;
-    const int head = sh % p.H;
-    const int seq = sh / p.H;
+    int seq, head;
+    if (!pair_of<RAG>(p, xcd, local, seq, head)) return;
     const int kvseq = (seq + p.shift) % p.nseq;
     const SeqGeom G = seq_geom<RAG>(p, seq, kvseq);
     if constexpr (RAG) { if (qt * QB >= G.Tq) return; }
@@ -931,6 +947,7 @@ int mmdm_attention_opts_rag(const float* Q, int ldq, const float* K, int ldk, co
     a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_bf16; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate; a.stamps = g_attn_stamps;
     a.Qp = a.Kp = nullptr; a.q_plane = a.k_plane = 0; a.ldqp = a.ldkp = 0;
     a.seq_off = rg ? rg->off : nullptr; a.seq_len = rg ? rg->len : nullptr;
+    a.seq_order = (rg && rg->order && rg->items > 0 && nseq % rg->items == 0) ? rg->order : nullptr; a.order_items = rg ? rg->items : 0;
     a.o_plane = (size_t)(rg ? (size_t)rg->total_rows : (size_t)nseq * Tq) * ldo;
     if (rg && (flags || !(dh == 128 || dh == 64))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "attention on ragged batches: head sizes 64 / 128, zero key, no mask (dh=%d flags=0x%x)", dh, flags);
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;
@@ -1005,6 +1022,7 @@ int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const voi
         return mmdm_set_error(MMDM_ERR_ARG, "mmdm_attention_planes: 16-bit V needs one (bf16) or two (fp16 split) planes, 16-byte aligned rows / planes and a row stride >= H*dh");
     a.nseq = nseq; a.Tq = Tq; a.Tk = Tk; a.H = H; a.out_bf16 = out_mode; a.flags = flags; a.dh = dh; a.ablate = g_attn_ablate; a.stamps = g_attn_stamps;
     a.seq_off = rg ? rg->off : nullptr; a.seq_len = rg ? rg->len : nullptr;
+    a.seq_order = (rg && rg->order && rg->items > 0 && nseq % rg->items == 0) ? rg->order : nullptr; a.order_items = rg ? rg->items : 0;
     a.o_plane = (size_t)(rg ? (size_t)rg->total_rows : (size_t)nseq * Tq) * ldo;
     if (rg && flags) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "attention on ragged batches: zero key, no mask (flags=0x%x)", flags);
     a.shift = ((kv_seq_shift % nseq) + nseq) % nseq;

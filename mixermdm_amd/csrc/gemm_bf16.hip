@@ -72,6 +72,7 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
 #define MMDM_BF16_TST_DEFAULT 1
 #endif
 int g_bf16_tst = MMDM_BF16_TST_DEFAULT;        // mmdm_diag_set "bf16_tst": 0 = the direct (row-per-lane) epilogue
+int g_bf16_lds_pad = 0;                        // mmdm_diag_set "bf16_lds_pad": extra dynamic LDS bytes per packed-W workgroup (occupancy experiments of tools/)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // Transposed epilogue.  In the D^T map a lane owns an output ROW: the direct form below writes bf16 results as 8-byte pieces (fp8: 4-byte) of
@@ -778,7 +779,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
     rda(0, 0, fa0);
     int cur = 0;
     bf16x8 fa2[TM];
-    for (int kt = 0; kt < nkt; kt += 2) {                  // nkt is even (host check): the two B register sets swap roles every step
+#ifndef MMDM_W_EXP
+#define MMDM_W_EXP 0            // experiments of tools/ (variant builds, never the shipped library): 1 = no epilogue, 2 = no K loop
+#endif
+    for (int kt = 0; kt < (MMDM_W_EXP == 2 ? 0 : nkt); kt += 2) {                  // nkt is even (host check): the two B register sets swap roles every step
         const int c1 = cur == 2 ? 0 : cur + 1, c2 = c1 == 2 ? 0 : c1 + 1;
         if constexpr (HALFB) {
             step8h(kt, cur, c1, c2, bl, bh, fa0, fa1, fa2);
@@ -798,8 +802,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16w_kernel(BArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[i][j]));
     if constexpr (TL) { t_r1 = __builtin_amdgcn_s_memrealtime(); t_c1 = __builtin_readcyclecounter(); }
+#if MMDM_W_EXP == 1
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
+        if (sacc == 1234.5678f) static_cast<float*>(p.C)[tid] = sacc;
+    }
+#else
     if (!(p.tst && bf16_finish_t<TM, TN, ET, BM, BN, NW, WSMEM_BYTES>(p, acc, m0, n0, wm, wn, lane, smem, ET == 1 ? sc : nullptr)))
         bf16_finish<TM, TN, ET, BM>(p, acc, m0, n0, wm, wn, l31, lh);
+#endif
     if constexpr (TL) {
         const unsigned long long t_iss = __builtin_amdgcn_s_memrealtime();      // every instruction of the epilogue issued; its stores may be in flight
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -817,8 +834,8 @@ int launch_w(BArgs a, hipStream_t st) {
     a.mt = (a.M + 127) / 128;
     a.nt = a.N / (128 * TN);
     mmdm_note_gemm("%s<14,4%d>", ET == 1 ? "gemm_fp8w" : "gemm_bf16w", TN);
-    if (a.tl) hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN, true>), dim3(a.mt * a.nt), dim3(256), wsmem_total(ET, TN), st, a);
-    else hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN>), dim3(a.mt * a.nt), dim3(256), wsmem_total(ET, TN), st, a);
+    if (a.tl) hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN, true>), dim3(a.mt * a.nt), dim3(256), wsmem_total(ET, TN) + g_bf16_lds_pad, st, a);
+    else hipLaunchKernelGGL((gemm_bf16w_kernel<ET, TN>), dim3(a.mt * a.nt), dim3(256), wsmem_total(ET, TN) + g_bf16_lds_pad, st, a);
     return mmdm_check_launch(ET == 1 ? "gemm_fp8w" : "gemm_bf16w");
 }
 
@@ -878,7 +895,7 @@ int mmdm_gemm_bf16_init(void) {
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 2>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 2, true>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 2, true>),
                           reinterpret_cast<const void*>(&gemm_bf16w_kernel<0, 1, true>), reinterpret_cast<const void*>(&gemm_bf16w_kernel<1, 1, true>)}) {
-        hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wsmem_total(1, 2));
+        hipError_t e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      // (the operand stages need wsmem_total(); "bf16_lds_pad" may ask for more)
         if (e2 != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_bf16w): %s", hipGetErrorString(e2));
     }
     return MMDM_OK;
@@ -888,6 +905,7 @@ int mmdm_gemm_bf16_init(void) {
 bool mmdm_diag_gemm_bf16(const char* key, long long v) {
     if (!strcmp(key, "bf16_cfg")) g_bf16_cfg = (int)v;
     else if (!strcmp(key, "bf16_tst")) g_bf16_tst = (int)v;
+    else if (!strcmp(key, "bf16_lds_pad")) g_bf16_lds_pad = (int)v;
     else if (!strcmp(key, "bf16_timeline")) g_bf16_tl = reinterpret_cast<unsigned long long*>((uintptr_t)v);
     else return false;
     return true;

@@ -530,7 +530,7 @@ int mmdm_blend_cfg_rag(const float* out1, const float* out2, const float* w, int
 struct RagLens { int v[MMDM_RAG_MAX_ITEMS]; };
 __global__ __launch_bounds__(256) void rag_setup_kernel(RagLens L, int B, int rows, int groups, int* __restrict__ item_off, int* __restrict__ item_len,
                                                         int* __restrict__ row_item, int* __restrict__ row_pos, int* __restrict__ row_seq,
-                                                        int* __restrict__ seq_off, int* __restrict__ seq_len) {
+                                                        int* __restrict__ seq_off, int* __restrict__ seq_len, int* __restrict__ item_order) {
     __shared__ int off[MMDM_RAG_MAX_ITEMS + 1];
     if (threadIdx.x == 0) {
         int a = 0;
@@ -553,14 +553,22 @@ __global__ __launch_bounds__(256) void rag_setup_kernel(RagLens L, int B, int ro
     }
     for (int s = tid; s < groups * B; s += nth) { seq_off[s] = (s / B) * rows + off[s % B]; seq_len[s] = L.v[s % B]; }
     for (int b = tid; b < B; b += nth) { item_off[b] = off[b]; item_len[b] = L.v[b]; }
+    // items by length, longest first (ties in index order): item b's rank = the number of items that come before it (B <= 256: a rank sort by one block)
+    if (blockIdx.x == 0 && item_order) {
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            int rank = 0;
+            for (int c = 0; c < B; ++c) rank += (L.v[c] > L.v[b] || (L.v[c] == L.v[b] && c < b)) ? 1 : 0;
+            item_order[rank] = b;
+        }
+    }
 }
 
 int mmdm_rag_setup(const int* lens_host, int B, int rows, int groups, int* item_off, int* item_len, int* row_item, int* row_pos, int* row_seq,
-                   int* seq_off, int* seq_len, hipStream_t st) {
+                   int* seq_off, int* seq_len, int* item_order, hipStream_t st) {
     if (B <= 0 || B > MMDM_RAG_MAX_ITEMS) return mmdm_set_error(MMDM_ERR_ARG, "ragged batch: %d items (1 .. %d)", B, MMDM_RAG_MAX_ITEMS);
     RagLens L;
     for (int b = 0; b < MMDM_RAG_MAX_ITEMS; ++b) L.v[b] = b < B ? lens_host[b] : 0;
-    hipLaunchKernelGGL(rag_setup_kernel, dim3(64), dim3(256), 0, st, L, B, rows, groups, item_off, item_len, row_item, row_pos, row_seq, seq_off, seq_len);
+    hipLaunchKernelGGL(rag_setup_kernel, dim3(64), dim3(256), 0, st, L, B, rows, groups, item_off, item_len, row_item, row_pos, row_seq, seq_off, seq_len, item_order);
     return mmdm_check_launch("rag_setup");
 }
 

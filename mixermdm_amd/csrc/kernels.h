@@ -108,7 +108,7 @@ struct mmdm_rag {
     int B, rows;           // items; group stride in frame rows (sum of lengths rounded up to the handle's row bucket)
 };
 int mmdm_rag_setup(const int* lens_host, int B, int rows, int groups, int* item_off, int* item_len, int* row_item, int* row_pos, int* row_seq,
-                   int* seq_off, int* seq_len, hipStream_t st);
+                   int* seq_off, int* seq_len, int* item_order, hipStream_t st);
 int mmdm_mixer_pre_rag(const float* o1, const float* o2, const float* stats, float* out1, float* out2, int groups, int align, const mmdm_rag& rg, hipStream_t st);
 int mmdm_blend_cfg_rag(const float* out1, const float* out2, const float* w, int mode, int use_force, float force, float cfg_scale,
                        float* model_out, const mmdm_hist_desc* hd, const int* loop_pos, const mmdm_rag& rg, hipStream_t st);
@@ -131,9 +131,24 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
 int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_mode, float* row_scale, int nseq, int T, int D, void* stream,
                    const int* row_seq = nullptr, int rows_rag = 0);
 int mmdm_mean_time_rag(const float* h, float* out, int nseq, const int* seq_off, const int* seq_len, int D, hipStream_t st);
+// rowops.hip's second build (rowops_nopk.o: no packed-fp32 VALU instructions; mixermdm_amd/build.py), taken by precision 1-3 handles through mmdm.hip's ROWOP
+int mmdm_adaln_any_nopk(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_mode, float* row_scale, int nseq, int T, int D, void* stream,
+                        const int* row_seq = nullptr, int rows_rag = 0);
+int mmdm_mean_time_rag_nopk(const float* h, float* out, int nseq, const int* seq_off, const int* seq_len, int D, hipStream_t st);
+int mmdm_mdm_pack_nopk(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
+                       int nseq, int T, int D, hipStream_t st);
+int mmdm_mdm_unpack_nopk(const float* src, float* dst, int nseq, int T, int D, hipStream_t st);
+extern "C" {
+int mmdm_layernorm_f32_nopk(const float* x, const float* gamma, const float* beta, float* out, int rows, int D, float eps, void* stream);
+int mmdm_cond_silu_f32_nopk(const float* time_tab, const int* step_idx, const float* txt, float* out, int rows, int D, void* stream);
+int mmdm_mean_time_f32_nopk(const float* h, float* out, int nseq, int T, int D, void* stream);
+}
 // Sequences of a RAGGED batch as the attention kernels see them (device arrays: one captured graph serves every batch of the same row bucket):
 // sequence s owns rows [off[s], off[s] + len[s]) of Q / K / V / O; total_rows = rows of O (plane stride of a split output); max_len sizes the grid.
-struct mmdm_rag_seq { const int* off; const int* len; int total_rows; int max_len; };
+// order / items (optional): the batch's B items sorted by length, longest first (written by mmdm_rag_setup); the nseq = k x B sequences of a launch are then
+// dealt to the workgroups longest first -- workgroup slot j / H handles sequence (j' % k) * B + order[j' / k] -- so that the launch does not end on a 300-frame
+// sequence that started late (a pure re-numbering of who computes what: every sequence's arithmetic is untouched).  nullptr: sequences in index order.
+struct mmdm_rag_seq { const int* off; const int* len; int total_rows; int max_len; const int* order = nullptr; int items = 0; };
 int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const void* Kp, int ldk, int64_t k_plane, int nplanes, const float* V, int ldv,
                              const void* Vp, int ldvp, int64_t v_plane, void* O, int ldo, int out_mode, int flags, int nseq, int Tq, int Tk, int H, int dh, int kv_seq_shift, void* stream,
                              const mmdm_rag_seq* rg = nullptr);

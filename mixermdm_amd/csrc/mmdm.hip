@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -51,12 +52,23 @@ int mmdm_kernels_init(void) {
 // capture / instantiation / exec destruction beside another thread's capture or launch (segfaults inside hipGraphLaunch, seen with two
 // threads at the real model sizes): captures, instantiations and evictions take this lock exclusively, replays take it shared.
 static std::shared_mutex g_graph_mu;
-// Sampling calls of different handles OVERLAP on the device in every precision mode.  (For most of round 5 the calls of low-precision handles
-// were serialised: two such handles side by side gave wrong motions.  The cause was not in this file: on gfx950 the result of a packed-fp32
-// VALU instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) read by a dependent VALU instruction one or two issue slots later can arrive
-// stale when the wave shares a SIMD with waves of the packed-W GEMM kernels -- the geometry kernels' rotation round trip turned one such bit
-// into a turned joint.  geometry.hip and rowops.hip are built without those instructions (build.py NO_PACKED_FP32; tools/canary.hip,
-// tools/overlap_bisect.py and LAB_NOTES.md hold the measurements), and tests/test_gpu_ragged.py keeps full-size handles side by side bit-exact.)
+// Sampling calls of different handles OVERLAP on the device in every precision mode (MMDM_SERIALIZE_HANDLES=1 serialises them again: below).
+// For most of round 5 the calls of low-precision handles were serialised: two such handles side by side gave wrong motions.  The cause was
+// not in this file: on gfx950 the geometry kernels' rotation round trip -- dense VALU code that held packed-fp32 instructions (v_pk_mul_f32 /
+// v_pk_fma_f32 / v_pk_add_f32) -- transiently computes OTHER bits while its wave shares a SIMD with waves of the packed-W GEMM kernels
+// (gemm_splitw / gemm_bf16w), and turned one such bit into a turned joint.  The result is wrong, not late (hand-assembled wait states behind
+// every packed instruction change nothing), the same code without packed-fp32 instructions never moves, and WHICH ingredient of the packed-W
+// kernels it takes is not isolated (LAB_NOTES.md; tools/canary.hip, tools/overlap_bisect.py).  The rule is therefore by construction
+// (mixermdm_amd/build.py): geometry.hip is built without packed-fp32 instructions for every handle, and precision 1-3 handles take the
+// row kernels (AdaLN, LayerNorm, cond SiLU, time mean, MDM pack / unpack) of rowops_nopk.o -- the second build of rowops.hip, without them --
+// through ROWOP below; tests/test_gpu_ragged.py keeps full-size handles of every precision pair side by side bit-exact.
+#define ROWOP(c, fn, ...) (((c).h && (c).h->cfg.precision != 0) ? fn##_nopk(__VA_ARGS__) : fn(__VA_ARGS__))
+// MMDM_SERIALIZE_HANDLES=1 (read once, by the first mmdm_create): every sampling call (mmdm_run) waits on the device for the previous
+// sampling call of ANY handle of the process -- one process-wide event, no host synchronisation -- so that overlap between handles can be
+// ruled out in the field as the cause of a wrong motion.  Off by default.
+static std::atomic<int> g_serialize_handles{-1};
+static std::mutex g_serial_mu;
+static hipEvent_t g_serial_ev = nullptr;        // recorded behind the last sampling call of any handle (g_serial_mu)
 
 static thread_local char g_gemm_note[160] = "";
 void mmdm_note_gemm_reset(void) { g_gemm_note[0] = 0; }
@@ -167,7 +179,7 @@ struct Geom {
     int rows = 0;                    // frame rows of one group of B sequences (uniform: B * T)
     int real_rows = 0;               // ragged: sum of the lengths (rows - real_rows padding rows per group)
     double tt1 = 0;                  // sum over the items of T_i (T_i + 1): attention FLOP accounting
-    const int *seq_off = nullptr, *seq_len = nullptr, *row_seq = nullptr;
+    const int *seq_off = nullptr, *seq_len = nullptr, *row_seq = nullptr, *item_order = nullptr;
     mmdm_rag rg{nullptr, nullptr, nullptr, nullptr, 0, 0};
     size_t rows_of(int nseq) const { return rag ? (size_t)(nseq / B) * rows : (size_t)nseq * T; }
 };
@@ -229,7 +241,7 @@ struct mmdm_handle_s {
     Geom geom;                                             // row geometry of the begun call (uniform or ragged)
     int rag_bucket = 128;                                  // ragged calls: the group stride is the sum of the lengths rounded up to this many rows (MMDM_RAG_BUCKET)
     int *d_rag = nullptr;                                  // ragged row maps: item_off | item_len | row_item | row_pos | row_seq | seq_off | seq_len
-    int *d_item_off = nullptr, *d_item_len = nullptr, *d_row_item = nullptr, *d_row_pos = nullptr, *d_row_seq = nullptr, *d_seq_off = nullptr, *d_seq_len = nullptr;
+    int *d_item_off = nullptr, *d_item_len = nullptr, *d_row_item = nullptr, *d_row_pos = nullptr, *d_row_seq = nullptr, *d_seq_off = nullptr, *d_seq_len = nullptr, *d_item_order = nullptr;
 
     // workspace
     Scratch sa, sb;                                        // sa: denoiser1 + Influence, sb: denoiser2 (runs concurrently)
@@ -570,7 +582,7 @@ double attn_bytes(const Ctx& c, int nseq, int H, int Tq, int Tk, int dh) {
 // the ragged call's sequence description for the attention kernels (nullptr in the uniform layout); `nseq` sequences = nseq / B groups
 const mmdm_rag_seq* rag_seq(const Ctx& c, int nseq, mmdm_rag_seq& tmp) {
     if (!c.rag()) return nullptr;
-    tmp = mmdm_rag_seq{c.g->seq_off, c.g->seq_len, (int)c.g->rows_of(nseq), c.g->T};
+    tmp = mmdm_rag_seq{c.g->seq_off, c.g->seq_len, (int)c.g->rows_of(nseq), c.g->T, c.g->item_order, c.g->B};
     return &tmp;
 }
 
@@ -630,7 +642,7 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
     };
     // AdaLN into the stack GEMMs' operand format: fp32 / bf16 / two fp16 planes, or fp8 + per-row scales
     auto norm = [&](const float* src, const float* ssp, int rows) -> int {
-        return mmdm_adaln_any(src, ssp, r.ss_ld, rows, S.xn, f8 ? 3 : ob, f8 ? S.xs : nullptr, r.nseq, r.T, D, c.st, row_seq, R);
+        return ROWOP(c, mmdm_adaln_any, src, ssp, r.ss_ld, rows, S.xn, f8 ? 3 : ob, f8 ? S.xs : nullptr, r.nseq, r.T, D, c.st, row_seq, R);
     };
     auto second = [&](void* buf, int ld, int cols) { Second s2; if (qkp) { s2.p = buf; s2.ld = ld; s2.cols = cols; s2.plane = (size_t)R * ld; } return s2; };
     // one-plane (bf16 / fp8) modes: the projection GEMMs' bf16 copy also covers V, and P.V runs on the bf16 matrix cores (attn_qkp_kernel<DH, 1, true>)
@@ -704,7 +716,7 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
 // emb rows -> silu -> all AdaLN projections of a module.  se = silu(time_tab[step] + txt), ss = se W_ada^T + b_ada.
 int cond_vectors(const Ctx& c, const ModuleW& m, const float* txt, float* se, float* ss, int rows) {
     const StackW& w = m.st;
-    RC(mmdm_cond_silu_f32(m.time_tab, c.h->d_step, txt, se, rows, w.D, c.st));
+    RC(ROWOP(c, mmdm_cond_silu_f32, m.time_tab, c.h->d_step, txt, se, rows, w.D, c.st));
     const int N = ss_ld_of(m);
     return linear(c, se, w.D, w.ada_w, w.D, w.ada_b, ss, N, rows, N, w.D);
 }
@@ -764,21 +776,21 @@ int encoder_layer(const Ctx& c, float* x, const EncLayerW& w, int nseq, int T, i
     const int R = nseq * T, dh = D / H;
     const int flags = MMDM_ATTN_NO_ZERO_KEY | (causal ? MMDM_ATTN_CAUSAL : 0);
     if (norm_first) {
-        RC(mmdm_layernorm_f32(x, w.n1_g, w.n1_b, tmp, R, D, eps, c.st));
+        RC(ROWOP(c, mmdm_layernorm_f32, x, w.n1_g, w.n1_b, tmp, R, D, eps, c.st));
         RC(linear(c, tmp, D, w.in_w, D, w.in_b, qkv, 3 * D, R, 3 * D, D));
         RC(attention_plain(c, qkv, 3 * D, att, D, nseq, T, H, dh, flags));
         RC(linear(c, att, D, w.out_w, D, w.out_b, x, D, R, D, D, MMDM_EPI_BIAS_RESID, x, D));
-        RC(mmdm_layernorm_f32(x, w.n2_g, w.n2_b, tmp, R, D, eps, c.st));
+        RC(ROWOP(c, mmdm_layernorm_f32, x, w.n2_g, w.n2_b, tmp, R, D, eps, c.st));
         RC(linear(c, tmp, D, w.l1_w, D, w.l1_b, f1, F, R, F, D, act_epi));
         return linear(c, f1, F, w.l2_w, F, w.l2_b, x, D, R, D, F, MMDM_EPI_BIAS_RESID, x, D);
     }
     RC(linear(c, x, D, w.in_w, D, w.in_b, qkv, 3 * D, R, 3 * D, D));
     RC(attention_plain(c, qkv, 3 * D, att, D, nseq, T, H, dh, flags));
     RC(linear(c, att, D, w.out_w, D, w.out_b, tmp, D, R, D, D, MMDM_EPI_BIAS_RESID, x, D));
-    RC(mmdm_layernorm_f32(tmp, w.n1_g, w.n1_b, x, R, D, eps, c.st));
+    RC(ROWOP(c, mmdm_layernorm_f32, tmp, w.n1_g, w.n1_b, x, R, D, eps, c.st));
     RC(linear(c, x, D, w.l1_w, D, w.l1_b, f1, F, R, F, D, act_epi));
     RC(linear(c, f1, F, w.l2_w, F, w.l2_b, tmp, D, R, D, F, MMDM_EPI_BIAS_RESID, x, D));
-    return mmdm_layernorm_f32(tmp, w.n2_g, w.n2_b, x, R, D, eps, c.st);
+    return ROWOP(c, mmdm_layernorm_f32, tmp, w.n2_g, w.n2_b, x, R, D, eps, c.st);
 }
 
 // MDMDenoiser.forward (mdm.py:273-298) on the CFG-doubled batch: `cond` rows are [n, ldc] with person p's latent-sized slice at
@@ -793,11 +805,11 @@ int run_denoiser_mdm(const Ctx& c, const ModuleW& m, const float* x, int xb, int
         for (int rep = 0; rep < n / xb; ++rep)
             RC(embed(c, m, S.xp, p, S.att + ((size_t)p * n + (size_t)rep * xb) * T * D, xb, T, 1));
     for (int p = 0; p < npers; ++p)
-        RC(mmdm_mdm_pack(S.att + (size_t)p * n * T * D, cond + (size_t)p * D, ldc, m.time_tab, c.h->d_step, m.pe,
+        RC(ROWOP(c, mmdm_mdm_pack, S.att + (size_t)p * n * T * D, cond + (size_t)p * D, ldc, m.time_tab, c.h->d_step, m.pe,
                          S.h + (size_t)p * n * (T + 1) * D, n, T, D, c.st));
     for (int l = 0; l < m.st.L; ++l)
         RC(encoder_layer(c, S.h, m.enc[l], nseq, T + 1, D, m.st.H, m.st.F, false, MMDM_EPI_BIAS_GELU, false, 1e-5f, S.qkv, S.att, S.xn, S.f1));
-    RC(mmdm_mdm_unpack(S.h, S.att, nseq, T, D, c.st));
+    RC(ROWOP(c, mmdm_mdm_unpack, S.h, S.att, nseq, T, D, c.st));
     for (int p = 0; p < npers; ++p)
         RC(linear(c, S.att + (size_t)p * n * T * D, D, m.out_w, D, m.out_b, out + (size_t)p * NF, ldo, n * T, NF, D));
     return MMDM_OK;
@@ -873,8 +885,8 @@ int mixer_core(const Ctx& c, int B, int T, bool dyn_hist) {
     // Influence.out + sigmoid (influence.py:124-125) as a GEMM with a sigmoid epilogue: N = 1 or 23 columns of a 64-wide MFMA tile --
     // wasteful per flop and still 8x faster than a wave-per-row dot-product kernel at 19 200 rows
     if (mode == 1 || mode == 3) {
-        if (rag) RC(mmdm_mean_time_rag(c.s->h, H->hpool, 2 * n, c.g->seq_off, c.g->seq_len, Dm, c.st));
-        else RC(mmdm_mean_time_f32(c.s->h, H->hpool, 2 * n, T, Dm, c.st));
+        if (rag) RC(ROWOP(c, mmdm_mean_time_rag, c.s->h, H->hpool, 2 * n, c.g->seq_off, c.g->seq_len, Dm, c.st));
+        else RC(ROWOP(c, mmdm_mean_time_f32, c.s->h, H->hpool, 2 * n, T, Dm, c.st));
         RC(linear(c, H->hpool, Dm, H->mx.out_w, Dm, H->mx.out_b, H->w23, H->nw, 2 * n, H->nw, Dm, MMDM_EPI_BIAS_SIGMOID));
     } else {
         RC(linear(c, c.s->h, Dm, H->mx.out_w, Dm, H->mx.out_b, H->w23, H->nw, (int)(2 * nT), H->nw, Dm, MMDM_EPI_BIAS_SIGMOID));
@@ -994,15 +1006,19 @@ size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 // Destroys a graph exec -- unless other handles share this handle's weights (mmdm_create_shared: several calls in flight).  In this runtime
 // (ROCm 7.0 / 7.2) destroying an exec while ANOTHER handle's execs are alive made that handle's next hipGraphLaunch crash inside
 // hip::Graph::UpdateStreams (seen with 2 and 4 handles at the real model sizes as soon as a graph cache evicted; waiting for the whole device
-// first does not help, never destroying does): such execs are parked for the life of the process instead.  Bounded by the number of distinct
-// shapes captured while handles shared weights; a handle that never shared frees its execs as before.  Caller holds g_graph_mu exclusively.
-// Once an exec has been parked, parked execs are alive for good -- so from then on EVERY exec of the process is parked rather than destroyed (the
-// full GPU suite crashed in a later, unrelated handle's hipGraphLaunch after the shared-handle test had parked some execs and later tests destroyed
-// theirs).  A process that never lets two handles share weights (bench.py's headline, one Sampler) never parks and frees its execs as before.
+// first does not help, never destroying does): such execs are parked for the life of the process instead.  Once an exec has been parked,
+// parked execs are alive for good -- so from then on EVERY exec of the process is parked rather than destroyed (the full GPU suite crashed in
+// a later, unrelated handle's hipGraphLaunch after the shared-handle test had parked some execs and later tests destroyed theirs).
+// What bounds the parked set: while parking is in force a graph cache does NOT evict (must_park() in mmdm_run: the cache grows to the
+// number of distinct shapes its handle samples, every shape is captured once and re-used), so only mmdm_destroy parks -- the execs of handles
+// that no longer exist, i.e. (handles ever destroyed while parking) x (distinct shapes each had sampled).  A process that never lets two
+// handles share weights (bench.py's headline, one Sampler) never parks, evicts at graph_cap and frees its execs as before.
+// Caller holds g_graph_mu exclusively.
 std::vector<hipGraphExec_t> g_parked_execs;
+bool must_park(mmdm_handle h) { return (h->wb && h->wb.use_count() > 1) || !g_parked_execs.empty(); }
 void retire_exec(mmdm_handle h, hipGraphExec_t exec) {
     if (!exec) return;
-    if ((h->wb && h->wb.use_count() > 1) || !g_parked_execs.empty()) g_parked_execs.push_back(exec);
+    if (must_park(h)) g_parked_execs.push_back(exec);
     else (void)hipGraphExecDestroy(exec);
 }
 
@@ -1128,6 +1144,7 @@ static int create_impl(const mmdm_config* cfg, mmdm_handle parent, mmdm_handle* 
         hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming) != hipSuccess)
         return fail(mmdm_set_error(MMDM_ERR_HIP, "mmdm_create: stream/event creation failed"));
     h->overlap = getenv("MMDM_NO_OVERLAP") == nullptr;
+    if (g_serialize_handles.load() < 0) { const char* v = getenv("MMDM_SERIALIZE_HANDLES"); g_serialize_handles.store(v && strcmp(v, "0") != 0 ? 1 : 0); }
     auto env_on = [](const char* k) { const char* v = getenv(k); return v != nullptr && strcmp(v, "0") != 0; };
     if (parent) {       // the switches that decide the FORMAT of the shared weights (and the kernels that read them) are the parent's
         h->force_qkp = parent->force_qkp; h->no_qkp = parent->no_qkp; h->no_pvb = parent->no_pvb; h->no_pack = parent->no_pack; h->no_split_embed = parent->no_split_embed;
@@ -1175,10 +1192,10 @@ static int create_impl(const mmdm_config* cfg, mmdm_handle parent, mmdm_handle* 
     // ragged calls (mmdm_begin_ragged): row maps for up to 4 groups of max_batch * max_frames rows, and per module the PE rows of a group
     if (so <= 1 && !mdm) {
         const size_t cap = (size_t)B * T, nb = (size_t)(B < MMDM_RAG_MAX_ITEMS ? B : MMDM_RAG_MAX_ITEMS), G = 4;
-        if ((rc = dalloc(h, &tmp, 2 * nb + 2 * cap + G * cap + 2 * G * nb))) return fail(rc);
+        if ((rc = dalloc(h, &tmp, 3 * nb + 2 * cap + G * cap + 2 * G * nb))) return fail(rc);
         h->d_rag = reinterpret_cast<int*>(tmp);
         h->d_item_off = h->d_rag; h->d_item_len = h->d_item_off + nb; h->d_row_item = h->d_item_len + nb; h->d_row_pos = h->d_row_item + cap;
-        h->d_row_seq = h->d_row_pos + cap; h->d_seq_off = h->d_row_seq + G * cap; h->d_seq_len = h->d_seq_off + G * nb;
+        h->d_row_seq = h->d_row_pos + cap; h->d_seq_off = h->d_row_seq + G * cap; h->d_seq_len = h->d_seq_off + G * nb; h->d_item_order = h->d_seq_len + G * nb;
         if (has_d1 && (rc = dalloc(h, &h->d1.pe_r, cap * D1))) return fail(rc);
         if (has_d2 && (rc = dalloc(h, &h->d2.pe_r, cap * D))) return fail(rc);
         if (has_mx && (rc = dalloc(h, &h->mx.pe_r, cap * Dm))) return fail(rc);
@@ -1406,7 +1423,7 @@ static int begin_impl(mmdm_handle h, const float* cond, const float* x_T, int B,
         if (rows > cap) rows = cap;
         T = mx;
         g.rag = true; g.rows = (int)rows; g.real_rows = (int)sum; g.tt1 = tt1;
-        g.seq_off = h->d_seq_off; g.seq_len = h->d_seq_len; g.row_seq = h->d_row_seq;
+        g.seq_off = h->d_seq_off; g.seq_len = h->d_seq_len; g.row_seq = h->d_row_seq; g.item_order = h->d_item_order;
         g.rg = mmdm_rag{h->d_row_item, h->d_row_pos, h->d_item_off, h->d_item_len, B, (int)rows};
     } else {
         if (B <= 0 || B > h->cfg.max_batch || T <= 0 || T > h->cfg.max_frames)
@@ -1426,7 +1443,7 @@ static int begin_impl(mmdm_handle h, const float* cond, const float* x_T, int B,
         return MMDM_OK;
     };
     if (g.rag) {
-        RC(herr(h, mmdm_rag_setup(lens, B, g.rows, 4, h->d_item_off, h->d_item_len, h->d_row_item, h->d_row_pos, h->d_row_seq, h->d_seq_off, h->d_seq_len, st)));
+        RC(herr(h, mmdm_rag_setup(lens, B, g.rows, 4, h->d_item_off, h->d_item_len, h->d_row_item, h->d_row_pos, h->d_row_seq, h->d_seq_off, h->d_seq_len, h->d_item_order, st)));
         for (ModuleW* m : {&h->d1, &h->d2, &h->mx})
             if (m->pe_r && m->pe) RC(herr(h, mmdm_gather_rows(m->pe, h->d_row_pos, m->pe_r, g.rows, m->st.D, st)));
     }
@@ -1509,9 +1526,24 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
         return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: %d steps requested, %d left in the schedule", nsteps, h->host_step + 1));
     hipStream_t st = static_cast<hipStream_t>(stream);
     Ctx c{h, st, &h->sa, &h->geom};
+    if (use_graph && !h->prof.on && !st) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: graph capture needs a non-default stream"));
+    if (nsteps == 0) return MMDM_OK;
+    // MMDM_SERIALIZE_HANDLES=1: this call's steps start behind the previous sampling call of any handle, and the next one behind them
+    struct Serial {
+        hipStream_t st; bool on;
+        std::unique_lock<std::mutex> lk;
+        explicit Serial(hipStream_t s) : st(s), on(g_serialize_handles.load() == 1) {
+            if (!on) return;
+            lk = std::unique_lock<std::mutex>(g_serial_mu);
+            if (g_serial_ev) (void)hipStreamWaitEvent(st, g_serial_ev, 0);
+        }
+        ~Serial() {
+            if (!on) return;
+            if (!g_serial_ev) (void)hipEventCreateWithFlags(&g_serial_ev, hipEventDisableTiming);
+            if (g_serial_ev) (void)hipEventRecord(g_serial_ev, st);
+        }
+    } serial(st);
     if (use_graph && !h->prof.on) {
-        if (!st) return herr(h, mmdm_set_error(MMDM_ERR_ARG, "mmdm_run: graph capture needs a non-default stream"));
-        if (nsteps == 0) return MMDM_OK;
         hipGraphExec_t exec = nullptr;
         hipEvent_t done = nullptr;
         int first = 0;
@@ -1532,7 +1564,7 @@ extern "C" int mmdm_run(mmdm_handle h, int nsteps, int use_graph, void* stream) 
             e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
             if (e != hipSuccess) return herr(h, mmdm_set_error(MMDM_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)));
-            if (h->graphs.size() >= h->graph_cap) {               // evict the least recently used entry
+            if (h->graphs.size() >= h->graph_cap && !must_park(h)) {      // evict the least recently used entry (never while execs are parked rather than destroyed: retire_exec)
                 size_t lru = 0;
                 for (size_t i = 1; i < h->graphs.size(); ++i)
                     if (h->graphs[i].used < h->graphs[lru].used) lru = i;
@@ -1717,6 +1749,11 @@ extern "C" int mmdm_module_forward(mmdm_handle h, int which, const float* x, con
         if (e != hipSuccess) rc = mmdm_set_error(MMDM_ERR_HIP, "mmdm_module_forward: %s", hipGetErrorString(e));
     }
     return done(rc);
+}
+
+extern "C" int mmdm_graph_parked(void) {
+    std::shared_lock<std::shared_mutex> lock(g_graph_mu);
+    return (int)g_parked_execs.size();
 }
 
 extern "C" int mmdm_graph_stats(mmdm_handle h, int64_t* captures, int64_t* replays, int* cached) {

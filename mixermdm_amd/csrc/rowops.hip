@@ -4,7 +4,21 @@
 #include <math.h>
 #include "kernels.h"
 
+// This file is built TWICE (mixermdm_amd/build.py): rowops.o as it stands, and rowops_nopk.o with -DMMDM_ROWOPS_NOPK and without the packed-fp32
+// VALU instructions -- the same kernels (inside `nopk::`, so that a kernel trace tells them apart) behind entry points named *_nopk, which the
+// handles of precision 1-3 take (mmdm.hip ROWOP): their row kernels run beside packed-W GEMMs, where dense packed-fp32 code was seen to
+// compute other bits on gfx950 (build.py has the story; AdaLN itself was never seen to move -- tests/test_gpu_hazard.py holds that -- the
+// second build removes the question instead of answering it).  The stateless entry points of include/mmdm.h exist in the first build only.
+#ifdef MMDM_ROWOPS_NOPK
+#define RO(name) name##_nopk
+#else
+#define RO(name) name
+#endif
+
 namespace {
+#ifdef MMDM_ROWOPS_NOPK
+inline namespace nopk {
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -255,8 +269,12 @@ __global__ void gauss1d_kernel(const float* __restrict__ x, float* __restrict__ 
     out[idx] = (float)acc;
 }
 
+#ifdef MMDM_ROWOPS_NOPK
+}  // namespace nopk
+#endif
 }  // namespace
 
+#ifndef MMDM_ROWOPS_NOPK
 extern "C" int mmdm_gaussian_filter1d_f32(const float* x, float* out, const double* weights, int radius, int n, int T, int C, void* stream) {
     if (n == 0 || T == 0 || C == 0) return MMDM_OK;
     if (!x || !out || !weights || radius < 0 || n < 0 || T < 0 || C < 0 || x == out)
@@ -280,8 +298,10 @@ extern "C" int mmdm_adaln_fp8(const float* h, const float* ss, int ss_ld, int ss
     return mmdm_adaln_any(h, ss, ss_ld, ss_rows, out, 3, row_scale, nseq, T, D, stream);
 }
 
+#endif  // !MMDM_ROWOPS_NOPK
+
 // row_seq != nullptr: ragged batch -- `rows_rag` rows in all, row r belongs to sequence row_seq[r] (device array); nseq / T are then unused
-int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, float* row_scale, int nseq, int T, int D, void* stream,
+int RO(mmdm_adaln_any)(const float* h, const float* ss, int ss_ld, int ss_rows, void* out, int out_bf16, float* row_scale, int nseq, int T, int D, void* stream,
                    const int* row_seq, int rows_rag) {
     if (row_seq) { nseq = 1; T = rows_rag; }
     if (nseq == 0 || T == 0) return MMDM_OK;
@@ -308,7 +328,7 @@ int mmdm_adaln_any(const float* h, const float* ss, int ss_ld, int ss_rows, void
     return mmdm_check_launch("adaln");
 }
 
-extern "C" int mmdm_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out, int rows, int D, float eps, void* stream) {
+extern "C" int RO(mmdm_layernorm_f32)(const float* x, const float* gamma, const float* beta, float* out, int rows, int D, float eps, void* stream) {
     if (rows == 0) return MMDM_OK;
     if (!x || !gamma || !beta || !out || rows < 0 || D <= 0 || !(eps > 0.f)) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_layernorm_f32: bad arguments rows=%d D=%d", rows, D);
     if ((D & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(out)) & 15))
@@ -323,7 +343,7 @@ extern "C" int mmdm_layernorm_f32(const float* x, const float* gamma, const floa
     return mmdm_check_launch("layernorm");
 }
 
-int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
+int RO(mmdm_mdm_pack)(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
                   int nseq, int T, int D, hipStream_t st) {
     const size_t n = (size_t)nseq * (T + 1) * D;
     if (n == 0) return MMDM_OK;
@@ -331,13 +351,14 @@ int mmdm_mdm_pack(const float* src, const float* cond, int ldc, const float* tim
     return mmdm_check_launch("mdm_pack");
 }
 
-int mmdm_mdm_unpack(const float* src, float* dst, int nseq, int T, int D, hipStream_t st) {
+int RO(mmdm_mdm_unpack)(const float* src, float* dst, int nseq, int T, int D, hipStream_t st) {
     const size_t n = (size_t)nseq * T * D;
     if (n == 0) return MMDM_OK;
     hipLaunchKernelGGL(mdm_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, nseq, T, D);
     return mmdm_check_launch("mdm_unpack");
 }
 
+#ifndef MMDM_ROWOPS_NOPK
 extern "C" int mmdm_token_embed_f32(const float* table, int vocab, const int* tokens, const float* pos, float* out, int n, int L, int D, void* stream) {
     if (n == 0 || L == 0) return MMDM_OK;
     if (!table || !tokens || !pos || !out || n < 0 || L < 0 || D <= 0 || vocab <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_token_embed_f32: bad arguments");
@@ -346,7 +367,9 @@ extern "C" int mmdm_token_embed_f32(const float* table, int vocab, const int* to
     return mmdm_check_launch("token_embed");
 }
 
-extern "C" int mmdm_cond_silu_f32(const float* time_tab, const int* step_idx, const float* txt, float* out, int rows, int D, void* stream) {
+#endif
+
+extern "C" int RO(mmdm_cond_silu_f32)(const float* time_tab, const int* step_idx, const float* txt, float* out, int rows, int D, void* stream) {
     if (rows == 0) return MMDM_OK;
     if (!time_tab || !step_idx || !txt || !out || rows < 0 || D <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_cond_silu_f32: bad arguments");
     const size_t n = (size_t)rows * D;
@@ -354,19 +377,20 @@ extern "C" int mmdm_cond_silu_f32(const float* time_tab, const int* step_idx, co
     return mmdm_check_launch("cond_silu");
 }
 
-extern "C" int mmdm_mean_time_f32(const float* h, float* out, int nseq, int T, int D, void* stream) {
+extern "C" int RO(mmdm_mean_time_f32)(const float* h, float* out, int nseq, int T, int D, void* stream) {
     if (nseq == 0) return MMDM_OK;
     if (!h || !out || nseq < 0 || T <= 0 || D <= 0) return mmdm_set_error(MMDM_ERR_ARG, "mmdm_mean_time_f32: bad arguments");
     hipLaunchKernelGGL(mean_time_kernel, dim3((D + 255) / 256, nseq), dim3(256), 0, static_cast<hipStream_t>(stream), h, out, T, D);
     return mmdm_check_launch("mean_time");
 }
 
-int mmdm_mean_time_rag(const float* h, float* out, int nseq, const int* seq_off, const int* seq_len, int D, hipStream_t st) {
+int RO(mmdm_mean_time_rag)(const float* h, float* out, int nseq, const int* seq_off, const int* seq_len, int D, hipStream_t st) {
     if (nseq == 0) return MMDM_OK;
     hipLaunchKernelGGL(mean_time_rag_kernel, dim3((D + 255) / 256, nseq), dim3(256), 0, st, h, out, seq_off, seq_len, D);
     return mmdm_check_launch("mean_time_rag");
 }
 
+#ifndef MMDM_ROWOPS_NOPK
 extern "C" int mmdm_influence_head_f32(const float* h, const float* Wout, const float* bout, float* w, int rows, int D, int nw, void* stream) {
     if (rows == 0) return MMDM_OK;
     if (!h || !Wout || !bout || !w || rows < 0 || D <= 0 || nw <= 0 || nw > 23)
@@ -374,3 +398,4 @@ extern "C" int mmdm_influence_head_f32(const float* h, const float* Wout, const 
     hipLaunchKernelGGL(influence_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), h, Wout, bout, w, rows, D, nw);
     return mmdm_check_launch("influence_head");
 }
+#endif

@@ -48,7 +48,10 @@ def generate_for_evaluation(model, items, max_length=300, mm_idxs=(), mm_num_rep
 
     batching: "sequential" = the reference's loop, one ``forward_test`` per item; "inflight" / "ragged" = the same calls handed to
     ``model.sample_many`` (several items in flight over one weight set / the items packed into ragged batches with per-sequence lengths on the
-    device) -- every motion is bit-identical to the sequential loop's on the same x_T, the loop is 1.4-2 x / 3 x faster (bench.py --eval-items).
+    device) -- every motion is bit-identical to the sequential loop's on the same x_T; measured (bench.py --eval-items, fp32): "ragged" 1.9 x the
+    sequential loop (3.0 x in fp32_split), "inflight" 1.00-1.03 x (kept for completeness, not a throughput lever).  "sequential" streams the
+    items (a lazy iterable or DataLoader is consumed one item at a time, as the reference's loop does); the other two need the calls at hand
+    together and materialise the batches first.
     seed: when given and an item carries no 'x_T', its noise is drawn from ``Generator(seed + item index)`` -- the same motions whatever the
     batching, the sharding or the world size (without it every call draws from the device's global generator, as the reference does).
 
@@ -69,31 +72,33 @@ def generate_for_evaluation(model, items, max_length=300, mm_idxs=(), mm_num_rep
         items = list(items)
         mine = set(D.shard_items(len(items)))
         gen_l, mm_l = {}, {}
-    todo, batches = [], []
-    for i, data in enumerate(items):
-        if shard_items and i not in mine:
-            continue
-        rep = mm_num_repeats if i in mm_idxs else 1
-        batch = {"text": list(data["text"]) * rep, "motion_lens": data["motion_lens"]}
-        if extended:
-            batch["text_individual1"] = list(data["text_individual1"]) * rep
-            batch["text_individual2"] = list(data["text_individual2"]) * rep
-        if "cond" in data:
-            batch["cond"] = data["cond"].repeat(rep, 1)
-        if "x_T" in data:
-            batch["x_T"] = data["x_T"]
-        elif seed is not None:
-            T = int(data["motion_lens"][0])
-            gen = torch.Generator().manual_seed(int(seed) + i)
-            batch["x_T"] = torch.randn(rep, T, 524, generator=gen)
-        todo.append((i, data))
-        batches.append(batch)
+    def calls():
+        for i, data in enumerate(items):
+            if shard_items and i not in mine:
+                continue
+            rep = mm_num_repeats if i in mm_idxs else 1
+            batch = {"text": list(data["text"]) * rep, "motion_lens": data["motion_lens"]}
+            if extended:
+                batch["text_individual1"] = list(data["text_individual1"]) * rep
+                batch["text_individual2"] = list(data["text_individual2"]) * rep
+            if "cond" in data:
+                batch["cond"] = data["cond"].repeat(rep, 1)
+            if "x_T" in data:
+                batch["x_T"] = data["x_T"]
+            elif seed is not None:
+                T = int(data["motion_lens"][0])
+                gen = torch.Generator().manual_seed(int(seed) + i)
+                batch["x_T"] = torch.randn(rep, T, 524, generator=gen)
+            yield i, data, batch
     with torch.no_grad():
         if batching != "sequential":
-            outs = [r["output"] for r in model.sample_many(batches, mode="eval_intermediate", batching=batching, inflight=inflight, max_rows=max_rows,
-                                                           max_items=max_items, keep_history=False)]
-        for k, (i, data) in enumerate(todo):
-            out = outs[k] if batching != "sequential" else model.forward_test(batches[k])["output"]
+            todo = list(calls())
+            outs = model.sample_many([b for _, _, b in todo], mode="eval_intermediate", batching=batching, inflight=inflight, max_rows=max_rows,
+                                     max_items=max_items, keep_history=False)
+            stream = ((i, data, r["output"]) for (i, data, _), r in zip(todo, outs))
+        else:
+            stream = ((i, data, model.forward_test(batch)["output"]) for i, data, batch in calls())
+        for i, data, out in stream:
             motions = out.reshape(out.shape[0], out.shape[1], 2, -1).cpu().numpy()
             if normalizer is not None:
                 motions = normalizer.backward(motions)

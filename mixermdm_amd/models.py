@@ -409,8 +409,9 @@ class MixerMDM(nn.Module):
         ``forward_test`` (mode="eval_intermediate") would -- every motion BIT-IDENTICAL to that call's on the same x_T.
 
         batching: "sequential" = the reference's loop (one call after the other on one handle);
-                  "inflight"   = `inflight` handles over one weight set, calls dealt round-robin, each on its own stream (a B = 1 call fills
-                                 ~60 % of one round of GEMM tiles on 256 CUs: two co-resident calls overlap);
+                  "inflight"   = `inflight` handles over one weight set, calls dealt round-robin, each on its own stream.  Bit-identical, and
+                                 measured worth 1.00-1.03 x (the GPU co-schedules two such streams hardly at all: LAB_NOTES.md round 5) --
+                                 kept for callers whose requests arrive at different times, not as a throughput lever;
                   "ragged"     = the calls' motions packed into ragged batches of <= max_rows frames / <= max_items motions
                                  (mmdm_begin_ragged: per-sequence lengths as device data; GEMMs at the efficiency of a full batch).
         keep_history: None = what the mode says (store_influence -> influence lists; "eval" -> out1 / out2 / out_influenced), False = outputs only."""
@@ -457,20 +458,31 @@ class MixerMDM(nn.Module):
             conds = [c.to(dev, torch.float32).contiguous() for c in conds]
             xs = [x.contiguous() for x in xs]
             wi = 262 if m.mixing_mode >= 3 else 1
-            outs = [torch.empty_like(x) for x in xs]
-            hists = [{nm: torch.empty(slots, 2 * nb, T, (wi if nm.startswith("influence") else 524), device=dev) for nm in names} for nb, T in zip(Bs, Ts)]
+            per_row = slots * 2 * 4 * sum(wi if n.startswith("influence") else 524 for n in names)      # history bytes per (motion, frame)
+            need = per_row * sum(nb * T for nb, T in zip(Bs, Ts))
+            # the history side outputs of EVERY call are the caller's to keep (as in the sequential and ragged paths): the same budget, summed
+            if need > HISTORY_BUDGET_BYTES:
+                raise MemoryError(f"history side outputs of {len(Bs)} in-flight calls need {need / 2**30:.1f} GiB; pass fewer batches per call, set "
+                                  "model.history_every, or pass keep_history=False")
             cur = torch.cuda.current_stream(dev)
-            for smp in pool:                         # inputs and buffers were produced on the caller's stream: order every handle's stream behind it
-                smp.stream.wait_stream(cur)
-            for i in range(len(conds)):
-                pool[i % len(pool)].enqueue(conds[i], xs[i], outs[i], hists[i], self.history_every)
-            for smp in pool:
-                cur.wait_stream(smp.stream)
-                smp.stream.synchronize()
-            for i in range(len(conds)):
-                results[i]["output"] = outs[i]
-                for k, v in hists[i].items():
-                    results[i][k] = list(v.unbind(0))
+            # calls are queued in windows of a few multiples of `inflight`: output and history buffers are allocated per window (the caching
+            # allocator is not touched while a window's calls are being queued), so lazily built inputs of later windows are not needed yet
+            win = 4 * len(pool)
+            for w0 in range(0, len(conds), win):
+                idx = range(w0, min(w0 + win, len(conds)))
+                outs = {i: torch.empty_like(xs[i]) for i in idx}
+                hists = {i: {nm: torch.empty(slots, 2 * Bs[i], Ts[i], (wi if nm.startswith("influence") else 524), device=dev) for nm in names} for i in idx}
+                for smp in pool:                     # inputs and buffers were produced on the caller's stream: order every handle's stream behind it
+                    smp.stream.wait_stream(cur)
+                for i in idx:
+                    pool[i % len(pool)].enqueue(conds[i], xs[i], outs[i], hists[i], self.history_every)
+                for smp in pool:
+                    cur.wait_stream(smp.stream)
+                    smp.stream.synchronize()
+                for i in idx:
+                    results[i]["output"] = outs[i]
+                    for k, v in hists[i].items():
+                        results[i][k] = list(v.unbind(0))
             return results
         # ragged: motions in call order, cut into groups of <= max_rows frames and <= max_items motions
         motions = [(i, j) for i, nb in enumerate(Bs) for j in range(nb)]

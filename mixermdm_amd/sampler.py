@@ -297,11 +297,13 @@ class Sampler:
         B, T = x_T.shape[:2]
         h = hist or {}
         ptr = lambda nm: C.c_void_p(h[nm].data_ptr() if nm in h else 0)
-        check(self.lib.mmdm_begin(self.h, C.c_void_p(cond.data_ptr()), C.c_void_p(x_T.data_ptr()), B, T, self._s()), self.h)
-        if h:
-            check(self.lib.mmdm_set_history(self.h, ptr("influence_i1"), ptr("influence_i2"), ptr("out1"), ptr("out2"), ptr("out_influenced"), history_every), self.h)
-        check(self.lib.mmdm_run(self.h, self.schedule.num_timesteps, int(use_graph), self._s()), self.h)
-        check(self.lib.mmdm_copy_result(self.h, C.c_void_p(out.data_ptr()), self._s()), self.h)
+        # the C side launches on whatever device is current: select the handle's (torch.cuda.device is a hipSetDevice pair, no allocator call)
+        with torch.cuda.device(self.device):
+            check(self.lib.mmdm_begin(self.h, C.c_void_p(cond.data_ptr()), C.c_void_p(x_T.data_ptr()), B, T, self._s()), self.h)
+            if h:
+                check(self.lib.mmdm_set_history(self.h, ptr("influence_i1"), ptr("influence_i2"), ptr("out1"), ptr("out2"), ptr("out_influenced"), history_every), self.h)
+            check(self.lib.mmdm_run(self.h, self.schedule.num_timesteps, int(use_graph), self._s()), self.h)
+            check(self.lib.mmdm_copy_result(self.h, C.c_void_p(out.data_ptr()), self._s()), self.h)
         self.B, self.T, self.lens, self.rows = B, T, None, B * T
 
     def sample_ragged_async(self, cond, x_T, lens, use_graph=True, history=None, history_every=1):
@@ -345,6 +347,10 @@ class Sampler:
         cap, rep, n = C.c_int64(), C.c_int64(), C.c_int()
         check(self.lib.mmdm_graph_stats(self.h, C.byref(cap), C.byref(rep), C.byref(n)), self.h)
         return cap.value, rep.value, n.value
+
+    def graphs_parked(self):
+        """Graph execs of the PROCESS kept past their cache entry's life (mmdm_graph_parked: include/mmdm.h, mmdm_create_shared)."""
+        return int(self.lib.mmdm_graph_parked())
 
     # ---- profiling ----------------------------------------------------------------------------------
     def profile(self, on=True):

@@ -156,7 +156,95 @@ def compare_step(out, ref32, ref64, what, tol=STEP_TOL, hard_joints=0):
     return worst, amplified, events
 
 
-def yardstick(out, ref32, ref64, what, factor=YARD_FACTOR, factor_posvel=YARD_FACTOR_POSVEL, floor=YARD_FLOOR, event=False):
+# ---- statistical form (round 6): many independent draws instead of a list of seeds that happen to pass ----------------------------------
+# compare_step's element tolerance follows the CPU fp32 oracle's own error in the element's (sample, person, class) group by GROUP_FACTOR.
+# For the centred chain's position / velocity channels both errors are ONE random rotation-angle error per (item, person) -- the HIP
+# path's and the CPU's are independent draws -- so their ratio is heavy-tailed: tools/ratio_distribution.py, 48 (item, person) draws at the
+# real sizes: ratio of the p50 errors median 2.3, p90 4.4, max 14.5 -- ONE draw of 48 beyond GROUP_FACTOR = 12.  A test on fixed inputs is
+# then green or red by the luck of its seed (round 5's ragged oracle test: seed 3 red, seeds 4-6 green).  The statement that can be
+# calibrated is about a POPULATION of draws:
+#   (i)   every draw keeps the hard bounds (finite, nothing beyond 5e-2 / HARD_FACTOR x the group scale outside the rot6d outlier
+#         allowance) -- asserted per draw, no exception;
+#   (ii)  the number of draws whose out-of-tolerance fraction exceeds STEP_TOL["frac"] is <= k(N), the smallest k with
+#         P[Binomial(N, DRAW_EXCEED_RATE) > k] <= DRAW_ALPHA: with the measured rate (1 of 48; DRAW_EXCEED_RATE = 0.05 is about the
+#         90 % one-sided upper confidence bound of that observation) an honest implementation fails the count once in a thousand runs,
+#         a kernel whose error is a few times larger fails (ii) or (iii) nearly always;
+#   (iii) the POOLED error quantiles (all draws of the test concatenated along the frame axis) obey the float64 yardstick at
+#         POOLED_FACTOR = 3 for every channel class at p50 -- pooling averages the per-draw random scalar of the position / velocity class
+#         away, so its MEDIAN needs no allowance -- and at p99 / p99.9 for the rot6d and foot classes.  The position / velocity class has
+#         no pooled TAIL bound: one draw is 1 / N >= 4 % of the pooled elements, so its p99 / p99.9 are the one or two largest per-draw
+#         scalars on either side -- exactly what (ii) counts draw by draw (a pooled bound there is either implied by (ii) or fails on the
+#         very draw (ii) allows); the pooled figures are recorded in the report.
+# Seeds are CONSECUTIVE from 0 and none is skipped; the report lists every draw.
+DRAW_EXCEED_RATE = 0.05
+DRAW_ALPHA = 1e-3
+POOLED_FACTOR = 3.0
+
+
+def binomial_bound(n, p=DRAW_EXCEED_RATE, alpha=DRAW_ALPHA):
+    """Smallest k with P[Binomial(n, p) > k] <= alpha."""
+    from math import comb
+    tail = 1.0
+    for k in range(n + 1):
+        tail -= comb(n, k) * p ** k * (1 - p) ** (n - k)
+        if tail <= alpha:
+            return k
+    return n
+
+
+def step_draws(out, ref32, ref64, label, tol=STEP_TOL):
+    """The (sample, person) draws of one compared step: per draw the worst out-of-tolerance fraction over the compared tensors (compare_step's
+    element tolerance, taken over that person's 262 channels of that sample) and whether it exceeds tol["frac"].  Asserts statement (i)."""
+    draws = {}
+    for nm, ref in ref32.items():
+        got, ref = out[nm].detach().cpu().double(), torch.as_tensor(ref).detach().cpu().double()
+        r64 = torch.as_tensor(ref64[nm]).detach().cpu().double()
+        assert got.shape == ref.shape == r64.shape, (nm, got.shape, ref.shape, r64.shape)
+        assert torch.isfinite(got).all(), f"{label} {nm}: non-finite"
+        B, T, C = got.shape
+        G, _ = group_scale((ref - r64).abs())
+        lim = torch.maximum(tol["atol"] + tol["rtol"] * ref.abs(), GROUP_FACTOR * G)
+        d = (got - ref).abs()
+        over = d > torch.maximum(torch.full_like(d, tol["hard"]), HARD_FACTOR * G)
+        ch = torch.arange(C) % 262
+        rot = ((ch >= 132) & (ch < 258))[None, None, :].expand_as(over)
+        assert not bool((over & ~rot).any()), f"{label} {nm}: position / velocity / foot element beyond the hard bound, max err {d.max().item():.2e}"
+        assert int(over.sum()) <= HARD_OUTLIERS, f"{label} {nm}: {int(over.sum())} rot6d components beyond the hard bound (fp32: {HARD_OUTLIERS} allowed)"
+        for b in range(B):
+            for p in range(C // 262):
+                sel = d[b, :, p * 262:(p + 1) * 262] > lim[b, :, p * 262:(p + 1) * 262]
+                nbad = int(sel.sum())
+                frac = 0.0 if nbad <= MIN_OUTLIERS else nbad / sel.numel()
+                e = draws.setdefault((b, p), {"label": label, "sample": b, "person": p, "worst_fraction": 0.0, "worst_tensor": None, "max_err": 0.0})
+                if frac >= e["worst_fraction"]:
+                    e["worst_fraction"], e["worst_tensor"] = frac, nm
+                e["max_err"] = max(e["max_err"], float(d[b, :, p * 262:(p + 1) * 262].max()))
+    for e in draws.values():
+        e["beyond_factor"] = e["worst_fraction"] > tol["frac"]
+    return list(draws.values())
+
+
+def compare_draws(steps, what, tol=STEP_TOL):
+    """steps: [(out, ref32, ref64, label)] -- independent one-step comparisons ([B, T, C] tensors per state name).  Asserts (i)-(iii) above and
+    records every draw.  Returns (number of draws beyond the factor, allowed k, N)."""
+    draws = []
+    for out, r32, r64, label in steps:
+        draws += step_draws(out, r32, r64, label, tol)
+    n, beyond = len(draws), sum(d["beyond_factor"] for d in draws)
+    k = binomial_bound(n)
+    REPORT.append({"what": what, "kind": "draws_vs_fp32_oracle", "draws": draws, "n_draws": n, "beyond_factor": beyond, "allowed": k,
+                   "exceed_rate_assumed": DRAW_EXCEED_RATE, "alpha": DRAW_ALPHA, "group_factor": GROUP_FACTOR})
+    assert beyond <= k, (f"{what}: {beyond} of {n} (item, person) draws beyond {GROUP_FACTOR} x the CPU oracle's own error "
+                         f"(allowed {k} at rate {DRAW_EXCEED_RATE}, alpha {DRAW_ALPHA}): " + "; ".join(f"{d['label']} person {d['person']} sample {d['sample']}: "
+                         f"{d['worst_fraction']:.1e} of {d['worst_tensor']}" for d in draws if d["beyond_factor"]))
+    # (iii) pooled yardstick: every class at POOLED_FACTOR (batch rows of different steps are concatenated along the frame axis, per batch row 0..B-1
+    # only where the shapes allow; ragged items come with B = 1)
+    cat = lambda idx: {k: torch.cat([torch.as_tensor(s[idx][k]).detach().cpu().double().reshape(1, -1, s[idx][k].shape[-1]) for s in steps], 1) for k in steps[0][1]}
+    yardstick(cat(0), cat(1), cat(2), f"{what}: {n} draws pooled", factor=POOLED_FACTOR, factor_posvel=YARD_FACTOR_POSVEL, factor_posvel_p50=POOLED_FACTOR)
+    return beyond, k, n
+
+
+def yardstick(out, ref32, ref64, what, factor=YARD_FACTOR, factor_posvel=YARD_FACTOR_POSVEL, floor=YARD_FLOOR, event=False, factor_posvel_p50=None):
     """Statement 2 for one step: |HIP - f64| <= factor x |fp32 oracle - f64| + floor at p50 / p99 / p99.9 of every channel class.
     The per-step MAXIMUM ratio is recorded and deliberately NOT bounded here: it is the ratio of two single elements -- in the position /
     velocity channels of two random rotation-angle errors, one per person and step -- and is heavy-tailed (45.9 x observed in one of 104
@@ -181,8 +269,12 @@ def yardstick(out, ref32, ref64, what, factor=YARD_FACTOR, factor_posvel=YARD_FA
         for cname, sel in channel_classes(got.shape[-1]).items():
             qh, qc = _quant(e_hip[..., sel]), _quant(e_cpu[..., sel])
             t[cname] = {"hip_vs_f64": qh, "cpu32_vs_f64": qc, "ratio": [h / max(c, floor) for h, c in zip(qh, qc)]}
-            f = factor_posvel if cname == "posvel" else factor
             for qn, h, c in list(zip(QNAMES, qh, qc))[:3]:
+                f = factor_posvel if cname == "posvel" else factor
+                if cname == "posvel" and factor_posvel_p50 is not None:
+                    if qn != "p50":
+                        continue                      # pooled draws (compare_draws): the tails of that class are statement (ii), recorded here, not bounded
+                    f = factor_posvel_p50             # ... and its median is no longer one random scalar
                 if h > f * c + floor:
                     fails.append(f"{nm}/{cname} {qn}: HIP {h:.3e} vs CPU-fp32 {c:.3e} (factor {f})")
     entry["ok"] = not fails

@@ -188,3 +188,22 @@ def test_bench_marks_the_roofline_of_calls_too_small_to_fill_the_machine():
     note = bench.small_launch_note(False, 1, 299)
     assert note and "1196 rows" in note and "not kernel quality" in note
     assert "240 rows" in bench.small_launch_note(True, 1, 120)
+
+
+def test_bench_stamps_the_library_and_names_the_same_batch_reference_point(monkeypatch):
+    """every bench line says which library it ran (version string, path, whether MMDM_LIB overrode the in-tree build), and
+    the N > 1 lines (32 motions per GPU) carry the committed one-GPU figure at the SAME per-GPU batch, labelled as not measured in that run."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    st = bench.lib_stamp()
+    assert st["mmdm_version"].startswith("gfx950;") and st["lib"] == os.path.join("mixermdm_amd", "libmmdm_hip.so") and st["lib_override"] is False
+    monkeypatch.setenv("MMDM_LIB", os.path.join(root, "mixermdm_amd", "libmmdm_hip.so"))
+    assert bench.lib_stamp()["lib_override"] is True
+    monkeypatch.delenv("MMDM_LIB")
+    ref = bench.n1_same_batch(32, "fp32")
+    assert ref and ref["measured_in_this_run"] is False and ref["n_gpus"] == 1 and ref["per_gpu_batch"] == 32 and ref["source"].startswith("profiles/r")
+    assert abs(ref["value"] - 32 / (ref["ms_per_step"] * 1e-3 * 1000)) < 1e-3
+    assert bench.n1_same_batch(16, "fp32") is None and bench.n1_same_batch(32, "bf16") is None

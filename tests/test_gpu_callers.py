@@ -252,7 +252,7 @@ def test_bench_runs_its_rccl_path_under_torchrun_on_the_gpu_box():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(MMDM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt", "--no-full-loop",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-alt", "--no-side", "--no-full-loop",
            "--profile-steps", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
@@ -265,3 +265,5 @@ def test_bench_runs_its_rccl_path_under_torchrun_on_the_gpu_box():
     # figure is claimed for a batch no PMC pass was taken at (profiles/gemm_traffic.json is the B = 16 headline's)
     assert line["per_gpu_batch"] == 32 and line["n_gpus"] == 1 and line["config"]["parallelism"].startswith("batch-sharded x1")
     assert line["roofline"] is None or line["roofline"]["traffic"] is None
+    # every line says which library it ran: the in-tree build, no MMDM_LIB override
+    assert line["mmdm_version"].startswith("gfx950;") and line["lib"] == os.path.join("mixermdm_amd", "libmmdm_hip.so") and line["lib_override"] is False

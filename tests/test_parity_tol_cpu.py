@@ -93,3 +93,49 @@ def test_one_turned_joint_passes_only_where_the_oracle_itself_is_ill_conditioned
     out4["pred_xstart"][b, t, c0:c0 + 2] += 0.2
     assert compare_step(out4, r32, r64, "two components")[2] == 0
     assert compare_step(out2, {k: v.clone() for k, v in ill32.items()}, r64, "event", hard_joints=1)[2] == 1
+
+
+def test_statistical_form_is_neither_brittle_nor_vacuous(pair):
+    """compare_draws (round 6): rounding-level noise on every draw passes; ONE draw beyond the group factor (the measured 1-in-50 event) passes the
+    count and is listed; the same deviation on MORE draws than the binomial bound allows fails the count; an error a few times the oracle's
+    own on every draw (no single draw spectacular) fails the pooled yardstick; one element beyond the hard bound fails whatever the count says."""
+    from parity_tol import compare_draws, binomial_bound, REPORT
+    r32, r64, _ = pair
+    assert [binomial_bound(n) for n in (12, 24, 48)] == [4, 5, 8]
+    steps = [(_noisy(r32, 2e-7), r32, r64, f"step {i}") for i in range(6)]          # 6 steps x 2 samples x 2 persons = 24 draws
+    beyond, k, n = compare_draws(steps, "noise x 24 draws")
+    assert (beyond, k, n) == (0, 5, 24)
+    assert REPORT[-2]["kind"] == "draws_vs_fp32_oracle" and len(REPORT[-2]["draws"]) == 24
+
+    # the measured event: the fp32 oracle itself is ill-conditioned for ONE (sample, person) -- 4e-5 from float64 in its position / velocity
+    # channels -- and the other implementation lands 14 x as far on the other side
+    def ill(ref, out, b, p, steps_idx=None):
+        ref, out = {k: v.clone() for k, v in ref.items()}, {k: v.clone() for k, v in out.items()}
+        g2 = torch.Generator().manual_seed(100 + 2 * b + p)
+        sgn = torch.sign(torch.randn(ref["pred_xstart"][b, :, :132].shape, generator=g2))
+        ref["pred_xstart"][b, :, p * 262:p * 262 + 132] += 4e-5 * sgn
+        out["pred_xstart"][b, :, p * 262:p * 262 + 132] -= 14 * 4e-5 * sgn
+        return out, ref
+    one = list(steps)
+    o, r = ill(r32, steps[2][0], 1, 0)
+    one[2] = (o, r, r64, "step 2")
+    beyond, k, n = compare_draws(one, "one heavy-tail draw")
+    assert beyond == 1
+    many = []
+    for (o, a, c, lab) in steps[:3]:
+        o, a = ill(a, o, 0, 0)
+        o, a = ill(a, o, 1, 1)
+        many.append((o, a, c, lab))
+    with pytest.raises(AssertionError, match="6 of 24"):
+        compare_draws(many + steps[3:], "six draws beyond the factor")
+    g = torch.Generator().manual_seed(3)
+    e = {k: (r32[k].double() - r64[k]).abs() for k in r32}
+    five = [({k: r32[k] + 5 * e[k].float() * torch.sign(torch.randn(r32[k].shape, generator=g)) for k in r32}, r32, r64, f"step {i}") for i in range(6)]
+    with pytest.raises(AssertionError, match="further from float64"):
+        compare_draws(five, "5 x the oracle's own error everywhere")
+    hard = list(steps)
+    bad = {k: v.clone() for k, v in steps[0][0].items()}
+    bad["x"][0, 3, 10] += 0.2
+    hard[0] = (bad, r32, r64, "step 0")
+    with pytest.raises(AssertionError, match="hard bound"):
+        compare_draws(hard, "a position element beyond the hard bound")

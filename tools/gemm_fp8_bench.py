@@ -10,6 +10,8 @@ if sel: shapes = [sh for sh in shapes if any(sh[3].replace(" ", "").startswith(t
 ITERS = int(os.environ.get("FP8_ITERS", "5"))
 MB = int(os.environ.get("FP8_M", "0"))
 if MB: shapes = [(MB,) + sh[1:] for sh in shapes]
+if os.environ.get("FP8_LDS_PAD"): lib.mmdm_diag_set(b"bf16_lds_pad", int(os.environ["FP8_LDS_PAD"]))      # extra dynamic LDS per packed-W workgroup: 2 instead of 3 workgroups per CU from ~7 KB up
+if os.environ.get("FP8_CFG"): lib.mmdm_diag_set(b"bf16_cfg", int(os.environ["FP8_CFG"]))                    # 12 / 13: force the wide / the narrow packed tile
 _w = torch.randn(4096, 4096, device=d)
 for _ in range(60 if ITERS > 1 else 2): ops.linear(_w, _w)
 for M,N,K,name,epi,od in shapes:

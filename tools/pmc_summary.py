@@ -91,6 +91,8 @@ if gemm["fetch"] and gemm["write"]:
     rec = {"precision": prec, "kernel": " + ".join(DOMINANT) + " (all instantiations of a step)", "kernel_sources_sha": sources_sha(prec),
            "workload": f"bench.py --precision {prec} --batch {PB} --frames {PT} --steps 2 --warmup 1 --no-graph, MMDM_NO_OVERLAP=1",
            "batch": PB, "frames": PT,        # bench.py reports this file as roofline.traffic only for the same motions per GPU and length
+           **({"rows": int(os.environ["PMC_ROWS"]), "workload": "tools/ragged_step.py: one ragged batch of the evaluation caller, %s group rows, 2 eager ddim50 steps, MMDM_NO_OVERLAP=1" % os.environ["PMC_ROWS"]}
+              if os.environ.get("PMC_ROWS") else {}),        # a ragged batch (tools/profile_ragged.sh): bench.py --eval-items matches on the group's rows
            "dispatches_averaged": len(gemm["fetch"]), "FETCH_SIZE_KB_per_launch_raw": round(mean(gemm["fetch"]), 1), "WRITE_SIZE_KB_per_launch": round(mean(gemm["write"]), 1),
            "fetch_correction": "x2 (gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16-B-per-lane streams; MI355X_MICROARCH.md, HBM)",
            "traffic_bytes_per_launch": round(fetch + write), "l2_hit_rate": round(mean(gemm["hit"]) / (mean(gemm["hit"]) + mean(gemm["miss"])), 4) if gemm["hit"] else None,

@@ -6,7 +6,7 @@ TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --no-cpu-baseline --no-alt --no-full-loop --no-clock"
+B="$R/bench.py --no-cpu-baseline --no-alt --no-side --no-full-loop --no-clock"
 MMDM_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -- python3 $B --steps 6 --warmup 2 > $O/serial.json 2> $O/serial.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/overlap -- python3 $B --steps 6 --warmup 2 > $O/overlap.json 2> $O/overlap.err
 for p in fp32_split bf16 bf16_fp8; do
