@@ -18,6 +18,9 @@ LIB = os.path.join(HERE, "libmmdm_hip.so")
 # precision 1-3 handle, and the geometry kernels of any handle (another handle's packed GEMMs may be on the device) -- is built without
 # packed-fp32 instructions, unless a test pins its bits beside the aggressor (DESIGN.md section 4 lists the remaining sites and their guards):
 #   geometry.hip        every handle: no packed-fp32 instructions (its kernels run once per step: no cost)
+#   gemm_bf16.hip, gemm_fp8p.hip, gemm_split.hip   the GEMMs of precision 1-3 handles (and the aggressors themselves): their epilogues held ~36 000 such
+#                       sites; without them the steps are FASTER (A/B on one box, round 6: fp32_split 26.02 -> 25.67 ms/step, bf16_fp8 9.29 -> 9.20 --
+#                       the guide's "packed f32 VALU beside MFMAs is an anti-lever"), so the flag costs less than nothing
 #   rowops.hip          built TWICE: rowops.o (packed; precision 0 handles and the stateless entry points: no aggressor beside them unless the
 #                       caller brings one, include/mmdm.h) and rowops_nopk.o (-DMMDM_ROWOPS_NOPK: the same kernels under *_nopk names, taken
 #                       by precision 1-3 handles: AdaLN, LayerNorm, cond SiLU, time mean, Influence head, MDM pack/unpack)
@@ -32,8 +35,9 @@ _HOST_PASS_NOISE = "'-packed-fp32-ops' is not a recognized feature for this targ
 UNITS = [
     ("mmdm.hip", "mmdm.o", []),
     ("gemm_f32.hip", "gemm_f32.o", []),
-    ("gemm_bf16.hip", "gemm_bf16.o", []),
-    ("gemm_split.hip", "gemm_split.o", []),
+    ("gemm_bf16.hip", "gemm_bf16.o", NO_PACKED_FP32_FLAGS),
+    ("gemm_fp8p.hip", "gemm_fp8p.o", NO_PACKED_FP32_FLAGS),
+    ("gemm_split.hip", "gemm_split.o", NO_PACKED_FP32_FLAGS),
     ("attn_f32.hip", "attn_f32.o", []),
     ("rowops.hip", "rowops.o", []),
     ("rowops.hip", "rowops_nopk.o", ["-DMMDM_ROWOPS_NOPK"] + NO_PACKED_FP32_FLAGS),
@@ -45,7 +49,7 @@ BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibili
 
 
 SHA_FILES = {"fp32": ("gemm_f32.hip", "mmdm.hip", "kernels.h"), "fp32_split": ("gemm_split.hip", "mmdm.hip", "kernels.h"),
-             "bf16": ("gemm_bf16.hip", "mmdm.hip", "kernels.h"), "bf16_fp8": ("gemm_bf16.hip", "mmdm.hip", "kernels.h")}
+             "bf16": ("gemm_bf16.hip", "mmdm.hip", "kernels.h"), "bf16_fp8": ("gemm_bf16.hip", "gemm_fp8p.hip", "gemm_fp8p.h", "mmdm.hip", "kernels.h")}
 
 _COMMENT_OR_STRING = re.compile(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\\n])*"|\'(?:\\.|[^\'\\\n])*\'', re.S)
 
@@ -91,6 +95,24 @@ def _object_stale(cmd, src, obj, hdrs):
     return any(os.path.getmtime(d) > os.path.getmtime(objp) for d in [os.path.join(CSRC, src)] + hdrs)
 
 
+_INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _headers(src=None):
+    """Headers an object depends on: the quoted includes of its source, followed recursively (csrc/*.h, include/mmdm.h)."""
+    if src is None:
+        return sorted({h for s_, _, _ in UNITS for h in _headers(s_)})
+    seen, todo = set(), [os.path.join(CSRC, src)]
+    while todo:
+        f = todo.pop()
+        for inc in _INCLUDE.findall(open(f, encoding="utf-8").read()):
+            h = os.path.normpath(os.path.join(os.path.dirname(f), inc))
+            if os.path.exists(h) and h not in seen:
+                seen.add(h)
+                todo.append(h)
+    return sorted(seen)
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -100,21 +122,19 @@ def needs_build():
     if any(os.path.getmtime(d) > t for d in deps):
         return True
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdrs = [os.path.join(CSRC, "kernels.h"), os.path.join(HERE, "..", "include", "mmdm.h")]
-    return any(_object_stale(_cmd(hipcc, s, o, x), s, o, hdrs) for s, o, x in UNITS)
+    return any(_object_stale(_cmd(hipcc, s, o, x), s, o, _headers(s)) for s, o, x in UNITS)
 
 
 def build(force=False, verbose=True, jobs=None):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdrs = [os.path.join(CSRC, "kernels.h"), os.path.join(HERE, "..", "include", "mmdm.h")]
     jobs = jobs or int(os.environ.get("MMDM_BUILD_JOBS", "8"))
     pending = []
     for src, obj, extra in UNITS:
         # -fvisibility=hidden: the shared library exports exactly what include/mmdm.h declares (its declarations sit inside a visibility pragma)
         cmd = _cmd(hipcc, src, obj, extra)
-        if force or _object_stale(cmd, src, obj, hdrs):
+        if force or _object_stale(cmd, src, obj, _headers(src)):
             pending.append((cmd, obj))
     running = []
 

@@ -18,6 +18,9 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "kernels.h"
+#include "gemm_fp8p.h"
+
+bool mmdm_diag_gemm_fp8p(const char* key, long long v);      // gemm_fp8p.hip
 
 namespace {
 
@@ -72,6 +75,10 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
 #define MMDM_BF16_TST_DEFAULT 1
 #endif
 int g_bf16_tst = MMDM_BF16_TST_DEFAULT;        // mmdm_diag_set "bf16_tst": 0 = the direct (row-per-lane) epilogue
+#ifndef MMDM_FP8P_DEFAULT
+#define MMDM_FP8P_DEFAULT 0
+#endif
+int g_fp8p = MMDM_FP8P_DEFAULT;                // mmdm_diag_set "fp8p": 1 = packed fp8 launches the persistent kernel covers (gemm_fp8p.hip) take it
 int g_bf16_lds_pad = 0;                        // mmdm_diag_set "bf16_lds_pad": extra dynamic LDS bytes per packed-W workgroup (occupancy experiments of tools/)
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -882,6 +889,7 @@ unsigned long long* g_bf16_tl = nullptr;
 
 int mmdm_gemm_bf16_init(void) {
     int rc;
+    if ((rc = mmdm_fp8p_init())) return rc;
     if ((rc = set_attr<22, 22>())) return rc;
     if ((rc = set_attr<42, 22>())) return rc;
     if ((rc = set_attr<42, 42>())) return rc;
@@ -906,6 +914,8 @@ bool mmdm_diag_gemm_bf16(const char* key, long long v) {
     if (!strcmp(key, "bf16_cfg")) g_bf16_cfg = (int)v;
     else if (!strcmp(key, "bf16_tst")) g_bf16_tst = (int)v;
     else if (!strcmp(key, "bf16_lds_pad")) g_bf16_lds_pad = (int)v;
+    else if (!strcmp(key, "fp8p")) g_fp8p = (int)v;
+    else if (!strncmp(key, "fp8p_", 5)) return mmdm_diag_gemm_fp8p(key, v);
     else if (!strcmp(key, "bf16_timeline")) g_bf16_tl = reinterpret_cast<unsigned long long*>((uintptr_t)v);
     else return false;
     return true;
@@ -1046,6 +1056,14 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
     a.tst = g_bf16_tst;
     if (bf16_copy && ((ld2 & 3) || (copy_cols & 3) || !al16(bf16_copy))) return mmdm_set_error(MMDM_ERR_UNSUPPORTED, "mmdm_linear_fp8: second output needs 8-byte aligned bf16 rows");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (packed && g_fp8p && !bf16_copy && a.tst && !a.tl) {
+        // the persistent form: a tile's epilogue under the next tile's K loop (gemm_fp8p.hip; bit-identical results)
+        Fp8pArgs q;
+        q.A = A; q.W = W; q.a_scale = a_scale; q.w_scale = w_scale; q.bias = bias; q.C = C; q.extra = extra;
+        q.lda = lda; q.ldc = ldc; q.ld_extra = ld_extra; q.M = M; q.N = N; q.K = K; q.epilogue = epilogue; q.period = a.period; q.out_mode = out_mode;
+        q.a_const = a_const; q.out_scale = out_scale; q.mt = q.nt = q.ntiles = 0; q.tl = nullptr;
+        if (mmdm_fp8p_covers(q)) return mmdm_fp8p_launch(q, st);
+    }
     if (packed) {
         // fp8 packed: 128 x 256 tiles (W fragments requested half a step ahead: gemm_bf16w_kernel, HALFB) for the large shards only -- measured
         // bf16_fp8 B = 64: 41.7 -> 41.0 ms/step, B = 16: 11.07 vs 11.08 (the shorter prefetch distance costs what the halved LDS reads

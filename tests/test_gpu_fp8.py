@@ -238,3 +238,54 @@ def test_packed_bf16_and_fp8_linear_are_bitwise_the_plane_kernels(M, N, K):
                 assert torch.equal(wide.view(it), want.view(it)), (epi, od, "128x256")
     with pytest.raises(Exception):
         ops.linear_bf16(xb, ops.pack_weight_frag(wb[:96].contiguous()), packed=True)       # N % 128
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 6: the persistent fp8 GEMM (gemm_fp8p.hip) -- a tile's epilogue under the next tile's K loop -- is bitwise the packed kernel
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,epi,od", [(19200, 3072, 1024, "bias", torch.bfloat16), (19200, 1024, 1024, "bias", torch.bfloat16),
+                                           (19200, 2048, 1024, "gelu", torch.float8_e4m3fn), (8192, 1024, 1024, "bias", torch.float8_e4m3fn),
+                                           (9344, 1152, 1024, "gelu", torch.bfloat16), (76800, 2048, 1024, "bias", torch.bfloat16)])
+def test_persistent_fp8_linear_is_bitwise_the_packed_kernel(M, N, K, epi, od):
+    """Same products in the same k order, same de-quantisation expression, activation and conversion: the persistent kernel's output equals
+    gemm_bf16w_kernel<1, .>'s bit for bit -- at the step's shapes (M = 19 200: 3600 / 1200 / 2400 tiles over 512 workgroups, i.e. uneven tile
+    counts per workgroup), at the smallest grid it takes (512 tiles: one tile per workgroup, nothing overlapped), at a tile count that is no
+    multiple of 8 (73 x 9 = 657: XCD ranges of unequal length) and at configs[4]'s 64-motion shard (M = 76 800).  Repeated launches are stable
+    (no stale LDS image / scale rows between tiles), also with a second launch of another shape in between."""
+    from mixermdm_amd._lib import load_library, diag
+    from mixermdm_amd import ops
+    lib = load_library()
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(d)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(d)
+    b = torch.randn(N, generator=g).to(d)
+    xq, xs = ops.quantize_rows_fp8(x)
+    wq, ws = ops.quantize_rows_fp8(w)
+    wp = ops.pack_weight_frag(wq)
+    ref = ops.linear_fp8(xq, xs, wp, ws, b, epi, None, out_dtype=od, packed=True)
+    assert "fp8w" in lib.mmdm_last_gemm_kernel().decode()
+    try:
+        diag("fp8p", 1)
+        for rep in range(3):
+            got = ops.linear_fp8(xq, xs, wp, ws, b, epi, None, out_dtype=od, packed=True)
+            assert lib.mmdm_last_gemm_kernel().decode().startswith("gemm_fp8p<"), lib.mmdm_last_gemm_kernel()
+            assert torch.equal(got.view(torch.uint8), ref.view(torch.uint8)), (rep, (got.float() - ref.float()).abs().max().item())
+            ops.linear_fp8(xq[:8192], xs[:8192], wp, ws, b, epi, None, out_dtype=od, packed=True)         # another tile walk in between
+        # a_const instead of per-row scales (the FFN's GELU tensor): same check
+        r2 = None
+        for on in (0, 1):
+            diag("fp8p", on)
+            o = torch.empty(M, N, device=d, dtype=od)
+            import ctypes as C
+            from mixermdm_amd._lib import check
+            check(lib.mmdm_linear_fp8_packed(C.c_void_p(xq.data_ptr()), K, C.c_void_p(0), C.c_void_p(wp.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_void_p(b.data_ptr()),
+                                             C.c_void_p(o.data_ptr()), N, {torch.bfloat16: 1, torch.float8_e4m3fn: 2}[od], M, N, K, ops.EPI[epi], C.c_void_p(0), 0, 0,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            if r2 is None:
+                r2 = o
+            else:
+                assert torch.equal(o.view(torch.uint8), r2.view(torch.uint8))
+    finally:
+        diag("fp8p", 0)

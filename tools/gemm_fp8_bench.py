@@ -37,4 +37,20 @@ for M,N,K,name,epi,od in shapes:
                 e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
             ms=statistics.median(res); line+=f" | {tag}{'-t' if tst else '-d'}: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:7.1f}TF"
     lib.mmdm_diag_set(b"bf16_tst", 1)
+    # the persistent kernel (gemm_fp8p.hip: the epilogue of tile i under tile i + 1's K loop), where it covers the shape: bitwise the packed kernel
+    if not ONLY or ONLY == "persist":
+        lib.mmdm_diag_set(b"fp8p", 1)
+        try:
+            f = lambda: ops.linear_fp8(xq, xs, wp, ws, b, epi, extra, out_dtype=od, packed=True)
+            o = f()
+            if lib.mmdm_last_gemm_kernel().decode().startswith("gemm_fp8p"):
+                if "packed" in ref and epi != "resid": assert torch.equal(o.view(torch.uint8), ref["packed"].view(torch.uint8)), f"persistent kernel changed bits: {name}"
+                res = []
+                for r in range(ITERS):
+                    e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e0.record()
+                    for _ in range(4): f()
+                    e1.record(); torch.cuda.synchronize(); res.append(e0.elapsed_time(e1)/4)
+                ms=statistics.median(res); line+=f" | persist: {ms*1e3:7.1f}us {2*M*N*K/ms/1e9:7.1f}TF"
+        finally:
+            lib.mmdm_diag_set(b"fp8p", 0)
     print(line, flush=True)
