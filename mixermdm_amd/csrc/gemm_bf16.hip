@@ -76,9 +76,13 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
 #endif
 int g_bf16_tst = MMDM_BF16_TST_DEFAULT;        // mmdm_diag_set "bf16_tst": 0 = the direct (row-per-lane) epilogue
 #ifndef MMDM_FP8P_DEFAULT
-#define MMDM_FP8P_DEFAULT 0
+#define MMDM_FP8P_DEFAULT 1
 #endif
-int g_fp8p = MMDM_FP8P_DEFAULT;                // mmdm_diag_set "fp8p": 1 = packed fp8 launches the persistent kernel covers (gemm_fp8p.hip) take it
+// mmdm_diag_set "fp8p": which packed fp8 launches take the persistent kernel (gemm_fp8p.hip: a tile's epilogue under the next tile's K loop; bit-identical).
+// 0 = none; 1 (default) = where it is measured faster -- the cross-attention projections (bf16 output, N <= 2048: 27.5 vs 29.4 us, 48.9 vs 50.4 us
+// at M = 19 200; QKV at N = 3072 is even at B = 16 and 4 % slower at M = 76 800, the GELU epilogue's VALU work loses inside one wave: LAB_NOTES.md round 6);
+// 2 = every shape it covers (tests, tools/gemm_fp8_bench.py)
+int g_fp8p = MMDM_FP8P_DEFAULT;
 int g_bf16_lds_pad = 0;                        // mmdm_diag_set "bf16_lds_pad": extra dynamic LDS bytes per packed-W workgroup (occupancy experiments of tools/)
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1062,7 +1066,7 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
         q.A = A; q.W = W; q.a_scale = a_scale; q.w_scale = w_scale; q.bias = bias; q.C = C; q.extra = extra;
         q.lda = lda; q.ldc = ldc; q.ld_extra = ld_extra; q.M = M; q.N = N; q.K = K; q.epilogue = epilogue; q.period = a.period; q.out_mode = out_mode;
         q.a_const = a_const; q.out_scale = out_scale; q.mt = q.nt = q.ntiles = 0; q.tl = nullptr;
-        if (mmdm_fp8p_covers(q)) return mmdm_fp8p_launch(q, st);
+        if (mmdm_fp8p_covers(q) && (g_fp8p >= 2 || (out_mode == 1 && N <= 2048 && epilogue == MMDM_EPI_BIAS))) return mmdm_fp8p_launch(q, st);
     }
     if (packed) {
         // fp8 packed: 128 x 256 tiles (W fragments requested half a step ahead: gemm_bf16w_kernel, HALFB) for the large shards only -- measured

@@ -36,13 +36,22 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int BM = 128, BN = 128, NW = 4, TM = 4, NKB = 4;
 constexpr int HALF = BM * 16, STAGE = 2 * HALF;        // 4-byte units: one 64-byte-row image of the tile's 128 rows; one stage = 128 operand bytes per row
-constexpr int NSTG = 3;
+#ifndef FP8P_DEEP
+#define FP8P_DEEP 0             // 1: the deeper request pipeline (measured, not faster: see step()); variant builds of tools/ only
+#endif
+constexpr bool DEEP = FP8P_DEEP != 0;
+constexpr int NSTG = DEEP ? 4 : 3;                     // A stages in LDS: the stage of step kt + NSTG - 1 is requested during step kt
 constexpr int NIA = 2 * (BM / 16) / NW;                // LDS-DMA pieces per wave and step (4)
 constexpr int NLB = NKB;                               // W fragment loads per wave and step (4)
 constexpr int NV = NIA + NLB;                          // operand requests of a step
-constexpr int IMG_BYTES = 32 * BN * 4;                 // the epilogue's image: 32 rows of the widest output form (fp32)
+constexpr int IMG_BYTES = 32 * BN * 2;                 // the epilogue's image: 32 rows of the widest output form covered (bf16)
 constexpr int SC_FLOATS = 3 * 128;                     // per tile: a_scale of its rows | w_scale | bias of its columns
-constexpr int SMEM_BYTES = NSTG * STAGE * 4 + IMG_BYTES + 2 * SC_FLOATS * 4;
+#ifdef FP8P_TL
+constexpr int TL_BYTES = (32 + 256) * 8;               // the stamps of the diagnostic build: 32 slots and a trash row
+#else
+constexpr int TL_BYTES = 0;
+#endif
+constexpr int SMEM_BYTES = NSTG * STAGE * 4 + IMG_BYTES + 2 * SC_FLOATS * 4 + TL_BYTES;
 
 __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {      // OCP e4m3, RNE, saturating at +-448 (as in gemm_bf16.hip)
     float c[4];
@@ -64,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
     constexpr int LPR = CPR, RPI = 64 / LPR;                      // R: lanes per row, rows per store instruction
     constexpr int NR = 8 / RPI;                                   // R: store instructions per wave and phase (a wave stores 8 of the phase's 32 rows)
     constexpr int SWM = CPR - 1 < 15 ? CPR - 1 : 15;
-    constexpr int NS = NR + (EXT ? NR : 0);                       // vector memory operations of an R chunk (stores, + residual loads), issued behind the step's counted wait
+    constexpr int NS = NR;                                        // the stores of an R chunk: what the next step's counted wait may leave in flight
     static_assert(8 % RPI == 0 && 32 * RB <= IMG_BYTES, "image geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const img = reinterpret_cast<char*>(smem + NSTG * STAGE);
@@ -106,16 +115,18 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p.W)), 0, 0xffffffff, 0x00020000);
     auto rsA_of = [&](int m0) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p.A)) + (size_t)m0 * p.lda, 0, 0xffffffff, 0x00020000); };
     auto voffW_of = [&](int n0) { return ((n0 >> 5) + wave) * (kbytes >> 5) * 1024 + lane * 16; };
-    auto stage = [&](int buf, __amdgpu_buffer_rsrc_t rs, int kt) {
-        const int koff = kt * 128;
-#pragma unroll
-        for (int u = 0; u < NIA; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + dstA[u] + buf * STAGE), 16, voffA[u], koff, 0, 0);
-    };
-    auto ldb = [&](int vw, int kt, bf16x8 (&b)[NKB]) {
+    // half a step of W fragments: k-blocks 2 h, 2 h + 1 of step kt -> b[2 h], b[2 h + 1]
+    auto ldbh = [&](int vw, int kt, int h, bf16x8 (&b)[NKB]) {
         const int so = kt * (NKB * 1024);
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) b[kb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, vw + kb * 1024, so, 0));
+        for (int kb = 2 * h; kb < 2 * h + 2; ++kb) b[kb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, vw + kb * 1024, so, 0));
+    };
+    // half a stage of A: pieces 2 h, 2 h + 1 of this wave
+    auto stageh = [&](int buf, __amdgpu_buffer_rsrc_t rs, int kt, int h) {
+        const int koff = kt * 128;
+#pragma unroll
+        for (int u = 2 * h; u < 2 * h + 2; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + dstA[u] + buf * STAGE), 16, voffA[u], koff, 0, 0);
     };
     const int sw = (l31 >> 2) & 3;
     const int a_row = l31 * 16;
@@ -198,19 +209,23 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
     const int sc_off1 = tid < 128 ? (p.a_scale ? tid : 0) : tid - 128, sc_dst1 = tid < 128 ? tid : tid + 128;
     v4i Tl[TM], Th[TM];                                       // the A fragments in flight: ONE set (k-blocks 0 | 1, then 2 | 3 of the step), refilled behind the MFMA that read it
     // ---- one K step.  POS: position in its group of 8; EPI: the previous tile's epilogue chunk of this position is issued; ZERO: the step's first
-    // MFMAs start the accumulators; XP: the extras of the PREVIOUS step (vector memory operations issued behind its counted wait) -- the
-    // counted wait leaves them and this step's requests in flight.
-    // On entry (Tl | Th) hold k-blocks 0 | 1 of stage `cur` and b the step's W fragments; each MFMA is followed by the two reads that refill ITS
-    // fragment pair -- k-blocks 2 | 3 behind the first group, k-blocks 0 | 1 of the next step's stage behind the second (behind the barrier that
-    // publishes that stage) -- so a fragment's LDS latency passes under the three other MFMAs of its group and one register set serves the loop.
-    auto step = [&](auto pos_c, auto epi_c, auto zero_c, auto xp_c, auto sc_c, f32x16 (&acc)[TM], const f32x16 (&accp)[TM], int cur, int nxt, int nn,
-                    int vw_b, int kt_b, __amdgpu_buffer_rsrc_t rs_s, int kt_s, int sc_m0, int sc_n0, int sc_par, bf16x8 (&b)[NKB], bf16x8 (&bn)[NKB]) {
+    // MFMAs start the accumulators; XP: the stores the PREVIOUS step issued last (its R chunk) -- the counted wait leaves them in flight.
+    // On entry (Tl | Th) hold k-blocks 0 | 1 of stage `cur` and b this step's W fragments.  Every MFMA is followed by the two reads that refill ITS A
+    // fragment pair (k-blocks 2 | 3 behind the first group, k-blocks 0 | 1 of the next stage behind the second, behind the barrier that publishes
+    // it) and by ONE operand request: a vector memory instruction costs its wave 60-180 issue cycles (MI355X_MICROARCH.md), so they go one per MFMA
+    // (eight in a row behind one MFMA: QKV 75.2 us; spread: 68.6 us against 70.8 of gemm_bf16w_kernel on the same box).  What is requested:
+    //   shipped (DEEP = 0): first group: the W fragments of step kt + 1 into the OTHER register set (bo); second group: stage kt + 2 of the
+    //      three-stage ring; the counted wait needs stage kt + 1, requested by step kt - 1's second group.
+    //   DEEP = 1: the W fragments a group has just consumed are re-requested for step kt + 2 INTO THE SAME REGISTERS (two per group: two steps to
+    //      arrive instead of one), stage kt + 3 of a four-stage ring (two pieces per group).  Built, bit-identical, and measured NO faster (QKV 72.4
+    //      vs 68.6 us, LAB_NOTES.md round 6): the loop does not wait for memory -- with all-zero operands (the same instruction stream at a
+    //      fraction of the matrix cores' power) either form runs 24 % faster: what bounds the real launch is the clock the power budget allows.
+    auto step = [&](auto pos_c, auto epi_c, auto zero_c, auto xp_c, auto sc_c, f32x16 (&acc)[TM], const f32x16 (&accp)[TM], int cur, int nxt, int nfill,
+                    int vw_b, int kt_b, __amdgpu_buffer_rsrc_t rs_s, int kt_s, int sc_m0, int sc_n0, int sc_par, bf16x8 (&b)[NKB], bf16x8 (&bo)[NKB]) {
         constexpr int POS = decltype(pos_c)::value;
         constexpr bool EPI = decltype(epi_c)::value != 0, ZERO = decltype(zero_c)::value != 0;
         constexpr int XP = decltype(xp_c)::value;
         constexpr int SC = decltype(sc_c)::value;                 // 1: this step requests the tile's scale / bias operands (two registers until ...); 2: ... this step parks them in LDS
-        ldb(vw_b, kt_b, bn);
-        stage(nn, rs_s, kt_s);
         if constexpr (EPI) {
             if constexpr ((POS & 1) == 0) epi_w(POS >> 1, accp[POS >> 1]);
             else epi_r_read();
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
             sc[sc_dst1] = sc_const ? p.a_const : sc1;                                              // a_scale[row t] | bias[column t - 128]
             sc[128 + (tid & 127)] = sc2;                                                           // w_scale (written twice with the same value)
         }
-        const v8i b01 = catb(b[0], b[1]), b23 = catb(b[2], b[3]);
+        const v8i b01 = catb(b[0], b[1]);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if constexpr (ZERO) {
@@ -231,28 +246,36 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
             Tl[i] = rda1(cur, 2, i);
             Th[i] = rda1(cur, 3, i);
         }
+        if constexpr (DEEP) { ldbh(vw_b, kt_b, 0, b); stageh(nfill, rs_s, kt_s, 0); }
+        else { ldbh(vw_b, kt_b, 0, bo); ldbh(vw_b, kt_b, 1, bo); }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+        for (int i = 0; i < TM; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV + XP) : "memory");            // the previous step's operand requests landed (its extras and this step's requests may be in flight)
+        // in flight behind the pieces of stage kt + 1: the previous step's stores and this group's 4 requests (DEEP: + the 8 requests of step kt - 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEEP ? NV : 0) + NV / 2 + XP) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // the step's EXTRAS -- the R chunk's stores (+ residual loads), the tile's scale / bias requests -- behind the wait: strictly younger than
-        // the step's operand requests (nothing moves across the asm statements above), which is what XP of the NEXT step counts on
-        if constexpr (SC == 1) {                                  // thread t: a_scale of row t (t < 128) or bias of column t - 128; w_scale of column t & 127
-            sc1 = sc_base1[(sc_rowsel ? sc_m0 : sc_n0) + sc_off1];  // (addresses selected, loads unconditional: a branch here would cut the step into blocks,
-            sc2 = p.w_scale[sc_n0 + (tid & 127)];                   //  and MFMAs sink across block boundaries -- and barriers -- to their first use)
-        }
-        if constexpr (EPI && (POS & 1)) epi_r_store(POS >> 1);
+        const v8i b23 = catb(b[2], b[3]);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b23, cat(Tl[i], Th[i]), acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
             Tl[i] = rda1(nxt, 0, i);
             Th[i] = rda1(nxt, 1, i);
         }
+        if constexpr (DEEP) { ldbh(vw_b, kt_b, 1, b); stageh(nfill, rs_s, kt_s, 1); }
+        else { stageh(nfill, rs_s, kt_s, 0); stageh(nfill, rs_s, kt_s, 1); }
+        // the step's EXTRAS, behind its requests: the tile's scale / bias operands, then -- pinned last, so that the next step's wait may count on them
+        // being younger than every request of this step -- the R chunk's stores
+        if constexpr (SC == 1) {                                  // thread t: a_scale of row t (t < 128) or bias of column t - 128; w_scale of column t & 127
+            sc1 = sc_base1[(sc_rowsel ? sc_m0 : sc_n0) + sc_off1];  // (addresses selected, loads unconditional: a branch here would cut the step into blocks,
+            sc2 = p.w_scale[sc_n0 + (tid & 127)];                   //  and MFMAs sink across block boundaries -- and barriers -- to their first use)
+        }
+        if constexpr (EPI && (POS & 1)) epi_r_store(POS >> 1);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 2, 1); }
+        for (int i = 0; i < TM; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 2, 1); __builtin_amdgcn_sched_group_barrier(0x020, 1, 1); }
+        __builtin_amdgcn_sched_group_barrier(0x020, 8, 1);        // (extras that READ: in no fixed order among the requests -- XP never counts them)
+        __builtin_amdgcn_sched_group_barrier(0x040, 8, 1);        // the stores: behind every read of this half step
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -264,7 +287,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
     // (cm0, cn0): this tile; (nm0, nn0): the next one (the last two steps request its first stages / fragments; a workgroup's last tile
     // re-requests its own -- valid addresses, never used).
     auto body = [&](f32x16 (&acc)[TM], const f32x16 (&accp)[TM], int cm0, int cn0, int cpar, int nm0, int nn0) {
-        constexpr int EPI = 1;
+#ifndef FP8P_EPI
+#define FP8P_EPI 1              // 0: experiment builds of tools/ only -- the K loops alone (no epilogue chunk under them; results wrong)
+#endif
+        constexpr int EPI = FP8P_EPI;
         constexpr int XP0 = NG == 1 ? NS : 0;                     // the previous body's last step issued an R chunk (the prologue drains its requests, so the first tile may wait loosely too)
         const __amdgpu_buffer_rsrc_t rsc = rsA_of(cm0), rsn = rsA_of(nm0);
         const int vwc = voffW_of(cn0), vwn = voffW_of(nn0);
@@ -276,10 +302,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
             // even / odd steps swap the fragment and W register sets (f0 <-> f2, b <-> bn)
 #define FP8P_STEP(POS, E, Z, XP, SC, B0, B1)                                                                                                           \
             {                                                                                                                                        \
-                const int c1 = cur == 2 ? 0 : cur + 1, c2 = c1 == 2 ? 0 : c1 + 1;                                                                     \
-                const bool nb = lastg && (POS) == 7, ns = lastg && (POS) >= 6;                                                                        \
-                step(IC<POS>{}, IC<E>{}, IC<Z>{}, IC<XP>{}, IC<SC>{}, acc, accp, cur, c1, c2, nb ? vwn : vwc, nb ? 0 : k0 + (POS) + 1,                 \
-                     ns ? rsn : rsc, ns ? (POS) - 6 : k0 + (POS) + 2, cm0, cn0, cpar, B0, B1);                                                         \
+                constexpr int DW = DEEP ? 2 : 1, DA = DEEP ? 3 : 2;                  /* steps ahead: W fragments, A stage */                          \
+                const int c1 = cur == NSTG - 1 ? 0 : cur + 1, cf = cur == 0 ? NSTG - 1 : cur - 1;       /* next stage; the one being refilled = cur + NSTG - 1 */ \
+                const bool nb = lastg && (POS) + DW >= 8, ns = lastg && (POS) + DA >= 8;        /* the NEXT tile's */                                    \
+                step(IC<POS>{}, IC<E>{}, IC<Z>{}, IC<XP>{}, IC<SC>{}, acc, accp, cur, c1, cf, nb ? vwn : vwc, nb ? (POS) + DW - 8 : k0 + (POS) + DW,   \
+                     ns ? rsn : rsc, ns ? (POS) + DA - 8 : k0 + (POS) + DA, cm0, cn0, cpar, B0, B1);                                                   \
                 cur = c1;                                                                                                                            \
             }
             if (g == 0) {
@@ -287,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
                 constexpr int X = E ? NS : 0;                                   // extras of an odd step of this group
                 FP8P_STEP(0, E, 1, XP0, 0, bx, by)
                 FP8P_STEP(1, E, 0, 0, 1, by, bx)
-                FP8P_STEP(2, E, 0, X + 2, 0, bx, by)
+                FP8P_STEP(2, E, 0, X, 0, bx, by)
                 FP8P_STEP(3, E, 0, 0, 2, by, bx)
                 FP8P_STEP(4, E, 0, X, 0, bx, by)
                 FP8P_STEP(5, E, 0, 0, 0, by, bx)
@@ -326,10 +353,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
     tile_mn(0, cm0, cn0);
     {
         const __amdgpu_buffer_rsrc_t rs0 = rsA_of(cm0);
-        stage(0, rs0, 0);
-        ldb(voffW_of(cn0), 0, bx);
-        stage(1, rs0, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (both stages: the first step's counted wait assumes an R chunk before it)
+        const int vw0 = voffW_of(cn0);
+#pragma unroll
+        for (int k = 0; k < NSTG - 1; ++k) { stageh(k, rs0, k, 0); stageh(k, rs0, k, 1); }   // the first stages (K >= 1024: at least 8 steps)
+        ldbh(vw0, 0, 0, bx); ldbh(vw0, 0, 1, bx);
+        if constexpr (DEEP) { ldbh(vw0, 1, 0, by); ldbh(vw0, 1, 1, by); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (everything: the first steps' counted waits assume a full pipeline behind them)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -337,6 +366,15 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
     }
     int j = 0, par = 0;
     tile_mn(1, nm0, nn0);
+#ifdef FP8P_TL              // diagnostic builds (tools/mk_variant.sh ... -DFP8P_TL; tools/fp8p_timeline.py): shader-clock stamps per tile, kept in LDS, dumped at the end
+    unsigned long long* const tls = reinterpret_cast<unsigned long long*>(scb + 2 * SC_FLOATS);
+    const unsigned long long t_r0 = __builtin_amdgcn_s_memrealtime();
+    FP8P_STAMP(0);
+    // (no branch: a divergent `if` in the loop cuts the step into blocks and the MFMAs sink to their uses -- every lane writes, lanes != 0 into a trash row)
+#define FP8P_STAMP(k) do { tls[tid == 0 ? ((k) < 30 ? (k) : 31) : 32 + tid] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FP8P_STAMP(k) do { } while (0)
+#endif
     auto advance = [&]() {                                               // the tile just computed becomes the one to store; false after the workgroup's last tile
         pm0 = cm0; pn0 = cn0; ppar = par; pvalid = true;
         ++j; par ^= 1;
@@ -347,8 +385,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
 #pragma nounroll
     for (;;) {
         body(accA, accB, cm0, cn0, par, nm0, nn0);
+        FP8P_STAMP(j + 1);
         if (!advance()) break;
         body(accB, accA, cm0, cn0, par, nm0, nn0);
+        FP8P_STAMP(j + 1);
         if (!advance()) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) accA[i] = accB[i];             // (once per workgroup: one drain for either parity)
@@ -356,6 +396,15 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8p_kernel(Fp8pArgs p) {
         }
     }
     drain(accA);
+#ifdef FP8P_TL
+    if (tid == 0 && p.tl) {
+        const unsigned long long t_r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = p.tl + 32 * (size_t)blockIdx.x;
+        for (int k = 0; k < 30; ++k) o[k] = k <= ntl ? tls[k] : 0;       // [0] start of the first tile's body, [k] end of tile k's body
+        o[30] = __builtin_readcyclecounter();                             // after the drain
+        o[31] = ((t_r1 - t_r0) << 32) | (unsigned)ntl;                    // 100 MHz ticks of the whole walk | tiles
+    }
+#endif
 #endif
 }
 
@@ -366,6 +415,7 @@ int launch_p(const Fp8pArgs& a, hipStream_t st, int grid) {
     return mmdm_check_launch("gemm_fp8p");
 }
 
+unsigned long long* g_fp8p_tl = nullptr;     // mmdm_diag_set "fp8p_timeline": 32 u64 per workgroup of the next launches (diagnostic build only)
 int g_fp8p_grid = 512;          // mmdm_diag_set "fp8p_grid": workgroups of a launch (a multiple of 8; two per CU by default)
 
 }  // namespace
@@ -392,6 +442,7 @@ int mmdm_fp8p_init(void) {
 
 int mmdm_fp8p_launch(Fp8pArgs a, hipStream_t st) {
     a.mt = a.M / 128; a.nt = a.N / 128; a.ntiles = a.mt * a.nt;
+    a.tl = g_fp8p_tl;
     const int grid = g_fp8p_grid;
     const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
     const bool gelu = a.epilogue == MMDM_EPI_BIAS_GELU;
@@ -402,6 +453,7 @@ int mmdm_fp8p_launch(Fp8pArgs a, hipStream_t st) {
 }
 
 bool mmdm_diag_gemm_fp8p(const char* key, long long v) {
+    if (!strcmp(key, "fp8p_timeline")) { g_fp8p_tl = reinterpret_cast<unsigned long long*>((uintptr_t)v); return true; }
     if (!strcmp(key, "fp8p_grid")) { if (v >= 8 && v <= 4096 && !(v & 7)) g_fp8p_grid = (int)v; return true; }
     return false;
 }

@@ -12,7 +12,7 @@ for p in sorted(glob.glob(out + "/pass*")):
     for f in glob.glob(p + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "gemm_bf16" not in k:
+            if "gemm_bf16" not in k and "gemm_fp8p" not in k:
                 continue
             key = (k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-48:], r["Grid_Size"])
             c = r["Counter_Name"]
@@ -30,6 +30,10 @@ for key, c in cnt.items():
         e["clock_ghz"] = round(cyc / (us * 1e3), 3)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in a and cyc:
         e["mfma_busy"] = round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc), 4)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in a and "SQ_BUSY_CYCLES" in a:
+        sq = a["SQ_BUSY_CYCLES"] / 32                  # per shader engine: the SQ's own busy cycles, shader clock domain (GRBM_GUI_ACTIVE reads high on short dispatches)
+        e["clock_ghz_sq"] = round(sq / (us * 1e3), 3)
+        e["mfma_busy_sq"] = round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * sq), 4)
     if "SQ_WAVE_CYCLES" in a:
         wc = a["SQ_WAVE_CYCLES"]
         e["wave_cycles"] = {k: round(a[k] / wc, 3) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS") if k in a}

@@ -63,8 +63,8 @@ for d in glob.glob(os.path.join(src, "pmc_*")):
                 per[k]["ns:" + r["Counter_Name"]].append(dur.get(r["Dispatch_Id"], ("", 0))[1])
 mean = lambda v: sum(v) / len(v) if v else None
 out = {"precision": prec, "kernel_sources_sha": sources_sha(prec), "note": "per-dispatch means over the profiled bench steps (eager launches, one stream); FETCH_SIZE / WRITE_SIZE in KB as "
-       "reported, fetch_bytes = 2 x FETCH_SIZE x 1024; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)", "kernels": {}}
-gemm = {"fetch": [], "write": [], "hit": [], "miss": [], "busy": [], "active": [], "ns": []}
+       "reported, fetch_bytes = 2 x FETCH_SIZE x 1024; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); mfma_busy_frac_sq = the same over SQ_BUSY_CYCLES / 32 shader engines (valid on short dispatches too: clock_ghz above 2.4 marks a dispatch on which the GRBM figure is not)", "kernels": {}}
+gemm = {"fetch": [], "write": [], "hit": [], "miss": [], "busy": [], "active": [], "ns": [], "sqbusy": []}
 for k, c in per.items():
     e = {"dispatches": len(c.get("GRBM_GUI_ACTIVE", c.get("FETCH_SIZE", c.get("WRITE_SIZE", []))))}
     if c.get("GRBM_GUI_ACTIVE"):
@@ -72,6 +72,13 @@ for k, c in per.items():
         e["avg_us"] = round(ns / 1e3, 1)
         e["clock_ghz"] = round(mean(c["GRBM_GUI_ACTIVE"]) / 8 / ns, 3)
         e["mfma_busy_frac"] = round(mean(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (1024 * mean(c["GRBM_GUI_ACTIVE"]) / 8), 4)
+        if c.get("SQ_BUSY_CYCLES"):
+            # the same busy cycles over the SQ's OWN busy cycles (summed over the 32 shader engines): both counters tick in the shader clock domain.
+            # GRBM_GUI_ACTIVE / 8 / duration reads high on short dispatches (MI355X_MICROARCH.md, DVFS give-back) -- 2.98 "GHz" on a 70 us fp8
+            # GEMM of 3600 workgroups, above the part's 2.4 GHz maximum -- and then understates the busy fraction by the same factor
+            sq = mean(c["SQ_BUSY_CYCLES"]) / 32
+            e["clock_ghz_sq"] = round(sq / ns, 3)
+            e["mfma_busy_frac_sq"] = round(mean(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (1024 * sq), 4)
     if c.get("FETCH_SIZE"):
         e["fetch_bytes"] = round(2 * 1024 * mean(c["FETCH_SIZE"]))
     if c.get("WRITE_SIZE"):
@@ -83,7 +90,7 @@ for k, c in per.items():
     out["kernels"][k] = e
     if k.startswith(DOMINANT):
         for nm, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("hit", "TCC_HIT_sum"), ("miss", "TCC_MISS_sum"), ("busy", "SQ_VALU_MFMA_BUSY_CYCLES"),
-                        ("active", "GRBM_GUI_ACTIVE"), ("ns", "ns:GRBM_GUI_ACTIVE")):
+                        ("active", "GRBM_GUI_ACTIVE"), ("ns", "ns:GRBM_GUI_ACTIVE"), ("sqbusy", "SQ_BUSY_CYCLES")):
             gemm[nm] += c.get(key, [])
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 if gemm["fetch"] and gemm["write"]:
@@ -98,6 +105,8 @@ if gemm["fetch"] and gemm["write"]:
            "traffic_bytes_per_launch": round(fetch + write), "l2_hit_rate": round(mean(gemm["hit"]) / (mean(gemm["hit"]) + mean(gemm["miss"])), 4) if gemm["hit"] else None,
            "mfma_busy_frac": round(sum(gemm["busy"]) / (1024 * sum(gemm["active"]) / 8), 4) if gemm["active"] else None,
            "clock_ghz": round(sum(gemm["active"]) / 8 / sum(gemm["ns"]), 3) if gemm["ns"] else None,
+           "mfma_busy_frac_sq": round(sum(gemm["busy"]) / (1024 * sum(gemm["sqbusy"]) / 32), 4) if gemm["sqbusy"] else None,
+           "clock_ghz_sq": round(sum(gemm["sqbusy"]) / 32 / sum(gemm["ns"]), 3) if gemm["sqbusy"] and gemm["ns"] else None,
            "hbm_side_TBps": round((fetch + write) / (sum(gemm["ns"]) / len(gemm["ns"])) / 1e3, 3) if gemm["ns"] else None,
            "note": "FETCH_SIZE includes Infinity-Cache hits (operand re-reads that miss the 4 MiB XCD L2)"}
     json.dump(rec, open(os.path.join(dst, "gemm_traffic.json"), "w"), indent=1)
