@@ -506,6 +506,9 @@ __device__ __forceinline__ void store_out(const AttnArgs& p, size_t idx, float y
 // (three v_mfma_f32_16x16x16_f16 per 16 columns), O = o / 2048 / l -- exact scalings.  fp32-accurate like the split GEMMs (the same argument:
 // representation error 2^-22 per operand, below the fp32 accumulation error of the 32x32x2 / 16x16x4 fp32 MFMA chains it replaces), at 36 short
 // MFMAs per 16-key chunk instead of 64 long ones.
+#ifndef QKP_TWO_CHAINS
+#define QKP_TWO_CHAINS 1              // (0: the four-chain form of rounds 2-5, for A/B builds: 55.7 vs 52.0 us at 64 x 8 x 300 x 128, 61.8 vs 60.8 at dh = 64)
+#endif
 template <int DH, int NP, bool PVB = false, bool H2 = false, bool RAG = false>
 __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {      // H2: four waves per SIMD (128 registers)
 #if defined(__HIP_DEVICE_COMPILE__)          // the buffer-resource type of the LDS-DMA builtin exists in the device pass only
@@ -649,6 +652,13 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
             st[0] = sa[0] + sa[1];
 #pragma unroll
             for (int r = 0; r < 4; ++r) st[0][r] = __builtin_fmaf(lo[r], MMDM_SPLIT_INV, st[0][r]);
+        } else if constexpr (NP == 1 && QKP_TWO_CHAINS) {
+            // one plane (the all-bf16 form of configs[4]): two accumulator chains (even / odd 32-deep steps: dependent MFMAs two apart, as in the H2 form)
+            // and ONE settle for both -- NS separate settles are 24 wait states each, 96 idle cycles of a chunk whose MFMAs take 128
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sa[s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][s], qf[0][s], sa[s & 1], 0, 0, 0);
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sa[0]), "+v"(sa[1]));
+            st[0] = sa[0] + sa[1];
         } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t)

@@ -1072,7 +1072,10 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
         // fp8 packed: 128 x 256 tiles (W fragments requested half a step ahead: gemm_bf16w_kernel, HALFB) for the large shards only -- measured
         // bf16_fp8 B = 64: 41.7 -> 41.0 ms/step, B = 16: 11.07 vs 11.08 (the shorter prefetch distance costs what the halved LDS reads
         // save) -- 128 x 128 otherwise (MMDM_BF16_CFG=12 / 13 force the wide / the narrow form)
-        const bool wide = (N & 255) == 0 && g_bf16_cfg != 11 && g_bf16_cfg != 13 && (g_bf16_cfg == 12 || (long)((M + 127) / 128) * (N / 256) >= 2400);
+        // (round 6: the GELU epilogue is VALU-bound -- ~30 instructions per element -- and the wide tile's two column tiles per wave halve the A-fragment
+        //  reads beside it: FFN-1 63.1 -> 59.6 us at M = 19 200 stand-alone, while QKV / CA-kv do not move: wide from 1200 tiles up for that epilogue)
+        const long wtiles = (long)((M + 127) / 128) * (N / 256);
+        const bool wide = (N & 255) == 0 && g_bf16_cfg != 11 && g_bf16_cfg != 13 && (g_bf16_cfg == 12 || wtiles >= 2400 || (epilogue == MMDM_EPI_BIAS_GELU && wtiles >= 1200));
         return wide ? launch_w<1, 2>(a, st) : launch_w<1, 1>(a, st);
     }
     switch (g_bf16_cfg) {

@@ -72,7 +72,10 @@ __device__ __forceinline__ float quick_gelu(float x) { return x * (1.0f / (1.0f 
 constexpr int MMDM_SPLIT_NPL = 2;
 constexpr float MMDM_SPLIT_SCALE = 2048.0f, MMDM_SPLIT_INV = 1.0f / 2048.0f;
 typedef _Float16 mmdm_h4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ _Float16 mmdm_split_hi(float x) { return (_Float16)x; }
+// (the empty asm keeps x a materialised fp32 value: without it the compiler may fuse the producer's last fma with this conversion into
+//  v_fma_mixlo_f16 -- ONE rounding of the exact fma result to fp16 instead of two -- and the hi plane of an epilogue then differs at exact fp16
+//  ties from the split of the same epilogue's fp32 output; seen once gemm_split.hip was built without packed-fp32 instructions, round 6)
+__device__ __forceinline__ _Float16 mmdm_split_hi(float x) { asm volatile("" : "+v"(x)); return (_Float16)x; }
 __device__ __forceinline__ _Float16 mmdm_split_lo(float x, _Float16 h) { return (_Float16)((x - (float)h) * MMDM_SPLIT_SCALE); }
 __device__ __forceinline__ void mmdm_split2(float x, _Float16& h, _Float16& l) { h = mmdm_split_hi(x); l = mmdm_split_lo(x, h); }
 __device__ __forceinline__ void mmdm_split2(const float (&x)[4], mmdm_h4& h, mmdm_h4& l) {

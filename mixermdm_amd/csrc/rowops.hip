@@ -22,11 +22,41 @@ inline namespace nopk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef MMDM_ROWOPS_NOPK
+// All-reduce over the wave WITHOUT the LDS (the second build only: the first keeps the bits of rounds 1-5).  __shfl_xor is a ds_bpermute: an LDS round
+// trip per butterfly step, six in sequence per reduction, and AdaLN makes two (three with the fp8 row maximum) per row -- the fp8 form ran at 4.45 TB/s
+// against the 5.7 of the two-reduction fp32 form although it moves fewer bytes.  Here: four DPP steps inside a 16-lane row (quad_perm 1032, quad_perm
+// 2301, row_half_mirror, row_mirror: a VALU modifier, no LDS) and gfx950's v_permlane16_swap / v_permlane32_swap across the four rows (attn_f32.hip).
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)); }
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp<0xB1>(v); v += dpp<0x4E>(v); v += dpp<0x141>(v); v += dpp<0x140>(v);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a = a + b; b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp<0xB1>(v)); v = fmaxf(v, dpp<0x4E>(v)); v = fmaxf(v, dpp<0x141>(v)); v = fmaxf(v, dpp<0x140>(v));
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a = fmaxf(a, b); b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+#else
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+#endif
 
 // out = LN(h) * (1 + scale) + shift ; one wave per row; row cached in registers (D <= 64*4*MAXV).
 // Reference: AdaLN.forward src/models/utils/layers.py:15-25 (LayerNorm eps 1e-6, biased variance, no affine).
@@ -86,8 +116,7 @@ __global__ __launch_bounds__(256, MAXV <= 4 ? 8 : 4) void adaln_kernel(const flo
                 amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i][0]), fabsf(v[i][1])), fmaxf(fabsf(v[i][2]), fabsf(v[i][3]))));
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        amax = wave_max(amax);
         const float scl = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f, inv = 1.0f / scl;
         if (lane == 0) row_scale[row] = scl;
 #pragma unroll

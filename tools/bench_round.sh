@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round bench lines (GPU box): every bench.py line profiles/README.md quotes, at HEAD.  Output: gpurun_out/bench_$TAG/*.json
 # (then: python tools/collect_bench.py $TAG, here).  usage: tools/bench_round.sh [tag, default r05]   (~22 minutes)
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=gpurun_out/bench_$TAG; rm -rf $O; mkdir -p $O
 # roofline.traffic needs the PMC traffic files of THESE sources: take them from a profile round that ran in the same call (tools/profile_round.sh)
 for pm in fp32: fp32_split:_fp32_split bf16_fp8:_bf16_fp8; do

@@ -2,7 +2,7 @@
 usage: python tools/collect_bench.py [round-tag, default r04]"""
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src, dst = os.path.join(ROOT, "gpurun_out", f"bench_{tag}"), os.path.join(ROOT, "profiles")
 for n in ("default", "single", "bf16", "bf16_fp8", "fp8_b64", "b32", "b32_split", "infer_b1", "infer_b15", "configs0"):
     f = os.path.join(src, n + ".json")

@@ -2,7 +2,7 @@
 usage: python tools/collect_profiles.py [round-tag, default r04]"""
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles")
 for n in ("serial", "overlap", "fp32_split_serial", "bf16_serial", "bf16_fp8_serial", "single_serial"):
     st = os.path.join(src, "summary", f"kernel_stats_{n}.csv")
@@ -24,7 +24,7 @@ for p in ("fp32", "fp32_split", "bf16_fp8"):
         out = os.path.join(dst, "gemm_traffic.json" if p == "fp32" else f"gemm_traffic_{p}.json")
         shutil.copy(os.path.join(sm, "gemm_traffic.json"), out)
         t = json.load(open(out))
-        print(f"traffic {p:11s} sha {t['kernel_sources_sha']}  {t['traffic_bytes_per_launch'] / 1e6:.0f} MB/launch  L2 hit {t['l2_hit_rate']}  MFMA busy {t.get('mfma_busy_frac')}  "
+        print(f"traffic {p:11s} sha {t['kernel_sources_sha']}  {t['traffic_bytes_per_launch'] / 1e6:.0f} MB/launch  L2 hit {t['l2_hit_rate']}  MFMA busy {t.get('mfma_busy_frac')} (sq {t.get('mfma_busy_frac_sq')}, sq clock {t.get('clock_ghz_sq')})  "
               f"clock {t.get('clock_ghz')} GHz  {t.get('hbm_side_TBps')} TB/s beyond L2")
 # the reference's own call shape (tools/profile_b1.sh): B = 1, T = 299, ddim50 through the facade
 b1 = os.path.join(ROOT, "gpurun_out", f"prof_b1_{tag}")
@@ -41,6 +41,16 @@ if os.path.exists(os.path.join(b1, "summary_fp32", "pmc_summary.json")):
     shutil.copy(os.path.join(b1, "summary_fp32", "pmc_summary.json"), os.path.join(dst, f"{tag}_pmc_infer_b1.json"))
     if os.path.exists(os.path.join(b1, "summary_fp32", "gemm_traffic.json")):
         shutil.copy(os.path.join(b1, "summary_fp32", "gemm_traffic.json"), os.path.join(dst, "gemm_traffic_b1t299.json"))
+# one ragged batch of the evaluation caller (tools/profile_ragged.sh)
+rg = os.path.join(ROOT, "gpurun_out", f"prof_ragged_{tag}")
+if os.path.exists(os.path.join(rg, "summary", "kernel_stats_serial.csv")):
+    shutil.copy(os.path.join(rg, "summary", "kernel_stats_serial.csv"), os.path.join(dst, f"{tag}_kernel_stats_ragged.csv"))
+    if os.path.exists(os.path.join(rg, "summary_pmc", "pmc_summary.json")):
+        shutil.copy(os.path.join(rg, "summary_pmc", "pmc_summary.json"), os.path.join(dst, f"{tag}_pmc_ragged.json"))
+    if os.path.exists(os.path.join(rg, "summary_pmc", "gemm_traffic.json")):
+        shutil.copy(os.path.join(rg, "summary_pmc", "gemm_traffic.json"), os.path.join(dst, "gemm_traffic_ragged.json"))
+        t = json.load(open(os.path.join(dst, "gemm_traffic_ragged.json")))
+        print(f"traffic ragged ({t.get('rows')} rows) sha {t['kernel_sources_sha']}  {t['traffic_bytes_per_launch'] / 1e6:.0f} MB/launch  L2 hit {t['l2_hit_rate']}  MFMA busy {t.get('mfma_busy_frac')} / sq {t.get('mfma_busy_frac_sq')}")
 # the stand-alone fp8 GEMM under the counters (tools/pmc_fp8.sh)
 f8 = os.path.join(ROOT, "gpurun_out", f"pmc_fp8_{tag}", "summary.txt")
 if os.path.exists(f8):

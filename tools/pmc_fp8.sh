@@ -2,7 +2,7 @@
 # PMC passes over the stand-alone fp8 GEMM bench (GPU box): what bounds gemm_bf16w_kernel<1, .> -- matrix-pipe busy and the wave-cycle
 # breakdown, the L1 -> L2 request rate (DESIGN 10.2's "L2 roof" as a number), LDS array cycles / bank conflicts.
 # usage: tools/pmc_fp8.sh [tag]      -> gpurun_out/pmc_fp8_$TAG/summary.json  (counters in their own runs beside --kernel-trace only)
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_fp8_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

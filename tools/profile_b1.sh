@@ -2,7 +2,7 @@
 # The reference's own call shape under the profiler (GPU box): B = 1, T = 299, ddim50 through the MixerMDM facade (src/scripts/infer/mixermdm.py:73,117-124) --
 # kernel trace (one stream: clean per-kernel durations) + PMC passes (matrix-pipe busy, HBM-side bytes).  Output: gpurun_out/prof_b1_$TAG/
 # usage: tools/profile_b1.sh [tag]     (then: python tools/collect_profiles.py picks the files up as profiles/${TAG}_*_infer_b1.*)
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_b1_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -2,7 +2,7 @@
 # Round profile (GPU box): kernel traces + PMC passes of the default bench workload at HEAD, for the headline fp32 mode and for the
 # fp32_split / bf16 / bf16_fp8 modes.  Output: gpurun_out/prof_$TAG/*  (then: python tools/collect_profiles.py $TAG, here).
 # usage: tools/profile_round.sh [tag, default r05]   (run from the repo root on the GPU box; ~10 minutes)
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
