@@ -778,6 +778,195 @@ __global__ __launch_bounds__(256, H2 ? 4 : 2) void attn_qkp_kernel(AttnArgs p) {
 #endif
 }
 
+// ---- the all-bf16 attention on 32-KEY chunks (round 6; configs[4]) -------------------------------------------------------------------------------------
+// attn_qkp_kernel<DH, 1, true> spends a 16-key chunk on 128 matrix-pipe cycles (4 Q K^T + 8 P.V short MFMAs) beside ~ 80 other instructions, one
+// s_waitcnt vmcnt(0) + barrier and two cross-row reductions: the matrix pipe is 23-29 % busy.  Here a chunk is 32 keys -- two 16 x 16 score tiles side by
+// side, ONE running-maximum / rescale / row-sum sequence and one barrier for both, and P.V on v_mfma_f32_16x16x32_bf16: the lane's eight probabilities
+// (keys 4g .. 4g+3 of tile 0 | of tile 1) against the two transposed V reads of the same keys -- the k index of the 32-deep MFMA is permuted identically on
+// both operands, so every product pairs the same key.  Same MFMA cycles per key, half the fixed work.  A last chunk whose second tile lies past Tk skips
+// that tile's score MFMAs (its probabilities are exact zeros).  Staging, swizzles, query ownership and output map as attn_qkp_kernel; results differ from
+// the 16-key form in the last bits (other rescale points, other summation order) -- the bf16 mode's stated accuracy, not a parity path.
+#ifndef B32_WAVES
+#define B32_WAVES 2
+#endif
+template <int DH, bool RAG = false>
+__global__ __launch_bounds__(256, B32_WAVES) void attn_b32_kernel(AttnArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    constexpr int KC2 = 32;
+    constexpr int NJ = DH / 16, NS = DH / 32;
+    constexpr int CPRK = DH / 8, RPPK = 64 / CPRK, NPK = KC2 / RPPK;       // 16-byte chunks per bf16 row, rows per 1-KiB DMA piece, pieces per operand
+    constexpr int NPIECE = 2 * NPK, NI = NPIECE / 4;
+    constexpr int PLANE = KC2 * DH / 2;                                    // floats per operand image (K or V)
+    constexpr int STAGE = 2 * PLANE;
+    static_assert(NPIECE % 4 == 0, "pieces divide over the four waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];          // [2 stages][K | V]
+
+    const int bid = blockIdx.x;
+    const int local = bid >> 3, xcd = bid & 7;
+    const int qt = local % p.qtiles;
+    int seq, head;
+    if (!pair_of<RAG>(p, xcd, local, seq, head)) return;
+    const int kvseq = (seq + p.shift) % p.nseq;
+    const SeqGeom G = seq_geom<RAG>(p, seq, kvseq);
+    if constexpr (RAG) { if (qt * QB >= G.Tq) return; }
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 15, g = lane >> 4;
+    const int q0 = qt * QB + wave * QW;
+
+    bf16x8 qf[NS];
+    {
+        int qrow = q0 + lq;
+        if (qrow >= G.Tq) qrow = G.Tq - 1;
+        const __bf16* qp = p.Qp + (G.qrow0 + qrow) * p.ldqp + head * DH + 8 * g;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 32 * s);
+    }
+    f32x4 o[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool nozero = (p.flags & MMDM_ATTN_NO_ZERO_KEY) != 0, causal = (p.flags & MMDM_ATTN_CAUSAL) != 0;
+    float m_run = nozero ? -INFINITY : 0.f, l_run = nozero ? 0.f : 1.f;
+
+    __amdgpu_buffer_rsrc_t rsp[NI];
+    int voff[NI], dsto[NI], rstep[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int pq = wave + 4 * u;                                   // wave-uniform
+        const bool isk = pq < NPK;
+        const int pp = isk ? pq : pq - NPK;
+        const int trow = RPPK * pp + lane / CPRK, pos = lane % CPRK;
+        const void* base; unsigned bytes;
+        if (isk) {
+            base = p.Kp + G.krow0 * p.ldkp + head * DH; bytes = (unsigned)(((size_t)(G.Tk - 1) * p.ldkp + DH) * 2);
+            voff[u] = (trow * p.ldkp + 8 * (pos ^ (trow & (CPRK - 1)))) * 2; rstep[u] = p.ldkp * 2;
+            dsto[u] = RPPK * pp * (DH / 2);
+        } else {
+            const int xv = DH == 128 ? (((trow & 3) << 2) | ((trow >> 2) & 3)) : (((trow >> 1) & 3) << 1);
+            base = p.Vp + G.krow0 * p.ldvp + head * DH; bytes = (unsigned)(((size_t)(G.Tk - 1) * p.ldvp + DH) * 2);
+            voff[u] = (trow * p.ldvp + 8 * (pos ^ xv)) * 2; rstep[u] = p.ldvp * 2;
+            dsto[u] = PLANE + RPPK * pp * (DH / 2);
+        }
+        rsp[u] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+    }
+    auto stage = [&](int c0, int buf) {
+#pragma unroll
+        for (int u = 0; u < NI; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsp[u], (lptr_t)(smem + buf * STAGE + dsto[u]), 16, voff[u], c0 * rstep[u], 0, 0);
+    };
+
+    int nchunks = (G.Tk + KC2 - 1) / KC2;
+    if (causal) {
+        const int last_q = min(qt * QB + QB - 1, G.Tq - 1);
+        nchunks = min(nchunks, last_q / KC2 + 1);
+    }
+    // transposed-read address of this lane inside a 16-key tile: row 4g + (lq >> 2), columns 16 j + 4 (lq & 3) .. + 3 (attn_qkp_kernel)
+    const int vrow = 4 * g + (lq >> 2), pp = lq & 3;
+    const int xv = DH == 128 ? (((vrow & 3) << 2) | ((vrow >> 2) & 3)) : (((vrow >> 1) & 3) << 1);      // (the same for row 16 + vrow)
+    stage(0, 0);
+    for (int cb2 = 0; cb2 < nchunks; cb2 += 2) {
+#pragma unroll
+      for (int cur = 0; cur < 2; ++cur) {
+        const int ci = cb2 + cur;
+        if (ci >= nchunks) break;
+        const int c0 = ci * KC2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ci + 1 < nchunks) stage(c0 + KC2, cur ^ 1);
+        const float* Ks = smem + cur * STAGE;
+        const char* Vs = reinterpret_cast<const char*>(Ks + PLANE);
+        if (q0 >= G.Tq) continue;                  // a wave with no query inside Tq keeps staging and the barriers, nothing else
+        const bool two = c0 + 16 < G.Tk;           // (wave-uniform) the second score tile holds at least one key
+        f32x4 sa[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
+        bf16x8 kf[2][NS];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                kf[t][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(&Ks[(16 * t + lq) * (DH / 2) + 4 * ((4 * s + g) ^ (lq & (CPRK - 1)))]));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sa[0][s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][s], qf[s], sa[0][s & 1], 0, 0, 0);
+        if (two) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sa[1][s & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][s], qf[s], sa[1][s & 1], 0, 0, 0);
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sa[0][0]), "+v"(sa[0][1]), "+v"(sa[1][0]), "+v"(sa[1][1]));
+        f32x4 st[2];
+        st[0] = (sa[0][0] + sa[0][1]) * p.scale2;
+        st[1] = (sa[1][0] + sa[1][1]) * p.scale2;
+        if (c0 + KC2 > G.Tk || (causal && c0 + KC2 - 1 > q0)) {
+            const int kmax = causal ? min(G.Tk - 1, q0 + lq) : G.Tk - 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + 16 * t + 4 * g + r > kmax) st[t][r] = -INFINITY;
+        }
+        float cmax = vmax(vmax3(st[0][0], st[0][1], st[0][2]), vmax3(st[0][3], st[1][0], vmax3(st[1][1], st[1][2], st[1][3])));
+        cmax = rows_max(cmax);
+        const float m_new = cmax > m_run + 8.0f ? cmax : m_run;         // deferred reference, as in attn_mfma_kernel
+        const float alpha = EXP2(m_run - m_new);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[t][r] = EXP2(st[t][r] - m_new);
+        float lsum = (((st[0][0] + st[0][1]) + st[0][2]) + st[0][3]) + (((st[1][0] + st[1][1]) + st[1][2]) + st[1][3]);
+        lsum = rows_sum(lsum);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {          // exact skip: x * 1.0f == x
+            float ar[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * g + r);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[j][r] *= ar[r];
+        }
+        const bf16x8 pa = {(__bf16)st[0][0], (__bf16)st[0][1], (__bf16)st[0][2], (__bf16)st[0][3], (__bf16)st[1][0], (__bf16)st[1][1], (__bf16)st[1][2], (__bf16)st[1][3]};
+        const char* vb0 = Vs + vrow * (DH * 2) + 8 * (pp & 1);
+        const char* vb1 = vb0 + 16 * (DH * 2);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int co = 16 * ((2 * j + (pp >> 1)) ^ xv);
+            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb0 + co));
+            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb1 + co));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 vb = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, __builtin_bit_cast(bf16x8, vb), o[j], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) MFMA_SETTLE(o[j]);
+    float lr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lr[r] = __shfl(l_run, 4 * g + r);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * g + r;
+        if (qrow >= G.Tq) continue;
+        const float inv = 1.0f / lr[r];
+        const size_t off = (G.qrow0 + qrow) * p.ldo + head * DH + lq;       // element (j, r) is column 16 j + lq of row 4g + r
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) store_out(p, off + 16 * j, o[j][r] * inv);
+    }
+#endif
+}
+
+int g_attn_kc32 = 1;          // mmdm_diag_set "attn_kc32": 0 = the 16-key form of rounds 2-5 for the all-bf16 attention (A/B, tests)
+
+template <int DH>
+int launch_b32(const AttnArgs& a, hipStream_t st) {
+    constexpr int smem_bytes = 2 * 2 * (32 * DH / 2) * 4;
+    if (a.seq_off) hipLaunchKernelGGL((attn_b32_kernel<DH, true>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), smem_bytes, st, a);
+    else hipLaunchKernelGGL((attn_b32_kernel<DH>), dim3(8 * a.pairs_per_xcd * a.qtiles), dim3(256), smem_bytes, st, a);
+    return mmdm_check_launch("attn_b32");
+}
+
 template <int DH, int NP, bool PVB = false, bool H2 = false>
 constexpr int qkp_smem() { return 2 * (NP * KC * DH / 2 + (PVB ? (H2 ? 2 : 1) * KC * DH / 2 : KC * DH)) * 4; }
 
@@ -1043,6 +1232,7 @@ int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const voi
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (nplanes == 3) return dh == 128 ? launch_qkp<128, 3>(a, st) : launch_qkp<64, 3>(a, st);
     if (nplanes == 2) return dh == 128 ? launch_qkp<128, 2, true, true>(a, st) : launch_qkp<64, 2, true, true>(a, st);
+    if (Vp && g_attn_kc32) return dh == 128 ? launch_b32<128>(a, st) : launch_b32<64>(a, st);
     if (Vp) return dh == 128 ? launch_qkp<128, 1, true>(a, st) : launch_qkp<64, 1, true>(a, st);
     return dh == 128 ? launch_qkp<128, 1>(a, st) : launch_qkp<64, 1>(a, st);
 }
@@ -1050,6 +1240,7 @@ int mmdm_attention_planes_ex(const void* Qp, int ldq, int64_t q_plane, const voi
 // diagnostics of this translation unit (mmdm_diag_set): ablation bits, in-kernel stamp buffer
 bool mmdm_diag_attn(const char* key, long long v) {
     if (!strcmp(key, "attn_ablate")) g_attn_ablate = (int)v;
+    else if (!strcmp(key, "attn_kc32")) g_attn_kc32 = (int)v;
     else if (!strcmp(key, "attn_stamps")) g_attn_stamps = reinterpret_cast<unsigned long long*>((uintptr_t)v);
     else return false;
     return true;

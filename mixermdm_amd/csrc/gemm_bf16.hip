@@ -76,12 +76,12 @@ __device__ __forceinline__ unsigned pack_fp8x4(f32x4 v) {
 #endif
 int g_bf16_tst = MMDM_BF16_TST_DEFAULT;        // mmdm_diag_set "bf16_tst": 0 = the direct (row-per-lane) epilogue
 #ifndef MMDM_FP8P_DEFAULT
-#define MMDM_FP8P_DEFAULT 1
+#define MMDM_FP8P_DEFAULT 0
 #endif
 // mmdm_diag_set "fp8p": which packed fp8 launches take the persistent kernel (gemm_fp8p.hip: a tile's epilogue under the next tile's K loop; bit-identical).
-// 0 = none; 1 (default) = where it is measured faster -- the cross-attention projections (bf16 output, N <= 2048: 27.5 vs 29.4 us, 48.9 vs 50.4 us
-// at M = 19 200; QKV at N = 3072 is even at B = 16 and 4 % slower at M = 76 800, the GELU epilogue's VALU work loses inside one wave: LAB_NOTES.md round 6);
-// 2 = every shape it covers (tests, tools/gemm_fp8_bench.py)
+// 0 (default) = none: stand-alone the kernel wins 3-5 % on the cross-attention projections (27.5 vs 29.4 us, 48.9 vs 50.4 us at M = 19 200), is even on QKV
+// and loses on the GELU epilogue -- and inside the two-stream step it is neutral at B = 16 (9.07 vs 9.06-9.10 ms/step) and costs 0.2 ms at B = 64
+// (tools/fp8_step_ab.py; LAB_NOTES.md round 6).  1 = the cross-attention projections (bf16 output, N <= 2048); 2 = every shape it covers (tests, tools/gemm_fp8_bench.py)
 int g_fp8p = MMDM_FP8P_DEFAULT;
 int g_bf16_lds_pad = 0;                        // mmdm_diag_set "bf16_lds_pad": extra dynamic LDS bytes per packed-W workgroup (occupancy experiments of tools/)
 
@@ -1072,10 +1072,9 @@ int mmdm_linear_fp8_ex(const void* A, int lda, const float* a_scale, const void*
         // fp8 packed: 128 x 256 tiles (W fragments requested half a step ahead: gemm_bf16w_kernel, HALFB) for the large shards only -- measured
         // bf16_fp8 B = 64: 41.7 -> 41.0 ms/step, B = 16: 11.07 vs 11.08 (the shorter prefetch distance costs what the halved LDS reads
         // save) -- 128 x 128 otherwise (MMDM_BF16_CFG=12 / 13 force the wide / the narrow form)
-        // (round 6: the GELU epilogue is VALU-bound -- ~30 instructions per element -- and the wide tile's two column tiles per wave halve the A-fragment
-        //  reads beside it: FFN-1 63.1 -> 59.6 us at M = 19 200 stand-alone, while QKV / CA-kv do not move: wide from 1200 tiles up for that epilogue)
-        const long wtiles = (long)((M + 127) / 128) * (N / 256);
-        const bool wide = (N & 255) == 0 && g_bf16_cfg != 11 && g_bf16_cfg != 13 && (g_bf16_cfg == 12 || wtiles >= 2400 || (epilogue == MMDM_EPI_BIAS_GELU && wtiles >= 1200));
+        // (round 6: for the GELU epilogue the wide tile is 5.5 % faster stand-alone at M = 19 200 -- 63.1 -> 59.6 us -- and SLOWER inside the two-stream step:
+        //  9.183 vs 9.14 ms/step, tools/fp8_step_ab.py on one box; the rule stays "large shards only")
+        const bool wide = (N & 255) == 0 && g_bf16_cfg != 11 && g_bf16_cfg != 13 && (g_bf16_cfg == 12 || (long)((M + 127) / 128) * (N / 256) >= 2400);
         return wide ? launch_w<1, 2>(a, st) : launch_w<1, 1>(a, st);
     }
     switch (g_bf16_cfg) {

@@ -862,6 +862,13 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
                 // the same order (bias + residual first, then k ascending), so a row's result does not depend on the tile that produced it.
                 const long t64 = (long)((M + 127) / 128) * ((N + 63) / 64);
                 if (t64 < 512) return launch_glds<21, 21, 16, 4, 1, 1>(a, st);
+                // Skinny M against a wide weight matrix -- the packed AdaLN projections of a step: M = 2B .. 4B conditioning rows, N = L x n_ada x 2D =
+                // 32 768 / 49 152 columns, 134 / 201 MB of fp32 weights read ONCE per step: a weight-streaming launch, not a matrix-pipe one.  The 128 x 128
+                // tile gives it 384 workgroups of 80 KB (two per CU) and multiplies padding rows: 158 us for M = 64, N = 49 152 with W cold (1.3 TB/s);
+                // 64 x 64 tiles (768 workgroups, 32 KB: five per CU, more bytes in flight) 79 us; 128 x 64 for 64 < M <= 256: 134 -> 110 us (M = 128),
+                // 258 -> 207 (M = 256).  Bit-identical like every tile choice (round 6; tools: a probe with W evicted between calls).
+                if (M <= 64 && N >= 4096) return launch_glds<21, 21, 16, 4, 1, 1>(a, st);
+                if (M <= 256 && N >= 4096) return launch_glds<22, 21, 16, 4, 1, 1>(a, st);
                 if (N <= 512 || K <= 512 || N == 2048) return launch_glds<22, 21, 16, 4, 1, 1>(a, st);
                 return launch_glds<22, 22, 16, 5, 1, 1>(a, st);
             }

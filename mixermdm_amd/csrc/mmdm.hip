@@ -92,7 +92,7 @@ extern "C" int mmdm_diag_set(const char* key, long long value) {
     if (mmdm_diag_gemm_f32(key, value) || mmdm_diag_gemm_bf16(key, value) || mmdm_diag_gemm_split(key, value) || mmdm_diag_attn(key, value)) return MMDM_OK;
     return mmdm_set_error(MMDM_ERR_ARG, "mmdm_diag_set: unknown key \"%s\"", key);
 }
-extern "C" const char* mmdm_version(void) { return "gfx950;mmdm-hip r5"; }
+extern "C" const char* mmdm_version(void) { return "gfx950;mmdm-hip r6"; }
 
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \

@@ -289,4 +289,4 @@ def test_persistent_fp8_linear_is_bitwise_the_packed_kernel(M, N, K, epi, od):
             else:
                 assert torch.equal(o.view(torch.uint8), r2.view(torch.uint8))
     finally:
-        diag("fp8p", 1)
+        diag("fp8p", 0)

@@ -23,7 +23,12 @@ for nseq, T, H, dh in [(64, 300, 8, 128), (128, 300, 8, 64), (256, 300, 8, 128),
     fl = 4.0 * nseq * H * T * (T + 1) * dh
     rows = [("fp32 16x16x4", lambda: ops.attention(q, k, v, H), 0), ("QK^T 3 planes", lambda: ops.attention_planes(qp3, kp3, v, H), 0),
             ("QK^T 1 plane", lambda: ops.attention_planes(qp1, kp1, v, H), 0)]
-    rows.append(("all-bf16", lambda: ops.attention_bf16(qb[..., :HD], qb[..., HD:2 * HD], qb[..., 2 * HD:], H), 0))
+    def bf16_16():
+        lib.mmdm_diag_set(b"attn_kc32", 0)
+        try: return ops.attention_bf16(qb[..., :HD], qb[..., HD:2 * HD], qb[..., 2 * HD:], H)
+        finally: lib.mmdm_diag_set(b"attn_kc32", 1)
+    rows.append(("all-bf16, 16-key chunks", bf16_16, 0))
+    rows.append(("all-bf16, 32-key chunks", lambda: ops.attention_bf16(qb[..., :HD], qb[..., HD:2 * HD], qb[..., 2 * HD:], H), 0))
     rows.append(("fp16 split", lambda: ops.attention_split(qs[..., :HD], qs[..., HD:2 * HD], qs[..., 2 * HD:], H), 0))
     for name, fn, _ in rows:
         ms = timeit(fn)

@@ -9,6 +9,7 @@ for pm in fp32: fp32_split:_fp32_split bf16_fp8:_bf16_fp8; do
   [ -f $f ] && cp $f profiles/gemm_traffic${pm##*:}.json
 done
 f=gpurun_out/prof_b1_$TAG/summary_fp32/gemm_traffic.json; [ -f $f ] && cp $f profiles/gemm_traffic_b1t299.json       # tools/profile_b1.sh of the same call
+f=gpurun_out/prof_ragged_$TAG/summary_pmc/gemm_traffic.json; [ -f $f ] && cp $f profiles/gemm_traffic_ragged.json        # tools/profile_ragged.sh of the same call
 Q="--no-cpu-baseline --no-alt --no-side --no-full-loop"
 python bench.py > $O/default.json 2> $O/default.err                                    # the driver's command: headline + fp32_split + full loop + CPU port
 python bench.py --workload single $Q > $O/single.json 2> $O/single.err                  # configs[1]

@@ -28,4 +28,4 @@ for M, N, K, epi, od in [(19200, 3072, 1024, "bias", torch.bfloat16), (19200, 10
     mhz = (100.0 * total / ticks.clamp(min=1)).median().item()
     print(f"{M}x{N}x{K} {epi} grid {grid}: tiles per workgroup {int(ntl.min())}-{int(ntl.max())}; first tile {first.median():.0f} clk, steady tile {steady.median():.0f} clk (p10 {steady.quantile(.1):.0f}, p90 {steady.quantile(.9):.0f}; "
           f"matrix pipe alone: 4096 per wave), drain {drain.median():.0f} clk; walk {total.median():.0f} clk = {ticks.median() / 100:.1f} us at {mhz:.0f} MHz", flush=True)
-lib.mmdm_diag_set(b"fp8p", 1)
+lib.mmdm_diag_set(b"fp8p", 0)

@@ -151,7 +151,8 @@ elif os.environ.get("MODE") == "gemm_aggr":
 elif os.environ.get("MODE") == "canary":
     # tools/canary.hip beside B's step: known values held in LDS / registers / global memory / an LDS-DMA image, re-checked for a few ms
     import ctypes as C
-    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", os.environ.get("CANARY_LIB", "libcanary.so")))
+    _cl = os.environ.get("CANARY_LIB", "libcanary.so")          # a file name under build/ (not shipped to the GPU box by gpurun) or a path (e.g. variants/libcanary.so)
+    lib = C.CDLL(_cl if os.sep in _cl else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", _cl))
     side = torch.cuda.Stream()
     nwg = int(os.environ.get("CANARY_WG", "512")); lds = int(os.environ.get("CANARY_LDS", "32768")); spin = int(os.environ.get("CANARY_US", "5000"))
     report = torch.zeros(80, dtype=torch.int32, device="cuda"); gbuf = torch.zeros(nwg * 4096, dtype=torch.int32, device="cuda")
