@@ -439,3 +439,42 @@ def test_evaluation_harness_batching_modes_agree(model):
             assert np.array_equal(a["motion1"], b["motion1"]) and np.array_equal(a["motion2"], b["motion2"])
         for a, b in zip(runs["sequential"][1], runs[batching][1]):
             assert np.array_equal(a["mm_motions"], b["mm_motions"])
+
+
+def test_serialize_handles_switch_runs_and_keeps_the_bits():
+    """MMDM_SERIALIZE_HANDLES=1 (read by the first mmdm_create of a process: a child process here): every sampling call waits on the device for the
+    previous one of any handle; results are the sequential ones, as without the switch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from mixermdm_amd.sampler import Sampler
+from mixermdm_amd.synthetic import synthetic_state_dict, synthetic_stats
+DIMS = dict(d_latent=128, d_ff=256, d_layers=2, m_latent=128, m_ff=256, m_layers=2)
+sd = synthetic_state_dict(seed=7, std=0.05, bias_std=0.02, **DIMS); st = synthetic_stats()
+def make(prec):
+    s = Sampler(d_heads=2, m_heads=2, max_batch=2, max_frames=64, precision=prec, **DIMS)
+    s.load_state_dict(sd); s.set_norm_stats(st["mean_hml"], st["std_hml"], st["mean_ih"], st["std_ih"]); s.prepare(); s.set_schedule("ddim20")
+    return s
+a, b = make("fp32"), make("fp32_split")
+items = []
+for i, T in enumerate((40, 17, 64, 33)):
+    g = torch.Generator().manual_seed(300 + i)
+    items.append((torch.randn(1, 8 * 768, generator=g).cuda(), torch.randn(1, T, 524, generator=g).cuda()))
+pool = [a, b]
+ref = [pool[i %% 2].sample(c, x) for i, (c, x) in enumerate(items)]
+for rnd in range(2):
+    outs = [torch.empty_like(x) for _, x in items]
+    torch.cuda.synchronize()
+    for i, (c, x) in enumerate(items):
+        pool[i %% 2].enqueue(c, x, outs[i])
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, r) for o, r in zip(outs, ref)), rnd
+print("SERIAL_OK")
+''' % root
+    env = dict(os.environ, MMDM_SERIALIZE_HANDLES="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "SERIAL_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
