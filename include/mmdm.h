@@ -19,6 +19,8 @@
  *   MMDM_NO_OVERLAP=1    mmdm_create: run the two denoisers and the two Influence calls of a step on ONE stream (profiling passes:
  *                        a kernel trace without concurrent kernels); results are bit-identical either way.
  *   MMDM_NO_SPLIT_EMBED=1  precision 1-3: keep motion_embed on the fp32 MFMA kernel instead of the fp32-split kernel (A/B timing and accuracy)
+ *   MMDM_NO_SPLIT_COND=1   precision 1-3: keep the AdaLN conditioning projections (silu(time + text) against [L*n_ada*2D, D]) on the fp32 MFMA kernel
+ *                        instead of the fp32-split kernel (A/B timing and accuracy)
  *   MMDM_GRAPH_CACHE=n   mmdm_create: capacity (1..64, default 8) of the handle's (B, T, S)-keyed cache of captured step graphs.
  *   MMDM_RAG_BUCKET=n    mmdm_create: row granularity (1..4096, default 128) to which a ragged call's group of frames is padded (mmdm_begin_ragged).
  *   MMDM_SERIALIZE_HANDLES=1  the first mmdm_create of the process: every sampling call (mmdm_run) waits ON THE DEVICE for the previous sampling call
@@ -316,11 +318,12 @@ typedef struct {
                         *    the AdaLN kernel, GELU outputs at unit scale -- fp32 accumulation and de-quantisation (mmdm_linear_fp8); the
                         *    attention output projections stay bf16
                         * RANGE PRECONDITION of precision 1, 2 and 3: some GEMM operands are carried in fp16 planes (precision 2: every operand of the
-                        *    transformer stacks -- AdaLN outputs, Q|K|V, attention outputs, GELU hidden; precision 1 and 3: the pose rows entering
-                        *    motion_embed, which run on the fp32-split kernel), so those values must satisfy |x| < 65504.  A larger pose or activation
+                        *    transformer stacks -- AdaLN outputs, Q|K|V, attention outputs, GELU hidden; precision 1, 2 and 3: the pose rows entering
+                        *    motion_embed and the conditioning rows silu(time + text) entering the AdaLN projections, which run on the fp32-split
+                        *    kernel), so those values must satisfy |x| < 65504.  A larger pose or activation
                         *    value becomes inf and then NaN in whole output rows (loud, never silently wrong); nothing clamps or checks at the boundary.
-                        *    Poses in the models' normalised space are O(10); precision 0 has no such limit.  MMDM_NO_SPLIT_EMBED=1 keeps the embedding
-                        *    of precision 1 / 3 handles on the fp32 MFMA kernel (no range limit there). */
+                        *    Poses in the models' normalised space are O(10); precision 0 has no such limit.  MMDM_NO_SPLIT_EMBED=1 / MMDM_NO_SPLIT_COND=1 keep
+                        *    the embedding / the conditioning projections of precision 1 / 3 handles on the fp32 MFMA kernel (no range limit there). */
     int model1_kind;   /* 0 = in2IN individual denoiser, 1 = MDMDenoiser (post-norm nn.TransformerEncoder with a conditioning token,
                         *    src/models/mdm.py:234-298; MODEL1.NAME == "MDM", src/models/mixermdm.py:32-40, 264-265).  Its cond slices are
                         *    latent-sized (mdm.py:279), so the mixer's cond rows are [3*text_dim | 2*d1_latent | 3*text_dim] */

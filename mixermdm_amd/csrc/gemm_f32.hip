@@ -658,6 +658,206 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small launches: the same accumulation chains on 16 x 16 blocks (v_mfma_f32_16x16x4_f32).
+//
+// An fp32 MFMA accumulator is ONE k-ordered chain of fused multiply-adds (tools/mfma_chain_bits.hip: 32x32x2, 16x16x4 and a scalar fmaf
+// chain over the same k order agree in every bit), and a chain keeps its SIMD's matrix pipe busy by itself -- so a launch lasts
+// ceil(chains / 1024 SIMDs) chain lengths whatever its tiling.  With 32 x 32 blocks the reference's own call (B = 1:
+// M = 1196 rows) has 1216 chains at N = 1024: two rounds on 1024 pipes, the second 19 % full.  A 16 x 16 block is a quarter of the chain
+// (32 cycles per 4 k instead of 64 per 2 k on 4x the outputs): 4800 chains = 4.7 -> 5 rounds of a quarter of the length.  This kernel
+// walks k in the production order (group g of 8 k: 8g, 8g+4, 8g+1, 8g+5 | 8g+2, 8g+6, 8g+3, 8g+7 -- what lane half h = k-slot h of the
+// 32x32x2 operands gives), starts the accumulators as the bias and adds the residual / PE row after the loop like the pipelined
+// 16-byte epilogue form: every output element is bit-identical to the production kernels'.
+//
+// Workgroup: 32 x (32 TN16) outputs, four waves as 2 x 2, each 16 rows x TN16 blocks of 16 columns; operands swapped (D^T = W A^T) so a lane
+// owns an output row and four consecutive columns.  K step 32 through an NBUF-stage LDS-DMA ring (one barrier per step; the request of
+// tile kt + NBUF - 1 follows the barrier of step kt; surplus requests of the last steps re-read the last tile into a free stage, so the
+// counted vmcnt stays a compile-time number).  128-byte LDS rows, 16-byte chunk c of row r at position c ^ ((r >> 1) & 7).
+// ---------------------------------------------------------------------------------------------------------
+template <int TN16_, int NBUF_>
+struct S16Cfg {
+    static constexpr int TN16 = TN16_, NBUF = NBUF_;
+    static constexpr int BM = 32, BN = 32 * TN16, BK = 32, NWAVES = 4, THREADS = 256;
+    static constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK;
+    static constexpr int SMEM_BYTES = NBUF * (A_FLOATS + B_FLOATS) * 4;
+    static constexpr int NA = BM / 8, NB = BN / 8, NI = (NA + NB) / NWAVES;       // 1-KiB pieces: 8 rows of 128 bytes
+    static_assert(NA % NWAVES == 0 && NB % NWAVES == 0, "pieces must divide evenly over the waves");
+};
+
+template <int TN16_, int NBUF_, bool LATE>
+__global__ __launch_bounds__(256) void gemm_s16_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C_ = S16Cfg<TN16_, NBUF_>;
+    constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TN = C_::TN16, NBUF = C_::NBUF, NI = C_::NI, UA = C_::NA / C_::NWAVES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                   // [NBUF][BM*BK]
+    float* Bs = smem + NBUF * C_::A_FLOATS;             // [NBUF][BN*BK]
+    const int nwg = p.mt * p.nt;
+    const int bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int m0 = (swz / p.nt) * BM;
+    const int n0 = (swz % p.nt) * BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, q = lane >> 4;
+
+    int voff[NI], dst[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int pq = wave + C_::NWAVES * u;
+        const int prow = lane >> 3, pc = lane & 7;
+        const bool isa = u < UA;
+        const int trow = 8 * (isa ? pq : pq - C_::NA) + prow;
+        const int gch = pc ^ ((trow >> 1) & 7);
+        if (isa) {
+            const int rel = min(trow, p.M - 1 - m0);                            // rows past M re-read the last row (never stored)
+            voff[u] = (rel * p.lda + 4 * gch) * 4;
+            dst[u] = 8 * pq * BK;
+        } else {
+            const int rel = min(trow, p.N - 1 - n0);
+            voff[u] = (rel * p.ldw + 4 * gch) * 4;
+            dst[u] = NBUF * C_::A_FLOATS + 8 * (pq - C_::NA) * BK;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + (size_t)m0 * p.lda), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W + (size_t)n0 * p.ldw), 0, 0xffffffff, 0x00020000);
+    const int nkt = p.K / BK;
+    auto stage = [&](int buf, int kt) {
+        const int koff = min(kt, nkt - 1) * (BK * 4);
+#pragma unroll
+        for (int u = 0; u < NI; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(u < UA ? rsA : rsW, (lptr_t)(smem + dst[u] + buf * (u < UA ? C_::A_FLOATS : C_::B_FLOATS)), 16, voff[u], koff, 0, 0);
+    };
+
+    // accumulators start as the bias; the residual / PE quads are requested here too (the oldest loads: the loop's counted waits cover them)
+    const int row = m0 + wm * 16 + r;
+    const int colw = n0 + wn * (16 * TN) + 4 * q;
+    f32x4 acc[TN], rv[LATE ? TN : 1];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = colw + 16 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (col < p.N && p.bias) v = *reinterpret_cast<const f32x4*>(p.bias + col);
+        acc[j] = v;
+        if constexpr (LATE) {
+            const int er = p.epilogue == MMDM_EPI_BIAS_PE ? row % p.period : row;
+            const int rr = row < p.M ? er : 0, cc = col < p.N ? col : 0;         // past the edge: a valid address, never stored
+            rv[j] = *reinterpret_cast<const f32x4*>(p.extra + (size_t)rr * p.ld_extra + cc);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t) stage(t, t);
+
+    const int sw = (r >> 1) & 7;                       // every tile row of this lane is r mod 16
+    const int a_row = (wm * 16 + r) * BK;
+    const int b_row = (wn * (16 * TN) + r) * BK;
+    int cur = 0, stg = NBUF - 1;
+    for (int kt = 0; kt < nkt; ++kt) {
+        wait_vm<(NBUF - 2) * NI>();                    // tile kt has landed (in-order retirement; NI requests per stage, surplus ones included)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // ... for every wave, and every wave is done with stage (kt - 1) % NBUF
+        stage(stg, kt + NBUF - 1);
+        // k-slot q of a group's first MFMA: 8g + {0, 4, 1, 5}[q] = element (q >> 1) of chunk 2g + (q & 1); of its second: element 2 + (q >> 1) -- two
+        // dwords 8 bytes apart per operand row (one ds_read2_b32: a 16-byte fragment read per lane would move twice the bytes a 16 x 16 block
+        // can use, and four waves of them fill the CU's LDS port); a step's fragments are requested together, ahead of its MFMAs
+        const float* Ac = As + cur * C_::A_FLOATS + a_row + (q >> 1);
+        const float* Bc = Bs + cur * C_::B_FLOATS + b_row + (q >> 1);
+        float fa[BK / 8][2], fb[BK / 8][TN][2];
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            const int cg = 4 * ((2 * g + (q & 1)) ^ sw);
+            fa[g][0] = Ac[cg]; fa[g][1] = Ac[cg + 2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { fb[g][j][0] = Bc[j * 16 * BK + cg]; fb[g][j][1] = Bc[j * 16 * BK + cg + 2]; }
+        }
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[g][j][0], fa[g][0], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[g][j][1], fa[g][1], acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, (BK / 8) * (1 + TN), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, (BK / 8) * 2 * TN, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur + 1 == NBUF ? 0 : cur + 1;
+        stg = stg + 1 == NBUF ? 0 : stg + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus requests of the last steps
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[j]));
+
+    const int rows_here = min(p.M - m0, BM);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + (size_t)m0 * p.ldc, 0, rows_here * p.ldc * 4, 0x00020000);
+    const int voffC = (wm * 16 + r) * p.ldc * 4 + (colw - n0) * 4 + n0 * 4;
+    auto finish = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t = acc[j][c];
+                if constexpr (LATE) t += rv[j][c];
+                if constexpr (ACT == MMDM_EPI_BIAS_GELU) t = gelu_erf(t);
+                else if constexpr (ACT == MMDM_EPI_BIAS_SILU) t = silu(t);
+                else if constexpr (ACT == MMDM_EPI_BIAS_QUICKGELU) t = quick_gelu(t);
+                else if constexpr (ACT == MMDM_EPI_BIAS_SIGMOID) t = sigmoidf(t);
+                v[c] = t;
+            }
+            if (colw + 16 * j < p.N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, voffC + 64 * j, 0, 0);
+        }
+    };
+    if constexpr (LATE) {
+        finish(std::integral_constant<int, MMDM_EPI_BIAS>{});
+    } else {
+        switch (p.epilogue) {
+            case MMDM_EPI_BIAS_GELU: finish(std::integral_constant<int, MMDM_EPI_BIAS_GELU>{}); break;
+            case MMDM_EPI_BIAS_SILU: finish(std::integral_constant<int, MMDM_EPI_BIAS_SILU>{}); break;
+            case MMDM_EPI_BIAS_QUICKGELU: finish(std::integral_constant<int, MMDM_EPI_BIAS_QUICKGELU>{}); break;
+            case MMDM_EPI_BIAS_SIGMOID: finish(std::integral_constant<int, MMDM_EPI_BIAS_SIGMOID>{}); break;
+            default: finish(std::integral_constant<int, MMDM_EPI_BIAS>{}); break;
+        }
+    }
+#endif
+}
+
+// what the 16-byte accesses of gemm_s16_kernel need (every epilogue: bias quads, result quads; residual / PE rows)
+inline bool s16_ok(const GemmArgs& a) {
+    const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
+    return (a.N & 3) == 0 && (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 && (a.K & 31) == 0 && a.Kw == a.K &&
+           (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
+           (!ext || ((a.ld_extra & 3) == 0 && (reinterpret_cast<uintptr_t>(a.extra) & 15) == 0));
+}
+
+template <int TN16_, int NBUF_>
+int launch_s16(GemmArgs a, hipStream_t st) {
+    using C_ = S16Cfg<TN16_, NBUF_>;
+    a.mt = (a.M + C_::BM - 1) / C_::BM;
+    a.nt = (a.N + C_::BN - 1) / C_::BN;
+    const bool late = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
+    mmdm_note_gemm("gemm_s16<%d,%d,%s>", TN16_, NBUF_, late ? "late" : "plain");
+    const dim3 grid(a.mt * a.nt), block(C_::THREADS);
+    if (late) hipLaunchKernelGGL((gemm_s16_kernel<TN16_, NBUF_, true>), grid, block, C_::SMEM_BYTES, st, a);
+    else hipLaunchKernelGGL((gemm_s16_kernel<TN16_, NBUF_, false>), grid, block, C_::SMEM_BYTES, st, a);
+    return mmdm_check_launch("gemm_s16");
+}
+
+template <int TN16_, int NBUF_>
+int set_attr_s16() {
+    constexpr int bytes = S16Cfg<TN16_, NBUF_>::SMEM_BYTES;
+    const void* fns[2] = {reinterpret_cast<const void*>(&gemm_s16_kernel<TN16_, NBUF_, true>), reinterpret_cast<const void*>(&gemm_s16_kernel<TN16_, NBUF_, false>)};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_s16): %s", hipGetErrorString(e));
+    }
+    return MMDM_OK;
+}
+
 inline bool vepi_ok(const GemmArgs& a) {
     const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID || a.epilogue == MMDM_EPI_BIAS_PE;
     return (a.N & 3) == 0 && (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
@@ -753,6 +953,10 @@ static thread_local int t_gemm_tail = 0;
 void mmdm_gemm_set_tail(int t) { t_gemm_tail = t; }
 int mmdm_gemm_get_tail(void) { return t_gemm_tail; }
 int g_gemm_ablate = 0;
+#ifndef MMDM_S16_DEFAULT
+#define MMDM_S16_DEFAULT -1
+#endif
+int g_gemm_s16 = MMDM_S16_DEFAULT;       // mmdm_diag_set "gemm_s16": -1 automatic, 0 off, 13 / 23 / 14 / 24: force <TN16, stages> wherever the kernel covers the call
 unsigned long long* g_gemm_stamps = nullptr;
 
 int mmdm_gemm_init(void) {
@@ -775,6 +979,10 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_glds<21, 21, 16, 4, 1, 1>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 2>())) return rc;
     if ((rc = set_attr_glds<22, 22, 16, 5, 1, 3>())) return rc;
+    if ((rc = set_attr_s16<1, 3>())) return rc;
+    if ((rc = set_attr_s16<2, 3>())) return rc;
+    if ((rc = set_attr_s16<1, 4>())) return rc;
+    if ((rc = set_attr_s16<2, 4>())) return rc;
     return MMDM_OK;
 }
 
@@ -784,6 +992,7 @@ bool mmdm_diag_gemm_f32(const char* key, long long v) {
     if (!strcmp(key, "gemm_cfg")) g_gemm_cfg = (int)v;
     else if (!strcmp(key, "gemm_ablate")) g_gemm_ablate = (int)v;
     else if (!strcmp(key, "gemm_tail")) g_gemm_tail = (int)v;
+    else if (!strcmp(key, "gemm_s16")) g_gemm_s16 = (int)v;
     else if (!strcmp(key, "gemm_stamps")) g_gemm_stamps = reinterpret_cast<unsigned long long*>((uintptr_t)v);
     else return false;
     return true;
@@ -861,6 +1070,17 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
                 // Few tiles (small batches): 64x64 tiles so that every CU has work.  All instantiations accumulate each output element in
                 // the same order (bias + residual first, then k ascending), so a row's result does not depend on the tile that produced it.
                 const long t64 = (long)((M + 127) / 128) * ((N + 63) / 64);
+                if (g_gemm_s16 > 0 && s16_ok(a)) {
+                    switch (g_gemm_s16) {
+                        case 13: return launch_s16<1, 3>(a, st);
+                        case 14: return launch_s16<1, 4>(a, st);
+                        case 24: return launch_s16<2, 4>(a, st);
+                        default: return launch_s16<2, 3>(a, st);
+                    }
+                }
+                // Small launches (the reference's B = 1 call and everything below it): quarter-length chains on 16 x 16 blocks, see gemm_s16_kernel.
+                // Not for the weight-streaming projections (M <= 64 against N >= 4096: below).
+                if (g_gemm_s16 < 0 && t64 < 512 && !(M <= 64 && N >= 4096) && s16_ok(a)) return launch_s16<2, 3>(a, st);
                 if (t64 < 512) return launch_glds<21, 21, 16, 4, 1, 1>(a, st);
                 // Skinny M against a wide weight matrix -- the packed AdaLN projections of a step: M = 2B .. 4B conditioning rows, N = L x n_ada x 2D =
                 // 32 768 / 49 152 columns, 134 / 201 MB of fp32 weights read ONCE per step: a weight-streaming launch, not a matrix-pipe one.  The 128 x 128

@@ -867,7 +867,8 @@ int mmdm_linear_split_ex(const void* A, int lda, int64_t a_plane, const void* W,
         // small M (the reference's B = 1 call: M = 1196): when the 128 x 128 grid gives fewer tiles than there are CUs, halve the tile (bit-identical results;
         // fp32_split at B = 1, T = 299: 3.70 -> 3.49 ms/step)
         const bool few = (long)((M + 127) / 128) * (N / 128) < 256;
-        if (g_split_cfg == 5 || (g_split_cfg != 6 && (N <= 512 || few))) return launch_w<12, 41>(a, st);
+        // (M <= 64: the conditioning projections of the low-precision handles, one 64-row tile deep -- a weight-streaming launch)
+        if (g_split_cfg == 5 || (g_split_cfg != 6 && (N <= 512 || few || M <= 64))) return launch_w<12, 41>(a, st);
         // (a main launch of whole rounds plus a 64x128 remainder, as the plane kernels do for N <= 1024, was measured: no gain or slower -- the
         // kernel runs against the power-managed clock, not against the round count: tools/split_timeline.py reads 1.5 GHz inside the loop)
         return launch_w<14, 41>(a, st);

@@ -141,6 +141,9 @@ int mmdm_mean_time_rag_nopk(const float* h, float* out, int nseq, const int* seq
 int mmdm_mdm_pack_nopk(const float* src, const float* cond, int ldc, const float* time_tab, const int* step_idx, const float* pe, float* dst,
                        int nseq, int T, int D, hipStream_t st);
 int mmdm_mdm_unpack_nopk(const float* src, float* dst, int nseq, int T, int D, hipStream_t st);
+// silu(time_tab[*step_idx] + txt) as the two fp16 planes of the fp32-split GEMM's A operand (rowops.hip)
+int mmdm_cond_silu_planes(const float* time_tab, const int* step_idx, const float* txt, _Float16* out, size_t plane, int rows, int D, hipStream_t st);
+int mmdm_cond_silu_planes_nopk(const float* time_tab, const int* step_idx, const float* txt, _Float16* out, size_t plane, int rows, int D, hipStream_t st);
 extern "C" {
 int mmdm_layernorm_f32_nopk(const float* x, const float* gamma, const float* beta, float* out, int rows, int D, float eps, void* stream);
 int mmdm_cond_silu_f32_nopk(const float* time_tab, const int* step_idx, const float* txt, float* out, int rows, int D, void* stream);

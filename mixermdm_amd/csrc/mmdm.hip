@@ -140,6 +140,7 @@ struct StackW {          // a transformer stack: denoiser blocks or Influence bl
     bool has_ca = false;
     bool w_packed = false;                      // low-precision weight twins stored in MFMA fragment order (gemm_splitw_kernel / gemm_bf16w_kernel take W straight from global memory)
     float *ada_w = nullptr, *ada_b = nullptr;   // [L*n_ada*2D, D], [L*n_ada*2D]  (slots: sa, [ca_q, ca_kv,] ffn)
+    void* ada_s = nullptr;                      // precision >= 1: ada_w as two fp16 planes in fragment order (cond_vectors on the fp32-split kernel)
     std::vector<LayerW> layers;
     std::vector<LayerWB> layers_b;
 };
@@ -283,6 +284,7 @@ struct mmdm_handle_s {
     // switches read from the environment ONCE, at mmdm_create (include/mmdm.h lists them): a handle's behaviour never changes afterwards
     bool force_qkp = false, no_qkp = false, no_pvb = false, no_pack = false;      // MMDM_QKP, MMDM_NO_QKP, MMDM_NO_BF16_PV, MMDM_NO_PACK
     bool no_split_embed = false;                                                  // MMDM_NO_SPLIT_EMBED
+    bool no_split_cond = false;                                                   // MMDM_NO_SPLIT_COND
 
     Prof prof;
 };
@@ -330,6 +332,11 @@ int build_stack(mmdm_handle h, StackW& st, const std::string& pfx, int D, int F,
     st.D = D; st.F = F; st.L = L; st.H = H; st.has_ca = has_ca; st.n_ada = has_ca ? 4 : 2;
     RC(dalloc(h, &st.ada_w, (size_t)L * st.n_ada * 2 * D * D));
     RC(dalloc(h, &st.ada_b, (size_t)L * st.n_ada * 2 * D));
+    if (h->cfg.precision >= 1 && D % 64 == 0) {       // two fp16 planes [2][L*n_ada*2D][D]: as many bytes as the fp32 matrix
+        float* q = nullptr;
+        RC(dalloc(h, &q, (size_t)L * st.n_ada * 2 * D * D));
+        st.ada_s = q;
+    }
     st.layers.resize(L);
     const bool bf = h->cfg.precision >= 1;
     const size_t planes = h->cfg.precision == 2 ? MMDM_SPLIT_NPL : 1;   // fp32-split: two fp16 planes per weight (gemm_split.hip)
@@ -716,8 +723,13 @@ int run_stack(const Ctx& c, const StackW& w, float* hbuf, const StackRun& r) {
 // emb rows -> silu -> all AdaLN projections of a module.  se = silu(time_tab[step] + txt), ss = se W_ada^T + b_ada.
 int cond_vectors(const Ctx& c, const ModuleW& m, const float* txt, float* se, float* ss, int rows) {
     const StackW& w = m.st;
-    RC(ROWOP(c, mmdm_cond_silu_f32, m.time_tab, c.h->d_step, txt, se, rows, w.D, c.st));
     const int N = ss_ld_of(m);
+    if (w.ada_s) {       // low-precision handles: `se` holds the two fp16 planes of silu(.) (as many bytes), the projection runs on the fp32-split kernel
+        const size_t pa = (size_t)rows * w.D;
+        RC(mmdm_cond_silu_planes_nopk(m.time_tab, c.h->d_step, txt, reinterpret_cast<_Float16*>(se), pa, rows, w.D, c.st));
+        return linear_s(c, se, w.D, pa, w.ada_s, c.h->no_pack ? w.D : 0, (size_t)N * w.D, w.ada_b, ss, N, 0, 0, rows, N, w.D, MMDM_EPI_BIAS, nullptr, 0);
+    }
+    RC(ROWOP(c, mmdm_cond_silu_f32, m.time_tab, c.h->d_step, txt, se, rows, w.D, c.st));
     return linear(c, se, w.D, w.ada_w, w.D, w.ada_b, ss, N, rows, N, w.D);
 }
 
@@ -1148,10 +1160,12 @@ static int create_impl(const mmdm_config* cfg, mmdm_handle parent, mmdm_handle* 
     auto env_on = [](const char* k) { const char* v = getenv(k); return v != nullptr && strcmp(v, "0") != 0; };
     if (parent) {       // the switches that decide the FORMAT of the shared weights (and the kernels that read them) are the parent's
         h->force_qkp = parent->force_qkp; h->no_qkp = parent->no_qkp; h->no_pvb = parent->no_pvb; h->no_pack = parent->no_pack; h->no_split_embed = parent->no_split_embed;
+        h->no_split_cond = parent->no_split_cond;
     } else {
         h->force_qkp = env_on("MMDM_QKP"); h->no_qkp = env_on("MMDM_NO_QKP"); h->no_pvb = env_on("MMDM_NO_BF16_PV");
         h->no_pack = env_on("MMDM_NO_PACK") || env_on("MMDM_SPLIT_NO_PACK");
         h->no_split_embed = env_on("MMDM_NO_SPLIT_EMBED");
+        h->no_split_cond = env_on("MMDM_NO_SPLIT_COND");
     }
     const size_t PT = (size_t)n * T * (so == 1 ? NF : NF2);
     const size_t PB = (size_t)B * T * (so == 1 ? NF : NF2);
@@ -1355,6 +1369,21 @@ extern "C" int mmdm_prepare(mmdm_handle h) {
             HIPCHK(hipMemcpy2DAsync(w32, NFS * sizeof(float), m->me_w, NFP * sizeof(float), NFP * sizeof(float), D, hipMemcpyDeviceToDevice, nullptr));
             int rc = mmdm_f32_split(w32, no_pack ? m->me_s : pl, n, n, nullptr);
             if (!rc && !no_pack) rc = mmdm_split_pack_weight(pl, NFS, n, m->me_s, n, (int)D, NFS, nullptr);
+            if (rc) return herr(h, rc);
+            HIPCHK(hipDeviceSynchronize());
+        }
+        // the AdaLN projection matrix of each stack [L*n_ada*2D, D] -> two fp16 planes in fragment order (cond_vectors: a weight-streaming GEMM of
+        // <= 6B rows, MFMA-bound on the fp32 kernel's 128-row tile, HBM-bound on the fp32-split one)
+        for (ModuleW* m : {&h->d1, &h->d2, &h->mx}) {
+            StackW& st = m->st;
+            if (h->no_split_cond) st.ada_s = nullptr;       // the projections stay on the fp32 MFMA kernel (A/B switch)
+            if (!st.ada_s) continue;
+            const int64_t N = (int64_t)st.L * st.n_ada * 2 * st.D, n = N * st.D;
+            void* pl = nullptr;
+            if (!no_pack) HIPCHK(hipMalloc(&pl, n * 4));
+            struct F3 { void* p; ~F3() { if (p) (void)hipFree(p); } } f3{pl};
+            int rc = mmdm_f32_split(st.ada_w, no_pack ? st.ada_s : pl, n, n, nullptr);
+            if (!rc && !no_pack) rc = mmdm_split_pack_weight(pl, st.D, n, st.ada_s, n, (int)N, st.D, nullptr);
             if (rc) return herr(h, rc);
             HIPCHK(hipDeviceSynchronize());
         }

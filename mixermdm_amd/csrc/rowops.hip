@@ -238,6 +238,19 @@ __global__ void cond_silu_kernel(const float* __restrict__ time_tab, const int* 
     out[i] = e / (1.0f + expf(-e));
 }
 
+// the same rows as the two fp16 operand planes of the fp32-split GEMM (out[i], out[plane + i]): cond_vectors of the low-precision handles
+__global__ void cond_silu_planes_kernel(const float* __restrict__ time_tab, const int* __restrict__ step_idx, const float* __restrict__ txt,
+                                        _Float16* __restrict__ out, size_t plane, int rows, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * D) return;
+    const int d = (int)(i % D);
+    const float e = time_tab[(size_t)(*step_idx) * D + d] + txt[i];
+    _Float16 h, l;
+    mmdm_split2(e / (1.0f + expf(-e)), h, l);
+    out[i] = h;
+    out[plane + i] = l;
+}
+
 __global__ void mean_time_kernel(const float* __restrict__ h, float* __restrict__ out, int T, int D) {
     const int seq = blockIdx.y;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -404,6 +417,13 @@ extern "C" int RO(mmdm_cond_silu_f32)(const float* time_tab, const int* step_idx
     const size_t n = (size_t)rows * D;
     hipLaunchKernelGGL(cond_silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), time_tab, step_idx, txt, out, rows, D);
     return mmdm_check_launch("cond_silu");
+}
+
+int RO(mmdm_cond_silu_planes)(const float* time_tab, const int* step_idx, const float* txt, _Float16* out, size_t plane, int rows, int D, hipStream_t st) {
+    if (rows == 0) return MMDM_OK;
+    const size_t n = (size_t)rows * D;
+    hipLaunchKernelGGL(cond_silu_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, time_tab, step_idx, txt, out, plane, rows, D);
+    return mmdm_check_launch("cond_silu_planes");
 }
 
 extern "C" int RO(mmdm_mean_time_f32)(const float* h, float* out, int nseq, int T, int D, void* stream) {

@@ -561,3 +561,36 @@ def test_linear_split_packed_is_bitwise_the_plane_kernel(M, N, K):
         assert torch.equal(out, ops.linear_split(xs, ws, b.to(d))[:, n0:])
     with pytest.raises(Exception):
         ops.linear_split(ops.split_f32(x[:, :48].contiguous().to(d)), ops.split_pack_weight(ops.split_f32(w[:, :48].contiguous().to(d))), packed=True)   # K % 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(1196, 1024, 1024), (1196, 2048, 1024), (240, 3072, 1024), (601, 1028, 512), (77, 1024, 96), (6, 512, 2048), (2400, 516, 1024)])
+def test_small_launch_gemm_on_16x16_chains_is_bitwise_the_production_kernel(M, N, K):
+    """gemm_s16_kernel (v_mfma_f32_16x16x4_f32: a quarter of a 32 x 32 block's chain; the dispatch of small launches, gemm_f32.hip) accumulates
+    every output element in the production kernels' k order: every forced <blocks per wave, stages> form, every epilogue, ragged M and N
+    against the 64 x 64-tile launch with the small-launch rule switched off -- and the automatic dispatch against both."""
+    import mixermdm_amd as mm
+    from mixermdm_amd import ops
+    lib, d = mm.load_library(), torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M * 11 + N)
+    x, w, b = torch.randn(M, K, generator=g).to(d), (torch.randn(N, K, generator=g) / K ** 0.5).to(d), torch.randn(N, generator=g).to(d)
+    r, pe = torch.randn(M, N, generator=g).to(d), torch.randn(299, N, generator=g).to(d)
+    try:
+        for epi, extra, period in [("bias", None, 0), ("gelu", None, 0), ("silu", None, 0), ("quickgelu", None, 0), ("sigmoid", None, 0), ("resid", r, 0), ("pe", pe, 299)]:
+            lib.mmdm_diag_set(b"gemm_s16", 0)
+            want = ops.linear(x, w, b, epi, extra, period)
+            assert torch.isfinite(want).all()
+            for cfg in (23, 13, 24, 14, -1):
+                lib.mmdm_diag_set(b"gemm_s16", cfg)
+                got = ops.linear(x, w, b, epi, extra, period, out=torch.full((M, N), float("nan"), device=d))
+                assert torch.equal(got, want), (epi, cfg, M, N, K, float((got - want).abs().max()))
+        # in place over the residual (the stack's `h += linear(...)`)
+        lib.mmdm_diag_set(b"gemm_s16", 0)
+        want = ops.linear(x, w, b, "resid", r.clone())
+        lib.mmdm_diag_set(b"gemm_s16", -1)
+        h = r.clone()
+        assert torch.equal(ops.linear(x, w, b, "resid", h, out=h), want)
+    finally:
+        lib.mmdm_diag_set(b"gemm_s16", -1)
+    ref = x.double() @ w.double().T + b.double()
+    assert float((ops.linear(x, w, b) .double() - ref).abs().max()) < 2e-5 * (K / 1024) ** 0.5 * 4
