@@ -662,13 +662,17 @@ __global__ __launch_bounds__((GCfg<TM_, TN_, BK_, NBUF_>::THREADS), MINW_) void 
 // Small launches: the same accumulation chains on 16 x 16 blocks (v_mfma_f32_16x16x4_f32).
 //
 // An fp32 MFMA accumulator is ONE k-ordered chain of fused multiply-adds (tools/mfma_chain_bits.hip: 32x32x2, 16x16x4 and a scalar fmaf
-// chain over the same k order agree in every bit), and a chain keeps its SIMD's matrix pipe busy by itself -- so a launch lasts
-// ceil(chains / 1024 SIMDs) chain lengths whatever its tiling.  With 32 x 32 blocks the reference's own call (B = 1:
-// M = 1196 rows) has 1216 chains at N = 1024: two rounds on 1024 pipes, the second 19 % full.  A 16 x 16 block is a quarter of the chain
-// (32 cycles per 4 k instead of 64 per 2 k on 4x the outputs): 4800 chains = 4.7 -> 5 rounds of a quarter of the length.  This kernel
-// walks k in the production order (group g of 8 k: 8g, 8g+4, 8g+1, 8g+5 | 8g+2, 8g+6, 8g+3, 8g+7 -- what lane half h = k-slot h of the
-// 32x32x2 operands gives), starts the accumulators as the bias and adds the residual / PE row after the loop like the pipelined
-// 16-byte epilogue form: every output element is bit-identical to the production kernels'.
+// chain over the same k order agree in every bit), and a chain of 32 x 32 blocks lasts K / 2 x 64 cycles however few of them a launch has:
+// a GEMM of M = 240 rows (configs[0]) against N = 1024 is 64 workgroups of 64 x 64 on 256 CUs, 15.6 us of chain at K = 1024 with three
+// quarters of the chip idle.  A 16 x 16 block is a quarter of the chain (32 cycles per 4 k instead of 64 per 2 k) on a quarter of the
+// outputs: four times the workgroups, a quarter of the latency.  This kernel walks k in the production order (group g of 8 k: 8g, 8g+4,
+// 8g+1, 8g+5 | 8g+2, 8g+6, 8g+3, 8g+7 -- what lane half h = k-slot h of the 32x32x2 operands gives), starts the accumulators as the bias
+// and adds the residual / PE row after the loop like the pipelined 16-byte epilogue form: every output element is BIT-IDENTICAL to the
+// production kernels' (tests/test_gpu_kernels.py).  Measured (tools/gemm_s16_bench.py, <1 block per wave, 4 stages> vs the 64 x 64 launch):
+// 240 x 1024 x 1024: 19.7 -> 13.7 us, x 2048: 36.4 -> 24.0; 6 x 1024 x 1024: 19.9 -> 12.8.  It does NOT carry the reference's B = 1 call
+// (M = 1196: 1216 chains of 32 x 32 = two rounds on 1024 matrix pipes, the case DESIGN 10.3 prices): 38.3 -> 35.0 us at N = K = 1024 but
+// 80 -> 94 at N = 3072, 50 -> 61 at N = 2048, the step 5.75 -> 6.6 ms -- half the operand reuse per LDS-DMA byte and per fragment read,
+// a barrier per 8 MFMAs of a wave.  The dispatch therefore takes it only where the 64 x 64 grid leaves half of the CUs idle.
 //
 // Workgroup: 32 x (32 TN16) outputs, four waves as 2 x 2, each 16 rows x TN16 blocks of 16 columns; operands swapped (D^T = W A^T) so a lane
 // owns an output row and four consecutive columns.  K step 32 through an NBUF-stage LDS-DMA ring (one barrier per step; the request of
@@ -685,18 +689,19 @@ struct S16Cfg {
     static_assert(NA % NWAVES == 0 && NB % NWAVES == 0, "pieces must divide evenly over the waves");
 };
 
-template <int TN16_, int NBUF_, bool LATE>
-__global__ __launch_bounds__(256) void gemm_s16_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+// tile index of workgroup `bid` of `nwg`: each XCD (bid % 8) walks a contiguous range
+__device__ __forceinline__ int xcd_swz(int bid, int nwg) {
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+}
+
+template <int TN16_, int NBUF_, bool LATE>
+__device__ __forceinline__ void s16_tile(const GemmArgs& p, float* smem, int swz) {
     using C_ = S16Cfg<TN16_, NBUF_>;
     constexpr int BM = C_::BM, BN = C_::BN, BK = C_::BK, TN = C_::TN16, NBUF = C_::NBUF, NI = C_::NI, UA = C_::NA / C_::NWAVES;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                   // [NBUF][BM*BK]
     float* Bs = smem + NBUF * C_::A_FLOATS;             // [NBUF][BN*BK]
-    const int nwg = p.mt * p.nt;
-    const int bid = blockIdx.x;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int m0 = (swz / p.nt) * BM;
     const int n0 = (swz % p.nt) * BN;
     const int tid = threadIdx.x;
@@ -755,35 +760,31 @@ __global__ __launch_bounds__(256) void gemm_s16_kernel(GemmArgs p) {
     const int sw = (r >> 1) & 7;                       // every tile row of this lane is r mod 16
     const int a_row = (wm * 16 + r) * BK;
     const int b_row = (wn * (16 * TN) + r) * BK;
+    const bool hi = (q >> 1) != 0;
     int cur = 0, stg = NBUF - 1;
     for (int kt = 0; kt < nkt; ++kt) {
         wait_vm<(NBUF - 2) * NI>();                    // tile kt has landed (in-order retirement; NI requests per stage, surplus ones included)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // ... for every wave, and every wave is done with stage (kt - 1) % NBUF
         stage(stg, kt + NBUF - 1);
-        // k-slot q of a group's first MFMA: 8g + {0, 4, 1, 5}[q] = element (q >> 1) of chunk 2g + (q & 1); of its second: element 2 + (q >> 1) -- two
-        // dwords 8 bytes apart per operand row (one ds_read2_b32: a 16-byte fragment read per lane would move twice the bytes a 16 x 16 block
-        // can use, and four waves of them fill the CU's LDS port); a step's fragments are requested together, ahead of its MFMAs
-        const float* Ac = As + cur * C_::A_FLOATS + a_row + (q >> 1);
-        const float* Bc = Bs + cur * C_::B_FLOATS + b_row + (q >> 1);
-        float fa[BK / 8][2], fb[BK / 8][TN][2];
+        // k-slot q of a group's first MFMA: 8g + {0, 4, 1, 5}[q] = element (q >> 1) of chunk 2g + (q & 1); of its second: element 2 + (q >> 1).
+        // One 16-byte fragment read per operand row and group, two selects.  (Two dwords by ds_read2_b32 -- half the LDS bytes -- and all of a
+        // step's reads ahead of its MFMAs were measured: 10-25 % slower on every shape, tools/gemm_s16_bench.py.)
+        const float* Ac = As + cur * C_::A_FLOATS + a_row;
+        const float* Bc = Bs + cur * C_::B_FLOATS + b_row;
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             const int cg = 4 * ((2 * g + (q & 1)) ^ sw);
-            fa[g][0] = Ac[cg]; fa[g][1] = Ac[cg + 2];
+            const f32x4 va = *reinterpret_cast<const f32x4*>(Ac + cg);
+            f32x4 vb[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) { fb[g][j][0] = Bc[j * 16 * BK + cg]; fb[g][j][1] = Bc[j * 16 * BK + cg + 2]; }
+            for (int j = 0; j < TN; ++j) vb[j] = *reinterpret_cast<const f32x4*>(Bc + j * 16 * BK + cg);
+            const float a0 = hi ? va[1] : va[0], a1 = hi ? va[3] : va[2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi ? vb[j][1] : vb[j][0], a0, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi ? vb[j][3] : vb[j][2], a1, acc[j], 0, 0, 0);
         }
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[g][j][0], fa[g][0], acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[g][j][1], fa[g][1], acc[j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, (BK / 8) * (1 + TN), 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, (BK / 8) * 2 * TN, 0);
-        __builtin_amdgcn_sched_barrier(0);
         cur = cur + 1 == NBUF ? 0 : cur + 1;
         stg = stg + 1 == NBUF ? 0 : stg + 1;
     }
@@ -823,6 +824,32 @@ __global__ __launch_bounds__(256) void gemm_s16_kernel(GemmArgs p) {
             default: finish(std::integral_constant<int, MMDM_EPI_BIAS>{}); break;
         }
     }
+}
+#endif
+
+template <int TN16_, int NBUF_, bool LATE>
+__global__ __launch_bounds__(256) void gemm_s16_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    s16_tile<TN16_, NBUF_, LATE>(p, smem, xcd_swz(blockIdx.x, p.mt * p.nt));
+#endif
+}
+
+// One launch, two tilings (the reference's own call shape, B = 1: M = 1196 rows).  With 64 x 64 tiles of 32 x 32 chains the rows that fill WHOLE
+// rounds of the 256 CUs -- 1024 of them at N = 1024 / 2048 / 3072 -- cost one chain length per round; the 172 rows behind them cost a whole further
+// round on a fifth of the chip.  Here workgroups [0, n_main) run the production 64 x 64 tile on the whole-round rows and the
+// workgroups after them the 16 x 16-chain tile on the remaining rows: quarter-length chains that the dispatcher places beside the main tiles
+// as soon as those are resident (both forms take 32 KB of LDS and 256 threads), so the launch lasts the whole rounds plus what the matrix
+// pipes still owe the remainder.  Same chains, same order: bit-identical to either kernel alone.
+struct MixArgs { GemmArgs main, rem; int n_main; };
+
+template <bool VEPI>
+__global__ __launch_bounds__(256) void gemm_mix_kernel(MixArgs q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    if (bid < q.n_main) gemm_tile<21, 21, 16, 4, VEPI, 1, false>(q.main, smem, xcd_swz(bid, q.n_main), bid);
+    else s16_tile<1, 4, VEPI>(q.rem, smem, xcd_swz(bid - q.n_main, q.rem.mt * q.rem.nt));
 #endif
 }
 
@@ -845,6 +872,39 @@ int launch_s16(GemmArgs a, hipStream_t st) {
     if (late) hipLaunchKernelGGL((gemm_s16_kernel<TN16_, NBUF_, true>), grid, block, C_::SMEM_BYTES, st, a);
     else hipLaunchKernelGGL((gemm_s16_kernel<TN16_, NBUF_, false>), grid, block, C_::SMEM_BYTES, st, a);
     return mmdm_check_launch("gemm_s16");
+}
+
+// rows [0, M1) on 64 x 64 tiles, rows [M1, M) on the 16 x 16-chain tiles, one launch (a.epilogue != PE: the row index restarts in the remainder)
+int launch_mix(const GemmArgs& a, int M1, hipStream_t st) {
+    using CM = GCfg<21, 21, 16, 4>;
+    using CR = S16Cfg<1, 4>;
+    static_assert(CM::SMEM_BYTES == CR::SMEM_BYTES && CM::THREADS == CR::THREADS, "the two tile forms share one launch configuration");
+    MixArgs q;
+    q.main = a; q.rem = a;
+    q.main.M = M1;
+    q.rem.M = a.M - M1;
+    q.rem.A = a.A + (size_t)M1 * a.lda;
+    q.rem.C = a.C + (size_t)M1 * a.ldc;
+    if (a.extra) q.rem.extra = a.extra + (size_t)M1 * a.ld_extra;
+    q.main.mt = (M1 + CM::BM - 1) / CM::BM; q.main.nt = (a.N + CM::BN - 1) / CM::BN;
+    q.rem.mt = (q.rem.M + CR::BM - 1) / CR::BM; q.rem.nt = (a.N + CR::BN - 1) / CR::BN;
+    q.main.ablate = q.rem.ablate = 0; q.main.stamps = q.rem.stamps = nullptr;
+    q.n_main = q.main.mt * q.main.nt;
+    const bool ext = a.epilogue == MMDM_EPI_BIAS_RESID;
+    mmdm_note_gemm("gemm_mix<%s,%d+%d>", ext ? "vepi" : "scalar", q.n_main, q.rem.mt * q.rem.nt);
+    const dim3 grid(q.n_main + q.rem.mt * q.rem.nt), block(CM::THREADS);
+    if (ext) hipLaunchKernelGGL((gemm_mix_kernel<true>), grid, block, CM::SMEM_BYTES, st, q);
+    else hipLaunchKernelGGL((gemm_mix_kernel<false>), grid, block, CM::SMEM_BYTES, st, q);
+    return mmdm_check_launch("gemm_mix");
+}
+
+int set_attr_mix() {
+    const void* fns[2] = {reinterpret_cast<const void*>(&gemm_mix_kernel<true>), reinterpret_cast<const void*>(&gemm_mix_kernel<false>)};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GCfg<21, 21, 16, 4>::SMEM_BYTES);
+        if (e != hipSuccess) return mmdm_set_error(MMDM_ERR_HIP, "hipFuncSetAttribute(gemm_mix): %s", hipGetErrorString(e));
+    }
+    return MMDM_OK;
 }
 
 template <int TN16_, int NBUF_>
@@ -983,6 +1043,7 @@ int mmdm_gemm_init(void) {
     if ((rc = set_attr_s16<2, 3>())) return rc;
     if ((rc = set_attr_s16<1, 4>())) return rc;
     if ((rc = set_attr_s16<2, 4>())) return rc;
+    if ((rc = set_attr_mix())) return rc;
     return MMDM_OK;
 }
 
@@ -1078,9 +1139,20 @@ int mmdm_linear_f32_ex(const float* A, int lda, const float* W, int ldw, int Kw,
                         default: return launch_s16<2, 3>(a, st);
                     }
                 }
-                // Small launches (the reference's B = 1 call and everything below it): quarter-length chains on 16 x 16 blocks, see gemm_s16_kernel.
-                // Not for the weight-streaming projections (M <= 64 against N >= 4096: below).
-                if (g_gemm_s16 < 0 && t64 < 512 && !(M <= 64 && N >= 4096) && s16_ok(a)) return launch_s16<2, 3>(a, st);
+                // Launches whose 64 x 64 grid leaves half of the CUs idle (configs[0]'s M = 240 against N <= 2048, conditioning / time-embedding rows):
+                // quarter-length chains on 16 x 16 blocks, four times the workgroups, bit-identical (gemm_s16_kernel).  Not the weight-streaming
+                // projections (M <= 64 against N >= 4096: below).
+                if (g_gemm_s16 < 0 && (long)((M + 63) / 64) * ((N + 63) / 64) <= 128 && !(M <= 64 && N >= 4096) && s16_ok(a)) return launch_s16<1, 4>(a, st);
+                // 64 x 64 tiles with a fractional last round (the reference's B = 1 call: 19 row tiles x N / 64 = 1.2 / 2.4 / 3.6 rounds of 256): the rows of
+                // the whole rounds on those tiles, the rest as quarter-length chains beside them, in one launch (gemm_mix_kernel)
+                if (t64 < 512 && g_gemm_s16 < 0 && epilogue != MMDM_EPI_BIAS_PE && s16_ok(a) && vepi_ok(a)) {
+                    // measured (tools/gemm_s16_bench.py, M = 1196; us, 64 x 64 launch -> mixed): N = 1024: 37.6 -> 30.1 (K = 2048: 63.5 -> 50.1), N = 2048: 51.2 -> 47.9,
+                    // N = 3072 (three whole rounds): 79.8 -> 82.7, N = 1536 at K = 512 (more remainder than main tiles): 19.5 -> 23.7 -- the remainder tiles
+                    // cost about twice their matrix-pipe time, so the launch is mixed for one or two whole rounds and a remainder no larger than the main part
+                    const long nt64 = (N + 63) / 64, tiles = (long)((M + 63) / 64) * nt64, rounds = tiles / 256, mt1 = rounds * 256 / nt64;
+                    const long rem_wgs = mt1 * 64 < M ? (long)((M - mt1 * 64 + 31) / 32) * ((N + 31) / 32) : 0;
+                    if (rounds >= 1 && rounds <= 2 && mt1 >= 1 && rem_wgs > 0 && rem_wgs <= mt1 * nt64 && tiles % 256 != 0) return launch_mix(a, (int)mt1 * 64, st);
+                }
                 if (t64 < 512) return launch_glds<21, 21, 16, 4, 1, 1>(a, st);
                 // Skinny M against a wide weight matrix -- the packed AdaLN projections of a step: M = 2B .. 4B conditioning rows, N = L x n_ada x 2D =
                 // 32 768 / 49 152 columns, 134 / 201 MB of fp32 weights read ONCE per step: a weight-streaming launch, not a matrix-pipe one.  The 128 x 128

@@ -115,7 +115,7 @@ def test_linear_strided_slices_k262():
 @pytest.mark.parametrize("M,N,K", [(777, 520, 1024), (130, 136, 128), (1000, 3000, 512), (129, 68, 2048), (19, 1028, 96)])
 @pytest.mark.parametrize("epi", ["bias", "gelu", "resid", "pe"])
 def test_linear_writes_only_its_window(M, N, K, epi):
-    """Ragged M and N on the pipelined kernels (rows past M are dropped by the buffer resource's range check, columns past N by a lane
+    """Ragged M and N on the pipelined kernels and the small-launch forms (rows past M are dropped by the buffer resource's range check, columns past N by a lane
     mask): the result goes into an interior window of a sentinel-filled buffer (ldc > N, rows above and below), and nothing outside
     the window may change -- in particular not the rows below it, which a store clipped only by its vector offset would reach."""
     from mixermdm_amd import ops
@@ -137,7 +137,7 @@ def test_linear_writes_only_its_window(M, N, K, epi):
     win = buf[PADR:PADR + M, PADC:PADC + N]
     ops.linear(x.to(d), w.to(d), b.to(d), epi, extra.to(d) if extra is not None else None, period=40 if epi == "pe" else 0, out=win)
     kern = load_library().mmdm_last_gemm_kernel().decode()
-    assert kern.startswith("gemm_pipe<"), kern
+    assert kern.startswith(("gemm_pipe<", "gemm_s16<", "gemm_mix<")), kern          # the pipelined tiles, the 16 x 16-chain tiles, both in one launch
     assert_close(win, y.float(), atol=2e-5 * math.sqrt(max(1.0, K / 1024)), rtol=1e-5, what=f"{M}x{N}x{K} {epi} on {kern}")
     chk = buf.clone()
     chk[PADR:PADR + M, PADC:PADC + N] = 7.25
@@ -564,11 +564,13 @@ def test_linear_split_packed_is_bitwise_the_plane_kernel(M, N, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(1196, 1024, 1024), (1196, 2048, 1024), (240, 3072, 1024), (601, 1028, 512), (77, 1024, 96), (6, 512, 2048), (2400, 516, 1024)])
+@pytest.mark.parametrize("M,N,K", [(1196, 1024, 1024), (1196, 2048, 1024), (1196, 3072, 1024), (3588, 1024, 2048), (240, 3072, 1024), (601, 1028, 512), (77, 1024, 96), (6, 512, 2048),
+                                   (2400, 516, 1024)])
 def test_small_launch_gemm_on_16x16_chains_is_bitwise_the_production_kernel(M, N, K):
     """gemm_s16_kernel (v_mfma_f32_16x16x4_f32: a quarter of a 32 x 32 block's chain; the dispatch of small launches, gemm_f32.hip) accumulates
     every output element in the production kernels' k order: every forced <blocks per wave, stages> form, every epilogue, ragged M and N
-    against the 64 x 64-tile launch with the small-launch rule switched off -- and the automatic dispatch against both."""
+    against the 64 x 64-tile launch with the small-launch rules switched off -- and the automatic dispatch against both: s16 alone where the 64 x 64
+    grid leaves half the CUs idle, gemm_mix_kernel (whole rounds on 64 x 64 tiles + the remaining rows on 16 x 16 chains, one launch) at M = 1196 / 3588."""
     import mixermdm_amd as mm
     from mixermdm_amd import ops
     lib, d = mm.load_library(), torch.device("cuda:0")

@@ -56,7 +56,7 @@ f8 = os.path.join(ROOT, "gpurun_out", f"pmc_fp8_{tag}", "summary.txt")
 if os.path.exists(f8):
     shutil.copy(f8, os.path.join(dst, f"{tag}_pmc_fp8_gemm.json"))
 rows = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats_serial.csv"))))
-g = [r for r in rows if r["Name"].startswith("gemm_glds_kernel")]
+g = [r for r in rows if r["Name"].startswith(("gemm_glds_kernel", "gemm_mix_kernel", "gemm_s16_kernel"))]
 tot, n = sum(float(r["TotalDurationNs"]) for r in g), sum(int(r["Calls"]) for r in g)
 steps = next(int(r["Calls"]) for r in rows if "xstart_ddim_kernel" in r["Name"])
 print(f"serial trace: {steps} steps; fp32 GEMM kernels {tot / 1e6:.1f} ms over {n} launches = {tot / n / 1e3:.1f} us average, {tot / steps / 1e6:.2f} ms/step "

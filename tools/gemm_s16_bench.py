@@ -5,7 +5,7 @@ import torch, math, statistics
 from mixermdm_amd import ops, load_library
 lib = load_library()
 d = torch.device("cuda:0")
-CFGS = [0, 23, 13, 24, 14]
+CFGS = [int(c) for c in os.environ.get('S16_CFGS', '0,-1,14').split(',')]      # 0 = the 64 x 64 launch, -1 = the automatic dispatch (s16 / mix / production), 13 .. 24 forced forms
 shapes = [(1196, 3072, 1024, "bias"), (1196, 1024, 1024, "resid"), (1196, 2048, 1024, "bias"), (1196, 2048, 1024, "gelu"), (1196, 1024, 2048, "resid"),
           (1196, 1536, 512, "bias"), (1196, 512, 512, "resid"), (1196, 1024, 512, "gelu"), (1196, 512, 1024, "resid"),
           (240, 3072, 1024, "bias"), (240, 1024, 1024, "resid"), (240, 1024, 2048, "resid"), (601, 1028, 1024, "silu"), (77, 1024, 96, "quickgelu"),
@@ -34,7 +34,7 @@ for M, N, K, epi in shapes:
             ts.append(e0.elapsed_time(e1) / 20)
         same = torch.equal(outs[c], outs[0]) and bool(torch.isfinite(outs[c]).all())
         bad += 0 if same else 1
-        line += f" | {c:2d}: {statistics.median(ts) * 1e3:6.1f}us{'' if same else ' DIFFERENT BITS'}"
+        line += f" | {c:2d}: {statistics.median(ts) * 1e3:6.1f}us" + (f" [{lib.mmdm_last_gemm_kernel().decode()}]" if c == -1 else "") + ("" if same else " DIFFERENT BITS")
     ref = (x.double() @ w.double().T + b.double())
     print(line + f" | max |prod - f64 pre-activation| {'-' if epi not in ('bias',) else format(float((outs[0].double() - ref).abs().max()), '.2e')}", flush=True)
 lib.mmdm_diag_set(b"gemm_s16", -1)

@@ -15,7 +15,7 @@ traces_only = len(sys.argv) > 4
 PB, PT = int(os.environ.get("PMC_BATCH", "16")), int(os.environ.get("PMC_FRAMES", "300"))     # the workload the PMC passes were taken at (tools/profile_round.sh: the default)
 os.makedirs(dst, exist_ok=True)
 # the dominant GEMM kernel(s) of each precision mode (prefix of the demangled name)
-DOMINANT = {"fp32": ("gemm_glds_kernel",), "fp32_split": ("gemm_splitw_kernel", "gemm_split_kernel"), "bf16_fp8": ("gemm_bf16w_kernel", "gemm_bf16_kernel"),
+DOMINANT = {"fp32": ("gemm_glds_kernel", "gemm_mix_kernel", "gemm_s16_kernel"), "fp32_split": ("gemm_splitw_kernel", "gemm_split_kernel"), "bf16_fp8": ("gemm_bf16w_kernel", "gemm_bf16_kernel"),
             "bf16": ("gemm_bf16w_kernel", "gemm_bf16_kernel")}[prec]
 
 
