@@ -769,7 +769,9 @@ __device__ __forceinline__ void s16_tile(const GemmArgs& p, float* smem, int swz
         stage(stg, kt + NBUF - 1);
         // k-slot q of a group's first MFMA: 8g + {0, 4, 1, 5}[q] = element (q >> 1) of chunk 2g + (q & 1); of its second: element 2 + (q >> 1).
         // One 16-byte fragment read per operand row and group, two selects.  (Two dwords by ds_read2_b32 -- half the LDS bytes -- and all of a
-        // step's reads ahead of its MFMAs were measured: 10-25 % slower on every shape, tools/gemm_s16_bench.py.)
+        // step's reads ahead of its MFMAs were measured: 10-25 % slower on every shape; so was a software-pipelined ring -- a step's MFMAs fed from
+        // registers read during the previous step, requests and reads interleaved behind them: 1196 x 1024 x 1024 36.3 -> 45.9 us alone, 30.1 -> 32.7
+        // in the mixed launch, the B = 1 step 5.46 -> 5.76 ms.  tools/gemm_s16_bench.py.)
         const float* Ac = As + cur * C_::A_FLOATS + a_row;
         const float* Bc = Bs + cur * C_::B_FLOATS + b_row;
 #pragma unroll
