@@ -465,6 +465,11 @@ int mmdm_profile_read(mmdm_handle h, int which, double* total_ms, int64_t* launc
  *                                                workgroup's LDS transposition (bit-identical results; A/B timing)
  *   "gemm_cfg" / "split_cfg" / "bf16_cfg"       force a tile configuration of the fp32 / fp32-split / bf16-fp8 GEMM dispatch (-1 = automatic)
  *   "gemm_tail"                                  force the row-split rule of the fp32 dispatch (t/10 of a round; -1 = the caller's handle decides)
+ *   "gemm_s16"                                   small-launch forms of the fp32 dispatch (gemm_s16_kernel / gemm_mix_kernel: 16 x 16-block chains, bit-identical
+ *                                                results): -1 = automatic, 0 = off (the 64 x 64-tile launch), 13 / 14 / 23 / 24 = force <blocks per wave, stages>
+ *   "fp8p"                                       the persistent fp8 GEMM (gemm_fp8p_kernel, bit-identical): 0 = off (default), 1 = on the cross-attention
+ *                                                projections, 2 = wherever it covers the call
+ *   "attn_kc32"                                  0 = the 16-key form of the all-bf16 attention instead of the 32-key one (A/B; results differ in rounding)
  *   "gemm_ablate" / "split_ablate" / "attn_ablate"   timing-ablation bits (wrong results)
  *   "gemm_stamps" / "attn_stamps" / "split_timeline" / "bf16_timeline"   device pointer (as an integer) of a stamp buffer, 0 = off
  * Returns MMDM_ERR_ARG for an unknown key. */
