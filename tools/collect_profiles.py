@@ -41,6 +41,21 @@ if os.path.exists(os.path.join(b1, "summary_fp32", "pmc_summary.json")):
     shutil.copy(os.path.join(b1, "summary_fp32", "pmc_summary.json"), os.path.join(dst, f"{tag}_pmc_infer_b1.json"))
     if os.path.exists(os.path.join(b1, "summary_fp32", "gemm_traffic.json")):
         shutil.copy(os.path.join(b1, "summary_fp32", "gemm_traffic.json"), os.path.join(dst, "gemm_traffic_b1t299.json"))
+# configs[4]'s per-GPU shard (tools/profile_fp8_b64.sh): bf16_fp8 at B = 64
+f8 = os.path.join(ROOT, "gpurun_out", f"prof_fp8_b64_{tag}")
+if os.path.exists(os.path.join(f8, "summary", "kernel_stats_serial.csv")):
+    shutil.copy(os.path.join(f8, "summary", "kernel_stats_serial.csv"), os.path.join(dst, f"{tag}_kernel_stats_fp8_b64_serial.csv"))
+    for line in open(os.path.join(f8, "serial.json")):
+        if line.startswith("{"):
+            d = json.loads(line)
+            json.dump(d, open(os.path.join(dst, f"{tag}_bench_fp8_b64_serial_under_rocprof.json"), "w"), indent=1)
+            print(f"fp8_b64 serial {d['ms_per_step']:7.3f} ms/step  fp8 GEMM live frac {d['roofline']['frac']}")
+    if os.path.exists(os.path.join(f8, "summary_bf16_fp8", "pmc_summary.json")):
+        shutil.copy(os.path.join(f8, "summary_bf16_fp8", "pmc_summary.json"), os.path.join(dst, f"{tag}_pmc_fp8_b64.json"))
+    if os.path.exists(os.path.join(f8, "summary_bf16_fp8", "gemm_traffic.json")):
+        shutil.copy(os.path.join(f8, "summary_bf16_fp8", "gemm_traffic.json"), os.path.join(dst, "gemm_traffic_bf16_fp8_b64t300.json"))
+        t = json.load(open(os.path.join(dst, "gemm_traffic_bf16_fp8_b64t300.json")))
+        print(f"traffic fp8 B=64 sha {t['kernel_sources_sha']}  {t['traffic_bytes_per_launch'] / 1e6:.0f} MB/launch  L2 hit {t['l2_hit_rate']}  MFMA busy {t.get('mfma_busy_frac')} (sq {t.get('mfma_busy_frac_sq')})  {t.get('hbm_side_TBps')} TB/s beyond L2")
 # one ragged batch of the evaluation caller (tools/profile_ragged.sh)
 rg = os.path.join(ROOT, "gpurun_out", f"prof_ragged_{tag}")
 if os.path.exists(os.path.join(rg, "summary", "kernel_stats_serial.csv")):
