@@ -85,14 +85,23 @@ def _step(s, x, x2, i, names=("x", "x2", "pred_xstart", "pred_xstart2")):
     return {k: st[k].clone() for k in names}
 
 
-def _check_step(s, x, x2, i, refs, what, ref64, mode="fp32"):
+def _denorm(stats, i):
+    """(mean, std) per channel of the tensors that hold normalised poses: pred_xstart (chain 1: HumanML statistics per person, gaussian_diffusion.py:2052-2056)
+    and pred_xstart2 (InterHuman statistics); None at i == 0, where both are the raw blend (quirk 6)."""
+    if stats is None or i == 0:
+        return None
+    mean_h, std_h, mean_i, std_i = [torch.as_tensor(v).double().flatten() for v in stats]
+    return {"pred_xstart": (mean_h.repeat(2), std_h.repeat(2)), "pred_xstart2": (mean_i.repeat(2), std_i.repeat(2))}
+
+
+def _check_step(s, x, x2, i, refs, what, ref64, mode="fp32", stats=None):
     """refs: {state name: fp32 reference tensor} (the oracle's, or the reference's own captured output); ref64: the float64 oracle's
     outputs of the same step.  Element-wise parity with `refs` at the float64-derived tolerance, and the float64 yardstick
     (tests/parity_tol.py).  Returns (HIP outputs, worst out-of-tolerance fraction, ill-conditioned groups, yardstick entry)."""
     out = _step(s, x, x2, i)
     r64 = {k: ref64[k] for k in refs}
     # a turned joint (tests/parity_tol.py) is tolerated in the fp32_split mode only; the native-fp32 headline mode must show none
-    worst, amplified, events = compare_step(out, refs, r64, what, hard_joints=HARD_JOINTS if mode == "fp32_split" else 0)
+    worst, amplified, events = compare_step(out, refs, r64, what, hard_joints=HARD_JOINTS if mode == "fp32_split" else 0, denorm=_denorm(stats, i))
     return out, worst, amplified, yardstick(out, refs, r64, what, event=events > 0)
 
 
@@ -169,14 +178,15 @@ def oracle_t300_b2(case, case64):
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_full_dims_T300_B2_step_vs_oracle(samplers, oracle_t300_b2, mode):
+def test_full_dims_T300_B2_step_vs_oracle(case, samplers, oracle_t300_b2, mode):
     cond, xT, x2, (first, f64a), (mid, f64b) = oracle_t300_b2
+    stats = case[3]
     s = samplers[mode]
     s.set_schedule("ddim1000")
     s.begin(cond, xT)
     names = ("x", "x2", "pred_xstart", "pred_xstart2")
-    _check_step(s, xT, xT, 999, dict(zip(names, first)), f"T=300 B=2 i=999 [{mode}]", f64a, mode)
-    _check_step(s, xT, x2, 500, dict(zip(names, mid)), f"T=300 B=2 i=500 [{mode}]", f64b, mode)      # chains that differ, mid-schedule coefficients
+    _check_step(s, xT, xT, 999, dict(zip(names, first)), f"T=300 B=2 i=999 [{mode}]", f64a, mode, stats)
+    _check_step(s, xT, x2, 500, dict(zip(names, mid)), f"T=300 B=2 i=500 [{mode}]", f64b, mode, stats)      # chains that differ, mid-schedule coefficients
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -212,8 +222,9 @@ def oracle_chains(case, case64, samplers):
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("which", ["first", "last"])
-def test_ddim1000_teacher_forced_20_steps(samplers, oracle_chains, mode, which):
+def test_ddim1000_teacher_forced_20_steps(case, samplers, oracle_chains, mode, which):
     cond, xT, chains = oracle_chains
+    stats = case[3]
     i0, states = chains[which]
     s = samplers[mode]
     s.set_schedule("ddim1000")
@@ -222,7 +233,7 @@ def test_ddim1000_teacher_forced_20_steps(samplers, oracle_chains, mode, which):
     for k in range(20):
         x, x2 = states[k][:2]
         rx, rx2, rp1, rp2, f64 = states[k + 1]
-        out, w, a, y = _check_step(s, x, x2, i0 - k, {"x": rx, "x2": rx2, "pred_xstart": rp1, "pred_xstart2": rp2}, f"ddim1000 {which} i={i0 - k} [{mode}]", f64, mode)
+        out, w, a, y = _check_step(s, x, x2, i0 - k, {"x": rx, "x2": rx2, "pred_xstart": rp1, "pred_xstart2": rp2}, f"ddim1000 {which} i={i0 - k} [{mode}]", f64, mode, stats)
         worst = max(worst, w)
         amplified += int(a > 0)
         events += int(y["turned_joint_event"])

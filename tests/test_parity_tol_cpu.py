@@ -139,3 +139,34 @@ def test_statistical_form_is_neither_brittle_nor_vacuous(pair):
     hard[0] = (bad, r32, r64, "step 0")
     with pytest.raises(AssertionError, match="hard bound"):
         compare_draws(hard, "a position element beyond the hard bound")
+
+
+def test_a_component_beyond_the_hard_bound_needs_a_joint_at_the_half_turn_discontinuity(pair):
+    """compare_step(denorm=): up to HARD_OUTLIERS rot6d components may pass the hard bound, but only on a joint whose rotation (float64 oracle) is at the
+    half-turn discontinuity of the reference's matrix_to_quaternion (its three sign decisions vanish there).  A joint planted AT a rotation by pi
+    passes with two wild components; the same two components on an ordinary joint fail once the evidence is asked for (and still pass without)."""
+    from parity_tol import CLIFF_MARGIN
+    r32, r64, stats = pair
+    mean_h, std_h = stats[0].double(), stats[1].double()
+    den = {"pred_xstart": (mean_h.repeat(2), std_h.repeat(2))}
+    b, t, c0 = 0, 5, 132 + 6 * 7
+    # a rotation by pi about a unit axis u: R = 2 u u^T - I (symmetric: all three sign differences are exactly 0); rot6d = first two rows, interleaved
+    u = torch.tensor([0.6, 0.0, 0.8], dtype=torch.float64)
+    R = 2 * torch.outer(u, u) - torch.eye(3, dtype=torch.float64)
+    d6 = R[:2].reshape(6)[[0, 3, 1, 4, 2, 5]]
+    planted = (d6 - mean_h[c0:c0 + 6]) / std_h[c0:c0 + 6]
+    r32p, r64p = {k: v.clone() for k, v in r32.items()}, {k: v.clone() for k, v in r64.items()}
+    r32p["pred_xstart"][b, t, c0:c0 + 6] = planted.to(r32p["pred_xstart"].dtype)
+    r64p["pred_xstart"][b, t, c0:c0 + 6] = planted.to(r64p["pred_xstart"].dtype)
+    out = {k: v.clone() for k, v in r32p.items()}
+    out["pred_xstart"][b, t, c0 + 1] += 0.4
+    out["pred_xstart"][b, t, c0 + 2] -= 0.3
+    assert compare_step(out, r32p, r64p, "two components at the half turn", denorm=den)[2] == 0
+    # the same excursion on an ordinary joint: allowed without the evidence (round 3's rule), refused with it
+    out2 = {k: v.clone() for k, v in r32.items()}
+    out2["pred_xstart"][b, t, c0 + 1] += 0.4
+    out2["pred_xstart"][b, t, c0 + 2] -= 0.3
+    assert compare_step(out2, r32, r64, "two components, no evidence asked")[2] == 0
+    with pytest.raises(AssertionError, match="NOT at the half-turn"):
+        compare_step(out2, r32, r64, "two components on an ordinary joint", denorm=den)
+    assert CLIFF_MARGIN <= 1e-3
