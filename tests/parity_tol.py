@@ -100,6 +100,17 @@ def group_scale(e_cpu):
     return G, torch.stack(per_group, dim=1)          # [B, groups]
 
 
+def half_turn_evidence(r64, mean_std, b, t, c):
+    """The rotation of the joint that channel c belongs to, from the float64 oracle's (normalised) output r64 [B, T, C]: 1 + trace (0 at a rotation
+    by pi) and the largest of the three sign differences the reference's matrix_to_quaternion decides on (rotation_conversions.py:98-120)."""
+    from oracle import geometry as _G
+    mean, std = [torch.as_tensor(v).double() for v in mean_std]
+    c0 = (c // 262) * 262 + 132 + (((c % 262) - 132) // 6) * 6
+    R = _G.rotation_6d_to_matrix((r64[b, t, c0:c0 + 6] * std[c0:c0 + 6] + mean[c0:c0 + 6])[None])[0]
+    return {"one_plus_trace": float(1 + R[0, 0] + R[1, 1] + R[2, 2]),
+            "max_sign_margin": float(max(abs(R[2, 1] - R[1, 2]), abs(R[0, 2] - R[2, 0]), abs(R[1, 0] - R[0, 1])))}
+
+
 def compare_step(out, ref32, ref64, what, tol=STEP_TOL, hard_joints=0, denorm=None):
     """out: {state name: HIP tensor [B, T, C]}; ref32 / ref64: the fp32 and the float64 oracle's outputs of this very step.
     Asserts statement 1 of the module docstring for every tensor of ref32; returns (worst out-of-tolerance fraction, largest number of
@@ -168,11 +179,7 @@ def compare_step(out, ref32, ref64, what, tol=STEP_TOL, hard_joints=0, denorm=No
                 ev = {"sample": b, "frame": t, "channel": c, "err": float(d[b, t, c]), "oracle_fp32_vs_f64_on_joint": own,
                       "median_rot6d_oracle_err": med, "ratio": own / max(med, 1e-30)}
                 if denorm is not None and nm in denorm:
-                    from oracle import geometry as _G
-                    mean, std = [torch.as_tensor(v).double() for v in denorm[nm]]
-                    R = _G.rotation_6d_to_matrix((r64[b, t, c0:c0 + 6] * std[c0:c0 + 6] + mean[c0:c0 + 6])[None])[0]
-                    ev["one_plus_trace"] = float(1 + R[0, 0] + R[1, 1] + R[2, 2])
-                    ev["max_sign_margin"] = float(max(abs(R[2, 1] - R[1, 2]), abs(R[0, 2] - R[2, 0]), abs(R[1, 0] - R[0, 1])))
+                    ev.update(half_turn_evidence(r64, denorm[nm], b, t, c))
                     assert ev["max_sign_margin"] <= CLIFF_MARGIN, \
                         f"{what} {nm}: a rot6d component beyond the hard bound (err {ev['err']:.2e}) on a joint that is NOT at the half-turn discontinuity: {ev}"
                 hard_ev.append(ev)
@@ -222,7 +229,7 @@ def binomial_bound(n, p=DRAW_EXCEED_RATE, alpha=DRAW_ALPHA):
     return n
 
 
-def step_draws(out, ref32, ref64, label, tol=STEP_TOL):
+def step_draws(out, ref32, ref64, label, tol=STEP_TOL, denorm=None):
     """The (sample, person) draws of one compared step: per draw the worst out-of-tolerance fraction over the compared tensors (compare_step's
     element tolerance, taken over that person's 262 channels of that sample) and whether it exceeds tol["frac"].  Asserts statement (i)."""
     draws = {}
@@ -240,6 +247,10 @@ def step_draws(out, ref32, ref64, label, tol=STEP_TOL):
         rot = ((ch >= 132) & (ch < 258))[None, None, :].expand_as(over)
         assert not bool((over & ~rot).any()), f"{label} {nm}: position / velocity / foot element beyond the hard bound, max err {d.max().item():.2e}"
         assert int(over.sum()) <= HARD_OUTLIERS, f"{label} {nm}: {int(over.sum())} rot6d components beyond the hard bound (fp32: {HARD_OUTLIERS} allowed)"
+        if denorm is not None and nm in denorm:          # ... and each of them on a joint at the half-turn discontinuity (compare_step has the rule)
+            for b, t, c in over.nonzero().tolist():
+                ev = half_turn_evidence(r64, denorm[nm], b, t, c)
+                assert ev["max_sign_margin"] <= CLIFF_MARGIN, f"{label} {nm}: a rot6d component beyond the hard bound (err {float(d[b, t, c]):.2e}) on a joint that is NOT at the half-turn discontinuity: {ev}"
         for b in range(B):
             for p in range(C // 262):
                 sel = d[b, :, p * 262:(p + 1) * 262] > lim[b, :, p * 262:(p + 1) * 262]
@@ -254,12 +265,12 @@ def step_draws(out, ref32, ref64, label, tol=STEP_TOL):
     return list(draws.values())
 
 
-def compare_draws(steps, what, tol=STEP_TOL):
+def compare_draws(steps, what, tol=STEP_TOL, denorm=None):
     """steps: [(out, ref32, ref64, label)] -- independent one-step comparisons ([B, T, C] tensors per state name).  Asserts (i)-(iii) above and
     records every draw.  Returns (number of draws beyond the factor, allowed k, N)."""
     draws = []
     for out, r32, r64, label in steps:
-        draws += step_draws(out, r32, r64, label, tol)
+        draws += step_draws(out, r32, r64, label, tol, denorm)
     n, beyond = len(draws), sum(d["beyond_factor"] for d in draws)
     k = binomial_bound(n)
     REPORT.append({"what": what, "kind": "draws_vs_fp32_oracle", "draws": draws, "n_draws": n, "beyond_factor": beyond, "allowed": k,
